@@ -1,0 +1,143 @@
+"""Pin the CPU oracle against every golden vector captured from the real reference (CPU only)."""
+import torch
+import pytest
+
+from oracle import st_maskgit_ref as R
+from tests.helpers import golden, tiny_ref_config, tiny_state_dict, tiny_inputs, rel_err
+
+TOL = 2e-5  # fp32 restatement vs fp32 reference: summation-order noise only
+
+
+def test_g1_factorize_bit_exact():
+    g = golden("g1_factorize")
+    fac = R.factorize_token_ids(g["ids"], 2, 512)
+    assert torch.equal(fac, g["fac"])
+    assert torch.equal(R.unfactorize_token_ids(fac, 2, 512), g["unfac"])
+    assert torch.equal(R.unfactorize_token_ids(fac, 2, 512), g["ids"])
+    assert torch.equal(R.factorize_labels(g["ids"]), g["labels"])
+
+
+def test_g2_embedding():
+    g = golden("g2_embedding")
+    cfg = tiny_ref_config()
+    sd = {"token_embed.factored_embeds.0.weight": g["E0"], "token_embed.factored_embeds.1.weight": g["E1"],
+          "token_embed.mask_token_embed": g["mask_embed"]}
+    assert torch.equal(R.token_embed(sd, cfg, g["ids"]), g["out"])
+
+
+@pytest.mark.parametrize("tag,scale", [("mup", 8 / 32), ("std", 32 ** -0.5)])
+def test_g3_attention(tag, scale):
+    g = golden("g3_attention")
+    for kind, causal in (("spatial", False), ("temporal", True)):
+        y = R.self_attention(g[f"{tag}.x_{kind}"], g[f"{tag}.qkv"], None, g[f"{tag}.proj_w"], g[f"{tag}.proj_b"],
+                             8, scale, causal)
+        assert rel_err(y, g[f"{tag}.y_{kind}"]) < TOL
+
+
+def test_g4_blocks():
+    g = golden("g4_blocks")
+    y = R.mlp(g["mlp.x"], g["mlp.fc1_w"], g["mlp.fc1_b"], g["mlp.fc2_w"], g["mlp.fc2_b"])
+    assert rel_err(y, g["mlp.y"]) < TOL
+    sd = {f"m.{k[4:]}": v for k, v in g.items() if k.startswith("mod.") and k[4:] not in ("x", "c", "y")}
+    B, S, T = 2, 5, 4
+    y = R.modulate_layer(sd, "m", g["mod.x"].reshape(B, S, T, 256), g["mod.c"]).reshape(B * S, T, 256)
+    assert rel_err(y, g["mod.y"]) < TOL
+    cfg = tiny_ref_config()
+    sd = {"action_preprocessor.d.mean": g["stem.mean"], "action_preprocessor.d.std": g["stem.std"]}
+    for k, v in g.items():
+        if k.startswith("stem.model."):
+            sd["action_mlp.d." + k[5:]] = v
+    assert rel_err(R.action_stem(sd, cfg, g["stem.a"], "d"), g["stem.y"]) < TOL
+
+
+def test_g5_stblock_and_decoder():
+    g = golden("g5_stblock")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    y = R.st_block(sd, cfg, 0, g["x"], g["a_emb"], "domA")
+    assert rel_err(y[:, :, ::8], g["y_layer0_domA"]) < TOL
+    y = R.st_block(sd, cfg, 0, g["x"][:, :, :256], None, None)
+    assert rel_err(y[:, :, ::8], g["y_layer0_noact"]) < TOL
+    x = g["x"]
+    for l in range(cfg.num_layers):
+        x = R.st_block(sd, cfg, l, x, g["a_emb"], "domB")
+    assert rel_err(x[:, :, ::8], g["y_decoder_domB"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["domA", "domB", "noact"])
+def test_g6_forward_backward(tag):
+    g = golden("g6_forward_backward")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    inp = tiny_inputs()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(params)
+    act = None if tag == "noact" else inp[f"actions_{tag}"]
+    dom = None if tag == "noact" else [tag] * 2
+    loss, acc, logits = R.forward(full, cfg, inp["input_ids"], inp["labels"], act, dom)
+    loss.backward()
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5
+    assert acc.item() == g[f"{tag}.acc"].item()
+    assert rel_err(logits.detach()[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) < TOL
+    n_checked = 0
+    for name, p in params.items():
+        key = f"{tag}.grad_head.{name}"
+        if key not in g:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
+            continue
+        n_checked += 1
+        gf = p.grad.reshape(-1)
+        idx = torch.linspace(0, gf.numel() - 1, 64).long()
+        scale = g[f"{tag}.grad_abs.{name}"].item() / gf.numel() + 1e-12
+        assert (gf[:64] - g[key]).abs().max().item() < 5e-4 * scale + 1e-9, name
+        assert (gf[idx] - g[f"{tag}.grad_samp.{name}"]).abs().max().item() < 5e-4 * scale + 1e-9, name
+        assert abs(gf.double().abs().sum().item() - g[f"{tag}.grad_abs.{name}"].item()) < 1e-4 * gf.numel() * scale
+    assert n_checked > 20
+
+
+def test_g7_generate_ids_bit_exact():
+    g = golden("g7_generate")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    inp = tiny_inputs()
+    out_t = cfg.T - 1
+    for steps in (1, 2, 8):
+        p = g["prompt0"].clone()
+        s, fl = R.maskgit_generate(sd, cfg, p, out_t, steps, 0.0, "greedy", inp["actions_domA"], ["domA"] * 2)
+        assert torch.equal(s, g[f"greedy{steps}.samples"]), steps
+        assert torch.equal(p, g[f"greedy{steps}.prompt_after"])
+        assert rel_err(fl[:, ::8], g[f"greedy{steps}.logits_sub"]) < TOL
+    p = g["prompt0"].clone()
+    s, _ = R.maskgit_generate(sd, cfg, p, out_t, 4, 0.0, "random", inp["actions_domA"], ["domA"] * 2,
+                              rand_draws=list(g["random4.draws"]))
+    assert torch.equal(s, g["random4.samples"])
+
+
+def test_g8_clip_adamw():
+    g = golden("g8_adamw")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    inp = tiny_inputs()
+    names = [k for k in sd if not (k.endswith(".mean") or k.endswith(".std"))]
+    params = {k: sd[k].clone() for k in names}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(v) for k, v in params.items()}
+    for it in range(2):
+        leaf = {k: p.clone().requires_grad_(True) for k, p in params.items()}
+        full = dict(sd)
+        full.update(leaf)
+        loss, _, _ = R.forward(full, cfg, inp["input_ids"], inp["labels"], inp["actions_domA"], ["domA"] * 2)
+        loss.backward()
+        grads = {k: leaf[k].grad for k in names}
+        norm = R.clip_and_adamw(params, grads, m, v, it + 1, 1e-3)
+        assert abs(loss.item() - g[f"step{it}.loss"].item()) < 2e-5
+        assert abs(norm - g[f"step{it}.grad_norm"].item()) < 1e-4 * max(1.0, norm)
+    for k in names:
+        flat = params[k].reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 64).long()
+        assert (flat[idx] - g[f"param_samp.{k}"]).abs().max().item() < 2e-5, k
+    # a globally-unused domain (domB) must be untouched: no decay, no moments
+    for k in names:
+        if ".domB." in k or "action_out_projectors" in k or k == "action_mask_tokens":
+            assert torch.equal(params[k], sd[k]), k
