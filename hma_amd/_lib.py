@@ -1,0 +1,107 @@
+"""ctypes binding of libhma_hip.so (include/hma_hip.h).  There is NO fallback: if the library is
+missing or a launch fails, the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhma_hip.so")
+
+A_BF16, A_F32, A_BF16_AFFINE = 0, 1, 2
+EPI_BF16, EPI_F32, EPI_RESID, EPI_GELU2, EPI_SILU2, EPI_DGELU, EPI_DSILU, EPI_ATOMIC_F32 = range(8)
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmNT(C.Structure):
+    _fields_ = [
+        ("A", c_vp), ("lda", c_i64), ("a_kind", c_i32), ("_pad0", c_i32),
+        ("a_group_rows", c_i64), ("a_group_stride", c_i64),
+        ("gamma", c_vp), ("beta", c_vp),
+        ("W", c_vp), ("ldw", c_i64),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("epi", c_i32), ("_pad1", c_i32),
+        ("bias", c_vp),
+        ("C", c_vp), ("ldc", c_i64), ("c_group_rows", c_i64), ("c_group_stride", c_i64),
+        ("C2", c_vp), ("ldc2", c_i64),
+        ("U", c_vp), ("ldu", c_i64),
+        ("batch", c_i32), ("_pad2", c_i32),
+        ("sA", c_i64), ("sW", c_i64), ("sBias", c_i64), ("sC", c_i64), ("sC2", c_i64), ("sU", c_i64),
+    ]
+
+
+class GemmTN(C.Structure):
+    _fields_ = [
+        ("dY", c_vp), ("ldy", c_i64), ("y_kind", c_i32), ("_pad0", c_i32),
+        ("y_group_rows", c_i64), ("y_group_stride", c_i64),
+        ("A", c_vp), ("lda", c_i64), ("a_kind", c_i32), ("_pad1", c_i32),
+        ("a_group_rows", c_i64), ("a_group_stride", c_i64),
+        ("gamma", c_vp), ("beta", c_vp),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("dW", c_vp), ("lddw", c_i64), ("dBias", c_vp),
+        ("splits", c_i32), ("batch", c_i32),
+        ("sY", c_i64), ("sA", c_i64), ("sdW", c_i64), ("sdBias", c_i64),
+    ]
+
+
+_PROTOS = {
+    "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
+    "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
+    "hma_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32],
+    "hma_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
+    "hma_modln_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32],
+    "hma_modln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64],
+    "hma_attn_spatial_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
+    "hma_attn_spatial_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
+    "hma_attn_temporal_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32],
+    "hma_attn_temporal_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32],
+    "hma_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64],
+    "hma_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64],
+    "hma_action_stem_fwd": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                            c_vp, c_i64, c_i32, c_i32],
+    "hma_action_stem_bwd": [c_vp] * 15 + [c_i64, c_i32],
+    "hma_count_masked": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64],
+    "hma_ce_fwd_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_i32, c_i64, c_f32],
+    "hma_maskgit_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64],
+    "hma_sqnorm": [c_vp, c_vp, c_i64, c_vp],
+    "hma_adamw": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp],
+    "hma_cast_bf16": [c_vp, c_vp, c_vp, c_i64],
+    "hma_transpose_cast_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64],
+    "hma_abi_version": [],
+}
+
+EXPORTS = tuple(_PROTOS)
+_lib = None
+
+
+class HmaKernelError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the in-tree shared object; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HmaKernelError(
+                f"{LIB_PATH} is missing: build it with `python -m hma_amd.build` (hipcc --offload-arch=gfx950). "
+                "hma_amd has no CPU or eager fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = c_i32
+        if lib.hma_abi_version() != 0x484D4101:
+            raise HmaKernelError("libhma_hip.so ABI mismatch: rebuild with `python -m hma_amd.build --force`")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, name: str) -> None:
+    if rc != 0:
+        raise HmaKernelError(f"{name} failed with code {rc}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,361 @@
+// Spatial (per-frame, bidirectional) multi-head attention for gfx950, head_dim 32, n = 256/320
+// tokens per frame: the whole K/V of one (frame, head) lives in LDS (20 KB each) and a 32-query
+// tile walks the keys in two register-resident chunks (one online-softmax merge).
+//
+// All three kernels use the "swapped" product S^T = K Q^T (v_mfma_f32_32x32x16_bf16): the MFMA
+// result puts one query (fwd, dq) or one key (dkv) per lane and 16 of the other index per lane in
+// registers, so the softmax reduction is in-lane + one lane^32 exchange, and the packed bf16
+// probabilities ARE the B operand of the second product (no LDS round trip): the contraction index
+// of the second MFMA is permuted (kappa below) to match how the first MFMA left it in registers.
+//
+// Reference: BasicSelfAttention.forward, hma/model/attention.py:37-61 (causal=False), called from
+// STBlock.forward hma/model/st_transformer.py:85-86; backward = its autograd mirror.
+#include "hma_common.h"
+#include "../../include/hma_hip.h"
+
+using namespace hma;
+
+namespace {
+
+constexpr int HD = 32;       // head dim
+constexpr int NH = 8;        // heads
+constexpr int DM = 256;      // d_model
+constexpr int QKV_LD = 768;  // packed qkv row
+constexpr int LDR = 40;      // row-major [token][32] tile, padded to 80 B rows
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// (frame, head) of a workgroup: the 8 heads of a frame are dispatched back-to-back on ONE XCD
+// (block b runs on XCD b % 8) so the 128-B lines shared by neighbouring heads hit the same L2.
+__device__ __forceinline__ void decode_block(int64_t b, int64_t frames, int64_t& frame, int& head) {
+  const int64_t full = (frames / 8) * 64;  // blocks covered by whole groups of 8 frames
+  if (b < full) {
+    const int xcd = (int)(b & 7);
+    const int64_t r = b >> 3;
+    head = (int)(r & 7);
+    frame = (r >> 3) * 8 + xcd;
+  } else {
+    const int64_t r = b - full;
+    head = (int)(r & 7);
+    frame = (frames / 8) * 8 + (r >> 3);
+  }
+}
+
+// row-major stage: dst[row][LDR] <- src[row * ld + 0..31] (bf16), n rows
+__device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, int64_t ld, int n, int tid, int nthr) {
+  for (int c = tid; c < n * 4; c += nthr) {
+    const int row = c >> 2, ch = c & 3;
+    *reinterpret_cast<uint4*>(&dst[row * LDR + ch * 8]) = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
+  }
+}
+// transposed stage: dst[d][ldv] (d = 0..31, token contiguous) <- src[token * ld + d]
+__device__ __forceinline__ void stage_cols(uint16_t* dst, int ldv, const uint16_t* src, int64_t ld, int n, int tid,
+                                           int nthr) {
+  for (int c = tid; c < n * 2; c += nthr) {
+    const int kp = c >> 2, ch = c & 3;
+    const uint4 a = *reinterpret_cast<const uint4*>(src + (int64_t)(2 * kp) * ld + ch * 8);
+    const uint4 b = *reinterpret_cast<const uint4*>(src + (int64_t)(2 * kp + 1) * ld + ch * 8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t x = (j & 1) ? ((aw[j >> 1] >> 16) | (bw[j >> 1] & 0xffff0000u))
+                                 : ((aw[j >> 1] & 0xffffu) | (bw[j >> 1] << 16));
+      *reinterpret_cast<uint32_t*>(&dst[(ch * 8 + j) * ldv + 2 * kp]) = x;
+    }
+  }
+}
+
+// A operand from a row-major tile: lane (row = l & 31, hi) reads dims 16*s + 8*hi .. +8
+__device__ __forceinline__ bf16x8_t frag_rows(const uint16_t* tile, int row0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(&tile[(row0 + (lane & 31)) * LDR + s * 16 + (lane >> 5) * 8]);
+}
+// A operand from a transposed tile for the second product: lane (d = l & 31, hi), k-step s2 of the
+// 32-token tile at tok0: tokens tok0 + 16*s2 + 4*hi + {0..3} and + 8 (the kappa permutation that
+// matches rows 8*s2 .. 8*s2+7 of a 32x32 accumulator).
+__device__ __forceinline__ bf16x8_t frag_cols(const uint16_t* tile, int ldv, int tok0, int s2, int lane) {
+  const uint16_t* p = &tile[(lane & 31) * ldv + tok0 + 16 * s2 + 4 * (lane >> 5)];
+  const uint2 lo = *reinterpret_cast<const uint2*>(p);
+  const uint2 hi = *reinterpret_cast<const uint2*>(p + 8);
+  const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// B operand straight from global: lane (token = l & 31, hi) reads dims 16*s + 8*hi .. +8 of its row
+__device__ __forceinline__ bf16x8_t frag_global(const uint16_t* base, int64_t ld, int s, int lane) {
+  const uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)(lane & 31) * ld + s * 16 + (lane >> 5) * 8);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t pack_acc_half(const f32x16_t& a, int s2) {
+  uint4 v;
+  v.x = pack_bf16(a[8 * s2 + 0], a[8 * s2 + 1]);
+  v.y = pack_bf16(a[8 * s2 + 2], a[8 * s2 + 3]);
+  v.z = pack_bf16(a[8 * s2 + 4], a[8 * s2 + 5]);
+  v.w = pack_bf16(a[8 * s2 + 6], a[8 * s2 + 7]);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ f32x16_t zero16() {
+  f32x16_t z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.f;
+  return z;
+}
+// store a [d x token] accumulator (lane = token, rows = d) as bf16 into row-major [token][ld] at column col0
+__device__ __forceinline__ void store_dt(uint16_t* base, int64_t ld, const f32x16_t& a, float mul, int lane) {
+  uint16_t* row = base + (int64_t)(lane & 31) * ld + 4 * (lane >> 5);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<uint2*>(row + 8 * g) =
+        make_uint2(pack_bf16(a[4 * g] * mul, a[4 * g + 1] * mul), pack_bf16(a[4 * g + 2] * mul, a[4 * g + 3] * mul));
+}
+
+// ------------------------------------------------------------------------------------- forward
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
+                                                          float* __restrict__ lse, int64_t frames, float c_log2) {
+  constexpr int N = NT * 32, LDV = N + 4;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Ks = smem;             // [N][LDR]
+  uint16_t* Vt = smem + N * LDR;   // [32][LDV]
+  int64_t frame; int head;
+  decode_block(blockIdx.x, frames, frame, head);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
+  stage_rows(Ks, base + DM, QKV_LD, N, tid, 256);
+  stage_cols(Vt, LDV, base + 2 * DM, QKV_LD, N, tid, 256);
+  __syncthreads();
+
+  for (int qt = wave; qt < NT; qt += 4) {
+    const uint16_t* qb = base + (int64_t)qt * 32 * QKV_LD;
+    const bf16x8_t q0 = frag_global(qb, QKV_LD, 0, lane), q1 = frag_global(qb, QKV_LD, 1, lane);
+    // two key chunks of NT/2 tiles with one online-softmax merge: keeps the live scores at 80 VGPRs
+    constexpr int NC = NT / 2;
+    float m = -INFINITY, l = 0.f;
+    f32x16_t acc = zero16();
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+      f32x16_t s[NC];
+#pragma unroll
+      for (int kt = 0; kt < NC; ++kt) {
+        s[kt] = mfma32(frag_rows(Ks, (c * NC + kt) * 32, 0, lane), q0, zero16());
+        s[kt] = mfma32(frag_rows(Ks, (c * NC + kt) * 32, 1, lane), q1, s[kt]);
+      }
+      float mc = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NC; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          s[kt][e] *= c_log2;
+          mc = fmaxf(mc, s[kt][e]);
+        }
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+      const float m_new = fmaxf(m, mc);
+      const float alpha = fast_exp2(m - m_new);  // 0 on the first chunk
+      l *= alpha;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < NC; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          s[kt][e] = fast_exp2(s[kt][e] - m_new);
+          l += s[kt][e];
+        }
+#pragma unroll
+      for (int kt = 0; kt < NC; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          acc = mfma32(frag_cols(Vt, LDV, (c * NC + kt) * 32, s2, lane), pack_acc_half(s[kt], s2), acc);
+      m = m_new;
+    }
+    l += __shfl_xor(l, 32, 64);
+    const int64_t row0 = frame * N + qt * 32;
+    store_dt(o + row0 * DM + head * HD, DM, acc, 1.0f / l, lane);
+    if (lane < 32) lse[(row0 + lane) * NH + head] = m + __log2f(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------- dQ
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                             const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                             int64_t frames, float c_log2, float scale) {
+  constexpr int N = NT * 32, LDV = N + 4;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Ks = smem;                 // [N][LDR]
+  uint16_t* Vs = Ks + N * LDR;         // [N][LDR]
+  uint16_t* Kt = Vs + N * LDR;         // [32][LDV]
+  int64_t frame; int head;
+  decode_block(blockIdx.x, frames, frame, head);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
+  stage_rows(Ks, base + DM, QKV_LD, N, tid, 256);
+  stage_rows(Vs, base + 2 * DM, QKV_LD, N, tid, 256);
+  stage_cols(Kt, LDV, base + DM, QKV_LD, N, tid, 256);
+  __syncthreads();
+
+  for (int qt = wave; qt < NT; qt += 4) {
+    const int64_t row0 = frame * N + qt * 32;
+    const uint16_t* qb = base + (int64_t)qt * 32 * QKV_LD;
+    const bf16x8_t q0 = frag_global(qb, QKV_LD, 0, lane), q1 = frag_global(qb, QKV_LD, 1, lane);
+    const uint16_t* dob = d_o + row0 * DM + head * HD;
+    const uint16_t* ob = o + row0 * DM + head * HD;
+    const bf16x8_t g0 = frag_global(dob, DM, 0, lane), g1 = frag_global(dob, DM, 1, lane);
+    const bf16x8_t o0 = frag_global(ob, DM, 0, lane), o1 = frag_global(ob, DM, 1, lane);
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)g0[j] * (float)o0[j] + (float)g1[j] * (float)o1[j];
+    dl += __shfl_xor(dl, 32, 64);
+    const float L2 = lse[(row0 + (lane & 31)) * NH + head];
+    if (lane < 32) delta[(row0 + lane) * NH + head] = dl;
+    f32x16_t acc = zero16();
+#pragma unroll 2
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x16_t s = mfma32(frag_rows(Ks, kt * 32, 0, lane), q0, zero16());
+      s = mfma32(frag_rows(Ks, kt * 32, 1, lane), q1, s);
+      f32x16_t dp = mfma32(frag_rows(Vs, kt * 32, 0, lane), g0, zero16());
+      dp = mfma32(frag_rows(Vs, kt * 32, 1, lane), g1, dp);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = fast_exp2(s[e] * c_log2 - L2) * (dp[e] - dl);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acc = mfma32(frag_cols(Kt, LDV, kt * 32, s2, lane), pack_acc_half(s, s2), acc);
+    }
+    store_dt(dqkv + row0 * QKV_LD + head * HD, QKV_LD, acc, scale, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------- dK, dV
+template <int NT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              uint16_t* __restrict__ dqkv, int64_t frames, float c_log2,
+                                                              float scale) {
+  constexpr int N = NT * 32, LDV = N + 4;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Qs = smem;                  // [N][LDR]
+  uint16_t* Gs = Qs + N * LDR;          // dO, [N][LDR]
+  uint16_t* Qt = Gs + N * LDR;          // [32][LDV]
+  uint16_t* Gt = Qt + 32 * LDV;         // [32][LDV]
+  float* L2s = reinterpret_cast<float*>(Gt + 32 * LDV);  // [N]
+  float* Dls = L2s + N;                                   // [N]
+  int64_t frame; int head;
+  decode_block(blockIdx.x, frames, frame, head);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
+  const uint16_t* gbase = d_o + frame * N * DM + head * HD;
+  stage_rows(Qs, base, QKV_LD, N, tid, 256);
+  stage_rows(Gs, gbase, DM, N, tid, 256);
+  stage_cols(Qt, LDV, base, QKV_LD, N, tid, 256);
+  stage_cols(Gt, LDV, gbase, DM, N, tid, 256);
+  for (int i = tid; i < N; i += 256) {
+    L2s[i] = lse[(frame * N + i) * NH + head];
+    Dls[i] = delta[(frame * N + i) * NH + head];
+  }
+  __syncthreads();
+
+  const int hi = lane >> 5;
+  for (int kt = wave; kt < NT; kt += 4) {
+    const uint16_t* kb = base + DM + (int64_t)kt * 32 * QKV_LD;
+    const uint16_t* vb = base + 2 * DM + (int64_t)kt * 32 * QKV_LD;
+    const bf16x8_t k0 = frag_global(kb, QKV_LD, 0, lane), k1 = frag_global(kb, QKV_LD, 1, lane);
+    const bf16x8_t v0 = frag_global(vb, QKV_LD, 0, lane), v1 = frag_global(vb, QKV_LD, 1, lane);
+    f32x16_t dk = zero16(), dv = zero16();
+#pragma unroll 2
+    for (int qt = 0; qt < NT; ++qt) {
+      // S[q][key]: lane = key, rows = q
+      f32x16_t s = mfma32(frag_rows(Qs, qt * 32, 0, lane), k0, zero16());
+      s = mfma32(frag_rows(Qs, qt * 32, 1, lane), k1, s);
+      f32x16_t dp = mfma32(frag_rows(Gs, qt * 32, 0, lane), v0, zero16());
+      dp = mfma32(frag_rows(Gs, qt * 32, 1, lane), v1, dp);
+      f32x16_t ds;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int q = qt * 32 + mfma32_row(e, hi);
+        const float p = fast_exp2(s[e] * c_log2 - L2s[q]);
+        s[e] = p;
+        ds[e] = p * (dp[e] - Dls[q]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        dv = mfma32(frag_cols(Gt, LDV, qt * 32, s2, lane), pack_acc_half(s, s2), dv);
+        dk = mfma32(frag_cols(Qt, LDV, qt * 32, s2, lane), pack_acc_half(ds, s2), dk);
+      }
+    }
+    const int64_t row0 = frame * N + kt * 32;
+    store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk, scale, lane);
+    store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv, 1.0f, lane);
+  }
+}
+
+template <auto Kern>
+int set_lds(int bytes) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return -(int)e;
+    done = true;
+  }
+  return 0;
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int NT>
+int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int64_t frames, float scale) {
+  constexpr int N = NT * 32, LDV = N + 4;
+  constexpr int bytes = (N * LDR + 32 * LDV) * 2;
+  int rc = set_lds<attn_fwd_kernel<NT>>(bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3((unsigned)(frames * NH)), dim3(256), bytes, s, (const uint16_t*)qkv,
+                     (uint16_t*)o, lse, frames, scale * LOG2E);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int NT>
+int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+               void* dqkv, int64_t frames, float scale) {
+  constexpr int N = NT * 32, LDV = N + 4;
+  constexpr int bytes_dq = (2 * N * LDR + 32 * LDV) * 2;
+  constexpr int bytes_dkv = (2 * N * LDR + 2 * 32 * LDV) * 2 + 2 * N * 4;
+  int rc = set_lds<attn_bwd_dq_kernel<NT>>(bytes_dq);
+  if (rc) return rc;
+  rc = set_lds<attn_bwd_dkv_kernel<NT>>(bytes_dkv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3((unsigned)(frames * NH)), dim3(256), bytes_dq, s,
+                     (const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames,
+                     scale * LOG2E, scale);
+  HMA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3((unsigned)(frames * NH)), dim3(256), bytes_dkv, s,
+                     (const uint16_t*)qkv, (const uint16_t*)d_o, lse, (const float*)delta, (uint16_t*)dqkv, frames,
+                     scale * LOG2E, scale);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int hma_attn_spatial_fwd(void* stream, const void* qkv, void* o, float* lse, int64_t frames, int32_t n,
+                                    float scale) {
+  if (!qkv || !o || !lse) return HMA_EINVAL;
+  if (frames <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (n) {
+    case 320: return launch_fwd<10>(s, qkv, o, lse, frames, scale);
+    case 256: return launch_fwd<8>(s, qkv, o, lse, frames, scale);
+    case 64: return launch_fwd<2>(s, qkv, o, lse, frames, scale);
+    default: return HMA_EINVAL;
+  }
+}
+
+extern "C" int hma_attn_spatial_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                                    float* delta, void* dqkv, int64_t frames, int32_t n, float scale) {
+  if (!qkv || !o || !d_o || !lse || !delta || !dqkv) return HMA_EINVAL;
+  if (frames <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (n) {
+    case 320: return launch_bwd<10>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
+    case 256: return launch_bwd<8>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
+    case 64: return launch_bwd<2>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
+    default: return HMA_EINVAL;
+  }
+}

@@ -1,0 +1,481 @@
+// bf16 MFMA GEMMs of the HMA hot path for gfx950.
+//
+//   hma_gemm_nt : C[m,n] = sum_k A'[m,k] W[n,k]        (nn.Linear forward / dgrad)
+//   hma_gemm_tn : dW[n,k] += sum_m dY[m,n] A'[m,k]     (nn.Linear wgrad, + bias grad)
+//
+// Both run the same inner product: a 128x128 output tile per 256-thread workgroup, 4 waves in a
+// 2x2 grid, each wave 2x2 v_mfma_f32_32x32x16_bf16 tiles (64 fp32 accumulator VGPRs), K-steps of
+// 64 double-buffered through LDS (rows padded to 144 B so every ds_read_b128 lane group lands on
+// 16 distinct 16-B slots).  The MFMA is issued "swapped" -- weight rows as the A operand, token
+// rows as the B operand -- so a lane owns ONE token row and 4 consecutive output columns per
+// accumulator quad: epilogues touch 8/16 contiguous bytes per lane (bias, residual, GELU pairs).
+//
+// Reference call sites replaced: see include/hma_hip.h.
+#include "hma_common.h"
+#include "../../include/hma_hip.h"
+
+using namespace hma;
+
+namespace {
+
+constexpr int BM = 128;  // token rows per tile (NT) / k-columns of dW per tile (TN)
+constexpr int BN = 128;  // weight rows per tile
+constexpr int BK = 64;   // contraction step
+constexpr int LDT = BK + 8;
+constexpr int TILE_ELEMS = 128 * LDT;
+constexpr int SMEM_BYTES = 4 * TILE_ELEMS * 2;  // 2 operands x 2 buffers, 73728 B
+
+__device__ __forceinline__ void mma_tile(const uint16_t* __restrict__ Ts, const uint16_t* __restrict__ Ws,
+                                         f32x16_t (&acc)[2][2], int wm, int wn, int lane) {
+  const int r = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk) {
+    bf16x8_t wf[2], tf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wf[i] = *reinterpret_cast<const bf16x8_t*>(&Ws[(wn * 64 + i * 32 + r) * LDT + kk * 16 + hi * 8]);
+      tf[i] = *reinterpret_cast<const bf16x8_t*>(&Ts[(wm * 64 + i * 32 + r) * LDT + kk * 16 + hi * 8]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mfma32(wf[nt], tf[mt], acc[nt][mt]);
+  }
+}
+
+__device__ __forceinline__ int64_t remap_row(int64_t r, int64_t group_rows, int64_t group_stride) {
+  return group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) : r;
+}
+
+// ------------------------------------------------------------------------------------------ NT
+template <int AKIND>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(hma_gemm_nt_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* As = smem;                   // [2][128][LDT]
+  uint16_t* Ws = smem + 2 * TILE_ELEMS;  // [2][128][LDT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t bm = (int64_t)blockIdx.x * BM;
+  const int64_t bn = (int64_t)blockIdx.y * BN;
+  const int64_t bz = blockIdx.z;
+
+  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+  const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW;
+
+  // per-thread staging coordinates: 4 chunks of 8 elements for each operand
+  const int kc = tid & 7;
+  int64_t a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + i * 32;
+    const int64_t gr = bm + row;
+    a_off[i] = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
+  }
+
+  uint4 ra[4][AKIND == HMA_A_F32 ? 2 : 1];
+  uint4 rw[4];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + i * 32;
+      rw[i] = *reinterpret_cast<const uint4*>(Wb + (bn + row) * p.ldw + k0 + kc * 8);
+      if (a_off[i] >= 0) {
+        if (AKIND == HMA_A_F32) {
+          const float* s = reinterpret_cast<const float*>(Ab) + a_off[i] + k0 + kc * 8;
+          ra[i][0] = *reinterpret_cast<const uint4*>(s);
+          ra[i][AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(s + 4);
+        } else {
+          const uint16_t* s = reinterpret_cast<const uint16_t*>(Ab) + a_off[i] + k0 + kc * 8;
+          ra[i][0] = *reinterpret_cast<const uint4*>(s);
+        }
+      } else {
+        ra[i][0] = make_uint4(0, 0, 0, 0);
+        ra[i][AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tiles = [&](int buf, int k0) {
+    float gm[8], bt[8];
+    if (AKIND == HMA_A_BF16_AFFINE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gm[j] = p.gamma[k0 + kc * 8 + j];
+        bt[j] = p.beta[k0 + kc * 8 + j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + i * 32;
+      uint4 v;
+      if (AKIND == HMA_A_F32) {
+        const float4 lo = __builtin_bit_cast(float4, ra[i][0]);
+        const float4 hi = __builtin_bit_cast(float4, ra[i][AKIND == HMA_A_F32 ? 1 : 0]);
+        v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
+        v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
+      } else if (AKIND == HMA_A_BF16_AFFINE) {
+        float f[8];
+        unpack8(ra[i][0], f);
+        if (a_off[i] >= 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = f[j] * gm[j] + bt[j];
+        }
+        v = pack8(f);
+      } else {
+        v = ra[i][0];
+      }
+      *reinterpret_cast<uint4*>(&As[buf * TILE_ELEMS + row * LDT + kc * 8]) = v;
+      *reinterpret_cast<uint4*>(&Ws[buf * TILE_ELEMS + row * LDT + kc * 8]) = rw[i];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int KT = (int)(p.K / BK);
+  load_tiles(0);
+  store_tiles(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_tiles((kt + 1) * BK);
+    mma_tile(As + cur * TILE_ELEMS, Ws + cur * TILE_ELEMS, acc, wm, wn, lane);
+    if (kt + 1 < KT) store_tiles(cur ^ 1, (kt + 1) * BK);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns token row m and 4 consecutive columns per accumulator quad
+  const int r = lane & 31, hi = lane >> 5;
+  const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int64_t m = bm + wm * 64 + mt * 32 + r;
+    if (m >= p.M) continue;
+    const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t n = bn + wn * 64 + nt * 32 + 8 * g + 4 * hi;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * g + e];
+        if (bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        switch (p.epi) {
+          case HMA_EPI_BF16: {
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
+            *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+          } break;
+          case HMA_EPI_F32: {
+            float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
+            *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+          } break;
+          case HMA_EPI_RESID: {
+            float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
+            float4 x = *reinterpret_cast<float4*>(C);
+            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+            *reinterpret_cast<float4*>(C) = x;
+            if (p.C2) {
+              uint16_t* C2 = reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n;
+              *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(x.x, x.y), pack_bf16(x.z, x.w));
+            }
+          } break;
+          case HMA_EPI_GELU2:
+          case HMA_EPI_SILU2: {
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
+            uint16_t* C2 = reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n;
+            // the saved pre-activation is bf16: activate the ROUNDED value so backward sees the same u
+            float u[4], a[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              u[e] = from_bf16(to_bf16(v[e]));
+              a[e] = p.epi == HMA_EPI_GELU2 ? gelu_f(u[e]) : silu_f(u[e]);
+            }
+            *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(u[0], u[1]), pack_bf16(u[2], u[3]));
+            *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+          } break;
+          case HMA_EPI_DGELU:
+          case HMA_EPI_DSILU: {
+            const uint16_t* U = reinterpret_cast<const uint16_t*>(p.U) + bz * p.sU + crow * p.ldu + n;
+            const uint2 uu = *reinterpret_cast<const uint2*>(U);
+            const float u[4] = {bf16_lo(uu.x), bf16_hi(uu.x), bf16_lo(uu.y), bf16_hi(uu.y)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= (p.epi == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
+            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
+            *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+          } break;
+          case HMA_EPI_ATOMIC_F32: {
+            float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(C + e, v[e]);
+          } break;
+          default: break;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ TN
+// Stage a 64(m) x 128(col) slab of a row-major matrix TRANSPOSED into LDS as [128 col][64 m].
+// Thread task: rows 4*mi..4*mi+3, columns w*32 + ci*8 .. +8 (mi = lane & 15, ci = lane >> 4):
+// a 16-lane ds_write_b64 group then writes 16 consecutive 8-B slots of one LDS row (conflict-free).
+template <int KIND>
+struct SlabRegs {
+  uint4 v[4][KIND == HMA_A_F32 ? 2 : 1];
+};
+
+template <int KIND>
+__device__ __forceinline__ void slab_load(SlabRegs<KIND>& r, const char* base, int64_t ld, int64_t m0, int64_t m_end,
+                                          int64_t group_rows, int64_t group_stride, int64_t col0, int lane, int wave) {
+  const int mi = lane & 15, ci = lane >> 4;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t gm = m0 + 4 * mi + rr;
+    if (gm < m_end) {
+      const int64_t off = remap_row(gm, group_rows, group_stride) * ld + col0 + wave * 32 + ci * 8;
+      if (KIND == HMA_A_F32) {
+        const float* s = reinterpret_cast<const float*>(base) + off;
+        r.v[rr][0] = *reinterpret_cast<const uint4*>(s);
+        r.v[rr][KIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(s + 4);
+      } else {
+        r.v[rr][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off);
+      }
+    } else {
+      r.v[rr][0] = make_uint4(0, 0, 0, 0);
+      r.v[rr][KIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+// converts to bf16 (applying the LN affine for HMA_A_BF16_AFFINE), optionally accumulates the
+// column sums of the fp32 values (bias gradient), transposes 4x8 in registers and writes LDS.
+template <int KIND, bool COLSUM>
+__device__ __forceinline__ void slab_store(const SlabRegs<KIND>& r, uint16_t* T, int lane, int wave, const float* gm,
+                                           const float* bt, float* colsum, int64_t m0, int64_t m_end) {
+  const int mi = lane & 15, ci = lane >> 4;
+  uint4 q[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    float f[8];
+    if (KIND == HMA_A_F32) {
+      const float4 lo = __builtin_bit_cast(float4, r.v[rr][0]);
+      const float4 hi = __builtin_bit_cast(float4, r.v[rr][KIND == HMA_A_F32 ? 1 : 0]);
+      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+      f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    } else {
+      unpack8(r.v[rr][0], f);
+      if (KIND == HMA_A_BF16_AFFINE) {
+        if (m0 + 4 * mi + rr < m_end) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = f[j] * gm[j] + bt[j];
+        }
+      }
+    }
+    if (COLSUM) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) colsum[j] += f[j];
+    }
+    q[rr] = pack8(f);
+  }
+  const uint32_t* d0 = reinterpret_cast<const uint32_t*>(&q[0]);
+  const uint32_t* d1 = reinterpret_cast<const uint32_t*>(&q[1]);
+  const uint32_t* d2 = reinterpret_cast<const uint32_t*>(&q[2]);
+  const uint32_t* d3 = reinterpret_cast<const uint32_t*>(&q[3]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int w = j >> 1;
+    uint32_t lo, hi;
+    if (j & 1) {
+      lo = (d0[w] >> 16) | (d1[w] & 0xffff0000u);
+      hi = (d2[w] >> 16) | (d3[w] & 0xffff0000u);
+    } else {
+      lo = (d0[w] & 0xffffu) | (d1[w] << 16);
+      hi = (d2[w] & 0xffffu) | (d3[w] << 16);
+    }
+    *reinterpret_cast<uint2*>(&T[(wave * 32 + ci * 8 + j) * LDT + 4 * mi]) = make_uint2(lo, hi);
+  }
+}
+
+template <int YKIND, int AKIND>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(hma_gemm_tn_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* At = smem;                   // [2][128 k][LDT]  (token-side operand of mma_tile)
+  uint16_t* Yt = smem + 2 * TILE_ELEMS;  // [2][128 n][LDT]  (weight-side operand of mma_tile)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_k = (int)(p.K / 128);
+  const int tile_n = blockIdx.y / tiles_k, tile_k = blockIdx.y % tiles_k;
+  const int64_t n0 = (int64_t)tile_n * 128, k0 = (int64_t)tile_k * 128;
+  const int64_t bz = blockIdx.z;
+
+  // M range of this split, rounded to whole 64-row slabs
+  const int64_t slabs = (p.M + 63) / 64;
+  const int64_t per = (slabs + p.splits - 1) / p.splits;
+  const int64_t m_begin = (int64_t)blockIdx.x * per * 64;
+  int64_t m_end = m_begin + per * 64;
+  if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+
+  const char* Yb = reinterpret_cast<const char*>(p.dY) + bz * p.sY * (YKIND == HMA_A_F32 ? 4 : 2);
+  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+
+  const int ci = lane >> 4;
+  float gm[8], bt[8];
+  if (AKIND == HMA_A_BF16_AFFINE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gm[j] = p.gamma[k0 + wave * 32 + ci * 8 + j];
+      bt[j] = p.beta[k0 + wave * 32 + ci * 8 + j];
+    }
+  }
+  float colsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
+  const bool do_bias = (p.dBias != nullptr) && (tile_k == 0);
+
+  SlabRegs<YKIND> ry;
+  SlabRegs<AKIND> ra;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  auto load = [&](int64_t m0) {
+    slab_load<YKIND>(ry, Yb, p.ldy, m0, m_end, p.y_group_rows, p.y_group_stride, n0, lane, wave);
+    slab_load<AKIND>(ra, Ab, p.lda, m0, m_end, p.a_group_rows, p.a_group_stride, k0, lane, wave);
+  };
+  auto store = [&](int buf, int64_t m0) {
+    if (do_bias)
+      slab_store<YKIND, true>(ry, Yt + buf * TILE_ELEMS, lane, wave, nullptr, nullptr, colsum, m0, m_end);
+    else
+      slab_store<YKIND, false>(ry, Yt + buf * TILE_ELEMS, lane, wave, nullptr, nullptr, colsum, m0, m_end);
+    slab_store<AKIND, false>(ra, At + buf * TILE_ELEMS, lane, wave, gm, bt, nullptr, m0, m_end);
+  };
+
+  const int iters = (int)((m_end - m_begin + 63) / 64);
+  load(m_begin);
+  store(0, m_begin);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    const int64_t m_next = m_begin + (int64_t)(it + 1) * 64;
+    if (it + 1 < iters) load(m_next);
+    mma_tile(At + cur * TILE_ELEMS, Yt + cur * TILE_ELEMS, acc, wm, wn, lane);
+    if (it + 1 < iters) store(cur ^ 1, m_next);
+    __syncthreads();
+  }
+
+  // D rows = n (weight-side rows of Yt), D cols = k (token-side rows of At)
+  const int r = lane & 31, hi = lane >> 5;
+  float* dW = p.dW + bz * p.sdW;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int64_t k = k0 + wm * 64 + mt * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t n = n0 + wn * 64 + nt * 32 + mfma32_row(e, hi);
+        atomicAdd(dW + n * p.lddw + k, acc[nt][mt][e]);
+      }
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = colsum[j];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      if ((lane & 15) == 0) atomicAdd(p.dBias + bz * p.sdBias + n0 + wave * 32 + ci * 8 + j, s);
+    }
+  }
+}
+
+template <auto Kern>
+int set_smem() {
+  static bool done = false;  // one flag per kernel instantiation
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return -(int)e;
+    done = true;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
+  if (!p || !p->A || !p->W || !p->C) return HMA_EINVAL;
+  if (p->M <= 0) return 0;
+  if (p->N % BN != 0 || p->K % BK != 0) return HMA_EINVAL;
+  if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
+  if ((p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2) && !p->C2) return HMA_EINVAL;
+  if ((p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU) && !p->U) return HMA_EINVAL;
+  const dim3 grid((unsigned)((p->M + BM - 1) / BM), (unsigned)(p->N / BN), (unsigned)(p->batch > 0 ? p->batch : 1));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  switch (p->a_kind) {
+    case HMA_A_BF16:
+      if ((rc = set_smem<gemm_nt_kernel<HMA_A_BF16>>())) return rc;
+      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_BF16>, grid, dim3(256), SMEM_BYTES, s, *p);
+      break;
+    case HMA_A_F32:
+      if ((rc = set_smem<gemm_nt_kernel<HMA_A_F32>>())) return rc;
+      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_F32>, grid, dim3(256), SMEM_BYTES, s, *p);
+      break;
+    case HMA_A_BF16_AFFINE:
+      if ((rc = set_smem<gemm_nt_kernel<HMA_A_BF16_AFFINE>>())) return rc;
+      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_BF16_AFFINE>, grid, dim3(256), SMEM_BYTES, s, *p);
+      break;
+    default:
+      return HMA_EINVAL;
+  }
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+#define HMA_TN_CASE(YK, AK)                                                               \
+  if (p->y_kind == YK && p->a_kind == AK) {                                               \
+    if ((rc = set_smem<gemm_tn_kernel<YK, AK>>())) return rc;                               \
+    hipLaunchKernelGGL((gemm_tn_kernel<YK, AK>), grid, dim3(256), SMEM_BYTES, s, q);      \
+    HMA_CHECK_LAUNCH();                                                                   \
+    return 0;                                                                             \
+  }
+
+extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
+  if (!p || !p->dY || !p->A || !p->dW) return HMA_EINVAL;
+  if (p->M <= 0) return 0;
+  if (p->N % 128 != 0 || p->K % 128 != 0) return HMA_EINVAL;
+  if (p->y_kind == HMA_A_BF16_AFFINE) return HMA_EINVAL;
+  if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
+  hma_gemm_tn_t q = *p;
+  const int64_t slabs = (q.M + 63) / 64;
+  if (q.splits <= 0) q.splits = 1;
+  if (q.splits > slabs) q.splits = (int32_t)slabs;
+  const dim3 grid((unsigned)q.splits, (unsigned)((q.N / 128) * (q.K / 128)), (unsigned)(q.batch > 0 ? q.batch : 1));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  HMA_TN_CASE(HMA_A_BF16, HMA_A_BF16)
+  HMA_TN_CASE(HMA_A_BF16, HMA_A_F32)
+  HMA_TN_CASE(HMA_A_BF16, HMA_A_BF16_AFFINE)
+  HMA_TN_CASE(HMA_A_F32, HMA_A_BF16)
+  HMA_TN_CASE(HMA_A_F32, HMA_A_F32)
+  HMA_TN_CASE(HMA_A_F32, HMA_A_BF16_AFFINE)
+  return HMA_EINVAL;
+}

@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the HMA hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define HMA_WAVE 64
+
+#define HMA_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return -(int)e__;                 \
+  } while (0)
+
+namespace hma {
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even pack of two floats into one dword of bf16 (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  bf16x2_t r;
+  r[0] = (__bf16)a;
+  r[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint16_t to_bf16(float a) {
+  __bf16 r = (__bf16)a;
+  return __builtin_bit_cast(uint16_t, r);
+}
+__device__ __forceinline__ float from_bf16(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x);
+  f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+  f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z);
+  f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack_bf16(f[0], f[1]);
+  v.y = pack_bf16(f[2], f[3]);
+  v.z = pack_bf16(f[4], f[5]);
+  v.w = pack_bf16(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU (nn.GELU() default, hma/model/st_transformer.py:20) and its derivative
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float u) {
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+__device__ __forceinline__ float dsilu_f(float u) {
+  const float s = 1.0f / (1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+__device__ __forceinline__ f32x16_t mfma32(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// row of element r (0..15) of a 32x32 MFMA accumulator held by a lane with hi = lane >> 5
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+}  // namespace hma

@@ -1,0 +1,229 @@
+// Factorised-vocabulary cross-entropy (2 x 512-way), accuracy and logits gradient; MaskGIT step.
+//
+// Reference: STMaskGIT.compute_video_loss_and_acc hma/model/st_mask_git.py:603-630 with the mask
+// rule of forward (:714-716), F.cross_entropy(label_smoothing=0.01, reduction="none").sum(factors),
+// factorize_labels defaults (2, 512) (:617, factorization_utils.py:85-96); readout channel
+// c = v * 512 + k (v = factor, :397-402, 610-615).  MaskGIT step: :397-453.
+// One wave64 per token row: 1024 fp32 logits = 16 per lane (8 per factor), wave reductions only.
+#include "hma_common.h"
+#include "../../include/hma_hip.h"
+
+using namespace hma;
+
+namespace {
+
+constexpr int V = 512;
+constexpr int C = 1024;
+
+__global__ __launch_bounds__(256) void count_masked_kernel(const int64_t* __restrict__ ids, float* __restrict__ stats,
+                                                           int64_t B, int T, int S, int64_t mask_id) {
+  const int64_t total = B * T * S;
+  float c = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)((i / S) % T);
+    if (t >= 1 && ids[i] == mask_id) c += 1.f;
+  }
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c != 0.f) atomicAdd(stats + 2, c);
+}
+
+struct FactorStats {
+  float m, sumexp, sumx, xt;
+  int arg;
+};
+
+// lane holds x[0..8) = logits[f*512 + lane*8 .. +8]
+__device__ __forceinline__ FactorStats factor_stats(const float (&x)[8], int lane, int target) {
+  FactorStats r;
+  float m = x[0];
+  int a = 0;
+#pragma unroll
+  for (int j = 1; j < 8; ++j)
+    if (x[j] > m) { m = x[j]; a = j; }
+  a += lane * 8;
+  float sx = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sx += x[j];
+  float xt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (lane * 8 + j == target) xt = x[j];
+  // wave arg-max, lowest index wins ties (torch.argmax on the reference path)
+  float bm = m;
+  int ba = a;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(bm, o, 64);
+    const int oa = __shfl_xor(ba, o, 64);
+    if (om > bm || (om == bm && oa < ba)) { bm = om; ba = oa; }
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) se += __expf(x[j] - bm);
+  r.m = bm;
+  r.arg = ba;
+  r.sumexp = wave_sum(se);
+  r.sumx = wave_sum(sx);
+  r.xt = wave_sum(xt);
+  return r;
+}
+
+__device__ __forceinline__ void load8(const float* p, float (&x)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+  x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ input_ids,
+                                                 const int64_t* __restrict__ labels, float* __restrict__ stats,
+                                                 uint16_t* __restrict__ dlogits, float grad_scale, int64_t rows, int T, int S,
+                                                 int64_t mask_id, float eps_ls) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const float nmask = stats[2];
+  const float wgt = grad_scale / nmask;
+  float loss_acc = 0.f, acc_acc = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+    const int t = (int)((row / S) % T);
+    const bool live = t >= 1 && input_ids[row] == mask_id;
+    if (!live) {
+      if (dlogits) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(dlogits + row * C + lane * 8) = z;
+        *reinterpret_cast<uint4*>(dlogits + row * C + V + lane * 8) = z;
+      }
+      continue;
+    }
+    const int64_t lab = labels[row];
+    float row_loss = 0.f;
+    bool ok = true;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int target = (int)(f == 0 ? lab % V : (lab / V) % V);
+      float x[8];
+      load8(logits + row * C + f * V + lane * 8, x);
+      const FactorStats st = factor_stats(x, lane, target);
+      const float lse = st.m + __logf(st.sumexp);
+      row_loss += (1.f - eps_ls) * (lse - st.xt) + eps_ls * (lse - st.sumx * (1.0f / V));
+      ok = ok && (st.arg == target);
+      if (dlogits) {
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __expf(x[j] - lse);
+          const float tgt = (lane * 8 + j == target ? (1.f - eps_ls) : 0.f) + eps_ls * (1.0f / V);
+          g[j] = wgt * (p - tgt);
+        }
+        *reinterpret_cast<uint4*>(dlogits + row * C + f * V + lane * 8) = pack8(g);
+      }
+    }
+    loss_acc += row_loss;
+    acc_acc += ok ? 1.f : 0.f;
+  }
+  if (lane == 0 && (loss_acc != 0.f || acc_acc != 0.f)) {
+    atomicAdd(stats + 0, loss_acc);
+    atomicAdd(stats + 1, acc_acc);
+  }
+}
+
+// --------------------------------------------------------------------------------- MaskGIT step
+__global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ logits, int64_t* __restrict__ prompt,
+                                                      uint8_t* __restrict__ unmasked, const float* __restrict__ conf_override,
+                                                      float* __restrict__ conf_out, int T, int S, int out_t, int n_mask, int last,
+                                                      int64_t mask_id) {
+  extern __shared__ float sm[];              // conf[S] | sample[S] (as int)
+  float* conf = sm;
+  int* samp = reinterpret_cast<int*>(sm + S);
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* lg = logits + ((b * T + out_t) * (int64_t)S) * C;
+  for (int s = w; s < S; s += 4) {
+    int sample = 0;
+    float c = 1.f;
+#pragma unroll
+    for (int f = 1; f >= 0; --f) {  // flip(2): highest factor first (:408)
+      float x[8];
+      load8(lg + (int64_t)s * C + f * V + lane * 8, x);
+      const FactorStats st = factor_stats(x, lane, -1);
+      sample = sample * V + st.arg;
+      c *= 1.0f / st.sumexp;  // softmax prob of the arg-max = exp(0) / sum exp(x - max)
+    }
+    if (lane == 0) {
+      conf[s] = c;
+      samp[s] = sample;
+    }
+  }
+  __syncthreads();
+  // S <= 256: thread s owns token s.  Rank = position in a STABLE ascending sort of the confidences
+  // (previously unmasked tokens pinned to +inf, :442-443); the n_mask lowest are re-masked (:446),
+  // the rest become unmasked (:445); previously unmasked tokens keep their prompt value (:449).
+  const int s = tid;
+  const bool active = s < S;
+  bool prev_unm = false;
+  int64_t out = 0;
+  if (active) {
+    prev_unm = unmasked[b * S + s] != 0;
+    out = samp[s];
+    if (conf_out) conf_out[b * S + s] = conf[s];
+    if (!last) {
+      float c = conf_override ? conf_override[b * S + s] : conf[s];
+      if (prev_unm) c = INFINITY;
+      int rank = 0;
+      for (int j = 0; j < S; ++j) {
+        float cj = conf_override ? conf_override[b * S + j] : conf[j];
+        if (unmasked[b * S + j] != 0) cj = INFINITY;
+        rank += (cj < c || (cj == c && j < s)) ? 1 : 0;
+      }
+      if (rank < n_mask) out = mask_id;
+    }
+    if (prev_unm) out = prompt[(b * T + out_t) * (int64_t)S + s];
+  }
+  __syncthreads();  // every thread has read `unmasked` before anyone updates it
+  if (active) {
+    prompt[(b * T + out_t) * (int64_t)S + s] = out;
+    if (!last && out != mask_id) unmasked[b * S + s] = 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int hma_count_masked(void* stream, const int64_t* input_ids, float* stats, int64_t B, int32_t T, int32_t S,
+                                int64_t mask_id) {
+  if (!input_ids || !stats) return HMA_EINVAL;
+  const int64_t total = B * T * S;
+  if (total <= 0) return 0;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(count_masked_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, input_ids, stats, B, (int)T,
+                     (int)S, mask_id);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* input_ids, const int64_t* labels, float* stats,
+                              void* dlogits, float grad_scale, int64_t B, int32_t T, int32_t S, int64_t mask_id,
+                              float label_smoothing) {
+  if (!logits || !input_ids || !labels || !stats) return HMA_EINVAL;
+  const int64_t rows = B * T * S;
+  if (rows <= 0) return 0;
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, input_ids, labels, stats,
+                     (uint16_t*)dlogits, grad_scale, rows, (int)T, (int)S, mask_id, label_smoothing);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                                const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
+                                int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id) {
+  if (!logits || !prompt || !unmasked) return HMA_EINVAL;
+  if (S > 256 || out_t < 0 || out_t >= T) return HMA_EINVAL;  // one pass of 256 threads covers the frame
+  if (B <= 0) return 0;
+  const size_t smem = (size_t)S * 8;
+  hipLaunchKernelGGL(maskgit_kernel, dim3((unsigned)B), dim3(256), smem, (hipStream_t)stream, logits, prompt, unmasked,
+                     conf_override, conf_out, (int)T, (int)S, (int)out_t, (int)n_mask, (int)last, mask_id);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}

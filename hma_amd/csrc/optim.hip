@@ -1,0 +1,140 @@
+// Flat-buffer optimizer kernels: gradient square-norm, clip + AdamW (+ bf16 weight copy), casts.
+//
+// Reference: accelerator.clip_grad_norm_(model.parameters(), 1.0) + MuAdamW.step() at
+// hma/train_multi.py:593-598, 900-922 (mup width_mult == 1 at d_model 256 => torch.optim.AdamW).
+// All parameters live in ONE flat fp32 buffer (ranges per weight-decay group / domain), so the
+// update is a handful of HBM-streaming launches instead of one tiny kernel per tensor.
+#include "hma_common.h"
+#include "../../include/hma_hip.h"
+
+#include <cmath>
+
+using namespace hma;
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += g[i] * g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, uint16_t* __restrict__ pb, int64_t n, float lr,
+                                                    float b1, float b2, float eps, float wd, float inv_bc1,
+                                                    float inv_sqrt_bc2, const float* __restrict__ sqnorm, float max_norm,
+                                                    const uint8_t* __restrict__ flags) {
+  float coef = 1.f;
+  if (sqnorm && max_norm > 0.f) {
+    const float c = max_norm / (sqrtf(*sqnorm) + 1e-6f);
+    coef = c < 1.f ? c : 1.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float wdi = wd;
+    if (flags) {  // one flag per 64 elements: 0 = frozen, 1 = no weight decay, 2 = weight decay
+      const uint8_t f = flags[i >> 6];
+      if (f == 0) continue;
+      wdi = f == 2 ? wd : 0.f;
+    }
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wdi);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi -= (lr * inv_bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (pb) pb[i] = to_bf16(pi);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = to_bf16(src[i]);
+}
+
+// dst[b][c][r] = bf16(src[b][r][c]); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int rows,
+                                                             int cols, int64_t src_stride, int64_t dst_stride) {
+  __shared__ float tile[32][33];
+  const float* s = src + (int64_t)blockIdx.z * src_stride;
+  uint16_t* d = dst + (int64_t)blockIdx.z * dst_stride;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? s[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) d[(int64_t)c * rows + r] = to_bf16(tile[tx][i]);
+  }
+}
+
+inline unsigned flat_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int hma_sqnorm(void* stream, const float* g, int64_t n, float* out) {
+  if (!g || !out) return HMA_EINVAL;
+  if (n <= 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) != 0) return HMA_EINVAL;
+  int64_t b = (n / 4 + 255) / 256;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_adamw(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int32_t step, const float* sqnorm,
+                         float max_norm, const uint8_t* flags) {
+  if (!p || !g || !m || !v || step < 1) return HMA_EINVAL;
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (uint16_t*)p_bf16, n, lr,
+                     beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / std::sqrt(bc2)), sqnorm, max_norm, flags);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_cast_bf16(void* stream, const float* src, void* dst, int64_t n) {
+  if (!src || !dst) return HMA_EINVAL;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t rows, int32_t cols, int32_t batch,
+                                       int64_t src_stride, int64_t dst_stride) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return HMA_EINVAL;
+  if (batch <= 0) return 0;
+  const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
+  hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, (int)rows, (int)cols,
+                     src_stride, dst_stride);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_abi_version(void) { return 0x484d4101; }

@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the C ABI (include/hma_hip.h).
+
+PyTorch here is plumbing only: device memory, streams.  Every function enqueues HIP kernels on
+the current stream through libhma_hip.so and raises if the library is missing -- there is no
+eager / CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
+                   EPI_RESID, EPI_SILU2, GemmNT, GemmTN)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _kind(t: torch.Tensor, affine: bool = False) -> int:
+    if t.dtype == F32:
+        assert not affine
+        return A_F32
+    assert t.dtype == BF16, t.dtype
+    return A_BF16_AFFINE if affine else A_BF16
+
+
+def make_gemm_nt(*, A: int, lda: int, a_kind: int, W: int, ldw: int, M: int, N: int, K: int, epi: int, Cp: int, ldc: int,
+                 bias: Optional[int] = None, gamma: Optional[int] = None, beta: Optional[int] = None,
+                 a_group=(0, 0), c_group=(0, 0), C2: Optional[int] = None, ldc2: int = 0, U: Optional[int] = None,
+                 ldu: int = 0, batch: int = 1, sA: int = 0, sW: int = 0, sBias: int = 0, sC: int = 0, sC2: int = 0,
+                 sU: int = 0) -> GemmNT:
+    g = GemmNT()
+    g.A, g.lda, g.a_kind = A, lda, a_kind
+    g.a_group_rows, g.a_group_stride = a_group
+    g.gamma, g.beta = gamma, beta
+    g.W, g.ldw = W, ldw
+    g.M, g.N, g.K = M, N, K
+    g.epi, g.bias = epi, bias
+    g.C, g.ldc = Cp, ldc
+    g.c_group_rows, g.c_group_stride = c_group
+    g.C2, g.ldc2, g.U, g.ldu = C2, ldc2, U, ldu
+    g.batch, g.sA, g.sW, g.sBias, g.sC, g.sC2, g.sU = batch, sA, sW, sBias, sC, sC2, sU
+    return g
+
+
+def make_gemm_tn(*, dY: int, ldy: int, y_kind: int, A: int, lda: int, a_kind: int, M: int, N: int, K: int, dW: int,
+                 lddw: int, dBias: Optional[int] = None, gamma: Optional[int] = None, beta: Optional[int] = None,
+                 y_group=(0, 0), a_group=(0, 0), splits: int = 0, batch: int = 1, sY: int = 0, sA: int = 0, sdW: int = 0,
+                 sdBias: int = 0) -> GemmTN:
+    g = GemmTN()
+    g.dY, g.ldy, g.y_kind = dY, ldy, y_kind
+    g.y_group_rows, g.y_group_stride = y_group
+    g.A, g.lda, g.a_kind = A, lda, a_kind
+    g.a_group_rows, g.a_group_stride = a_group
+    g.gamma, g.beta = gamma, beta
+    g.M, g.N, g.K = M, N, K
+    g.dW, g.lddw, g.dBias = dW, lddw, dBias
+    if splits <= 0:
+        tiles = (N // 128) * (K // 128) * max(batch, 1)
+        splits = max(1, min((M + 63) // 64, 1024 // max(tiles, 1)))
+    g.splits, g.batch = splits, batch
+    g.sY, g.sA, g.sdW, g.sdBias = sY, sA, sdW, sdBias
+    return g
+
+
+# ----------------------------------------------------------------------------------------------
+# tensor conveniences (used by the module-level API and the parity tests)
+# ----------------------------------------------------------------------------------------------
+def linear(x: torch.Tensor, w_bf16: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epi: int = EPI_F32,
+           gamma=None, beta=None, out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+           aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x' @ w^T (+ bias) with x (M, K) bf16/f32 and w (N, K) bf16; epilogue per `epi`."""
+    assert x.dim() == 2 and w_bf16.dim() == 2 and w_bf16.dtype == BF16 and x.is_contiguous() and w_bf16.is_contiguous()
+    M, K = x.shape
+    N = w_bf16.shape[0]
+    if out is None:
+        dt = F32 if epi in (EPI_F32, EPI_RESID, EPI_ATOMIC_F32) else BF16
+        out = torch.empty(M, N, dtype=dt, device=x.device)
+    g = make_gemm_nt(A=ptr(x), lda=K, a_kind=_kind(x, gamma is not None), W=ptr(w_bf16), ldw=K, M=M, N=N, K=K, epi=epi,
+                     Cp=ptr(out), ldc=N, bias=ptr(bias), gamma=ptr(gamma), beta=ptr(beta), C2=ptr(out2), ldc2=N,
+                     U=ptr(aux), ldu=N)
+    _lib.call("hma_gemm_nt", stream_ptr(), C.byref(g))
+    return out
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None, *,
+                 gamma=None, beta=None, splits: int = 0) -> None:
+    """dW (N, K) fp32 += dy^T x' ; dbias += column sums of dy."""
+    M, N = dy.shape
+    K = x.shape[1]
+    g = make_gemm_tn(dY=ptr(dy), ldy=N, y_kind=_kind(dy), A=ptr(x), lda=K, a_kind=_kind(x, gamma is not None), M=M, N=N,
+                     K=K, dW=ptr(dW), lddw=K, dBias=ptr(dbias), gamma=ptr(gamma), beta=ptr(beta), splits=splits)
+    _lib.call("hma_gemm_tn", stream_ptr(), C.byref(g))
+
+
+def ln_fwd(x: torch.Tensor, eps: float):
+    rows = x.numel() // 256
+    xhat = torch.empty(x.shape, dtype=BF16, device=x.device)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    _lib.call("hma_ln_fwd", stream_ptr(), ptr(x), ptr(xhat), ptr(rstd), rows, eps)
+    return xhat, rstd
+
+
+def attn_spatial_fwd(qkv: torch.Tensor, frames: int, n: int, scale: float):
+    o = torch.empty(frames * n, 256, dtype=BF16, device=qkv.device)
+    lse = torch.empty(frames * n, 8, dtype=F32, device=qkv.device)
+    _lib.call("hma_attn_spatial_fwd", stream_ptr(), ptr(qkv), ptr(o), ptr(lse), frames, n, scale)
+    return o, lse
+
+
+def attn_spatial_bwd(qkv, o, d_o, lse, frames: int, n: int, scale: float):
+    delta = torch.empty_like(lse)
+    dqkv = torch.empty_like(qkv)
+    _lib.call("hma_attn_spatial_bwd", stream_ptr(), ptr(qkv), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dqkv), frames, n,
+              scale)
+    return dqkv
+
+
+def attn_temporal_fwd(qkv: torch.Tensor, batch: int, T: int, n_s: int, scale: float):
+    o = torch.empty(batch * T * n_s, 256, dtype=BF16, device=qkv.device)
+    _lib.call("hma_attn_temporal_fwd", stream_ptr(), ptr(qkv), ptr(o), batch, T, n_s, scale)
+    return o
+
+
+def attn_temporal_bwd(qkv, o, d_o, batch: int, T: int, n_s: int, scale: float):
+    dqkv = torch.empty_like(qkv)
+    _lib.call("hma_attn_temporal_bwd", stream_ptr(), ptr(qkv), ptr(o), ptr(d_o), ptr(dqkv), batch, T, n_s, scale)
+    return dqkv

@@ -1,0 +1,176 @@
+/*
+ * hma_hip.h -- C ABI of libhma_hip.so: the MI355X (gfx950) kernels of the HMA hot path.
+ *
+ * Drop-in boundary.  The reference (liruiw/HMA) is pure PyTorch: what it
+ * binds for this path are ATen / xformers operators called from the hma/model Python files.  Each entry point
+ * below names the reference call sites (file:line under /root/reference) whose arithmetic it
+ * replaces.  Conventions:
+ *   - plain pointers into device memory + sizes; no torch types; nothing is allocated or retained;
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*) and returns
+ *     0, or a negative hipError_t / HMA_E* code; it never synchronises;
+ *   - activations are row-major "token grids": rows = (b, t, s) with s fastest, d_model = 256
+ *     columns; bf16 means the 16 high bits of an IEEE float32 (round-to-nearest-even);
+ *   - re-entrant and stateless: safe from the autograd thread and from hipGraph capture.
+ */
+#ifndef HMA_HIP_H
+#define HMA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMA_EINVAL (-10001) /* unsupported shape / null pointer */
+
+/* A-operand element type / prologue and epilogue selectors of the two GEMM entry points */
+enum { HMA_A_BF16 = 0, HMA_A_F32 = 1, HMA_A_BF16_AFFINE = 2 };
+enum {
+  HMA_EPI_BF16 = 0,      /* C(bf16)  = acc (+bias)                                            */
+  HMA_EPI_F32 = 1,       /* C(f32)   = acc (+bias)                                            */
+  HMA_EPI_RESID = 2,     /* C(f32)  += acc (+bias); optional C2(bf16) = new C                 */
+  HMA_EPI_GELU2 = 3,     /* C(bf16)  = u = acc+bias ; C2(bf16) = gelu(u)                      */
+  HMA_EPI_SILU2 = 4,     /* C(bf16)  = u = acc+bias ; C2(bf16) = silu(u)                      */
+  HMA_EPI_DGELU = 5,     /* C(bf16)  = acc * gelu'(U)   (U bf16, may alias C)                 */
+  HMA_EPI_DSILU = 6,     /* C(bf16)  = acc * silu'(U)                                         */
+  HMA_EPI_ATOMIC_F32 = 7 /* atomicAdd(C(f32), acc)                                            */
+};
+
+/* C[m, n] = sum_k A'[m, k] * W[n, k]  -- nn.Linear forward / input-gradient.
+ * Replaces: nn.Linear in attention.py:28,30,39,60; st_transformer.py:19-21,25-26;
+ * st_mask_git.py:60-63,75,784-789 and their autograd mirrors.
+ * A' = A (bf16), float->bf16 of A (f32), or bf16(xhat * gamma[k] + beta[k]) (LayerNorm affine,
+ * st_transformer.py:50,75).  Row remap: logical row r reads/writes physical row
+ * (r / group_rows) * group_stride + r % group_rows when group_rows > 0 (slices the image tokens
+ * out of the (S + 64)-token frames, st_mask_git.py:681).  N % 128 == 0, K % 64 == 0. */
+typedef struct {
+  const void* A; int64_t lda; int32_t a_kind; int32_t _pad0;
+  int64_t a_group_rows, a_group_stride;
+  const float* gamma; const float* beta;
+  const void* W; int64_t ldw;
+  int64_t M, N, K;
+  int32_t epi; int32_t _pad1;
+  const float* bias;
+  void* C; int64_t ldc; int64_t c_group_rows, c_group_stride;
+  void* C2; int64_t ldc2;
+  const void* U; int64_t ldu;
+  /* batching over blockIdx.z (per-layer adaLN stacks): element strides, 0 = shared */
+  int32_t batch; int32_t _pad2;
+  int64_t sA, sW, sBias, sC, sC2, sU;
+} hma_gemm_nt_t;
+int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p);
+
+/* dW[n, k] += sum_m dY[m, n] * A'[m, k] ; dBias[n] += sum_m dY[m, n]  (fp32 atomics) -- the
+ * weight/bias gradient of nn.Linear (autograd mirror of the call sites above).
+ * N % 128 == 0, K % 128 == 0.  `splits` partitions M over blocks. */
+typedef struct {
+  const void* dY; int64_t ldy; int32_t y_kind; int32_t _pad0;   /* HMA_A_BF16 | HMA_A_F32 */
+  int64_t y_group_rows, y_group_stride;
+  const void* A; int64_t lda; int32_t a_kind; int32_t _pad1;
+  int64_t a_group_rows, a_group_stride;
+  const float* gamma; const float* beta;
+  int64_t M, N, K;
+  float* dW; int64_t lddw; float* dBias;
+  int32_t splits; int32_t batch;
+  int64_t sY, sA, sdW, sdBias;
+} hma_gemm_tn_t;
+int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p);
+
+/* LayerNorm over d_model = 256 without the affine (applied by the consumer GEMM's prologue):
+ * xhat = (x - mean) * rstd (bf16), rstd saved.  st_transformer.py:50,75,86,112 (eps 1e-5). */
+int hma_ln_fwd(void* stream, const float* x, void* xhat, float* rstd, int64_t rows, float eps);
+/* dx += LN-backward(dxn * gamma); dgamma += sum dxn*xhat; dbeta += sum dxn  (gamma may be NULL:
+ * no affine, then dgamma/dbeta are untouched) */
+int hma_ln_bwd(void* stream, const void* dxn, const void* xhat, const float* rstd, const float* gamma,
+               float* dx, float* dgamma, float* dbeta, int64_t rows);
+/* ModulateLayer prologue, st_mask_git.py:71-74: xhat = LN(x, eps 1e-6, no affine);
+ * xm = xhat * (1 + scale[bt]) + shift[bt], ss = [shift | scale] (fp32, 512 per (b,t)). */
+int hma_modln_fwd(void* stream, const float* x, const float* ss, void* xhat, void* xm, float* rstd,
+                  int64_t frames, int64_t rows_per_frame, float eps);
+/* backward of the above: dss[bt] = [sum_s dxm | sum_s dxm*xhat]; dx += LN-backward(dxm*(1+scale)) */
+int hma_modln_bwd(void* stream, const void* dxm, const void* xhat, const float* rstd, const float* ss,
+                  float* dx, float* dss, int64_t frames, int64_t rows_per_frame);
+
+/* Bidirectional spatial self-attention on packed qkv rows, attention.py:37-61 with causal=False:
+ * qkv (bf16) [frames * n, 3 * 256] = [q | k | v], heads of 32; o (bf16) [frames * n, 256];
+ * lse (fp32) [frames * n, 8] = log-sum-exp of the scaled scores (saved for backward). n % 32 == 0,
+ * n <= 320. */
+int hma_attn_spatial_fwd(void* stream, const void* qkv, void* o, float* lse, int64_t frames, int32_t n,
+                         float scale);
+/* dqkv (bf16, same layout as qkv) from do (bf16); delta is [frames*n, 8] fp32 scratch */
+int hma_attn_spatial_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                         float* delta, void* dqkv, int64_t frames, int32_t n, float scale);
+/* Causal temporal self-attention over the T frames of each (b, s) column, attention.py:37-61 with
+ * causal=True as called from st_transformer.py:111; rows are (b, t, s): stride between frames is
+ * n_s rows.  T <= 16. */
+int hma_attn_temporal_fwd(void* stream, const void* qkv, void* o, int64_t batch, int32_t T, int32_t n_s,
+                          float scale);
+int hma_attn_temporal_bwd(void* stream, const void* qkv, const void* o, const void* d_o, void* dqkv,
+                          int64_t batch, int32_t T, int32_t n_s, float scale);
+
+/* Fused token + action + positional embedding, factorization_utils.py:31-54 +
+ * st_mask_git.py:640-672: x[b,t,s,:] = (id == mask_id ? mask_embed : E0[id % V] + E1[id / V]) +
+ * pos[t,s,:] for s < S; = a_emb[b,t,:] + pos[t,s,:] for S <= s < S + A (A = 0 when a_emb is NULL).
+ * ids int64 [B,T,S]; pos has row stride pos_frame_rows per frame. */
+int hma_embed_fwd(void* stream, const int64_t* ids, const float* E0, const float* E1, const float* mask_embed,
+                  const float* pos, const float* a_emb, float* x, int64_t B, int32_t T, int32_t S, int32_t A,
+                  int32_t pos_frame_rows, int32_t V, int64_t mask_id);
+int hma_embed_bwd(void* stream, const int64_t* ids, const float* dx, float* dE0, float* dE1, float* dmask_embed,
+                  float* dpos, float* da_emb, int64_t B, int32_t T, int32_t S, int32_t A,
+                  int32_t pos_frame_rows, int32_t V, int64_t mask_id);
+
+/* ActionStat + BasicMLP, st_mask_git.py:134-138, 90-102 (fp32): rows = B*T.
+ * Saves an (normalised input), xhat, rstd, h for backward. */
+int hma_action_stem_fwd(void* stream, const float* a, const float* mean, const float* std, int32_t action_dim,
+                        const float* W1, const float* b1, const float* ln_w, const float* ln_b,
+                        const float* W2, const float* b2, float* an, float* xhat, float* rstd, float* h,
+                        float* out, int64_t rows, int32_t d_a, int32_t skip_norm);
+int hma_action_stem_bwd(void* stream, const float* dout, const float* an, const float* xhat, const float* rstd,
+                        const float* h, const float* ln_w, const float* W2, float* dW1, float* db1,
+                        float* dln_w, float* dln_b, float* dW2, float* db2, float* scratch,
+                        int64_t rows, int32_t d_a);
+
+/* Factorised-vocabulary cross-entropy + accuracy + logits gradient, st_mask_git.py:603-630, 714-716.
+ * logits f32 [B*T*S, 2*512] (row = (b,t,s)); frames t >= 1 only; label smoothing 0.01; masked mean.
+ * stats[0] = sum loss*mask, stats[1] = sum acc*mask, stats[2] = num masked (fp32; zero them first).
+ * dlogits (bf16, may be NULL) = mask / num_masked * (softmax - smoothed one-hot): needs the count
+ * first, so call hma_count_masked before it. */
+int hma_count_masked(void* stream, const int64_t* input_ids, float* stats, int64_t B, int32_t T, int32_t S,
+                     int64_t mask_id);
+int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* input_ids, const int64_t* labels,
+                   float* stats, void* dlogits, float grad_scale, int64_t B, int32_t T, int32_t S,
+                   int64_t mask_id, float label_smoothing);
+
+/* One MaskGIT sampling step on frame logits, st_mask_git.py:397-453 (temperature <= 1e-8):
+ * logits f32 [B, T, S, 1024] frame out_t; writes samples into prompt[b, out_t, :] (int64 [B,T,S]),
+ * updates unmasked (uint8 [B,S]).  conf_override (f32 [B,S]) replaces the confidences when not
+ * NULL ("random" unmask mode, the torch.rand_like draw of :435); conf_out (f32 [B,S], may be NULL)
+ * receives the model confidences.  n_mask = tokens to re-mask (ignored when last != 0). S <= 256. */
+int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                     const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
+                     int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id);
+
+/* sum of squares of g[0:n) accumulated into *out (fp32 atomic; zero it first) -- clip_grad_norm_,
+ * train_multi.py:594 */
+int hma_sqnorm(void* stream, const float* g, int64_t n, float* out);
+/* AdamW on a flat range with the clip coefficient min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) read
+ * on device (sqnorm NULL or max_norm <= 0: no clip); also emits the bf16 copy of the new weights.
+ * torch.optim.AdamW semantics (decoupled decay, bias correction), train_multi.py:900-922.
+ * flags (may be NULL) holds one byte per 64 elements of the range (which must start on a multiple
+ * of 64): 0 = frozen, 1 = update without weight decay ("bias" parameters, :907-918), 2 = decay. */
+int hma_adamw(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+              float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+              const float* sqnorm, float max_norm, const uint8_t* flags);
+/* dst(bf16) = src(f32) for n elements */
+int hma_cast_bf16(void* stream, const float* src, void* dst, int64_t n);
+/* dst[b][c][r] (bf16) = src[b][r][c] (f32): transposed bf16 copies of weights for the dgrad GEMMs */
+int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t rows, int32_t cols,
+                            int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* out[r] = sum_{j<reps} in[(r / inner) * reps * inner + j * inner + r % inner] helper is not exported */
+
+/* library identity, for the loader: returns 0x484d4101 */
+int hma_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMA_HIP_H */

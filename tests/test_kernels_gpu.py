@@ -1,0 +1,434 @@
+"""Op-level parity of every C-ABI entry point against plain fp32 math on the CPU (GPU box only).
+
+Inputs are rounded to bf16 first wherever the kernel consumes bf16, so the tolerances below only
+cover accumulation order and the bf16 rounding of OUTPUTS (2^-9 relative)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hma_amd import _lib, ops  # noqa: E402
+from hma_amd._lib import (A_BF16, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID,
+                          EPI_SILU2)  # noqa: E402
+from oracle import st_maskgit_ref as R  # noqa: E402
+
+DEV = "cuda"
+
+
+def rb(t):  # round to bf16 and back (fp32 values exactly representable in bf16)
+    return t.to(torch.bfloat16).float()
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(a, b, rtol, what=""):
+    a = a.float().cpu().double()
+    b = b.float().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= rtol * ref, f"{what}: max err {err:.3e} vs ref scale {ref:.3e} (rtol {rtol})"
+
+
+BF = 2.0 ** -8  # one bf16 ulp of the output scale, with margin
+
+
+# ------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 256), (1000, 768, 256), (384, 256, 1024)])
+def test_gemm_nt_plain_and_bias(M, N, K):
+    x = rb(torch.randn(M, K, generator=g(1)))
+    w = rb(torch.randn(N, K, generator=g(2)) * 0.1)
+    b = torch.randn(N, generator=g(3))
+    ref = x @ w.t() + b
+    y = ops.linear(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV), epi=EPI_F32)
+    close(y, ref, 1e-5, "f32 out")
+    y = ops.linear(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), None, epi=EPI_BF16)
+    close(y, x @ w.t(), BF, "bf16 out")
+    # asymmetric check: catches a transposed tile
+    assert (y.float().cpu() - (x @ w.t())).abs().max() < (y.float().cpu() - (x @ w.t()).flip(0)).abs().max()
+
+
+def test_gemm_nt_f32_and_affine_inputs():
+    M, N, K = 300, 256, 256
+    x = torch.randn(M, K, generator=g(4))
+    w = rb(torch.randn(N, K, generator=g(5)) * 0.1)
+    y = ops.linear(x.to(DEV), w.to(DEV).bfloat16(), None, epi=EPI_F32)
+    close(y, rb(x) @ w.t(), 1e-5, "f32 A")
+    gam = torch.randn(K, generator=g(6)) * 0.2 + 1.0
+    bet = torch.randn(K, generator=g(7)) * 0.2
+    xh = rb(torch.randn(M, K, generator=g(8)))
+    y = ops.linear(xh.to(DEV).bfloat16(), w.to(DEV).bfloat16(), None, epi=EPI_F32, gamma=gam.to(DEV), beta=bet.to(DEV))
+    close(y, rb(xh * gam + bet) @ w.t(), 2e-4, "affine A")  # fma vs mul+add can flip one bf16 rounding of an input
+
+
+def test_gemm_nt_epilogues():
+    M, N, K = 260, 256, 128
+    x = rb(torch.randn(M, K, generator=g(9)))
+    w = rb(torch.randn(N, K, generator=g(10)) * 0.2)
+    b = torch.randn(N, generator=g(11)) * 0.5
+    xd, wd, bd = x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV)
+    lin = x @ w.t() + b
+    # residual (+ bf16 copy)
+    res = torch.randn(M, N, generator=g(12))
+    out = res.to(DEV).clone()
+    out2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.linear(xd, wd, bd, epi=EPI_RESID, out=out, out2=out2)
+    close(out, res + lin, 1e-5, "resid")
+    close(out2, res + lin, BF, "resid bf16 copy")
+    # GELU2 / SILU2: u (rounded) and act(u)
+    for epi, act in ((EPI_GELU2, F.gelu), (EPI_SILU2, F.silu)):
+        u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.linear(xd, wd, bd, epi=epi, out=u, out2=h)
+        close(u, lin, BF, "pre-activation")
+        close(h, act(u.float().cpu()), BF, "activation of the rounded u")
+    # DGELU / DSILU
+    uu = rb(torch.randn(M, N, generator=g(13)))
+    for epi, act in ((EPI_DGELU, F.gelu), (EPI_DSILU, F.silu)):
+        ur = uu.clone().requires_grad_(True)
+        act(ur).backward(lin - b)
+        y = ops.linear(xd, wd, None, epi=epi, aux=uu.to(DEV).bfloat16())
+        close(y, ur.grad, 2 * BF, "d-activation")
+    # atomic accumulate
+    acc = torch.ones(M, N, device=DEV)
+    ops.linear(xd, wd, None, epi=EPI_ATOMIC_F32, out=acc)
+    close(acc, 1 + (lin - b), 1e-5, "atomic")
+
+
+def test_gemm_nt_row_remap_and_batch():
+    # A rows sliced out of (S + A)-row frames, C written back remapped
+    frames, S, SA, K, N = 3, 64, 80, 256, 128
+    xa = torch.randn(frames * SA, K, generator=g(14))
+    w = rb(torch.randn(N, K, generator=g(15)) * 0.1)
+    ref = rb(xa).reshape(frames, SA, K)[:, :S].reshape(-1, K) @ w.t()
+    out = torch.empty(frames * S, N, device=DEV)
+    xa_d, w_d = xa.to(DEV), w.to(DEV).bfloat16()
+    gm = ops.make_gemm_nt(A=xa_d.data_ptr(), lda=K, a_kind=A_F32, W=w_d.data_ptr(), ldw=K, M=frames * S, N=N, K=K,
+                          epi=EPI_F32, Cp=out.data_ptr(), ldc=N, a_group=(S, SA))
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gm))
+    close(out, ref, 1e-5, "a remap")
+    out2 = torch.zeros(frames * SA, N, device=DEV)
+    gm.C, gm.c_group_rows, gm.c_group_stride = out2.data_ptr(), S, SA
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gm))
+    full = torch.zeros(frames, SA, N)
+    full[:, :S] = ref.reshape(frames, S, N)
+    close(out2, full.reshape(-1, N), 1e-5, "c remap")
+    # batched: shared A, per-batch W / bias / C
+    Bz, M = 3, 70
+    x = rb(torch.randn(M, K, generator=g(16)))
+    ws = rb(torch.randn(Bz, N, K, generator=g(17)) * 0.1)
+    bs = torch.randn(Bz, N, generator=g(18))
+    x_d, ws_d, bs_d = x.to(DEV).bfloat16(), ws.to(DEV).bfloat16(), bs.to(DEV)
+    outb = torch.empty(Bz, M, N, device=DEV)
+    gb = ops.make_gemm_nt(A=x_d.data_ptr(), lda=K, a_kind=A_BF16, W=ws_d.data_ptr(), ldw=K, M=M, N=N, K=K, epi=EPI_F32,
+                          Cp=outb.data_ptr(), ldc=N, bias=bs_d.data_ptr(), batch=Bz, sA=0, sW=N * K, sBias=N, sC=M * N)
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gb))
+    close(outb, torch.einsum("mk,bnk->bmn", x, ws) + bs[:, None], 1e-5, "batched")
+
+
+# ------------------------------------------------------------------------------------------ GEMM TN
+@pytest.mark.parametrize("M,N,K,splits", [(64, 128, 128, 1), (1000, 256, 256, 0), (1920, 768, 256, 7), (333, 256, 1024, 3)])
+def test_gemm_tn(M, N, K, splits):
+    dy = rb(torch.randn(M, N, generator=g(20)))
+    x = rb(torch.randn(M, K, generator=g(21)))
+    dW = torch.ones(N, K, device=DEV)
+    db = torch.ones(N, device=DEV)
+    ops.linear_wgrad(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), dW, db, splits=splits)
+    close(dW, 1 + dy.t() @ x, 2e-5, "dW")
+    close(db, 1 + dy.sum(0), 2e-5, "dbias")
+    # fp32 sources are rounded to bf16 on the way in; bias grad uses the fp32 values
+    dyf = torch.randn(M, N, generator=g(22))
+    xf = torch.randn(M, K, generator=g(23))
+    dW.zero_(); db.zero_()
+    ops.linear_wgrad(dyf.to(DEV), xf.to(DEV), dW, db, splits=splits)
+    close(dW, rb(dyf).t() @ rb(xf), 2e-5, "dW f32 sources")
+    close(db, dyf.sum(0), 2e-5, "dbias f32")
+    # LN affine on the activation operand
+    gam = torch.randn(K, generator=g(24)) * 0.2 + 1
+    bet = torch.randn(K, generator=g(25)) * 0.2
+    dW.zero_()
+    ops.linear_wgrad(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), dW, None, gamma=gam.to(DEV), beta=bet.to(DEV), splits=splits)
+    close(dW, dy.t() @ rb(x * gam + bet), 2e-5, "dW affine")
+
+
+def test_gemm_tn_remap_and_batch():
+    frames, S, SA, N, K = 3, 64, 80, 128, 256
+    dy = rb(torch.randn(frames * S, N, generator=g(26)))
+    xa = torch.randn(frames * SA, K, generator=g(27))
+    dW = torch.zeros(N, K, device=DEV)
+    dy_d, xa_d = dy.to(DEV).bfloat16(), xa.to(DEV)
+    gt = ops.make_gemm_tn(dY=dy_d.data_ptr(), ldy=N, y_kind=A_BF16, A=xa_d.data_ptr(), lda=K, a_kind=A_F32, M=frames * S,
+                          N=N, K=K, dW=dW.data_ptr(), lddw=K, a_group=(S, SA), splits=2)
+    _lib.call("hma_gemm_tn", ops.stream_ptr(), C.byref(gt))
+    close(dW, dy.t() @ rb(xa).reshape(frames, SA, K)[:, :S].reshape(-1, K), 2e-5, "tn remap")
+    Bz, M = 3, 70
+    dys = torch.randn(Bz, M, N, generator=g(28))
+    x = torch.randn(M, K, generator=g(29))
+    dWs = torch.zeros(Bz, N, K, device=DEV)
+    dbs = torch.zeros(Bz, N, device=DEV)
+    dys_d, x_d = dys.to(DEV), x.to(DEV)
+    gt = ops.make_gemm_tn(dY=dys_d.data_ptr(), ldy=N, y_kind=A_F32, A=x_d.data_ptr(), lda=K, a_kind=A_F32, M=M, N=N, K=K,
+                          dW=dWs.data_ptr(), lddw=K, dBias=dbs.data_ptr(), batch=Bz, sY=M * N, sA=0, sdW=N * K, sdBias=N)
+    _lib.call("hma_gemm_tn", ops.stream_ptr(), C.byref(gt))
+    close(dWs, torch.einsum("bmn,mk->bnk", rb(dys), rb(x)), 2e-5, "tn batched")
+    close(dbs, dys.sum(1), 2e-5, "tn batched bias")
+
+
+# ------------------------------------------------------------------------------------------ norms
+def test_layernorm_fwd_bwd():
+    rows = 777
+    x = torch.randn(rows, 256, generator=g(30)) * 2 + 0.5
+    xhat, rstd = ops.ln_fwd(x.to(DEV), 1e-5)
+    ref = F.layer_norm(x, (256,), None, None, 1e-5)
+    close(xhat, ref, BF, "xhat")
+    close(rstd, 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5), 1e-5, "rstd")
+    gam = torch.randn(256, generator=g(31)) * 0.3 + 1
+    dxn = rb(torch.randn(rows, 256, generator=g(32)))
+    xr = x.clone().requires_grad_(True)
+    gr = gam.clone().requires_grad_(True)
+    br = torch.zeros(256, requires_grad=True)
+    F.layer_norm(xr, (256,), gr, br, 1e-5).backward(dxn)
+    dx = torch.ones(rows, 256, device=DEV)
+    dg = torch.zeros(256, device=DEV)
+    db = torch.zeros(256, device=DEV)
+    _lib.call("hma_ln_bwd", ops.stream_ptr(), dxn.to(DEV).bfloat16().data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+              gam.to(DEV).data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows)
+    close(dx, 1 + xr.grad, 2 * BF, "ln dx")
+    close(dg, gr.grad, 2 * BF, "dgamma")
+    close(db, br.grad, 1e-4, "dbeta")
+
+
+def test_modulate_ln_fwd_bwd():
+    frames, rpf = 5, 320
+    x = torch.randn(frames * rpf, 256, generator=g(33)) * 1.5
+    ss = torch.randn(frames, 512, generator=g(34)) * 0.3
+    xd, ssd = x.to(DEV), ss.to(DEV)
+    xhat = torch.empty(frames * rpf, 256, dtype=torch.bfloat16, device=DEV)
+    xm = torch.empty_like(xhat)
+    rstd = torch.empty(frames * rpf, device=DEV)
+    _lib.call("hma_modln_fwd", ops.stream_ptr(), xd.data_ptr(), ssd.data_ptr(), xhat.data_ptr(), xm.data_ptr(),
+              rstd.data_ptr(), frames, rpf, 1e-6)
+    xr = x.clone().requires_grad_(True)
+    sr = ss.clone().requires_grad_(True)
+    shift, scale = sr[:, None, :256], sr[:, None, 256:]
+    y = F.layer_norm(xr.reshape(frames, rpf, 256), (256,), None, None, 1e-6) * (1 + scale) + shift
+    close(xm, y.detach().reshape(-1, 256), BF, "xm")
+    dxm = rb(torch.randn(frames * rpf, 256, generator=g(35)))
+    y.backward(dxm.reshape(frames, rpf, 256))
+    dx = torch.zeros(frames * rpf, 256, device=DEV)
+    dss = torch.empty(frames, 512, device=DEV)
+    _lib.call("hma_modln_bwd", ops.stream_ptr(), dxm.to(DEV).bfloat16().data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+              ssd.data_ptr(), dx.data_ptr(), dss.data_ptr(), frames, rpf)
+    close(dx, xr.grad, 2 * BF, "modln dx")
+    close(dss, sr.grad, 2 * BF, "dss")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _ref_attn(qkv, n_seq, n, scale, causal):
+    """fp32 attention on packed (rows, 768) qkv, sequences of n rows."""
+    q, k, v = qkv.reshape(n_seq, n, 3, 8, 32).permute(2, 0, 3, 1, 4)
+    att = (q * scale) @ k.transpose(-1, -2)
+    if causal:
+        att = att.masked_fill(~torch.ones(n, n, dtype=torch.bool).tril(), -torch.finfo(att.dtype).max)
+    return (att.softmax(-1) @ v).transpose(1, 2).reshape(n_seq * n, 256)
+
+
+@pytest.mark.parametrize("frames,n", [(3, 320), (9, 256), (2, 64)])
+def test_attn_spatial(frames, n):
+    scale = 0.25
+    qkv = rb(torch.randn(frames * n, 768, generator=g(40)))
+    qr = qkv.clone().requires_grad_(True)
+    ref = _ref_attn(qr, frames, n, scale, False)
+    o, lse = ops.attn_spatial_fwd(qkv.to(DEV).bfloat16(), frames, n, scale)
+    close(o, ref.detach(), 2 * BF, "spatial fwd")
+    d_o = rb(torch.randn(frames * n, 256, generator=g(41)))
+    ref.backward(d_o)
+    dqkv = ops.attn_spatial_bwd(qkv.to(DEV).bfloat16(), o, d_o.to(DEV).bfloat16(), lse, frames, n, scale)
+    for name, sl in (("dq", slice(0, 256)), ("dk", slice(256, 512)), ("dv", slice(512, 768))):
+        close(dqkv[:, sl], qr.grad[:, sl], 4 * BF, f"spatial {name}")
+
+
+@pytest.mark.parametrize("B,T,n_s", [(2, 16, 5), (3, 3, 7), (1, 1, 4)])
+def test_attn_temporal(B, T, n_s):
+    scale = 0.25
+    rows = B * T * n_s
+    qkv = rb(torch.randn(rows, 768, generator=g(42)))
+    # rows are (b, t, s): gather each column's T rows for the reference
+    idx = torch.arange(rows).reshape(B, T, n_s).permute(0, 2, 1).reshape(-1)
+    qr = qkv.clone().requires_grad_(True)
+    ref_cols = _ref_attn(qr[idx], B * n_s, T, scale, True)
+    ref = torch.empty(rows, 256)
+    ref[idx] = ref_cols.detach()
+    o = ops.attn_temporal_fwd(qkv.to(DEV).bfloat16(), B, T, n_s, scale)
+    close(o, ref, 2 * BF, "temporal fwd")
+    d_o = rb(torch.randn(rows, 256, generator=g(43)))
+    ref_cols.backward(d_o[idx])
+    dqkv = ops.attn_temporal_bwd(qkv.to(DEV).bfloat16(), o, d_o.to(DEV).bfloat16(), B, T, n_s, scale)
+    close(dqkv, qr.grad, 4 * BF, "temporal dqkv")
+
+
+# ------------------------------------------------------------------------------------------ embedding / stem
+def test_embed_fwd_bwd():
+    B, T, S, A, V = 2, 3, 256, 64, 512
+    mask_id = V * V
+    ids = torch.randint(0, V * V, (B, T, S), generator=g(50))
+    ids[torch.rand(B, T, S, generator=g(51)) < 0.4] = mask_id
+    E0 = torch.randn(V, 256, generator=g(52)); E1 = torch.randn(V, 256, generator=g(53))
+    me = torch.randn(1, 256, generator=g(54)); pos = torch.randn(T + 1, S + A, 256, generator=g(55))
+    a_emb = torch.randn(B, T, 256, generator=g(56))
+    P = {k: v.clone().requires_grad_(True) for k, v in dict(E0=E0, E1=E1, me=me, pos=pos, a=a_emb).items()}
+    sd = {"token_embed.factored_embeds.0.weight": P["E0"], "token_embed.factored_embeds.1.weight": P["E1"],
+          "token_embed.mask_token_embed": P["me"]}
+    cfg = R.RefConfig(num_layers=1, num_heads=8, d_model=256, T=T)
+    ref = torch.cat([R.token_embed(sd, cfg, ids), P["a"][:, :, None].expand(B, T, A, 256)], 2) + P["pos"][None, :T]
+    x = torch.empty(B, T, S + A, 256, device=DEV)
+    d = lambda t: t.to(DEV).contiguous()
+    ids_d, E0d, E1d, med, posd, ad = d(ids), d(E0), d(E1), d(me), d(pos), d(a_emb)
+    _lib.call("hma_embed_fwd", ops.stream_ptr(), ids_d.data_ptr(), E0d.data_ptr(), E1d.data_ptr(), med.data_ptr(),
+              posd.data_ptr(), ad.data_ptr(), x.data_ptr(), B, T, S, A, S + A, V, mask_id)
+    assert torch.equal(x.cpu(), ref.detach())
+    dx = torch.randn(B, T, S + A, 256, generator=g(57))
+    ref.backward(dx)
+    G = {k: torch.zeros_like(v, device=DEV) for k, v in dict(E0=E0, E1=E1, me=me, pos=pos, a=a_emb).items()}
+    dxd = d(dx)
+    _lib.call("hma_embed_bwd", ops.stream_ptr(), ids_d.data_ptr(), dxd.data_ptr(), G["E0"].data_ptr(), G["E1"].data_ptr(),
+              G["me"].data_ptr(), G["pos"].data_ptr(), G["a"].data_ptr(), B, T, S, A, S + A, V, mask_id)
+    for k in G:
+        close(G[k], P[k].grad, 1e-5, f"embed grad {k}")
+
+
+@pytest.mark.parametrize("d_a,adim", [(7, 7), (14, 7), (70, 7)])
+def test_action_stem(d_a, adim):
+    rows = 6
+    cfg = R.RefConfig(num_layers=1, num_heads=8, d_model=256, T=3)
+    gen = g(60)
+    sd = {"action_preprocessor.d.mean": torch.randn(adim, generator=gen), "action_preprocessor.d.std": torch.rand(adim, generator=gen) + 0.5,
+          "action_mlp.d.model.0.weight": torch.randn(256, d_a, generator=gen) * 0.3, "action_mlp.d.model.0.bias": torch.randn(256, generator=gen) * 0.1,
+          "action_mlp.d.model.1.weight": torch.randn(256, generator=gen) * 0.2 + 1, "action_mlp.d.model.1.bias": torch.randn(256, generator=gen) * 0.1,
+          "action_mlp.d.model.3.weight": torch.randn(256, 256, generator=gen) * 0.1, "action_mlp.d.model.3.bias": torch.randn(256, generator=gen) * 0.1}
+    a = torch.randn(2, 3, d_a, generator=gen)
+    leaf = {k: v.clone().requires_grad_(k.startswith("action_mlp")) for k, v in sd.items()}
+    ref = R.action_stem(leaf, cfg, a, "d")
+    dd = {k: v.to(DEV).contiguous() for k, v in sd.items()}
+    an = torch.empty(rows, d_a, device=DEV); xh = torch.empty(rows, 256, device=DEV); rs = torch.empty(rows, device=DEV)
+    h = torch.empty(rows, 256, device=DEV); out = torch.empty(rows, 256, device=DEV)
+    a_d = a.to(DEV).contiguous()
+    p = "action_mlp.d.model"
+    _lib.call("hma_action_stem_fwd", ops.stream_ptr(), a_d.data_ptr(), dd["action_preprocessor.d.mean"].data_ptr(),
+              dd["action_preprocessor.d.std"].data_ptr(), adim, dd[f"{p}.0.weight"].data_ptr(), dd[f"{p}.0.bias"].data_ptr(),
+              dd[f"{p}.1.weight"].data_ptr(), dd[f"{p}.1.bias"].data_ptr(), dd[f"{p}.3.weight"].data_ptr(),
+              dd[f"{p}.3.bias"].data_ptr(), an.data_ptr(), xh.data_ptr(), rs.data_ptr(), h.data_ptr(), out.data_ptr(), rows, d_a, 0)
+    close(out, ref.detach().reshape(rows, 256), 1e-5, "stem fwd")
+    dout = torch.randn(rows, 256, generator=gen)
+    ref.backward(dout.reshape(2, 3, 256))
+    Gd = {k: torch.zeros_like(v) for k, v in dd.items() if k.startswith(p)}
+    scratch = torch.empty(rows, 256, device=DEV)
+    dout_d = dout.to(DEV)
+    _lib.call("hma_action_stem_bwd", ops.stream_ptr(), dout_d.data_ptr(), an.data_ptr(), xh.data_ptr(), rs.data_ptr(),
+              h.data_ptr(), dd[f"{p}.1.weight"].data_ptr(), dd[f"{p}.3.weight"].data_ptr(), Gd[f"{p}.0.weight"].data_ptr(),
+              Gd[f"{p}.0.bias"].data_ptr(), Gd[f"{p}.1.weight"].data_ptr(), Gd[f"{p}.1.bias"].data_ptr(),
+              Gd[f"{p}.3.weight"].data_ptr(), Gd[f"{p}.3.bias"].data_ptr(), scratch.data_ptr(), rows, d_a)
+    for k in Gd:
+        close(Gd[k], leaf[k].grad, 2e-5, f"stem grad {k}")
+
+
+# ------------------------------------------------------------------------------------------ loss / sampling
+def test_ce_loss_acc_and_grad():
+    B, T, S = 2, 3, 256
+    mask_id = 262144
+    gen = g(70)
+    logits = torch.randn(B, T, S, 1024, generator=gen) * 2
+    labels = torch.randint(0, 262144, (B, T * S), generator=gen)
+    inputs = labels.clone().reshape(B, T, S)
+    inputs[:, 1:][torch.rand(B, T - 1, S, generator=gen) < 0.5] = mask_id
+    # make some rows "correct" so the accuracy is not trivially zero
+    fl = R.factorize_token_ids(labels.reshape(B, T, S), 2, 512)
+    for b, t, s in [(0, 1, 3), (1, 2, 100), (0, 2, 255)]:
+        logits[b, t, s, fl[b, t, s, 0]] = 30.0
+        logits[b, t, s, 512 + fl[b, t, s, 1]] = 30.0
+        inputs[b, t, s] = mask_id
+    cfg = R.RefConfig(num_layers=1, num_heads=8, d_model=256, T=T)
+    lr = logits.clone().requires_grad_(True)
+    loss, acc = R.video_loss_and_acc(cfg, lr.reshape(B, T, 16, 16, 1024).permute(0, 4, 1, 2, 3), labels,
+                                     inputs.reshape(B, T, 16, 16))
+    (loss * 3.0).backward()
+    stats = torch.zeros(4, device=DEV)
+    dl = torch.empty(B * T * S, 1024, dtype=torch.bfloat16, device=DEV)
+    ld, idd, lbd = logits.to(DEV), inputs.to(DEV), labels.to(DEV)
+    _lib.call("hma_count_masked", ops.stream_ptr(), idd.data_ptr(), stats.data_ptr(), B, T, S, mask_id)
+    _lib.call("hma_ce_fwd_bwd", ops.stream_ptr(), ld.data_ptr(), idd.data_ptr(), lbd.data_ptr(), stats.data_ptr(),
+              dl.data_ptr(), 3.0, B, T, S, mask_id, 0.01)
+    st = stats.cpu()
+    assert st[2].item() == float((inputs[:, 1:] == mask_id).sum())
+    assert abs(st[0].item() / st[2].item() - loss.item()) < 1e-5 * abs(loss.item())
+    assert abs(st[1].item() / st[2].item() - acc.item()) < 1e-7
+    close(dl, lr.grad.reshape(-1, 1024), 2 * BF, "dlogits")
+
+
+def test_maskgit_step_bit_exact():
+    B, T, S = 3, 4, 256
+    mask_id = 262144
+    gen = g(80)
+    logits = torch.randn(B, T, S, 1024, generator=gen) * 3
+    out_t = 2
+    prompt = torch.randint(0, 262144, (B, T, S), generator=gen)
+    prompt[:, out_t:] = mask_id
+    unmasked = torch.zeros(B, S, dtype=torch.uint8)
+    ld = logits.to(DEV)
+    pd, ud = prompt.to(DEV), unmasked.to(DEV)
+    conf = torch.empty(B, S, device=DEV)
+    steps = 4
+    p_ref, u_ref = prompt.clone(), unmasked.bool().clone()
+    for step in range(steps):
+        last = step == steps - 1
+        n = math.ceil(R.cosine_schedule((step + 1) / steps) * S)
+        rnd = torch.rand(B, S, generator=gen) if step % 2 else None  # alternate greedy / "random" confidences
+        rd = None if rnd is None else rnd.to(DEV)
+        _lib.call("hma_maskgit_step", ops.stream_ptr(), ld.data_ptr(), pd.data_ptr(), ud.data_ptr(),
+                  None if rd is None else rd.data_ptr(), conf.data_ptr(), B, T, S, out_t, n, int(last), mask_id)
+        # oracle: argmax ids are bit-exact; ranks use the kernel's own confidences (fp32 summation order differs from torch)
+        fl = logits[:, out_t].reshape(B, S, 2, 512)
+        a = fl.argmax(-1)
+        samples = a[..., 1] * 512 + a[..., 0]
+        pr = fl.softmax(-1).max(-1).values
+        close(conf, pr[..., 1] * pr[..., 0], 1e-5, "confidence")
+        c = conf.cpu() if rnd is None else rnd
+        new, u_ref = R.maskgit_select(c, samples, u_ref, p_ref[:, out_t], n, mask_id, last)
+        p_ref[:, out_t] = new
+        assert torch.equal(pd.cpu(), p_ref), f"step {step}"
+        if not last:
+            assert torch.equal(ud.cpu().bool(), u_ref), f"step {step}"
+        # a new forward would change the logits; emulate by perturbing them
+        logits = logits + torch.randn(B, T, S, 1024, generator=gen) * 0.5
+        ld = logits.to(DEV)
+    assert (p_ref[:, out_t] != mask_id).all()
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def test_sqnorm_adamw_cast_transpose():
+    n = 100_003 + 61
+    gen = g(90)
+    p = torch.randn(n, generator=gen); gr = torch.randn(n, generator=gen) * 3
+    m = torch.randn(n, generator=gen) * 0.1; v = torch.rand(n, generator=gen) * 0.1
+    pd, gd, md, vd = p.to(DEV), gr.to(DEV), m.to(DEV), v.to(DEV)
+    sq = torch.zeros(1, device=DEV)
+    _lib.call("hma_sqnorm", ops.stream_ptr(), gd.data_ptr(), n, sq.data_ptr())
+    assert abs(sq.item() - (gr.double() ** 2).sum().item()) < 1e-4 * sq.item()
+    pb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    params, grads, ms, vs = {"w": p.clone()}, {"w": gr.clone()}, {"w": m.clone()}, {"w": v.clone()}
+    R.clip_and_adamw(params, grads, ms, vs, step=3, lr=1e-2, max_norm=1.0)
+    _lib.call("hma_adamw", ops.stream_ptr(), pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), pb.data_ptr(), n,
+              1e-2, 0.9, 0.95, 1e-8, 0.05, 3, sq.data_ptr(), 1.0, None)
+    close(pd, params["w"], 1e-6, "adamw p")
+    close(md, ms["w"], 1e-6, "adamw m")
+    close(vd, vs["w"], 1e-6, "adamw v")
+    assert torch.equal(pb.cpu(), pd.cpu().bfloat16())
+    src = torch.randn(3, 40, 70, generator=gen).to(DEV)
+    dst = torch.empty(3, 70, 40, dtype=torch.bfloat16, device=DEV)
+    _lib.call("hma_transpose_cast_bf16", ops.stream_ptr(), src.data_ptr(), dst.data_ptr(), 40, 70, 3, 40 * 70, 40 * 70)
+    assert torch.equal(dst.cpu(), src.cpu().transpose(1, 2).bfloat16())
