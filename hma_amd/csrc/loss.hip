@@ -77,12 +77,12 @@ __device__ __forceinline__ void load8(const float* p, float (&x)[8]) {
 
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ input_ids,
                                                  const int64_t* __restrict__ labels, float* __restrict__ stats,
-                                                 uint16_t* __restrict__ dlogits, float grad_scale, int64_t rows, int T, int S,
-                                                 int64_t mask_id, float eps_ls) {
+                                                 uint16_t* __restrict__ dlogits, const float* __restrict__ grad_scale_dev,
+                                                 float grad_scale, int64_t rows, int T, int S, int64_t mask_id, float eps_ls) {
   const int lane = threadIdx.x & 63;
   const int64_t nw = (int64_t)gridDim.x * 4;
   const float nmask = stats[2];
-  const float wgt = grad_scale / nmask;
+  const float wgt = grad_scale * (grad_scale_dev ? *grad_scale_dev : 1.0f) / nmask;
   float loss_acc = 0.f, acc_acc = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
     const int t = (int)((row / S) % T);
@@ -202,15 +202,15 @@ extern "C" int hma_count_masked(void* stream, const int64_t* input_ids, float* s
 }
 
 extern "C" int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* input_ids, const int64_t* labels, float* stats,
-                              void* dlogits, float grad_scale, int64_t B, int32_t T, int32_t S, int64_t mask_id,
-                              float label_smoothing) {
+                              void* dlogits, const float* grad_scale_dev, float grad_scale, int64_t B, int32_t T, int32_t S,
+                              int64_t mask_id, float label_smoothing) {
   if (!logits || !input_ids || !labels || !stats) return HMA_EINVAL;
   const int64_t rows = B * T * S;
   if (rows <= 0) return 0;
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(ce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, input_ids, labels, stats,
-                     (uint16_t*)dlogits, grad_scale, rows, (int)T, (int)S, mask_id, label_smoothing);
+                     (uint16_t*)dlogits, grad_scale_dev, grad_scale, rows, (int)T, (int)S, mask_id, label_smoothing);
   HMA_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,555 @@
+"""STEngine -- runs the STMaskGIT hot path (forward, loss, backward, clip+AdamW, MaskGIT step) as
+replayable plans of libhma_hip.so launches over static device buffers.
+
+Host side of the drop-in boundary: Python here only sequences C-ABI calls (include/hma_hip.h) on the
+current HIP stream; all arithmetic is in the HIP kernels.  Reference path being replaced:
+STMaskGIT.compute_logits / forward (hma/model/st_mask_git.py:632-735), STTransformerDecoder / STBlock
+(hma/model/st_transformer.py:79-114, 172-177) and the update at hma/train_multi.py:593-598.
+
+Data layout in HBM: the residual stream x is fp32 [B*T*(S+A), 256], rows
+(b, t, s) with s fastest -- spatial attention reads 320-row frames contiguously, temporal attention
+gathers the T rows of a column at stride (S+A) rows; every saved activation is bf16 in the same row
+order; weights live in one flat fp32 buffer (params.py) with bf16 + transposed bf16 copies.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
+                   EPI_RESID, EPI_SILU2)
+from .ops import make_gemm_nt, make_gemm_tn
+from .params import ALIGN, ParamLayout
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class Plan:
+    """A recorded sequence of C-ABI launches with fixed arguments; `run` replays it on a stream."""
+
+    def __init__(self):
+        self.calls: List[Tuple[Callable, str, tuple]] = []
+        self.marks: Dict[str, int] = {}
+        self.keep: list = []
+
+    def add(self, name: str, *args) -> None:
+        self.calls.append((getattr(_lib.load(), name), name, args))
+
+    def gemm_nt(self, **kw) -> None:
+        g = make_gemm_nt(**kw)
+        self.keep.append(g)
+        self.add("hma_gemm_nt", C.byref(g))
+
+    def gemm_tn(self, **kw) -> None:
+        g = make_gemm_tn(**kw)
+        self.keep.append(g)
+        self.add("hma_gemm_tn", C.byref(g))
+
+    def mark(self, label: str) -> None:
+        self.marks[label] = len(self.calls)
+
+    def run(self, stream: int, start: int = 0, stop: Optional[int] = None) -> None:
+        for fn, name, args in self.calls[start:stop]:
+            rc = fn(stream, *args)
+            if rc != 0:
+                raise _lib.HmaKernelError(f"{name} failed with code {rc}")
+
+
+class STEngine:
+    def __init__(self, cfg, domains: Sequence[str], d_actions: Sequence[int], action_dims: Sequence[int], device):
+        if cfg.d_model != 256 or cfg.num_heads != 8:
+            raise NotImplementedError("the gfx950 kernels are specialised for d_model=256, 8 heads of 32 (HMA-base)")
+        if cfg.qk_norm:
+            raise NotImplementedError("qk_norm=True is not used by the shipped MagVit configs and is not built")
+        if cfg.num_factored_vocabs != 2 or cfg.factored_vocab_size != 512:
+            raise NotImplementedError("readout/loss kernels are built for the 2 x 512 factorised vocabulary")
+        if cfg.jointly_predict_actions:
+            raise NotImplementedError("jointly_predict_actions is outside the accelerated path")
+        _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.domains = list(domains)
+        self.d_actions = dict(zip(domains, d_actions))
+        self.action_dims = dict(zip(domains, action_dims))
+        self.layout = ParamLayout(cfg, domains, d_actions, action_dims)
+        n = self.layout.total
+        self.P = torch.zeros(n, dtype=F32, device=self.device)
+        self.G = torch.zeros(n, dtype=F32, device=self.device)
+        self.Wb = torch.zeros(n, dtype=BF16, device=self.device)
+        self.M: Optional[torch.Tensor] = None  # Adam moments, allocated on first optimizer step
+        self.V: Optional[torch.Tensor] = None
+        self.flags = self.layout.decay_flags().to(self.device)
+        self.sqnorm = torch.zeros(1, dtype=F32, device=self.device)
+        self.opt_step = 0
+        L, d = cfg.num_layers, cfg.d_model
+        hid = int(d * cfg.mlp_ratio)
+        mk = lambda *s: torch.zeros(*s, dtype=BF16, device=self.device)
+        # transposed bf16 weight copies for the input-gradient GEMMs
+        self.WT = {"qkv_s": mk(L, d, 3 * d), "proj_s": mk(L, d, d), "qkv_t": mk(L, d, 3 * d), "proj_t": mk(L, d, d),
+                   "fc1": mk(L, d, hid), "fc2": mk(L, hid, d), "out": mk(d, 1024)}
+        self.modulate = "modulate" in cfg.action_network
+        if self.modulate:
+            for dom in self.domains:
+                self.WT[f"lin:{dom}"] = mk(L, d, d)
+                self.WT[f"ada0:{dom}"] = mk(L, d, d)
+                self.WT[f"ada2:{dom}"] = mk(L, d, 2 * d)
+        self.buffers: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}  # domain -> (mean, std) of ActionStat
+        self._seen_version = -1       # P._version at the last refresh (detects external in-place updates)
+        self._wb_ok = False           # flat bf16 copy current
+        self._wt_ok = False           # dense transposed copies current
+        self._dom_fresh: set = set()  # domains whose transposed copies are current
+        self.max_d_a = max(list(d_actions) + [1])
+        self.gscale = torch.ones(1, dtype=F32, device=self.device)  # device-side loss-gradient scale
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._ws_key = None
+        self._plans: Dict[tuple, Plan] = {}
+        self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
+        self.grad_scale = C.c_float(1.0)
+
+    # ------------------------------------------------------------------------------ pointers
+    def _p(self, name: str) -> int:
+        return self.P.data_ptr() + 4 * self.layout.off(name)
+
+    def _g(self, name: str) -> int:
+        return self.G.data_ptr() + 4 * self.layout.off(name)
+
+    def _wb(self, name: str) -> int:
+        return self.Wb.data_ptr() + 2 * self.layout.off(name)
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        e = self.layout.entries[name]
+        buf = self.P if buf is None else buf
+        return buf[e.offset:e.offset + e.numel].view(e.shape)
+
+    # ------------------------------------------------------------------------------ weights
+    def refresh_weights(self, domain: Optional[str], stream: int) -> None:
+        """(Re)build the bf16 and transposed-bf16 copies if the fp32 masters changed."""
+        lay, cfg = self.layout, self.cfg
+        L, d = cfg.num_layers, cfg.d_model
+        hid = int(d * cfg.mlp_ratio)
+        if self._seen_version != self.P._version:  # load_state_dict / an external optimizer wrote the views
+            self._seen_version = self.P._version
+            self._wb_ok = self._wt_ok = False
+            self._dom_fresh = set()
+        if not self._wb_ok:
+            _lib.call("hma_cast_bf16", stream, self.P.data_ptr(), self.Wb.data_ptr(), lay.total)
+            self._wb_ok = True
+        if not self._wt_ok:
+            # layers are stored L-1 .. 0 at a constant stride: batch index j reads layer L-1-j and writes slot L-1-j
+            ls = lay.layer_stride
+            for key, suffix, rows, cols in (("qkv_s", "spatial_attn.qkv.weight", 3 * d, d),
+                                            ("proj_s", "spatial_attn.proj.weight", d, d),
+                                            ("qkv_t", "temporal_attn.qkv.weight", 3 * d, d),
+                                            ("proj_t", "temporal_attn.proj.weight", d, d),
+                                            ("fc1", "mlp.fc1.weight", hid, d), ("fc2", "mlp.fc2.weight", d, hid)):
+                _lib.call("hma_transpose_cast_bf16", stream, self._p(f"decoder.layers.{L - 1}.{suffix}"),
+                          self.WT[key][L - 1].data_ptr(), rows, cols, L, ls, -rows * cols)
+            _lib.call("hma_transpose_cast_bf16", stream, self._p("out_x_proj.weight"), self.WT["out"].data_ptr(), 1024, d, 1, 0, 0)
+            self._wt_ok = True
+        if domain is not None and self.modulate and domain not in self._dom_fresh:
+            pre = f"decoder.layers.0.action_projectors.{domain}"
+            _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.linear_out.weight"), self.WT[f"lin:{domain}"].data_ptr(),
+                      d, d, L, d * d, d * d)
+            _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.0.weight"),
+                      self.WT[f"ada0:{domain}"].data_ptr(), d, d, L, d * d, d * d)
+            _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.2.weight"),
+                      self.WT[f"ada2:{domain}"].data_ptr(), 2 * d, d, L, 2 * d * d, 2 * d * d)
+            self._dom_fresh.add(domain)
+
+    def weights_changed(self) -> None:
+        self._wb_ok = self._wt_ok = False
+        self._dom_fresh = set()
+
+    # ------------------------------------------------------------------------------ workspace
+    def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
+        key = (B, T, S, A, train)
+        if self._ws_key == key:
+            return self._ws
+        self._ws, self._plans = {}, {}
+        torch.cuda.empty_cache()
+        L = self.cfg.num_layers
+        Ls = L if train else 1
+        SA = S + A
+        M, Mi, Fr = B * T * SA, B * T * S, B * T
+        dev = self.device
+        ws: Dict[str, torch.Tensor] = {}
+
+        def buf(name, shape, dtype):
+            ws[name] = torch.empty(shape, dtype=dtype, device=dev)
+
+        buf("ids", (B, T, S), torch.int64)
+        buf("labels", (B, T * S), torch.int64)
+        buf("x", (M, 256), F32)
+        for nm in ("xh1", "o_s", "x2b", "o_t", "xh2"):
+            buf(nm, (Ls, M, 256), BF16)
+        buf("qkv_s", (Ls, M, 768), BF16)
+        buf("qkv_t", (Ls, M, 768), BF16)
+        buf("lse_s", (Ls, M, 8), F32)
+        buf("rstd1", (Ls, M), F32)
+        buf("rstd2", (Ls, M), F32)
+        buf("u", (Ls, M, 1024), BF16)
+        buf("hg", (Ls, M, 1024), BF16)
+        if A > 0:
+            buf("xhm", (Ls, M, 256), BF16)
+            buf("xm", (Ls, M, 256), BF16)
+            buf("rstdm", (Ls, M), F32)
+            buf("ada_pre", (L, Fr, 256), BF16)
+            buf("ada_act", (L, Fr, 256), BF16)
+            buf("ss", (L, Fr, 512), F32)
+            buf("actions", (Fr * self.max_d_a,), F32)
+            buf("an", (Fr * self.max_d_a,), F32)
+            buf("sxhat", (Fr, 256), F32)
+            buf("srstd", (Fr,), F32)
+            buf("sh", (Fr, 256), F32)
+            buf("a_emb", (Fr, 256), F32)
+        buf("logits", (Mi, 1024), F32)
+        buf("stats", (4,), F32)
+        if train:
+            buf("dlogits", (Mi, 1024), BF16)
+            buf("dx", (M, 256), F32)
+            buf("t256", (M, 256), BF16)
+            buf("dqkv", (M, 768), BF16)
+            buf("delta", (M, 8), F32)
+            if A > 0:
+                buf("dss", (L, Fr, 512), F32)
+                buf("dpre", (L, Fr, 256), BF16)
+                buf("da_emb", (Fr, 256), F32)
+                buf("stem_scratch", (Fr, 256), F32)
+        self._ws, self._ws_key = ws, key
+        return ws
+
+    # ------------------------------------------------------------------------------ plans
+    def _lw(self, l: int, suffix: str, kind: str = "wb") -> int:
+        name = f"decoder.layers.{l}.{suffix}"
+        return {"wb": self._wb, "p": self._p, "g": self._g}[kind](name)
+
+    def _has(self, name: str) -> bool:
+        return name in self.layout.entries
+
+    def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True) -> Plan:
+        l1 = self.cfg.num_layers if l1 is None else l1
+        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout)
+        if key in self._plans:
+            return self._plans[key]
+        cfg, ws = self.cfg, self._ws
+        L = cfg.num_layers
+        SA, M, Mi, Fr = S + A, B * T * (S + A), B * T * S, B * T
+        pl = Plan()
+        dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
+        sl = (lambda l: l) if train else (lambda l: 0)
+        if A > 0:
+            dom = domain
+            am = f"action_mlp.{dom}.model"
+            if embed:
+              pl.add("hma_action_stem_fwd", ws["actions"].data_ptr(), self.buffers[dom][0].data_ptr(),
+                   self.buffers[dom][1].data_ptr(), self.action_dims[dom], self._p(f"{am}.0.weight"),
+                   self._p(f"{am}.0.bias"), self._p(f"{am}.1.weight"), self._p(f"{am}.1.bias"), self._p(f"{am}.3.weight"),
+                   self._p(f"{am}.3.bias"), ws["an"].data_ptr(), ws["sxhat"].data_ptr(), ws["srstd"].data_ptr(),
+                   ws["sh"].data_ptr(), ws["a_emb"].data_ptr(), Fr, self.d_actions[dom], self._skip_norm)
+            if self.modulate:
+                ap = f"decoder.layers.0.action_projectors.{dom}"
+                pl.gemm_nt(A=ws["a_emb"].data_ptr(), lda=256, a_kind=A_F32, W=self._wb(f"{ap}.adaLN_modulation.0.weight"),
+                           ldw=256, M=Fr, N=256, K=256, epi=EPI_SILU2, Cp=ws["ada_pre"].data_ptr(), ldc=256,
+                           bias=self._p(f"{ap}.adaLN_modulation.0.bias"), C2=ws["ada_act"].data_ptr(), ldc2=256, batch=L,
+                           sA=0, sW=256 * 256, sBias=256, sC=Fr * 256, sC2=Fr * 256)
+                pl.gemm_nt(A=ws["ada_act"].data_ptr(), lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.adaLN_modulation.2.weight"),
+                           ldw=256, M=Fr, N=512, K=256, epi=EPI_F32, Cp=ws["ss"].data_ptr(), ldc=512,
+                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=Fr * 256, sW=512 * 256, sBias=512,
+                           sC=Fr * 512)
+        if embed:
+            pl.add("hma_embed_fwd", ws["ids"].data_ptr(), self._p("token_embed.factored_embeds.0.weight"),
+                   self._p("token_embed.factored_embeds.1.weight"), self._p("token_embed.mask_token_embed"),
+                   self._p("pos_embed_TSC"), ws["a_emb"].data_ptr() if A > 0 else None, ws["x"].data_ptr(), B, T, S, A,
+                   cfg.S + cfg.action_token_size, cfg.factored_vocab_size, cfg.image_vocab_size)
+        x = ws["x"].data_ptr()
+        for l in range(l0, l1):
+            s = sl(l)
+            xh1, rstd1 = dp(ws["xh1"], s, M * 256), dp(ws["rstd1"], s, M)
+            qkv_s, o_s, lse_s = dp(ws["qkv_s"], s, M * 768), dp(ws["o_s"], s, M * 256), dp(ws["lse_s"], s, M * 8)
+            x2b = dp(ws["x2b"], s, M * 256)
+            qkv_t, o_t = dp(ws["qkv_t"], s, M * 768), dp(ws["o_t"], s, M * 256)
+            xh2, rstd2 = dp(ws["xh2"], s, M * 256), dp(ws["rstd2"], s, M)
+            u, hg = dp(ws["u"], s, M * 1024), dp(ws["hg"], s, M * 1024)
+            qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
+            pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
+            use_mod = A > 0 and self.modulate
+            # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
+            pl.add("hma_ln_fwd", x, xh1, rstd1, M, 1e-5)
+            pl.gemm_nt(A=xh1, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
+                       beta=self._lw(l, "norm1.bias", "p"), W=self._lw(l, "spatial_attn.qkv.weight"), ldw=256, M=M, N=768,
+                       K=256, epi=EPI_BF16, Cp=qkv_s, ldc=768, bias=qb("spatial_attn"))
+            pl.add("hma_attn_spatial_fwd", qkv_s, o_s, lse_s, Fr, SA, self.scale)
+            pl.gemm_nt(A=o_s, lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else x2b, ldc2=256)
+            # action modulation: x += Lin(LN0(x) (1 + scale) + shift)   st_mask_git.py:66-76
+            if use_mod:
+                xhm, xm, rstdm = dp(ws["xhm"], s, M * 256), dp(ws["xm"], s, M * 256), dp(ws["rstdm"], s, M)
+                ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                pl.add("hma_modln_fwd", x, dp(ws["ss"], l, Fr * 512), xhm, xm, rstdm, Fr, SA, 1e-6)
+                pl.gemm_nt(A=xm, lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
+                           epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=x2b, ldc2=256)
+            # temporal (causal, un-normed input)                st_transformer.py:111
+            pl.gemm_nt(A=x2b, lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768, K=256,
+                       epi=EPI_BF16, Cp=qkv_t, ldc=768, bias=qb("temporal_attn"))
+            pl.add("hma_attn_temporal_fwd", qkv_t, o_t, B, T, SA, self.scale)
+            pl.gemm_nt(A=o_t, lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"))
+            # MLP                                               st_transformer.py:112
+            pl.add("hma_ln_fwd", x, xh2, rstd2, M, 1e-5)
+            pl.gemm_nt(A=xh2, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
+                       beta=self._lw(l, "norm2.bias", "p"), W=self._lw(l, "mlp.fc1.weight"), ldw=256, M=M, N=1024, K=256,
+                       epi=EPI_GELU2, Cp=u, ldc=1024, C2=hg, ldc2=1024,
+                       bias=self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None)
+            pl.gemm_nt(A=hg, lda=1024, a_kind=A_BF16, W=self._lw(l, "mlp.fc2.weight"), ldw=1024, M=M, N=256, K=1024,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None)
+        # readout on the image tokens only                      st_mask_git.py:681-683
+        if readout:
+          pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,
+                   epi=EPI_F32, Cp=ws["logits"].data_ptr(), ldc=1024, bias=self._p("out_x_proj.bias"))
+        self._plans[key] = pl
+        return pl
+
+    def _loss_plan(self, B, T, S, with_grad: bool) -> Plan:
+        key = ("loss", B, T, S, with_grad)
+        if key in self._plans:
+            return self._plans[key]
+        ws, cfg = self._ws, self.cfg
+        pl = Plan()
+        pl.add("hma_count_masked", ws["ids"].data_ptr(), ws["stats"].data_ptr(), B, T, S, cfg.image_vocab_size)
+        pl.add("hma_ce_fwd_bwd", ws["logits"].data_ptr(), ws["ids"].data_ptr(), ws["labels"].data_ptr(), ws["stats"].data_ptr(),
+               ws["dlogits"].data_ptr() if with_grad else None, self.gscale.data_ptr(), self.grad_scale, B, T, S,
+               cfg.image_vocab_size, 0.01)
+        self._plans[key] = pl
+        return pl
+
+    def _backward_plan(self, B, T, S, A, domain) -> Plan:
+        key = ("bwd", B, T, S, A, domain)
+        if key in self._plans:
+            return self._plans[key]
+        cfg, ws = self.cfg, self._ws
+        L = cfg.num_layers
+        SA, M, Mi, Fr = S + A, B * T * (S + A), B * T * S, B * T
+        pl = Plan()
+        dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
+        x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
+        # readout
+        pl.gemm_tn(dY=ws["dlogits"].data_ptr(), ldy=1024, y_kind=A_BF16, A=x, lda=256, a_kind=A_F32, a_group=(S, SA), M=Mi,
+                   N=1024, K=256, dW=self._g("out_x_proj.weight"), lddw=256, dBias=self._g("out_x_proj.bias"))
+        pl.gemm_nt(A=ws["dlogits"].data_ptr(), lda=1024, a_kind=A_BF16, W=self.WT["out"].data_ptr(), ldw=1024, M=Mi, N=256,
+                   K=1024, epi=EPI_F32, Cp=dx, ldc=256, c_group=(S, SA))
+        use_mod = A > 0 and self.modulate
+        for l in reversed(range(L)):
+            xh1, rstd1 = dp(ws["xh1"], l, M * 256), dp(ws["rstd1"], l, M)
+            qkv_s, o_s, lse_s = dp(ws["qkv_s"], l, M * 768), dp(ws["o_s"], l, M * 256), dp(ws["lse_s"], l, M * 8)
+            x2b = dp(ws["x2b"], l, M * 256)
+            qkv_t, o_t = dp(ws["qkv_t"], l, M * 768), dp(ws["o_t"], l, M * 256)
+            xh2, rstd2 = dp(ws["xh2"], l, M * 256), dp(ws["rstd2"], l, M)
+            u, hg = dp(ws["u"], l, M * 1024), dp(ws["hg"], l, M * 1024)
+            gw = lambda suffix: self._lw(l, suffix, "g")
+            gb = lambda suffix, on=True: self._lw(l, suffix, "g") if on else None
+            wt = lambda k: dp(self.WT[k], l, self.WT[k][0].numel())
+            # ---- MLP
+            pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024, dW=gw("mlp.fc2.weight"),
+                       lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias))
+            pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
+                       U=u, ldu=1024)  # dU overwrites u in place
+            pl.gemm_tn(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
+                       beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024, K=256, dW=gw("mlp.fc1.weight"), lddw=256,
+                       dBias=gb("mlp.fc1.bias", cfg.mlp_bias))
+            pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
+            pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M)
+            # ---- temporal attention
+            pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                       dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias))
+            pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
+            pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale)
+            pl.gemm_tn(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
+                       dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias))
+            pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256)
+            # ---- action modulation
+            if use_mod:
+                xhm, xm, rstdm = dp(ws["xhm"], l, M * 256), dp(ws["xm"], l, M * 256), dp(ws["rstdm"], l, M)
+                ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                           dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
+                pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=dp(self.WT[f"lin:{domain}"], l, 256 * 256), ldw=256, M=M, N=256, K=256,
+                           epi=EPI_BF16, Cp=t256, ldc=256)
+                pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA)
+            # ---- spatial attention
+            pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                       dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias))
+            pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
+            pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale)
+            pl.gemm_tn(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, a_kind=A_BF16_AFFINE,
+                       gamma=self._lw(l, "norm1.weight", "p"), beta=self._lw(l, "norm1.bias", "p"), M=M, N=768, K=256,
+                       dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias))
+            pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
+            pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M)
+            pl.mark(f"layer{l}")
+        # ---- embedding, adaLN stacks, action stem
+        pl.add("hma_embed_bwd", ws["ids"].data_ptr(), dx, self._g("token_embed.factored_embeds.0.weight"),
+               self._g("token_embed.factored_embeds.1.weight"), self._g("token_embed.mask_token_embed"), self._g("pos_embed_TSC"),
+               ws["da_emb"].data_ptr() if A > 0 else None, B, T, S, A, cfg.S + cfg.action_token_size, cfg.factored_vocab_size,
+               cfg.image_vocab_size)
+        if A > 0:
+            dom = domain
+            if self.modulate:
+                ap = f"decoder.layers.0.action_projectors.{dom}"
+                pl.gemm_tn(dY=ws["dss"].data_ptr(), ldy=512, y_kind=A_F32, A=ws["ada_act"].data_ptr(), lda=256, a_kind=A_BF16,
+                           M=Fr, N=512, K=256, dW=self._g(f"{ap}.adaLN_modulation.2.weight"), lddw=256,
+                           dBias=self._g(f"{ap}.adaLN_modulation.2.bias"), batch=L, sY=Fr * 512, sA=Fr * 256, sdW=512 * 256,
+                           sdBias=512)
+                pl.gemm_nt(A=ws["dss"].data_ptr(), lda=512, a_kind=A_F32, W=self.WT[f"ada2:{dom}"].data_ptr(), ldw=512, M=Fr,
+                           N=256, K=512, epi=EPI_DSILU, Cp=ws["dpre"].data_ptr(), ldc=256, U=ws["ada_pre"].data_ptr(), ldu=256,
+                           batch=L, sA=Fr * 512, sW=256 * 512, sC=Fr * 256, sU=Fr * 256)
+                pl.gemm_tn(dY=ws["dpre"].data_ptr(), ldy=256, y_kind=A_BF16, A=ws["a_emb"].data_ptr(), lda=256, a_kind=A_F32,
+                           M=Fr, N=256, K=256, dW=self._g(f"{ap}.adaLN_modulation.0.weight"), lddw=256,
+                           dBias=self._g(f"{ap}.adaLN_modulation.0.bias"), batch=L, sY=Fr * 256, sA=0, sdW=256 * 256, sdBias=256)
+                pl.gemm_nt(A=ws["dpre"].data_ptr(), lda=256, a_kind=A_BF16, W=self.WT[f"ada0:{dom}"].data_ptr(), ldw=256, M=Fr,
+                           N=256, K=256, epi=EPI_ATOMIC_F32, Cp=ws["da_emb"].data_ptr(), ldc=256, batch=L, sA=Fr * 256,
+                           sW=256 * 256, sC=0)
+            am = f"action_mlp.{dom}.model"
+            pl.add("hma_action_stem_bwd", ws["da_emb"].data_ptr(), ws["an"].data_ptr(), ws["sxhat"].data_ptr(),
+                   ws["srstd"].data_ptr(), ws["sh"].data_ptr(), self._p(f"{am}.1.weight"), self._p(f"{am}.3.weight"),
+                   self._g(f"{am}.0.weight"), self._g(f"{am}.0.bias"), self._g(f"{am}.1.weight"), self._g(f"{am}.1.bias"),
+                   self._g(f"{am}.3.weight"), self._g(f"{am}.3.bias"), ws["stem_scratch"].data_ptr(), Fr, self.d_actions[dom])
+        pl.mark("end")
+        self._plans[key] = pl
+        return pl
+
+    # ------------------------------------------------------------------------------ public ops
+    _skip_norm = 0
+
+    def stats_buffers(self) -> Dict[str, torch.Tensor]:
+        return self._ws
+
+    def forward(self, ids_BTS: torch.Tensor, labels: Optional[torch.Tensor], actions: Optional[torch.Tensor],
+                domain: Optional[str], train: bool, skip_normalization: bool = False, loss_grad: bool = False
+                ) -> Dict[str, torch.Tensor]:
+        """Embeds, runs the trunk and the readout; with `labels` also the loss (and, with `loss_grad`, dlogits
+        scaled by `self.grad_scale * self.gscale`)."""
+        B, T, S = ids_BTS.shape
+        A = self.cfg.action_token_size if (actions is not None and "concat" in self.cfg.action_network) else 0
+        if actions is not None and A == 0:
+            raise NotImplementedError("only the 'concat+modulate' action network is built")
+        if actions is not None and domain not in self.d_actions:
+            raise KeyError(f"unknown action domain {domain!r}")
+        d_a = self.d_actions[domain] if actions is not None else 0
+        if T > 16:
+            raise NotImplementedError("temporal attention kernel handles T <= 16 frames")
+        skip = 1 if skip_normalization else 0
+        if skip != self._skip_norm:
+            self._skip_norm, self._plans = skip, {}
+        ws = self._workspace(B, T, S, A, train)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(domain if actions is not None else None, stream)
+        ws["ids"].copy_(ids_BTS, non_blocking=True)
+        if actions is not None:
+            if actions.shape[-1] != d_a:
+                raise ValueError(f"action_ids last dim {actions.shape[-1]} != d_action {d_a} of domain {domain}")
+            ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
+        self._forward_plan(B, T, S, A, train, domain if A > 0 else None).run(stream)
+        self._last = (B, T, S, A, domain if A > 0 else None)
+        if labels is not None:
+            ws["labels"].copy_(labels.reshape(B, T * S), non_blocking=True)
+            ws["stats"].zero_()
+            self._loss_plan(B, T, S, train and loss_grad).run(stream)
+        return ws
+
+    def run_trunk(self, x_BTSD: torch.Tensor, a_emb: Optional[torch.Tensor], domain: Optional[str], l0: int = 0,
+                  l1: Optional[int] = None) -> torch.Tensor:
+        """Layers [l0, l1) of the decoder on a given residual stream (inference; STTransformerDecoder.forward)."""
+        B, T, SA, D = x_BTSD.shape
+        A = self.cfg.action_token_size if a_emb is not None else 0
+        S = SA - A
+        if a_emb is not None and not self.modulate:
+            raise NotImplementedError("only the 'modulate' action projector is built")
+        ws = self._workspace(B, T, S, A, False)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(domain if a_emb is not None else None, stream)
+        ws["x"].view(B, T, SA, D).copy_(x_BTSD, non_blocking=True)
+        if a_emb is not None:
+            ws["a_emb"].view(B, T, D).copy_(a_emb[:, :T], non_blocking=True)
+        self._forward_plan(B, T, S, A, False, domain if A > 0 else None, embed=False, l0=l0, l1=l1, readout=False).run(stream)
+        return ws["x"].view(B, T, SA, D).clone()
+
+    def maskgit_step(self, prompt_BTS: torch.Tensor, unmasked: torch.Tensor, out_t: int, n_mask: int, last: bool,
+                     conf_override: Optional[torch.Tensor] = None, conf_out: Optional[torch.Tensor] = None) -> None:
+        """One sampling step on the logits of the last forward (st_mask_git.py:397-453); updates in place."""
+        B, T, S = prompt_BTS.shape
+        assert prompt_BTS.is_contiguous() and prompt_BTS.dtype == torch.int64 and unmasked.dtype == torch.uint8
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.call("hma_maskgit_step", stream, self._ws["logits"].data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(),
+                  None if conf_override is None else conf_override.data_ptr(), None if conf_out is None else conf_out.data_ptr(),
+                  B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size)
+
+    def zero_grad(self, active_domains: Optional[Sequence[str]] = None) -> None:
+        """Zero the whole gradient buffer, or only the ranges that can receive gradients this step."""
+        if active_domains is None:
+            self.G.zero_()
+        else:
+            for a, b in self.layout.trainable_ranges(active_domains):
+                self.G[a:b].zero_()
+
+    def backward(self, grad_scale: float = 1.0, on_segment: Optional[Callable[[str], None]] = None,
+                 segment_layers: int = 0) -> None:
+        """Accumulates parameter gradients of the last `forward(train=True)` into the flat G buffer.
+
+        `on_segment(label)` is called after every `segment_layers` layers have been enqueued (labels
+        'layer<l>' then 'end') so a data-parallel driver can start all-reducing finished buckets."""
+        B, T, S, A, domain = self._last
+        ws = self._ws
+        stream = torch.cuda.current_stream().cuda_stream
+        if grad_scale != self.grad_scale.value:
+            # dlogits were produced with the scale captured at forward time: redo the (cheap) CE pass
+            self.grad_scale.value = grad_scale
+            ws["stats"].zero_()
+            self._loss_plan(B, T, S, True).run(stream)
+        lay = self.layout
+        ws["dx"].zero_()
+        if A > 0:
+            ws["da_emb"].zero_()
+        pl = self._backward_plan(B, T, S, A, domain)
+        if on_segment is None or segment_layers <= 0:
+            pl.run(stream)
+            return
+        L = self.cfg.num_layers
+        start = 0
+        for l in reversed(range(L)):
+            if (L - l) % segment_layers == 0 or l == 0:
+                stop = pl.marks[f"layer{l}"]
+                pl.run(stream, start, stop)
+                start = stop
+                on_segment(f"layer{l}")
+        pl.run(stream, start, None)
+        on_segment("end")
+
+    def optimizer_step(self, lr: float, active_domains: Sequence[str], betas=(0.9, 0.95), eps: float = 1e-8,
+                       weight_decay: float = 0.05, max_norm: Optional[float] = 1.0) -> None:
+        """Global-norm clip + AdamW over the ranges that received gradients (hma/train_multi.py:593-598)."""
+        if self.M is None:
+            self.M = torch.zeros_like(self.P)
+            self.V = torch.zeros_like(self.P)
+        stream = torch.cuda.current_stream().cuda_stream
+        ranges = self.layout.trainable_ranges(active_domains)
+        self.opt_step += 1
+        sq = None
+        if max_norm is not None and max_norm > 0:
+            self.sqnorm.zero_()
+            for a, b in ranges:
+                _lib.call("hma_sqnorm", stream, self.G.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr())
+            sq = self.sqnorm.data_ptr()
+        for a, b in ranges:
+            _lib.call("hma_adamw", stream, self.P.data_ptr() + 4 * a, self.G.data_ptr() + 4 * a, self.M.data_ptr() + 4 * a,
+                      self.V.data_ptr() + 4 * a, self.Wb.data_ptr() + 2 * a, b - a, lr, betas[0], betas[1], eps, weight_decay,
+                      self.opt_step, sq, float(max_norm or 0.0), self.flags.data_ptr() + a // ALIGN)
+        # bf16 copies were emitted by the update itself; only the transposed copies are stale
+        self._wt_ok = False
+        self._dom_fresh = set()
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.sqnorm.sqrt()

@@ -1,0 +1,175 @@
+"""Training-step driver for the MI355X engine: the hot slice of hma/train_multi.py:556-599.
+
+One process per GPU.  Per optimizer step:
+  1. ranks exchange their batch's action domain (a tiny all-gather) -> the union of active domains;
+  2. forward + fused CE, hand-written backward into the flat gradient buffer;
+  3. gradients are all-reduced (RCCL, `nccl` backend) in contiguous buckets of the flat buffer that
+     become final as backward walks layers L-1..0 -- launched on a side HIP stream behind an event so
+     they overlap the remaining backward; only the dense trunk and the domains that are active on
+     SOME rank are reduced (the reference's DDP reduces all 362 M parameters, ~90 % zeros);
+  4. global-norm clip + AdamW over exactly those ranges.  Parameters unused on every rank are left
+     untouched (no moment update, no weight decay) -- DDP's globally-unused rule.
+The per-micro-step barrier of the reference (train_multi.py:568) is dropped on purpose.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .params import ParamLayout
+
+
+class GradReducer:
+    """Bucketed sum-all-reduce of a flat gradient buffer, sparse by action domain.
+
+    Device-agnostic on purpose (pure torch.distributed on 1-D slices) so the N > 1 logic is covered
+    by world_size-2 gloo tests on CPU; on the GPU box the backend is RCCL over xGMI."""
+
+    def __init__(self, layout: ParamLayout, G: torch.Tensor, layers_per_bucket: int = 8, group=None):
+        self.layout, self.G, self.group = layout, G, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dense_buckets = layout.buckets(layers_per_bucket)
+        L = layout.cfg.num_layers
+        order = list(reversed(range(L)))
+        # label of the backward segment after which bucket i is final
+        self.bucket_label = [f"layer{order[min(i + layers_per_bucket, L) - 1]}" for i in range(0, L, layers_per_bucket)]
+        self.tail = layout.regions["tail"]
+        self._pending: List = []
+        self._next = 0
+        self.side = torch.cuda.Stream() if G.is_cuda else None
+        self._dom_index = {d: i for i, d in enumerate(layout.domains)}
+
+    def active_domains(self, local_domain: Optional[str]) -> List[str]:
+        """Union over ranks of this step's domains, in layout order (same list on every rank)."""
+        if self.world == 1:
+            return [local_domain] if local_domain is not None else []
+        idx = -1 if local_domain is None else self._dom_index[local_domain]
+        mine = torch.tensor([idx], dtype=torch.int64, device=self.G.device)
+        allv = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allv, mine, group=self.group)
+        seen = sorted({int(v.item()) for v in allv if int(v.item()) >= 0})
+        return [self.layout.domains[i] for i in seen]
+
+    def _launch(self, a: int, b: int) -> None:
+        if self.world == 1 or b <= a:
+            return
+        sl = self.G[a:b]
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin(self) -> None:
+        self._pending, self._next = [], 0
+
+    def on_segment(self, label: str) -> None:
+        """Called by STEngine.backward after each enqueued segment; reduces every bucket that is final."""
+        while self._next < len(self.dense_buckets) and label == self.bucket_label[self._next]:
+            self._launch(*self.dense_buckets[self._next])
+            self._next += 1
+
+    def finish(self, active: Sequence[str]) -> None:
+        """Reduce what is left (unlaunched dense buckets, embeddings, active domain blocks) and wait."""
+        while self._next < len(self.dense_buckets):
+            self._launch(*self.dense_buckets[self._next])
+            self._next += 1
+        self._launch(*self.tail)
+        for dom in active:
+            self._launch(*self.layout.regions[f"dom:{dom}"])
+        for w in self._pending:
+            w.wait()
+        if self.side is not None and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._pending = []
+
+
+def lr_at(step: int, base_lr: float, warmup_steps: int) -> float:
+    """`constant_with_warmup` (train_multi.py:194-199, 979-986); `step` counts completed optimizer steps."""
+    if warmup_steps <= 0:
+        return base_lr
+    return base_lr * min(1.0, float(step + 1) / float(warmup_steps))
+
+
+class Trainer:
+    """Fused train step on one GPU of a data-parallel job (no autograd, no per-tensor optimizer)."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
+                 max_grad_norm: Optional[float] = 1.0, warmup_steps: int = 0, layers_per_bucket: int = 8,
+                 grad_accum: int = 1, device=None):
+        self.model = model
+        dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.engine = model._get_engine(dev)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_grad_norm, self.warmup = max_grad_norm, warmup_steps
+        self.accum = grad_accum
+        self.reducer = GradReducer(self.engine.layout, self.engine.G, layers_per_bucket)
+        self.layers_per_bucket = layers_per_bucket
+        self.completed = 0
+        self._micro = 0
+        self._active: List[str] = []
+
+    def micro_step(self, input_ids, labels, action_ids=None, domain=None) -> Dict[str, torch.Tensor]:
+        """forward + backward of one micro-batch; gradients accumulate in the flat buffer."""
+        eng, red = self.engine, self.reducer
+        dom = None if action_ids is None else (domain if isinstance(domain, str) else domain[0])
+        first, last = self._micro == 0, self._micro == self.accum - 1
+        if first:
+            self._active = red.active_domains(dom)
+            eng.zero_grad(self._active)
+        elif dom is not None and dom not in self._active:
+            raise RuntimeError("all micro-batches of one optimizer step must use the domains announced by its first micro-batch")
+        B = input_ids.shape[0]
+        T = self.model.config.T
+        eng.grad_scale.value = 1.0 / (self.accum * red.world)
+        eng.gscale.fill_(1.0)
+        ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True)
+        if last and red.world > 1:
+            red.begin()
+            eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
+            red.finish(self._active)
+        else:
+            eng.backward(eng.grad_scale.value)
+        self._micro += 1
+        return ws
+
+    def optimizer_step(self) -> None:
+        lr = lr_at(self.completed, self.lr, self.warmup)
+        self.engine.optimizer_step(lr, self._active, self.betas, self.eps, self.wd, self.max_grad_norm)
+        self.completed += 1
+        self._micro = 0
+
+    def step(self, input_ids, labels, action_ids=None, domain=None) -> Dict[str, torch.Tensor]:
+        """One full optimizer step on one micro-batch (grad_accum must be 1)."""
+        ws = self.micro_step(input_ids, labels, action_ids, domain)
+        self.optimizer_step()
+        return ws
+
+    def loss_and_acc(self, ws) -> Tuple[torch.Tensor, torch.Tensor]:
+        st = ws["stats"]
+        return st[0] / st[2], st[1] / st[2]
+
+
+class FusedAdamW:
+    """torch.optim-shaped facade over the engine's fused clip + AdamW for the autograd (drop-in) path:
+    `loss.backward(); opt.step(); opt.zero_grad()`."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
+                 max_grad_norm: Optional[float] = 1.0):
+        self.model, self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = model, lr, betas, eps, weight_decay, max_grad_norm
+
+    def step(self) -> None:
+        eng = self.model._engine
+        if eng is None:
+            raise RuntimeError("no backward has run yet")
+        active = [d for d in eng.domains if d in self.model.touched_domains]
+        eng.optimizer_step(self.lr, active, self.betas, self.eps, self.wd, self.max_grad_norm)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self.model.zero_grad()

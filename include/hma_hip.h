@@ -132,13 +132,14 @@ int hma_action_stem_bwd(void* stream, const float* dout, const float* an, const 
 /* Factorised-vocabulary cross-entropy + accuracy + logits gradient, st_mask_git.py:603-630, 714-716.
  * logits f32 [B*T*S, 2*512] (row = (b,t,s)); frames t >= 1 only; label smoothing 0.01; masked mean.
  * stats[0] = sum loss*mask, stats[1] = sum acc*mask, stats[2] = num masked (fp32; zero them first).
- * dlogits (bf16, may be NULL) = mask / num_masked * (softmax - smoothed one-hot): needs the count
+ * dlogits (bf16, may be NULL) = grad_scale * (*grad_scale_dev if not NULL) * mask / num_masked *
+ * (softmax - smoothed one-hot): needs the count
  * first, so call hma_count_masked before it. */
 int hma_count_masked(void* stream, const int64_t* input_ids, float* stats, int64_t B, int32_t T, int32_t S,
                      int64_t mask_id);
 int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* input_ids, const int64_t* labels,
-                   float* stats, void* dlogits, float grad_scale, int64_t B, int32_t T, int32_t S,
-                   int64_t mask_id, float label_smoothing);
+                   float* stats, void* dlogits, const float* grad_scale_dev, float grad_scale, int64_t B,
+                   int32_t T, int32_t S, int64_t mask_id, float label_smoothing);
 
 /* One MaskGIT sampling step on frame logits, st_mask_git.py:397-453 (temperature <= 1e-8):
  * logits f32 [B, T, S, 1024] frame out_t; writes samples into prompt[b, out_t, :] (int64 [B,T,S]),

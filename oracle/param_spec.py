@@ -68,8 +68,8 @@ def state_dict_spec(cfg, domains: Sequence[str] = (), d_actions: Sequence[int] =
     return out
 
 
-def seeded_state_dict(spec: "OrderedDict[str, Tuple[int, ...]]", seed: int = 0, std: float = 0.05
-                      ) -> Dict[str, torch.Tensor]:
+def seeded_state_dict(spec: "OrderedDict[str, Tuple[int, ...]]", seed: int = 0, std: float = 0.05,
+                      embed_std: float = 0.5) -> Dict[str, torch.Tensor]:
     """Deterministic fill (sorted-name order, CPU generator).
 
     The default init leaves pos-embed / mask tokens at exactly zero which would hide indexing
@@ -85,6 +85,6 @@ def seeded_state_dict(spec: "OrderedDict[str, Tuple[int, ...]]", seed: int = 0, 
         if name.endswith(".std"):
             t = t.abs() / std + 0.5
         if "factored_embeds" in name:
-            t = t / std * 0.5
+            t = t / std * embed_std
         sd[name] = t
     return sd

@@ -223,6 +223,33 @@ def g5_g6_model():
     return cfg, model, sd
 
 
+def g6b_initlike():
+    """Same forward/backward on an init-scale state-dict (N(0, 0.02) like STMaskGIT.init_weights, :737-753):
+    the regime the north-star loss tolerance (1e-3) is quoted for."""
+    cfg, model, _ = build_tiny()
+    from oracle.st_maskgit_ref import RefConfig
+    rc = RefConfig(**{k: v for k, v in TINY["config"].items() if k in RefConfig.__dataclass_fields__})
+    spec = state_dict_spec(rc, TINY["domains"], TINY["d_actions"], [len(s[0]) for s in TINY["action_stats"]])
+    sd = seeded_state_dict(spec, seed=TINY["seed"] + 1, std=0.02, embed_std=0.02)
+    ref_sd = model.state_dict()
+    for dom in TINY["domains"]:
+        sd[f"action_preprocessor.{dom}.mean"] = ref_sd[f"action_preprocessor.{dom}.mean"].clone()
+        sd[f"action_preprocessor.{dom}.std"] = ref_sd[f"action_preprocessor.{dom}.std"].clone()
+    model.load_state_dict(sd, strict=True)
+    inp = tiny_inputs()
+    out = {}
+    model.zero_grad(set_to_none=True)
+    o = model(input_ids=inp["input_ids"], labels=inp["labels"], action_ids=inp["actions_domA"], domain=["domA"] * 2,
+              h=[16, 16], w=[16, 16])
+    o.loss.backward()
+    out["domA.loss"] = o.loss.detach()
+    out["domA.acc"] = o.acc.detach()
+    out["domA.logits_sub"] = o.logits.detach()[:, :, :, ::4, ::4]
+    for k, v in grad_digest(model.named_parameters()).items():
+        out[f"domA.{k}"] = v
+    save("g6b_initlike", out)
+
+
 def g7_generate(cfg, model):
     inp = tiny_inputs()
     out = {}
@@ -301,6 +328,7 @@ if __name__ == "__main__":
     g3_attention()
     g4_blocks()
     cfg, model, sd = g5_g6_model()
+    g6b_initlike()
     g7_generate(cfg, model)
     cfg, model, sd = build_tiny()
     g8_adamw(cfg, model)

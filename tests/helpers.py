@@ -21,10 +21,15 @@ def tiny_ref_config(**over):
     return RefConfig(**kw)
 
 
-def tiny_state_dict(cfg=None):
+def tiny_state_dict(cfg=None, initlike: bool = False):
+    """The seeded fixture weights: N(0, 0.05) with unit-scale embeddings (adversarially large activations),
+    or -- `initlike` -- N(0, 0.02) everywhere like the reference's init_weights (st_mask_git.py:737-753)."""
     cfg = cfg or tiny_ref_config()
     spec = state_dict_spec(cfg, TINY["domains"], TINY["d_actions"], [len(s[0]) for s in TINY["action_stats"]])
-    sd = seeded_state_dict(spec, seed=TINY["seed"])
+    if initlike:
+        sd = seeded_state_dict(spec, seed=TINY["seed"] + 1, std=0.02, embed_std=0.02)
+    else:
+        sd = seeded_state_dict(spec, seed=TINY["seed"])
     for dom, st in zip(TINY["domains"], TINY["action_stats"]):
         sd[f"action_preprocessor.{dom}.mean"] = torch.tensor(st[0], dtype=torch.float32)
         sd[f"action_preprocessor.{dom}.std"] = torch.tensor(st[1], dtype=torch.float32)

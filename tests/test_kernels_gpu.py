@@ -362,7 +362,7 @@ def test_ce_loss_acc_and_grad():
     ld, idd, lbd = logits.to(DEV), inputs.to(DEV), labels.to(DEV)
     _lib.call("hma_count_masked", ops.stream_ptr(), idd.data_ptr(), stats.data_ptr(), B, T, S, mask_id)
     _lib.call("hma_ce_fwd_bwd", ops.stream_ptr(), ld.data_ptr(), idd.data_ptr(), lbd.data_ptr(), stats.data_ptr(),
-              dl.data_ptr(), 3.0, B, T, S, mask_id, 0.01)
+              dl.data_ptr(), None, 3.0, B, T, S, mask_id, 0.01)
     st = stats.cpu()
     assert st[2].item() == float((inputs[:, 1:] == mask_id).sum())
     assert abs(st[0].item() / st[2].item() - loss.item()) < 1e-5 * abs(loss.item())

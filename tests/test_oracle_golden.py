@@ -96,6 +96,27 @@ def test_g6_forward_backward(tag):
     assert n_checked > 20
 
 
+def test_g6b_initlike_forward_backward():
+    g = golden("g6b_initlike")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg, initlike=True)
+    inp = tiny_inputs()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(params)
+    loss, acc, logits = R.forward(full, cfg, inp["input_ids"], inp["labels"], inp["actions_domA"], ["domA"] * 2)
+    loss.backward()
+    assert abs(loss.item() - g["domA.loss"].item()) < 1e-5
+    assert rel_err(logits.detach()[:, :, :, ::4, ::4], g["domA.logits_sub"]) < TOL
+    for name, p in params.items():
+        key = f"domA.grad_samp.{name}"
+        if key in g:
+            gf = p.grad.reshape(-1)
+            idx = torch.linspace(0, gf.numel() - 1, 64).long()
+            scale = g[f"domA.grad_abs.{name}"].item() / gf.numel() + 1e-12
+            assert (gf[idx] - g[key]).abs().max().item() < 5e-4 * scale + 1e-9, name
+
+
 def test_g7_generate_ids_bit_exact():
     g = golden("g7_generate")
     cfg = tiny_ref_config()
