@@ -83,6 +83,10 @@ def load() -> C.CDLL:
     """Load the in-tree shared object; raises if it has not been built (no CPU fallback exists)."""
     global _lib
     if _lib is None:
+        # torch must be imported first: it brings its own libamdhip64.so.7, and the library has to bind to
+        # THAT runtime (a second copy from /opt/rocm would see no device inside this process).
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise HmaKernelError(
                 f"{LIB_PATH} is missing: build it with `python -m hma_amd.build` (hipcc --offload-arch=gfx950). "

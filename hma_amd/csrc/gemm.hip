@@ -14,6 +14,8 @@
 #include "hma_common.h"
 #include "../../include/hma_hip.h"
 
+#include <cstdlib>
+
 using namespace hma;
 
 namespace {
@@ -45,6 +47,60 @@ __device__ __forceinline__ void mma_tile(const uint16_t* __restrict__ Ts, const 
 
 __device__ __forceinline__ int64_t remap_row(int64_t r, int64_t group_rows, int64_t group_stride) {
   return group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) : r;
+}
+
+// One accumulator quad: 4 consecutive output columns n..n+3 of (remapped) row crow; bias already added.
+__device__ __forceinline__ void epilogue_quad(const hma_gemm_nt_t& p, int64_t bz, int64_t crow, int64_t n, float (&v)[4]) {
+  switch (p.epi) {
+    case HMA_EPI_BF16: {
+      uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
+      *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    } break;
+    case HMA_EPI_F32: {
+      float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
+      *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+    } break;
+    case HMA_EPI_RESID: {
+      float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
+      float4 x = *reinterpret_cast<float4*>(C);
+      x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+      *reinterpret_cast<float4*>(C) = x;
+      if (p.C2) {
+        uint16_t* C2 = reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n;
+        *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(x.x, x.y), pack_bf16(x.z, x.w));
+      }
+    } break;
+    case HMA_EPI_GELU2:
+    case HMA_EPI_SILU2: {
+      uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
+      uint16_t* C2 = reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n;
+      // the saved pre-activation is bf16: activate the ROUNDED value so backward sees the same u
+      float u[4], a[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u[e] = from_bf16(to_bf16(v[e]));
+        a[e] = p.epi == HMA_EPI_GELU2 ? gelu_f(u[e]) : silu_f(u[e]);
+      }
+      *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(u[0], u[1]), pack_bf16(u[2], u[3]));
+      *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+    } break;
+    case HMA_EPI_DGELU:
+    case HMA_EPI_DSILU: {
+      const uint16_t* U = reinterpret_cast<const uint16_t*>(p.U) + bz * p.sU + crow * p.ldu + n;
+      const uint2 uu = *reinterpret_cast<const uint2*>(U);
+      const float u[4] = {bf16_lo(uu.x), bf16_hi(uu.x), bf16_lo(uu.y), bf16_hi(uu.y)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= (p.epi == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
+      uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
+      *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    } break;
+    case HMA_EPI_ATOMIC_F32: {
+      float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(C + e, v[e]);
+    } break;
+    default: break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ NT
@@ -170,58 +226,187 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(hma_gemm_nt_t p) {
           const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
           v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         }
-        switch (p.epi) {
-          case HMA_EPI_BF16: {
-            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
-            *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-          } break;
-          case HMA_EPI_F32: {
-            float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
-            *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-          } break;
-          case HMA_EPI_RESID: {
-            float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
-            float4 x = *reinterpret_cast<float4*>(C);
-            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
-            *reinterpret_cast<float4*>(C) = x;
-            if (p.C2) {
-              uint16_t* C2 = reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n;
-              *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(x.x, x.y), pack_bf16(x.z, x.w));
-            }
-          } break;
-          case HMA_EPI_GELU2:
-          case HMA_EPI_SILU2: {
-            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
-            uint16_t* C2 = reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n;
-            // the saved pre-activation is bf16: activate the ROUNDED value so backward sees the same u
-            float u[4], a[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              u[e] = from_bf16(to_bf16(v[e]));
-              a[e] = p.epi == HMA_EPI_GELU2 ? gelu_f(u[e]) : silu_f(u[e]);
-            }
-            *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(u[0], u[1]), pack_bf16(u[2], u[3]));
-            *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
-          } break;
-          case HMA_EPI_DGELU:
-          case HMA_EPI_DSILU: {
-            const uint16_t* U = reinterpret_cast<const uint16_t*>(p.U) + bz * p.sU + crow * p.ldu + n;
-            const uint2 uu = *reinterpret_cast<const uint2*>(U);
-            const float u[4] = {bf16_lo(uu.x), bf16_hi(uu.x), bf16_lo(uu.y), bf16_hi(uu.y)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= (p.epi == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
-            uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
-            *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-          } break;
-          case HMA_EPI_ATOMIC_F32: {
-            float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(C + e, v[e]);
-          } break;
-          default: break;
-        }
+        epilogue_quad(p, bz, crow, n, v);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------- NT, persistent
+// The layer GEMMs of this model have K = 256..1024: a tile-per-workgroup launch spends most of its
+// time filling a 4..16-step pipeline.  Here a workgroup (512 threads, 8 waves, one per CU) walks a
+// list of 128 x 256 output tiles and keeps ONE software pipeline running across tile boundaries:
+// global loads are issued two 64-deep K-steps ahead into registers, LDS is double buffered with a
+// single barrier per step, and consecutive workgroup ids of one XCD share the A rows of an m-tile.
+constexpr int PM = 128, PN = 256, PK = 64;
+constexpr int P_A = PM * LDT, P_W = PN * LDT, P_STAGE = P_A + P_W;
+constexpr int P_SMEM_BYTES = 2 * P_STAGE * 2;  // 110592 B
+
+template <int AKIND>
+struct PRegs {
+  uint4 a[2][AKIND == HMA_A_F32 ? 2 : 1];
+  uint4 w[4];
+  bool a_ok[2];
+  int k0;
+};
+
+template <int AKIND>
+__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(hma_gemm_nt_t p, int tiles_m, int tiles_n, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int KT = (int)(p.K / PK);
+  const int kc = tid & 7;
+
+  // XCD-aware virtual id: the workgroups of one XCD (b % 8) take a contiguous run of tiles
+  const int G = gridDim.x;
+  const int b = blockIdx.x;
+  const int per = G >> 3;
+  const int vid = ((G & 7) == 0) ? (b & 7) * per + (b >> 3) : b;
+  const int my_tiles = vid < total_tiles ? (total_tiles - vid + G - 1) / G : 0;
+  const int total_it = my_tiles * KT;
+  if (total_it == 0) return;
+
+  struct Cursor { int tile; int kt; int64_t a_off[2]; int64_t w_off; int64_t bz; };
+  auto decode = [&](Cursor& c) {
+    const int per_b = tiles_m * tiles_n;
+    c.bz = c.tile / per_b;
+    const int r = c.tile % per_b;
+    const int mt = r / tiles_n, nt = r % tiles_n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t gr = (int64_t)mt * PM + (tid >> 3) + i * 64;
+      c.a_off[i] = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
+    }
+    c.w_off = ((int64_t)nt * PN + (tid >> 3)) * p.ldw;
+  };
+  Cursor ld;
+  ld.tile = vid; ld.kt = 0;
+  decode(ld);
+
+  auto load = [&](PRegs<AKIND>& r) {
+    const int k0 = ld.kt * PK + kc * 8;
+    r.k0 = k0;
+    const char* Ab = reinterpret_cast<const char*>(p.A) + ld.bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + ld.bz * p.sW + ld.w_off + k0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.w[i] = *reinterpret_cast<const uint4*>(Wb + (int64_t)i * 64 * p.ldw);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      r.a_ok[i] = ld.a_off[i] >= 0;
+      if (r.a_ok[i]) {
+        if (AKIND == HMA_A_F32) {
+          const float* s = reinterpret_cast<const float*>(Ab) + ld.a_off[i] + k0;
+          r.a[i][0] = *reinterpret_cast<const uint4*>(s);
+          r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(s + 4);
+        } else {
+          r.a[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Ab) + ld.a_off[i] + k0);
+        }
+      } else {
+        r.a[i][0] = make_uint4(0, 0, 0, 0);
+        r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    if (++ld.kt == KT) {
+      ld.kt = 0;
+      ld.tile += G;
+      if (ld.tile < total_tiles) decode(ld);
+    }
+  };
+  auto store = [&](const PRegs<AKIND>& r, int buf) {
+    uint16_t* As = smem + buf * P_STAGE;
+    uint16_t* Ws = As + P_A;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&Ws[((tid >> 3) + i * 64) * LDT + kc * 8]) = r.w[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint4 v;
+      if (AKIND == HMA_A_F32) {
+        const float4 lo = __builtin_bit_cast(float4, r.a[i][0]);
+        const float4 hi = __builtin_bit_cast(float4, r.a[i][AKIND == HMA_A_F32 ? 1 : 0]);
+        v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
+        v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
+      } else if (AKIND == HMA_A_BF16_AFFINE) {
+        float f[8];
+        unpack8(r.a[i][0], f);
+        if (r.a_ok[i]) {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + r.k0), g1 = *reinterpret_cast<const float4*>(p.gamma + r.k0 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(p.beta + r.k0), b1 = *reinterpret_cast<const float4*>(p.beta + r.k0 + 4);
+          f[0] = f[0] * g0.x + b0.x; f[1] = f[1] * g0.y + b0.y; f[2] = f[2] * g0.z + b0.z; f[3] = f[3] * g0.w + b0.w;
+          f[4] = f[4] * g1.x + b1.x; f[5] = f[5] * g1.y + b1.y; f[6] = f[6] * g1.z + b1.z; f[7] = f[7] * g1.w + b1.w;
+        }
+        v = pack8(f);
+      } else {
+        v = r.a[i][0];
+      }
+      *reinterpret_cast<uint4*>(&As[((tid >> 3) + i * 64) * LDT + kc * 8]) = v;
+    }
+  };
+
+  f32x16_t acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+  };
+  zero_acc();
+
+  int cur_tile = vid, cur_kt = 0;
+  auto finish_tile = [&]() {
+    const int per_b = tiles_m * tiles_n;
+    const int64_t bz = cur_tile / per_b;
+    const int rr = cur_tile % per_b;
+    const int64_t bm = (int64_t)(rr / tiles_n) * PM, bn = (int64_t)(rr % tiles_n) * PN;
+    const int r = lane & 31, hi = lane >> 5;
+    const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int64_t m = bm + wm * 64 + mt * 32 + r;
+      if (m < p.M) {
+        const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int64_t n = bn + wn * 64 + nt * 32 + 8 * g + 4 * hi;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * g + e];
+            if (bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+              v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            }
+            epilogue_quad(p, bz, crow, n, v);
+          }
+      }
+    }
+    zero_acc();
+  };
+
+  PRegs<AKIND> r0, r1;
+  load(r0);
+  if (total_it > 1) load(r1);
+  store(r0, 0);
+  __syncthreads();
+  auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
+    // `mine` held step `it` (already in LDS) and is free: refill it with step it + 2
+    if (it + 2 < total_it) load(mine);
+    const uint16_t* As = smem + (it & 1) * P_STAGE;
+    mma_tile(As, As + P_A, acc, wm, wn, lane);
+    if (++cur_kt == KT) {
+      finish_tile();
+      cur_kt = 0;
+      cur_tile += G;
+    }
+    if (it + 1 < total_it) store(other, (it + 1) & 1);
+    __syncthreads();
+  };
+  for (int it = 0; it < total_it; it += 2) {
+    step(it, r0, r1);
+    if (it + 1 < total_it) step(it + 1, r1, r0);
   }
 }
 
@@ -407,6 +592,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(hma_gemm_tn_t p) {
 }
 
 template <auto Kern>
+int set_smem_bytes(int bytes) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return -(int)e;
+    done = true;
+  }
+  return 0;
+}
+
+template <auto Kern>
 int set_smem() {
   static bool done = false;  // one flag per kernel instantiation
   if (!done) {
@@ -427,9 +623,35 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2) && !p->C2) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU) && !p->U) return HMA_EINVAL;
-  const dim3 grid((unsigned)((p->M + BM - 1) / BM), (unsigned)(p->N / BN), (unsigned)(p->batch > 0 ? p->batch : 1));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
+  static const bool use_v1 = getenv("HMA_GEMM_NT_V1") != nullptr;
+  if (!use_v1 && p->N % PN == 0) {
+    const int tiles_m = (int)((p->M + PM - 1) / PM), tiles_n = (int)(p->N / PN);
+    const int total = tiles_m * tiles_n * (p->batch > 0 ? p->batch : 1);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HMA_EINVAL;
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const dim3 pgrid((unsigned)(total < n_cu ? total : n_cu));
+#define HMA_NTP_CASE(AK)                                                                              \
+  case AK:                                                                                            \
+    if ((rc = set_smem_bytes<gemm_nt_persist_kernel<AK>>(P_SMEM_BYTES))) return rc;                   \
+    hipLaunchKernelGGL(gemm_nt_persist_kernel<AK>, pgrid, dim3(512), P_SMEM_BYTES, s, *p, tiles_m, tiles_n, total); \
+    break;
+    switch (p->a_kind) {
+      HMA_NTP_CASE(HMA_A_BF16)
+      HMA_NTP_CASE(HMA_A_F32)
+      HMA_NTP_CASE(HMA_A_BF16_AFFINE)
+      default: return HMA_EINVAL;
+    }
+    HMA_CHECK_LAUNCH();
+    return 0;
+  }
+  const dim3 grid((unsigned)((p->M + BM - 1) / BM), (unsigned)(p->N / BN), (unsigned)(p->batch > 0 ? p->batch : 1));
   switch (p->a_kind) {
     case HMA_A_BF16:
       if ((rc = set_smem<gemm_nt_kernel<HMA_A_BF16>>())) return rc;

@@ -61,12 +61,31 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact-erf GELU (nn.GELU() default, hma/model/st_transformer.py:20) and its derivative
-__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU() default, hma/model/st_transformer.py:20) and its derivative.
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the outputs):
+// one v_rcp + one v_exp + 7 FMAs instead of ocml's branchy erff -- the GELU epilogues were VALU-bound.
+// The exp(-u^2/2) it needs is also the Gaussian of the derivative, so dgelu costs no second exp.
+__device__ __forceinline__ void gelu_parts(float u, float& cdf, float& gauss) {
+  const float x = fabsf(u) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+  gauss = __builtin_amdgcn_exp2f(-0.72134752044448170f * u * u);  // exp(-u^2 / 2)
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float erfc_half = 0.5f * poly * t * gauss;  // 0.5 * erfc(|u| / sqrt 2)
+  cdf = u >= 0.f ? 1.0f - erfc_half : erfc_half;      // Phi(u)
+}
+__device__ __forceinline__ float gelu_f(float u) {
+  float cdf, gauss;
+  gelu_parts(u, cdf, gauss);
+  return u * cdf;
+}
 __device__ __forceinline__ float dgelu_f(float u) {
-  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
-  return cdf + u * pdf;
+  float cdf, gauss;
+  gelu_parts(u, cdf, gauss);
+  return cdf + u * 0.3989422804014327f * gauss;
 }
 __device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
 __device__ __forceinline__ float dsilu_f(float u) {

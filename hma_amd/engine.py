@@ -33,30 +33,64 @@ class Plan:
 
     def __init__(self):
         self.calls: List[Tuple[Callable, str, tuple]] = []
+        self.flops: List[float] = []   # algorithmic FLOPs of each call (0 for non-GEMM launches)
         self.marks: Dict[str, int] = {}
         self.keep: list = []
 
-    def add(self, name: str, *args) -> None:
+    def add(self, name: str, *args, flops: float = 0.0) -> None:
         self.calls.append((getattr(_lib.load(), name), name, args))
+        self.flops.append(flops)
 
     def gemm_nt(self, **kw) -> None:
         g = make_gemm_nt(**kw)
         self.keep.append(g)
-        self.add("hma_gemm_nt", C.byref(g))
+        self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
 
     def gemm_tn(self, **kw) -> None:
         g = make_gemm_tn(**kw)
         self.keep.append(g)
-        self.add("hma_gemm_tn", C.byref(g))
+        self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
 
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
 
-    def run(self, stream: int, start: int = 0, stop: Optional[int] = None) -> None:
-        for fn, name, args in self.calls[start:stop]:
-            rc = fn(stream, *args)
+    def run(self, stream: int, start: int = 0, stop: Optional[int] = None, timer: "Optional[LaunchTimer]" = None) -> None:
+        if timer is None:
+            for fn, name, args in self.calls[start:stop]:
+                rc = fn(stream, *args)
+                if rc != 0:
+                    raise _lib.HmaKernelError(f"{name} failed with code {rc}")
+            return
+        stop = len(self.calls) if stop is None else stop
+        for i in range(start, stop):
+            fn, name, args = self.calls[i]
+            if name in timer.names:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(stream, *args)
+                e1.record()
+                timer.pairs.append((name, self.flops[i], e0, e1))
+            else:
+                rc = fn(stream, *args)
             if rc != 0:
                 raise _lib.HmaKernelError(f"{name} failed with code {rc}")
+
+
+class LaunchTimer:
+    """HIP-event brackets around chosen launches, recorded on the stream the kernels run on."""
+
+    def __init__(self, names: Sequence[str]):
+        self.names = set(names)
+        self.pairs: list = []
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        out: Dict[str, Dict[str, float]] = {}
+        for name, flops, e0, e1 in self.pairs:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
 
 
 class STEngine:
@@ -109,6 +143,7 @@ class STEngine:
         self._plans: Dict[tuple, Plan] = {}
         self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
         self.grad_scale = C.c_float(1.0)
+        self.timer: Optional[LaunchTimer] = None
 
     # ------------------------------------------------------------------------------ pointers
     def _p(self, name: str) -> int:
@@ -452,7 +487,7 @@ class STEngine:
             if actions.shape[-1] != d_a:
                 raise ValueError(f"action_ids last dim {actions.shape[-1]} != d_action {d_a} of domain {domain}")
             ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
-        self._forward_plan(B, T, S, A, train, domain if A > 0 else None).run(stream)
+        self._forward_plan(B, T, S, A, train, domain if A > 0 else None).run(stream, timer=self.timer)
         self._last = (B, T, S, A, domain if A > 0 else None)
         if labels is not None:
             ws["labels"].copy_(labels.reshape(B, T * S), non_blocking=True)
@@ -515,17 +550,17 @@ class STEngine:
             ws["da_emb"].zero_()
         pl = self._backward_plan(B, T, S, A, domain)
         if on_segment is None or segment_layers <= 0:
-            pl.run(stream)
+            pl.run(stream, timer=self.timer)
             return
         L = self.cfg.num_layers
         start = 0
         for l in reversed(range(L)):
             if (L - l) % segment_layers == 0 or l == 0:
                 stop = pl.marks[f"layer{l}"]
-                pl.run(stream, start, stop)
+                pl.run(stream, start, stop, timer=self.timer)
                 start = stop
                 on_segment(f"layer{l}")
-        pl.run(stream, start, None)
+        pl.run(stream, start, None, timer=self.timer)
         on_segment("end")
 
     def optimizer_step(self, lr: float, active_domains: Sequence[str], betas=(0.9, 0.95), eps: float = 1e-8,
