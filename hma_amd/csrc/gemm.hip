@@ -591,6 +591,142 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(hma_gemm_tn_t p) {
   }
 }
 
+// ------------------------------------------------------------------------------- TN, wide tile
+// Weight gradients contract over M = B*T*(S+A) = 163840 rows but produce only N x K <= 1024 x 256
+// outputs: the cost is streaming dY and the activations.  A 512-thread workgroup owns a FULL
+// 256 (n) x 256 (k) block of dW for its slice of M, so for the d_model-sized layers every byte of dY
+// and A is read exactly once; each wave keeps a 128 x 64 corner (8 accumulators, 128 VGPRs).
+constexpr int WT = 256;                       // n-group = k-group = 256
+constexpr int W_TILE = WT * LDT;              // one transposed operand slab [256][64 + 8]
+constexpr int W_SMEM_BYTES = 4 * W_TILE * 2;  // 2 operands x 2 buffers = 147456 B
+
+template <int YKIND, int AKIND>
+__global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, int groups_n, int groups_k) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* At = smem;               // [2][256 k][LDT]
+  uint16_t* Yt = smem + 2 * W_TILE;  // [2][256 n][LDT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn2 = wave >> 2, wk4 = wave & 3;
+
+  const int G = gridDim.x;
+  const int b = blockIdx.x;
+  const int vid = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+  const int groups = groups_n * groups_k;
+  const int per_batch = groups * p.splits;
+  const int64_t bz = vid / per_batch;
+  const int r0 = vid % per_batch;
+  const int split = r0 / groups, g = r0 % groups;
+  const int64_t n0 = (int64_t)(g / groups_k) * WT, k0 = (int64_t)(g % groups_k) * WT;
+
+  const int64_t slabs = (p.M + 63) / 64;
+  const int64_t per = (slabs + p.splits - 1) / p.splits;
+  const int64_t m_begin = (int64_t)split * per * 64;
+  int64_t m_end = m_begin + per * 64;
+  if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+
+  const char* Yb = reinterpret_cast<const char*>(p.dY) + bz * p.sY * (YKIND == HMA_A_F32 ? 4 : 2);
+  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+  const int ci = lane >> 4;
+  float gm[8], bt[8];
+  if (AKIND == HMA_A_BF16_AFFINE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gm[j] = p.gamma[k0 + wave * 32 + ci * 8 + j];
+      bt[j] = p.beta[k0 + wave * 32 + ci * 8 + j];
+    }
+  }
+  float colsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
+  const bool do_bias = (p.dBias != nullptr) && (k0 == 0);
+
+  SlabRegs<YKIND> ry;
+  SlabRegs<AKIND> ra;
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+
+  auto load = [&](int64_t m0) {
+    slab_load<YKIND>(ry, Yb, p.ldy, m0, m_end, p.y_group_rows, p.y_group_stride, n0, lane, wave);
+    slab_load<AKIND>(ra, Ab, p.lda, m0, m_end, p.a_group_rows, p.a_group_stride, k0, lane, wave);
+  };
+  auto store = [&](int buf, int64_t m0) {
+    if (do_bias)
+      slab_store<YKIND, true>(ry, Yt + buf * W_TILE, lane, wave, nullptr, nullptr, colsum, m0, m_end);
+    else
+      slab_store<YKIND, false>(ry, Yt + buf * W_TILE, lane, wave, nullptr, nullptr, colsum, m0, m_end);
+    slab_store<AKIND, false>(ra, At + buf * W_TILE, lane, wave, gm, bt, nullptr, m0, m_end);
+  };
+
+  const int iters = (int)((m_end - m_begin + 63) / 64);
+  const int r = lane & 31, hi = lane >> 5;
+  load(m_begin);
+  store(0, m_begin);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    const int64_t m_next = m_begin + (int64_t)(it + 1) * 64;
+    if (it + 1 < iters) load(m_next);
+    const uint16_t* Ys = Yt + cur * W_TILE;
+    const uint16_t* As = At + cur * W_TILE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8_t yf[4], af[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        yf[i] = *reinterpret_cast<const bf16x8_t*>(&Ys[(wn2 * 128 + i * 32 + r) * LDT + kk * 16 + hi * 8]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        af[j] = *reinterpret_cast<const bf16x8_t*>(&As[(wk4 * 64 + j * 32 + r) * LDT + kk * 16 + hi * 8]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(yf[i], af[j], acc[i][j]);
+    }
+    if (it + 1 < iters) store(cur ^ 1, m_next);
+    __syncthreads();
+  }
+
+  // D rows = n, D cols = k.  Rotate the tile order by the split index so concurrent workgroups hit
+  // different addresses with their atomics.
+  float* dW = p.dW + bz * p.sdW;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int qq = (q + split) & 7;
+    const int i = qq >> 1, j = qq & 1;
+    const int64_t k = k0 + wk4 * 64 + j * 32 + r;
+    f32x16_t v;
+    // static indexing of the accumulator array (a dynamic index would spill it to scratch)
+    switch (qq) {
+      case 0: v = acc[0][0]; break; case 1: v = acc[0][1]; break;
+      case 2: v = acc[1][0]; break; case 3: v = acc[1][1]; break;
+      case 4: v = acc[2][0]; break; case 5: v = acc[2][1]; break;
+      case 6: v = acc[3][0]; break; default: v = acc[3][1]; break;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t n = n0 + wn2 * 128 + i * 32 + mfma32_row(e, hi);
+      atomicAdd(dW + n * p.lddw + k, v[e]);
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float sj = colsum[j];
+      sj += __shfl_xor(sj, 1, 64);
+      sj += __shfl_xor(sj, 2, 64);
+      sj += __shfl_xor(sj, 4, 64);
+      sj += __shfl_xor(sj, 8, 64);
+      if ((lane & 15) == 0) atomicAdd(p.dBias + bz * p.sdBias + n0 + wave * 32 + ci * 8 + j, sj);
+    }
+  }
+}
+
 template <auto Kern>
 int set_smem_bytes(int bytes) {
   static bool done = false;
@@ -688,11 +824,35 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
   hma_gemm_tn_t q = *p;
   const int64_t slabs = (q.M + 63) / 64;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  static const bool tn_v1 = getenv("HMA_GEMM_TN_V1") != nullptr;
+  if (!tn_v1 && q.N % WT == 0 && q.K % WT == 0) {
+    const int gn = (int)(q.N / WT), gk = (int)(q.K / WT);
+    const int nb = q.batch > 0 ? q.batch : 1;
+    int splits = 256 / (gn * gk * nb);  // one resident workgroup per CU
+    if (splits < 1) splits = 1;
+    if (splits > slabs) splits = (int)slabs;
+    q.splits = splits;
+    const dim3 wgrid((unsigned)(gn * gk * nb * splits));
+#define HMA_TNW_CASE(YK, AK)                                                                        \
+  if (q.y_kind == YK && q.a_kind == AK) {                                                            \
+    if ((rc = set_smem_bytes<gemm_tn_wide_kernel<YK, AK>>(W_SMEM_BYTES))) return rc;                 \
+    hipLaunchKernelGGL((gemm_tn_wide_kernel<YK, AK>), wgrid, dim3(512), W_SMEM_BYTES, s, q, gn, gk); \
+    HMA_CHECK_LAUNCH();                                                                              \
+    return 0;                                                                                        \
+  }
+    HMA_TNW_CASE(HMA_A_BF16, HMA_A_BF16)
+    HMA_TNW_CASE(HMA_A_BF16, HMA_A_F32)
+    HMA_TNW_CASE(HMA_A_BF16, HMA_A_BF16_AFFINE)
+    HMA_TNW_CASE(HMA_A_F32, HMA_A_BF16)
+    HMA_TNW_CASE(HMA_A_F32, HMA_A_F32)
+    HMA_TNW_CASE(HMA_A_F32, HMA_A_BF16_AFFINE)
+    return HMA_EINVAL;
+  }
   if (q.splits <= 0) q.splits = 1;
   if (q.splits > slabs) q.splits = (int32_t)slabs;
   const dim3 grid((unsigned)q.splits, (unsigned)((q.N / 128) * (q.K / 128)), (unsigned)(q.batch > 0 ? q.batch : 1));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int rc;
   HMA_TN_CASE(HMA_A_BF16, HMA_A_BF16)
   HMA_TN_CASE(HMA_A_BF16, HMA_A_F32)
   HMA_TN_CASE(HMA_A_BF16, HMA_A_BF16_AFFINE)
