@@ -15,6 +15,7 @@
 #include "../../include/hma_hip.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace hma;
 
@@ -50,8 +51,8 @@ __device__ __forceinline__ int64_t remap_row(int64_t r, int64_t group_rows, int6
 }
 
 // One accumulator quad: 4 consecutive output columns n..n+3 of (remapped) row crow; bias already added.
-__device__ __forceinline__ void epilogue_quad(const hma_gemm_nt_t& p, int64_t bz, int64_t crow, int64_t n, float (&v)[4]) {
-  switch (p.epi) {
+__device__ __forceinline__ void epilogue_quad(const hma_gemm_nt_t& p, const int epi, int64_t bz, int64_t crow, int64_t n, float (&v)[4]) {
+  switch (epi) {
     case HMA_EPI_BF16: {
       uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
       *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -79,7 +80,7 @@ __device__ __forceinline__ void epilogue_quad(const hma_gemm_nt_t& p, int64_t bz
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         u[e] = from_bf16(to_bf16(v[e]));
-        a[e] = p.epi == HMA_EPI_GELU2 ? gelu_f(u[e]) : silu_f(u[e]);
+        a[e] = epi == HMA_EPI_GELU2 ? gelu_f(u[e]) : silu_f(u[e]);
       }
       *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(u[0], u[1]), pack_bf16(u[2], u[3]));
       *reinterpret_cast<uint2*>(C2) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
@@ -90,7 +91,7 @@ __device__ __forceinline__ void epilogue_quad(const hma_gemm_nt_t& p, int64_t bz
       const uint2 uu = *reinterpret_cast<const uint2*>(U);
       const float u[4] = {bf16_lo(uu.x), bf16_hi(uu.x), bf16_lo(uu.y), bf16_hi(uu.y)};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= (p.epi == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
+      for (int e = 0; e < 4; ++e) v[e] *= (epi == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
       uint16_t* C = reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n;
       *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
     } break;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(hma_gemm_nt_t p) {
           const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
           v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
         }
-        epilogue_quad(p, bz, crow, n, v);
+        epilogue_quad(p, p.epi, bz, crow, n, v);
       }
     }
   }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(hma_gemm_nt_t p
               const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
               v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
             }
-            epilogue_quad(p, bz, crow, n, v);
+            epilogue_quad(p, p.epi, bz, crow, n, v);
           }
       }
     }
@@ -391,13 +392,201 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(hma_gemm_nt_t p
   if (total_it > 1) load(r1);
   store(r0, 0);
   __syncthreads();
+  const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
   auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
     // `mine` held step `it` (already in LDS) and is free: refill it with step it + 2
-    if (it + 2 < total_it) load(mine);
+    if (it + 2 < total_it && !(ablate & 2)) load(mine);
     const uint16_t* As = smem + (it & 1) * P_STAGE;
-    mma_tile(As, As + P_A, acc, wm, wn, lane);
+    if (!(ablate & 4)) mma_tile(As, As + P_A, acc, wm, wn, lane);
     if (++cur_kt == KT) {
-      finish_tile();
+      if (!(ablate & 1)) finish_tile();
+      cur_kt = 0;
+      cur_tile += G;
+    }
+    if (it + 1 < total_it) store(other, (it + 1) & 1);
+    __syncthreads();
+  };
+  for (int it = 0; it < total_it; it += 2) {
+    step(it, r0, r1);
+    if (it + 1 < total_it) step(it + 1, r1, r0);
+  }
+}
+
+// --------------------------------------------------------------------- NT, persistent, 2 per CU
+// Measured on MI355X (tools/ablate.sh): with one 8-wave workgroup per CU the epilogue of a tile (its
+// HBM stores, at ~5 TB/s aggregate, plus the GELU VALU work) and the MFMA main loop (~1 PFLOP/s without
+// it) simply add up, because every wave of the CU is in the same phase.  This variant keeps the same
+// 128 x 256 tile and cross-tile software pipeline but runs it with 4 waves (each 64 x 128, 128
+// accumulator VGPRs), 32-deep K-steps and 60 KB of LDS, so TWO workgroups are resident per CU and one's
+// store/VALU epilogue overlaps the other's MFMA phase.
+constexpr int QM = 128, QN = 256, QK = 32, QLD = 40;
+constexpr int Q_A = QM * QLD, Q_W = QN * QLD, Q_STAGE = Q_A + Q_W;
+constexpr int Q_SMEM_BYTES = 2 * Q_STAGE * 2;  // 61440 B
+
+
+template <int AKIND, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int tiles_m, int tiles_n, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int KT = (int)(p.K / QK);
+  const int kc = tid & 3;
+  const int srow = tid >> 2;  // 0..63
+
+  const int G = gridDim.x;
+  const int b = blockIdx.x;
+  const int vid = ((G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+  const int my_tiles = vid < total_tiles ? (total_tiles - vid + G - 1) / G : 0;
+  const int total_it = my_tiles * KT;
+  if (total_it == 0) return;
+
+  struct Cursor { int tile; int kt; int64_t a_off[2]; int64_t w_off; int64_t bz; };
+  auto decode = [&](Cursor& c) {
+    const int per_b = tiles_m * tiles_n;
+    c.bz = c.tile / per_b;
+    const int r = c.tile % per_b;
+    const int mt = r / tiles_n, nt = r % tiles_n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t gr = (int64_t)mt * QM + srow + i * 64;
+      c.a_off[i] = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
+    }
+    c.w_off = ((int64_t)nt * QN + srow) * p.ldw;
+  };
+  Cursor ld;
+  ld.tile = vid; ld.kt = 0;
+  decode(ld);
+
+  auto load = [&](PRegs<AKIND>& r) {
+    const int k0 = ld.kt * QK + kc * 8;
+    r.k0 = k0;
+    const char* Ab = reinterpret_cast<const char*>(p.A) + ld.bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + ld.bz * p.sW + ld.w_off + k0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.w[i] = *reinterpret_cast<const uint4*>(Wb + (int64_t)i * 64 * p.ldw);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      r.a_ok[i] = ld.a_off[i] >= 0;
+      if (r.a_ok[i]) {
+        if (AKIND == HMA_A_F32) {
+          const float* s = reinterpret_cast<const float*>(Ab) + ld.a_off[i] + k0;
+          r.a[i][0] = *reinterpret_cast<const uint4*>(s);
+          r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(s + 4);
+        } else {
+          r.a[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Ab) + ld.a_off[i] + k0);
+        }
+      } else {
+        r.a[i][0] = make_uint4(0, 0, 0, 0);
+        r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    if (++ld.kt == KT) {
+      ld.kt = 0;
+      ld.tile += G;
+      if (ld.tile < total_tiles) decode(ld);
+    }
+  };
+  auto store = [&](const PRegs<AKIND>& r, int buf) {
+    uint16_t* As = smem + buf * Q_STAGE;
+    uint16_t* Ws = As + Q_A;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&Ws[(srow + i * 64) * QLD + kc * 8]) = r.w[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint4 v;
+      if (AKIND == HMA_A_F32) {
+        const float4 lo = __builtin_bit_cast(float4, r.a[i][0]);
+        const float4 hi = __builtin_bit_cast(float4, r.a[i][AKIND == HMA_A_F32 ? 1 : 0]);
+        v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
+        v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
+      } else if (AKIND == HMA_A_BF16_AFFINE) {
+        float f[8];
+        unpack8(r.a[i][0], f);
+        if (r.a_ok[i]) {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + r.k0), g1 = *reinterpret_cast<const float4*>(p.gamma + r.k0 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(p.beta + r.k0), b1 = *reinterpret_cast<const float4*>(p.beta + r.k0 + 4);
+          f[0] = f[0] * g0.x + b0.x; f[1] = f[1] * g0.y + b0.y; f[2] = f[2] * g0.z + b0.z; f[3] = f[3] * g0.w + b0.w;
+          f[4] = f[4] * g1.x + b1.x; f[5] = f[5] * g1.y + b1.y; f[6] = f[6] * g1.z + b1.z; f[7] = f[7] * g1.w + b1.w;
+        }
+        v = pack8(f);
+      } else {
+        v = r.a[i][0];
+      }
+      *reinterpret_cast<uint4*>(&As[(srow + i * 64) * QLD + kc * 8]) = v;
+    }
+  };
+
+  f32x16_t acc[4][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+  };
+  zero_acc();
+
+  int cur_tile = vid, cur_kt = 0;
+  auto finish_tile = [&]() {
+    const int per_b = tiles_m * tiles_n;
+    const int64_t bz = cur_tile / per_b;
+    const int rr = cur_tile % per_b;
+    const int64_t bm = (int64_t)(rr / tiles_n) * QM, bn = (int64_t)(rr % tiles_n) * QN;
+    const int r = lane & 31, hi = lane >> 5;
+    const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int64_t m = bm + wm * 64 + mt * 32 + r;
+      if (m < p.M) {
+        const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int64_t n = bn + wn * 128 + nt * 32 + 8 * g + 4 * hi;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * g + e];
+            if (bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+              v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            }
+            epilogue_quad(p, EPI, bz, crow, n, v);
+          }
+      }
+    }
+    zero_acc();
+  };
+  const int r = lane & 31, hi = lane >> 5;
+  const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+  PRegs<AKIND> r0, r1;
+  load(r0);
+  if (total_it > 1) load(r1);
+  store(r0, 0);
+  __syncthreads();
+  auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
+    if (it + 2 < total_it && !(ablate & 2)) load(mine);
+    const uint16_t* As = smem + (it & 1) * Q_STAGE;
+    const uint16_t* Ws = As + Q_A;
+    if (!(ablate & 4)) {
+#pragma unroll
+      for (int kk = 0; kk < QK / 16; ++kk) {
+        bf16x8_t wf[4], tf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          wf[i] = *reinterpret_cast<const bf16x8_t*>(&Ws[(wn * 128 + i * 32 + r) * QLD + kk * 16 + hi * 8]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          tf[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 64 + i * 32 + r) * QLD + kk * 16 + hi * 8]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mfma32(wf[nt], tf[mt], acc[nt][mt]);
+      }
+    }
+    if (++cur_kt == KT) {
+      if (!(ablate & 1)) finish_tile();
       cur_kt = 0;
       cur_tile += G;
     }
@@ -772,11 +961,33 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HMA_EINVAL;
       n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    static const int ablate = getenv("HMA_GEMM_ABLATE") ? atoi(getenv("HMA_GEMM_ABLATE")) : 0;
+    static const bool use_p1 = getenv("HMA_GEMM_NT_P1") != nullptr;
+    hma_gemm_nt_t pa = *p;
+    pa._pad2 = ablate;
+    if (!use_p1 && p->K % QK == 0) {
+      const dim3 qgrid((unsigned)(total < 2 * n_cu ? total : 2 * n_cu));
+#define HMA_NTQ_CASE(AK, EP)                                                                          \
+  if (p->a_kind == AK && p->epi == EP) {                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_p2_kernel<AK, EP>>(Q_SMEM_BYTES))) return rc;                    \
+    hipLaunchKernelGGL((gemm_nt_p2_kernel<AK, EP>), qgrid, dim3(256), Q_SMEM_BYTES, s, pa, tiles_m, tiles_n, total); \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+#define HMA_NTQ_ALL(AK)                                                                               \
+  HMA_NTQ_CASE(AK, HMA_EPI_BF16) HMA_NTQ_CASE(AK, HMA_EPI_F32) HMA_NTQ_CASE(AK, HMA_EPI_RESID)        \
+  HMA_NTQ_CASE(AK, HMA_EPI_GELU2) HMA_NTQ_CASE(AK, HMA_EPI_SILU2) HMA_NTQ_CASE(AK, HMA_EPI_DGELU)     \
+  HMA_NTQ_CASE(AK, HMA_EPI_DSILU) HMA_NTQ_CASE(AK, HMA_EPI_ATOMIC_F32)
+      HMA_NTQ_ALL(HMA_A_BF16)
+      HMA_NTQ_ALL(HMA_A_F32)
+      HMA_NTQ_ALL(HMA_A_BF16_AFFINE)
+      return HMA_EINVAL;
+    }
     const dim3 pgrid((unsigned)(total < n_cu ? total : n_cu));
 #define HMA_NTP_CASE(AK)                                                                              \
   case AK:                                                                                            \
     if ((rc = set_smem_bytes<gemm_nt_persist_kernel<AK>>(P_SMEM_BYTES))) return rc;                   \
-    hipLaunchKernelGGL(gemm_nt_persist_kernel<AK>, pgrid, dim3(512), P_SMEM_BYTES, s, *p, tiles_m, tiles_n, total); \
+    hipLaunchKernelGGL(gemm_nt_persist_kernel<AK>, pgrid, dim3(512), P_SMEM_BYTES, s, pa, tiles_m, tiles_n, total); \
     break;
     switch (p->a_kind) {
       HMA_NTP_CASE(HMA_A_BF16)
