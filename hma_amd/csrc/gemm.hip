@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
     zero_acc();
   };
   const int r = lane & 31, hi = lane >> 5;
-  const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+  const int ablate = p._pad2 & 7;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
   PRegs<AKIND> r0, r1;
   load(r0);
   if (total_it > 1) load(r1);
