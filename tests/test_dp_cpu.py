@@ -1,0 +1,123 @@
+"""N > 1 path on CPU: the flat layout, bucket plan and the sparse-by-domain gradient all-reduce
+(world_size 2, gloo).  The same GradReducer runs over RCCL on the GPU box."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hma_amd.config import GenieConfig
+from hma_amd.params import ALIGN, ParamLayout
+from hma_amd.train import GradReducer, lr_at
+from oracle.param_spec import state_dict_spec
+from tests.golden.golden_cfg import TINY
+from tests.helpers import tiny_ref_config
+
+
+def make_layout(num_layers=4, domains=("domA", "domB", "domC"), d_actions=(7, 14, 21)):
+    cfg = GenieConfig(**{**TINY["config"], "num_layers": num_layers})
+    return cfg, ParamLayout(cfg, list(domains), list(d_actions), [7] * len(domains))
+
+
+def test_layout_matches_reference_state_dict_and_is_aligned():
+    cfg, lay = make_layout(2, TINY["domains"], TINY["d_actions"])
+    spec = state_dict_spec(tiny_ref_config(), TINY["domains"], TINY["d_actions"], [7, 7])
+    params = {k: v for k, v in spec.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    assert set(lay.entries) == set(params)
+    spans = []
+    for name, e in lay.entries.items():
+        assert tuple(params[name]) == e.shape, name
+        assert e.offset % ALIGN == 0
+        spans.append((e.offset, e.offset + e.numel))
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0, "views overlap"
+    assert spans[-1][1] <= lay.total
+    # constant per-layer stride, layers stored L-1 .. 0 (backward-completion order)
+    assert lay.off("decoder.layers.0.mlp.fc1.weight") - lay.off("decoder.layers.1.mlp.fc1.weight") == lay.layer_stride > 0
+    # per-domain adaLN stacks are type-major with a constant layer stride (batched GEMMs)
+    a = lay.off("decoder.layers.0.action_projectors.domA.adaLN_modulation.2.weight")
+    b = lay.off("decoder.layers.1.action_projectors.domA.adaLN_modulation.2.weight")
+    assert b - a == 512 * 256
+
+
+def test_decay_flags_follow_the_reference_grouping():
+    _, lay = make_layout(2, TINY["domains"], TINY["d_actions"])
+    flags = lay.decay_flags()
+    for name, e in lay.entries.items():
+        f = int(flags[e.offset // ALIGN])
+        if e.region == "frozen":
+            assert f == 0, name
+        else:
+            assert f == (1 if "bias" in name else 2), name  # train_multi.py:907-918: only "bias" names are un-decayed
+    assert int(flags[lay.off("decoder.layers.0.norm1.weight") // ALIGN]) == 2  # LN weights ARE decayed
+
+
+@pytest.mark.parametrize("lpb", [1, 3, 8])
+def test_buckets_tile_the_dense_region_in_backward_order(lpb):
+    _, lay = make_layout(4)
+    buckets = lay.buckets(lpb)
+    assert buckets[0][0] == lay.regions["head"][0]
+    assert buckets[-1][1] == lay.regions["layer0"][1] == lay.regions["tail"][0]
+    for (a0, a1), (b0, b1) in zip(buckets, buckets[1:]):
+        assert a1 == b0 and a0 < a1
+    ranges = lay.trainable_ranges(["domB"])
+    assert ranges[0] == (lay.regions["head"][0], lay.regions["tail"][1])
+    assert ranges[1:] == [lay.regions["dom:domB"]]
+
+
+def test_lr_schedule_constant_with_warmup():
+    assert lr_at(0, 1e-4, 500) == pytest.approx(1e-4 / 500)
+    assert lr_at(499, 1e-4, 500) == pytest.approx(1e-4)
+    assert lr_at(10_000, 1e-4, 500) == 1e-4
+    assert lr_at(3, 2e-4, 0) == 2e-4
+
+
+def _worker(rank, world, port, lpb, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, lay = make_layout(4)
+        G = torch.zeros(lay.total)
+        red = GradReducer(lay, G, layers_per_bucket=lpb)
+        local = ["domC", "domA"][rank]  # ranks hold different domains; domB is idle everywhere
+        active = red.active_domains(local)
+        assert active == ["domA", "domC"], active
+        # what a rank's backward leaves in G: dense range + its own domain block, zeros elsewhere
+        dense = lay.trainable_ranges([])[0]
+        G[dense[0]:dense[1]] = torch.arange(dense[1] - dense[0], dtype=torch.float32) * (rank + 1) * 1e-3
+        a, b = lay.regions[f"dom:{local}"]
+        G[a:b] = float(rank + 1)
+        red.begin()
+        L = cfg.num_layers
+        for l in reversed(range(L)):           # the labels STEngine.backward emits with segment_layers = lpb
+            if (L - l) % lpb == 0 or l == 0:
+                red.on_segment(f"layer{l}")
+        red.on_segment("end")
+        red.finish(active)
+        exp = torch.zeros(lay.total)
+        exp[dense[0]:dense[1]] = torch.arange(dense[1] - dense[0], dtype=torch.float32) * 3e-3  # ranks 1x + 2x
+        a, b = lay.regions["dom:domC"]
+        exp[a:b] = 1.0   # only rank 0 had domC
+        a, b = lay.regions["dom:domA"]
+        exp[a:b] = 2.0   # only rank 1 had domA
+        ok = torch.allclose(G, exp, rtol=1e-6, atol=0)
+        idle = lay.regions["dom:domB"]
+        ok = ok and float(G[idle[0]:idle[1]].abs().sum()) == 0.0
+        fr = lay.regions["frozen"]
+        ok = ok and float(G[fr[0]:fr[1]].abs().sum()) == 0.0
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lpb", [1, 3])
+def test_sparse_by_domain_allreduce_world2_gloo(lpb):
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + lpb
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, lpb, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
