@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into profiles-ready summaries (per-kernel time, HBM bytes per launch)."""
+import csv, glob, os, sys, collections, json
+
+out, tag = sys.argv[1], sys.argv[2]
+summary = {}
+stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, f"kernel_stats_{tag}.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for r in rows[:40]:
+            w.writerow([r.get("Name"), r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")])
+    for r in rows[:12]:
+        print(f"{float(r['Percentage']):6.2f}%  {int(r['Calls']):6d} x {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:90]}")
+for kind in ("fetch", "write"):
+    files = glob.glob(os.path.join(out, f"pmc_{kind}", "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(files[0])):
+        name = r.get("Kernel_Name", "")
+        agg[name][0] += 1
+        agg[name][1] += float(r.get("Counter_Value", 0) or 0)
+    summary[kind] = {k: {"launches": v[0], "counter_sum_kb": v[1]} for k, v in agg.items()}
+if summary:
+    json.dump(summary, open(os.path.join(out, f"pmc_{tag}.json"), "w"), indent=1)
+    for kind, d in summary.items():
+        top = sorted(d.items(), key=lambda kv: -kv[1]["counter_sum_kb"])[:8]
+        for k, v in top:
+            print(f"{kind:6s} {v['counter_sum_kb']/max(v['launches'],1)/1024:10.1f} MB/launch (raw counter, KB units) x {v['launches']:5d}  {k[:80]}")
