@@ -412,6 +412,84 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(hma_gemm_nt_t p
   }
 }
 
+// Two adjacent accumulator quads (columns nq + 8*g2 + 4*hi + {0..3} and the same for g2 + 1) of one row.
+// Measured (tools/probes/store_pattern.hip): 8-byte-per-lane stores at a row stride reach 3.2-3.6 TB/s,
+// 16-byte ones 5.8-7.0 TB/s.  For bf16 outputs the two half-waves therefore trade quads with
+// v_permlane32_swap so that every lane owns 8 consecutive bf16 = one 16-byte access: lane (r, hi = 0)
+// ends with columns 8*g2 .. +7, lane (r, hi = 1) with 8*(g2+1) .. +7.  The swap is an involution, so the
+// same exchange turns a 16-byte load back into the lane's own two quads.
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+__device__ __forceinline__ void store_bf16_oct(uint16_t* row_q, int g2, int hi, const float (&v0)[4], const float (&v1)[4]) {
+  uint32_t ax = pack_bf16(v0[0], v0[1]), ay = pack_bf16(v0[2], v0[3]);
+  uint32_t bx = pack_bf16(v1[0], v1[1]), by = pack_bf16(v1[2], v1[3]);
+  swap_halves(ax, bx);
+  swap_halves(ay, by);
+  *reinterpret_cast<uint4*>(row_q + 8 * (g2 + hi)) = make_uint4(ax, ay, bx, by);
+}
+__device__ __forceinline__ void load_bf16_oct(const uint16_t* row_q, int g2, int hi, float (&u0)[4], float (&u1)[4]) {
+  uint4 q = *reinterpret_cast<const uint4*>(row_q + 8 * (g2 + hi));
+  swap_halves(q.x, q.z);
+  swap_halves(q.y, q.w);
+  u0[0] = bf16_lo(q.x); u0[1] = bf16_hi(q.x); u0[2] = bf16_lo(q.y); u0[3] = bf16_hi(q.y);
+  u1[0] = bf16_lo(q.z); u1[1] = bf16_hi(q.z); u1[2] = bf16_lo(q.w); u1[3] = bf16_hi(q.w);
+}
+
+// row_q pointers address column nq (the 32-wide MFMA tile's first column) of the output row
+template <int EPI>
+__device__ __forceinline__ void epilogue_oct(const hma_gemm_nt_t& p, int64_t bz, int64_t crow, int64_t nq, int g2, int hi,
+                                             float (&v0)[4], float (&v1)[4]) {
+  if (EPI == HMA_EPI_BF16) {
+    store_bf16_oct(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + nq, g2, hi, v0, v1);
+  } else if (EPI == HMA_EPI_F32) {
+    float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + nq + 8 * g2 + 4 * hi;
+    *reinterpret_cast<float4*>(C) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    *reinterpret_cast<float4*>(C + 8) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+  } else if (EPI == HMA_EPI_RESID) {
+    float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + nq + 8 * g2 + 4 * hi;
+    float4 x0 = *reinterpret_cast<float4*>(C), x1 = *reinterpret_cast<float4*>(C + 8);
+    x0.x += v0[0]; x0.y += v0[1]; x0.z += v0[2]; x0.w += v0[3];
+    x1.x += v1[0]; x1.y += v1[1]; x1.z += v1[2]; x1.w += v1[3];
+    *reinterpret_cast<float4*>(C) = x0;
+    *reinterpret_cast<float4*>(C + 8) = x1;
+    if (p.C2) {
+      const float a[4] = {x0.x, x0.y, x0.z, x0.w}, b[4] = {x1.x, x1.y, x1.z, x1.w};
+      store_bf16_oct(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + nq, g2, hi, a, b);
+    }
+  } else if (EPI == HMA_EPI_GELU2 || EPI == HMA_EPI_SILU2) {
+    // the saved pre-activation is bf16: activate the ROUNDED value so backward sees the same u
+    float u0[4], u1[4], a0[4], a1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u0[e] = from_bf16(to_bf16(v0[e]));
+      u1[e] = from_bf16(to_bf16(v1[e]));
+      a0[e] = EPI == HMA_EPI_GELU2 ? gelu_f(u0[e]) : silu_f(u0[e]);
+      a1[e] = EPI == HMA_EPI_GELU2 ? gelu_f(u1[e]) : silu_f(u1[e]);
+    }
+    store_bf16_oct(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + nq, g2, hi, u0, u1);
+    store_bf16_oct(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + nq, g2, hi, a0, a1);
+  } else if (EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) {
+    float u0[4], u1[4];
+    load_bf16_oct(reinterpret_cast<const uint16_t*>(p.U) + bz * p.sU + crow * p.ldu + nq, g2, hi, u0, u1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v0[e] *= (EPI == HMA_EPI_DGELU ? dgelu_f(u0[e]) : dsilu_f(u0[e]));
+      v1[e] *= (EPI == HMA_EPI_DGELU ? dgelu_f(u1[e]) : dsilu_f(u1[e]));
+    }
+    store_bf16_oct(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + nq, g2, hi, v0, v1);
+  } else {
+    float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + nq + 8 * g2 + 4 * hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(C + e, v0[e]);
+      atomicAdd(C + 8 + e, v1[e]);
+    }
+  }
+}
+
 // --------------------------------------------------------------------- NT, persistent, 2 per CU
 // Measured on MI355X (tools/ablate.sh): with one 8-wave workgroup per CU the epilogue of a tile (its
 // HBM stores, at ~5 TB/s aggregate, plus the GELU VALU work) and the MFMA main loop (~1 PFLOP/s without
@@ -543,16 +621,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int64_t n = bn + wn * 128 + nt * 32 + 8 * g + 4 * hi;
-            float v[4];
+          for (int g2 = 0; g2 < 4; g2 += 2) {
+            const int64_t nq = bn + wn * 128 + nt * 32;
+            float v0[4], v1[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * g + e];
-            if (bias) {
-              const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-              v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = acc[nt][mt][4 * g2 + e];
+              v1[e] = acc[nt][mt][4 * g2 + 4 + e];
             }
-            epilogue_quad(p, EPI, bz, crow, n, v);
+            if (bias) {
+              const float4 b0 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 4 * hi);
+              const float4 b1 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 8 + 4 * hi);
+              v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+              v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+            }
+            epilogue_oct<EPI>(p, bz, crow, nq, g2, hi, v0, v1);
           }
       }
     }
