@@ -42,6 +42,7 @@ class GemmTN(C.Structure):
         ("dW", c_vp), ("lddw", c_i64), ("dBias", c_vp),
         ("splits", c_i32), ("batch", c_i32),
         ("sY", c_i64), ("sA", c_i64), ("sdW", c_i64), ("sdBias", c_i64),
+        ("ws", c_vp), ("ws_elems", c_i64),
     ]
 
 

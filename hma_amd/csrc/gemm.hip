@@ -964,8 +964,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
     __syncthreads();
   }
 
-  // D rows = n, D cols = k.  Rotate the tile order by the split index so concurrent workgroups hit
-  // different addresses with their atomics.
+  // D rows = n, D cols = k.
+  if (p.ws) {
+    // two-stage reduction: plain coalesced stores of this workgroup's 256 x 256 partial; tn_reduce_kernel
+    // sums the splits.  (Device-scope fp32 atomics from 256 workgroups onto the same 64 K addresses cost
+    // more than the whole main loop for the d_model-sized layers.)
+    float* part = p.ws + (int64_t)vid * (WT * WT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kl = wk4 * 64 + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[(wn2 * 128 + i * 32 + mfma32_row(e, hi)) * WT + kl] = acc[i][j][e];
+      }
+  } else {
+  // Rotate the tile order by the split index so concurrent workgroups hit different addresses with
+  // their atomics.
   float* dW = p.dW + bz * p.sdW;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -986,6 +1001,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
       atomicAdd(dW + n * p.lddw + k, v[e]);
     }
   }
+  }
   if (do_bias) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -996,6 +1012,36 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
       sj += __shfl_xor(sj, 8, 64);
       if ((lane & 15) == 0) atomicAdd(p.dBias + bz * p.sdBias + n0 + wave * 32 + ci * 8 + j, sj);
     }
+  }
+}
+
+// dW[bz][n0 + nl][k0 + kl] += sum over splits of ws[((bz * splits + s) * groups + g)][nl][kl]
+// 256 workgroups per 256 x 256 block: 64 lanes x float4 = 256 outputs each, the splits dealt over the 4 waves.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int groups_n, int groups_k) {
+  __shared__ float4 red[4][64];
+  const int groups = groups_n * groups_k;
+  const int g = blockIdx.y % groups;
+  const int64_t bz = blockIdx.y / groups;
+  const int64_t n0 = (int64_t)(g / groups_k) * WT, k0 = (int64_t)(g % groups_k) * WT;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int idx = (blockIdx.x * 64 + lane) * 4;  // 4 consecutive k of one n row
+  const int nl = idx / WT, kl = idx % WT;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* base = p.ws + (bz * p.splits * groups + g) * (int64_t)(WT * WT) + idx;
+#pragma unroll 4
+  for (int sp = w; sp < p.splits; sp += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)sp * groups * (WT * WT));
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    const float4 a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
+    float4* dst = reinterpret_cast<float4*>(p.dW + bz * p.sdW + (n0 + nl) * p.lddw + k0 + kl);
+    float4 o = *dst;
+    o.x += acc.x + a1.x + a2.x + a3.x; o.y += acc.y + a1.y + a2.y + a3.y;
+    o.z += acc.z + a1.z + a2.z + a3.z; o.w += acc.w + a1.w + a2.w + a3.w;
+    *dst = o;
   }
 }
 
@@ -1128,12 +1174,22 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     if (splits < 1) splits = 1;
     if (splits > slabs) splits = (int)slabs;
     q.splits = splits;
-    const dim3 wgrid((unsigned)(gn * gk * nb * splits));
+    const int nblocks = gn * gk * nb * splits;
+    const dim3 wgrid((unsigned)nblocks);
+    // the workspace path needs every split to own a full slice (no early-exit workgroups) and a grid the
+    // XCD remap leaves in (batch, split, group) order
+    const int64_t per = (slabs + splits - 1) / splits;
+    if (q.ws && (q.ws_elems < (int64_t)nblocks * WT * WT || per * (splits - 1) >= slabs || splits == 1)) q.ws = nullptr;
+    const dim3 rgrid((unsigned)(WT * WT / 256), (unsigned)(gn * gk * nb));
 #define HMA_TNW_CASE(YK, AK)                                                                        \
   if (q.y_kind == YK && q.a_kind == AK) {                                                            \
     if ((rc = set_smem_bytes<gemm_tn_wide_kernel<YK, AK>>(W_SMEM_BYTES))) return rc;                 \
     hipLaunchKernelGGL((gemm_tn_wide_kernel<YK, AK>), wgrid, dim3(512), W_SMEM_BYTES, s, q, gn, gk); \
     HMA_CHECK_LAUNCH();                                                                              \
+    if (q.ws) {                                                                                      \
+      hipLaunchKernelGGL(tn_reduce_kernel, rgrid, dim3(256), 0, s, q, gn, gk);                       \
+      HMA_CHECK_LAUNCH();                                                                            \
+    }                                                                                                \
     return 0;                                                                                        \
   }
     HMA_TNW_CASE(HMA_A_BF16, HMA_A_BF16)

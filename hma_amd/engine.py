@@ -31,6 +31,8 @@ BF16, F32 = torch.bfloat16, torch.float32
 class Plan:
     """A recorded sequence of C-ABI launches with fixed arguments; `run` replays it on a stream."""
 
+    tn_workspace: Optional[torch.Tensor] = None  # scratch for the two-stage weight-gradient reduction
+
     def __init__(self):
         self.calls: List[Tuple[Callable, str, tuple]] = []
         self.flops: List[float] = []   # algorithmic FLOPs of each call (0 for non-GEMM launches)
@@ -47,6 +49,9 @@ class Plan:
         self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
 
     def gemm_tn(self, **kw) -> None:
+        if Plan.tn_workspace is not None:
+            kw.setdefault("ws", Plan.tn_workspace.data_ptr())
+            kw.setdefault("ws_elems", Plan.tn_workspace.numel())
         g = make_gemm_tn(**kw)
         self.keep.append(g)
         self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
@@ -144,6 +149,8 @@ class STEngine:
         self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
         self.grad_scale = C.c_float(1.0)
         self.timer: Optional[LaunchTimer] = None
+        if Plan.tn_workspace is None or Plan.tn_workspace.device != self.device:
+            Plan.tn_workspace = torch.empty(256 * 65536, dtype=F32, device=self.device)  # 64 MB
 
     # ------------------------------------------------------------------------------ pointers
     def _p(self, name: str) -> int:

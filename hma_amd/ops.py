@@ -57,7 +57,7 @@ def make_gemm_nt(*, A: int, lda: int, a_kind: int, W: int, ldw: int, M: int, N: 
 def make_gemm_tn(*, dY: int, ldy: int, y_kind: int, A: int, lda: int, a_kind: int, M: int, N: int, K: int, dW: int,
                  lddw: int, dBias: Optional[int] = None, gamma: Optional[int] = None, beta: Optional[int] = None,
                  y_group=(0, 0), a_group=(0, 0), splits: int = 0, batch: int = 1, sY: int = 0, sA: int = 0, sdW: int = 0,
-                 sdBias: int = 0) -> GemmTN:
+                 sdBias: int = 0, ws: Optional[int] = None, ws_elems: int = 0) -> GemmTN:
     g = GemmTN()
     g.dY, g.ldy, g.y_kind = dY, ldy, y_kind
     g.y_group_rows, g.y_group_stride = y_group
@@ -71,6 +71,7 @@ def make_gemm_tn(*, dY: int, ldy: int, y_kind: int, A: int, lda: int, a_kind: in
         splits = max(1, min((M + 63) // 64, 1024 // max(tiles, 1)))
     g.splits, g.batch = splits, batch
     g.sY, g.sA, g.sdW, g.sdBias = sY, sA, sdW, sdBias
+    g.ws, g.ws_elems = ws, ws_elems
     return g
 
 
@@ -95,12 +96,13 @@ def linear(x: torch.Tensor, w_bf16: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None, *,
-                 gamma=None, beta=None, splits: int = 0) -> None:
+                 gamma=None, beta=None, splits: int = 0, ws: Optional[torch.Tensor] = None) -> None:
     """dW (N, K) fp32 += dy^T x' ; dbias += column sums of dy."""
     M, N = dy.shape
     K = x.shape[1]
     g = make_gemm_tn(dY=ptr(dy), ldy=N, y_kind=_kind(dy), A=ptr(x), lda=K, a_kind=_kind(x, gamma is not None), M=M, N=N,
-                     K=K, dW=ptr(dW), lddw=K, dBias=ptr(dbias), gamma=ptr(gamma), beta=ptr(beta), splits=splits)
+                     K=K, dW=ptr(dW), lddw=K, dBias=ptr(dbias), gamma=ptr(gamma), beta=ptr(beta), splits=splits,
+                     ws=ptr(ws), ws_elems=0 if ws is None else ws.numel())
     _lib.call("hma_gemm_tn", stream_ptr(), C.byref(g))
 
 

@@ -72,6 +72,9 @@ typedef struct {
   float* dW; int64_t lddw; float* dBias;
   int32_t splits; int32_t batch;
   int64_t sY, sA, sdW, sdBias;
+  /* optional scratch for a two-stage (atomic-free) reduction of the M-splits: >= 256 * 65536 floats
+   * covers every shape of this model; NULL or too small -> fp32 atomics */
+  float* ws; int64_t ws_elems;
 } hma_gemm_tn_t;
 int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p);
 

@@ -27,9 +27,10 @@ def nt(name, a, w, epi, bias=None, out=None, out2=None, aux=None, gamma=None, be
     ms = timeit(fn)
     fl = 2.0 * a.shape[0] * w.shape[0] * w.shape[1]
     rows.append((name, ms * 1e3, fl / ms / 1e9))
+WS = torch.empty(256 * 65536, device=dev)
 def tn(name, dy, x, N, K, bias=True, gamma=None, beta=None):
     dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev) if bias else None
-    fn = lambda: ops.linear_wgrad(dy, x, dW, db, gamma=gamma, beta=beta)
+    fn = lambda: ops.linear_wgrad(dy, x, dW, db, gamma=gamma, beta=beta, ws=None if os.environ.get('TN_ATOMIC') else WS)
     ms = timeit(fn)
     rows.append((name, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
 
