@@ -64,7 +64,8 @@ _PROTOS = {
     "hma_action_stem_bwd": [c_vp] * 15 + [c_i64, c_i32],
     "hma_count_masked": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64],
     "hma_ce_fwd_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_i32, c_i64, c_f32],
-    "hma_maskgit_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64],
+    "hma_maskgit_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32],
+    "hma_attn_temporal_cached": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32],
     "hma_sqnorm": [c_vp, c_vp, c_i64, c_vp],
     "hma_adamw": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp],
     "hma_cast_bf16": [c_vp, c_vp, c_vp, c_i64],

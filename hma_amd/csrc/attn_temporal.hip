@@ -93,14 +93,14 @@ __device__ __forceinline__ void causal_softmax(float (&s)[TM], int t, int T) {
 }
 
 __global__ __launch_bounds__(128) void attn_t_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int T,
-                                                         int n_s, float c_log2) {
+                                                         int n_s, float c_log2, int64_t qkv_batch_rows) {
   __shared__ __attribute__((aligned(16))) uint16_t sm[TM * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, h = wave * 4 + (lane >> 4);
   const int64_t col = blockIdx.x;  // b * n_s + s
   const int64_t b = col / n_s, s_idx = col % n_s;
   const int64_t row0 = b * T * n_s + s_idx;
-  load_column(sm, LD, qkv, LD, LD / 8, row0, n_s, T, tid);
+  load_column(sm, LD, qkv, LD, LD / 8, b * qkv_batch_rows + s_idx, n_s, T, tid);
   __syncthreads();
   float out[32];
 #pragma unroll
@@ -220,6 +220,44 @@ __global__ __launch_bounds__(128) void attn_t_bwd_kernel(const uint16_t* __restr
   store_column(dqkv, LD, sm, LD, 0, LD / 8, row0, n_s, T, tid);
 }
 
+// Incremental decode: only frame t_query is new.  One lane per (column, head): q from the cache row of frame
+// t_query, K/V rows of frames 0..t_query streamed straight from the per-layer cache (64 B per head and frame).
+// Rows of the cache are (b, t, s) with T_cache frames per sample; o holds frame t_query only, rows (b, s).
+__global__ __launch_bounds__(64) void attn_t_decode_kernel(const uint16_t* __restrict__ cache, uint16_t* __restrict__ o,
+                                                           int64_t cols, int t_query, int T_cache, int n_s, float c_log2) {
+  const int lane = threadIdx.x;
+  const int64_t col = (int64_t)blockIdx.x * 8 + (lane >> 3);
+  const int h = lane & 7;
+  if (col >= cols) return;
+  const int64_t b = col / n_s, s_idx = col % n_s;
+  const uint16_t* base = cache + ((b * T_cache) * n_s + s_idx) * LD + h * 32;
+  uint32_t q[16];
+  ld16(base + (int64_t)t_query * n_s * LD, q);
+  float s[TM];
+#pragma unroll
+  for (int tp = 0; tp < TM; ++tp) {
+    s[tp] = 0.f;
+    if (tp <= t_query) {
+      uint32_t k[16];
+      ld16(base + (int64_t)tp * n_s * LD + DM, k);
+      s[tp] = dot32(q, k) * c_log2;
+    }
+  }
+  causal_softmax(s, t_query, t_query + 1);
+  float out[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) out[i] = 0.f;
+#pragma unroll
+  for (int tp = 0; tp < TM; ++tp) {
+    if (tp <= t_query) {
+      uint32_t v[16];
+      ld16(base + (int64_t)tp * n_s * LD + 2 * DM, v);
+      axpy32(out, s[tp], v);
+    }
+  }
+  st32(o + col * DM + h * 32, out, 1.0f);
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 
 }  // namespace
@@ -230,7 +268,26 @@ extern "C" int hma_attn_temporal_fwd(void* stream, const void* qkv, void* o, int
   if (T < 1 || T > TM || n_s < 1) return HMA_EINVAL;
   if (batch <= 0) return 0;
   hipLaunchKernelGGL(attn_t_fwd_kernel, dim3((unsigned)(batch * n_s)), dim3(128), 0, (hipStream_t)stream,
-                     (const uint16_t*)qkv, (uint16_t*)o, (int)T, (int)n_s, scale * LOG2E);
+                     (const uint16_t*)qkv, (uint16_t*)o, (int)T, (int)n_s, scale * LOG2E, (int64_t)T * n_s);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_attn_temporal_cached(void* stream, const void* qkv_cache, void* o, int64_t batch, int32_t T, int32_t t_query,
+                                        int32_t T_cache, int32_t n_s, float scale) {
+  if (!qkv_cache || !o) return HMA_EINVAL;
+  if (T_cache < 1 || T_cache > TM || n_s < 1 || T < 1 || T > T_cache) return HMA_EINVAL;
+  if (batch <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (t_query < 0) {  // prefill: all T frames attend causally, keys read from the cache layout
+    hipLaunchKernelGGL(attn_t_fwd_kernel, dim3((unsigned)(batch * n_s)), dim3(128), 0, s, (const uint16_t*)qkv_cache,
+                       (uint16_t*)o, (int)T, (int)n_s, scale * LOG2E, (int64_t)T_cache * n_s);
+  } else {
+    if (t_query >= T_cache) return HMA_EINVAL;
+    hipLaunchKernelGGL(attn_t_decode_kernel, dim3((unsigned)((batch * n_s + 7) / 8)), dim3(64), 0, s,
+                       (const uint16_t*)qkv_cache, (uint16_t*)o, batch * n_s, (int)t_query, (int)T_cache, (int)n_s,
+                       scale * LOG2E);
+  }
   HMA_CHECK_LAUNCH();
   return 0;
 }

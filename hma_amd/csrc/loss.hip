@@ -131,13 +131,13 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 __global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ logits, int64_t* __restrict__ prompt,
                                                       uint8_t* __restrict__ unmasked, const float* __restrict__ conf_override,
                                                       float* __restrict__ conf_out, int T, int S, int out_t, int n_mask, int last,
-                                                      int64_t mask_id) {
+                                                      int64_t mask_id, int logits_T, int logits_t) {
   extern __shared__ float sm[];              // conf[S] | sample[S] (as int)
   float* conf = sm;
   int* samp = reinterpret_cast<int*>(sm + S);
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const float* lg = logits + ((b * T + out_t) * (int64_t)S) * C;
+  const float* lg = logits + ((b * logits_T + logits_t) * (int64_t)S) * C;
   for (int s = w; s < S; s += 4) {
     int sample = 0;
     float c = 1.f;
@@ -217,13 +217,17 @@ extern "C" int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* 
 
 extern "C" int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
                                 const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
-                                int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id) {
+                                int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id, int32_t logits_T,
+                                int32_t logits_t) {
   if (!logits || !prompt || !unmasked) return HMA_EINVAL;
   if (S > 256 || out_t < 0 || out_t >= T) return HMA_EINVAL;  // one pass of 256 threads covers the frame
+  if (logits_T <= 0) { logits_T = T; logits_t = out_t; }
+  if (logits_t < 0 || logits_t >= logits_T) return HMA_EINVAL;
   if (B <= 0) return 0;
   const size_t smem = (size_t)S * 8;
   hipLaunchKernelGGL(maskgit_kernel, dim3((unsigned)B), dim3(256), smem, (hipStream_t)stream, logits, prompt, unmasked,
-                     conf_override, conf_out, (int)T, (int)S, (int)out_t, (int)n_mask, (int)last, mask_id);
+                     conf_override, conf_out, (int)T, (int)S, (int)out_t, (int)n_mask, (int)last, mask_id, (int)logits_T,
+                     (int)logits_t);
   HMA_CHECK_LAUNCH();
   return 0;
 }

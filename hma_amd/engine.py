@@ -145,6 +145,9 @@ class STEngine:
         self.gscale = torch.ones(1, dtype=F32, device=self.device)  # device-side loss-gradient scale
         self._ws: Dict[str, torch.Tensor] = {}
         self._ws_key = None
+        self._dws: Dict[str, torch.Tensor] = {}
+        self._dws_key = None
+        self._dplans: Dict[tuple, Plan] = {}
         self._plans: Dict[tuple, Plan] = {}
         self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
         self.grad_scale = C.c_float(1.0)
@@ -272,9 +275,53 @@ class STEngine:
     def _has(self, name: str) -> bool:
         return name in self.layout.entries
 
-    def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True) -> Plan:
+    def _emit_layer(self, pl: Plan, l: int, x: int, b: Dict[str, int], M: int, Fr: int, B: int, T: int, SA: int,
+                    use_mod: bool, domain: Optional[str], kv: Optional[dict] = None) -> None:
+        """One STBlock forward (st_transformer.py:79-114) on M rows = Fr frames of SA tokens.  `kv` redirects the
+        temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
+        "t_query": -1 | t, "T_cache": frames}."""
+        cfg = self.cfg
+        qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
+        pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
+        # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
+        pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
+        pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
+                   beta=self._lw(l, "norm1.bias", "p"), W=self._lw(l, "spatial_attn.qkv.weight"), ldw=256, M=M, N=768, K=256,
+                   epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=qb("spatial_attn"))
+        pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale)
+        pl.gemm_nt(A=b["o_s"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else b["x2b"], ldc2=256)
+        # action modulation: x += Lin(LN0(x) (1 + scale) + shift)   st_mask_git.py:66-76
+        if use_mod:
+            ap = f"decoder.layers.{l}.action_projectors.{domain}"
+            pl.add("hma_modln_fwd", x, b["ss"], b["xhm"], b["xm"], b["rstdm"], Fr, SA, 1e-6)
+            pl.gemm_nt(A=b["xm"], lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=b["x2b"], ldc2=256)
+        # temporal (causal, un-normed input)                st_transformer.py:111
+        if kv is None:
+            pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
+                       K=256, epi=EPI_BF16, Cp=b["qkv_t"], ldc=768, bias=qb("temporal_attn"))
+            pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale)
+        else:
+            pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
+                       K=256, epi=EPI_BF16, Cp=kv["cache"] + kv["row_off"] * 768 * 2, ldc=768, c_group=kv["c_group"],
+                       bias=qb("temporal_attn"))
+            pl.add("hma_attn_temporal_cached", kv["cache"], b["o_t"], B, T, kv["t_query"], kv["T_cache"], SA, self.scale)
+        pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"))
+        # MLP                                               st_transformer.py:112
+        pl.add("hma_ln_fwd", x, b["xh2"], b["rstd2"], M, 1e-5)
+        pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
+                   beta=self._lw(l, "norm2.bias", "p"), W=self._lw(l, "mlp.fc1.weight"), ldw=256, M=M, N=1024, K=256,
+                   epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024,
+                   bias=self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None)
+        pl.gemm_nt(A=b["hg"], lda=1024, a_kind=A_BF16, W=self._lw(l, "mlp.fc2.weight"), ldw=1024, M=M, N=256, K=1024,
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None)
+
+    def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True, kv_cache=None,
+                      T_cache=0) -> Plan:
         l1 = self.cfg.num_layers if l1 is None else l1
-        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout)
+        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else kv_cache.data_ptr())
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -283,6 +330,13 @@ class STEngine:
         pl = Plan()
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         sl = (lambda l: l) if train else (lambda l: 0)
+
+        def kv_for_layer(l):
+            if kv_cache is None:
+                return None
+            return {"cache": kv_cache[l].data_ptr(), "row_off": 0, "c_group": (T * (S + A), T_cache * (S + A)), "t_query": -1,
+                    "T_cache": T_cache}
+
         if A > 0:
             dom = domain
             am = f"action_mlp.{dom}.model"
@@ -310,44 +364,12 @@ class STEngine:
         x = ws["x"].data_ptr()
         for l in range(l0, l1):
             s = sl(l)
-            xh1, rstd1 = dp(ws["xh1"], s, M * 256), dp(ws["rstd1"], s, M)
-            qkv_s, o_s, lse_s = dp(ws["qkv_s"], s, M * 768), dp(ws["o_s"], s, M * 256), dp(ws["lse_s"], s, M * 8)
-            x2b = dp(ws["x2b"], s, M * 256)
-            qkv_t, o_t = dp(ws["qkv_t"], s, M * 768), dp(ws["o_t"], s, M * 256)
-            xh2, rstd2 = dp(ws["xh2"], s, M * 256), dp(ws["rstd2"], s, M)
-            u, hg = dp(ws["u"], s, M * 1024), dp(ws["hg"], s, M * 1024)
-            qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
-            pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
-            use_mod = A > 0 and self.modulate
-            # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
-            pl.add("hma_ln_fwd", x, xh1, rstd1, M, 1e-5)
-            pl.gemm_nt(A=xh1, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
-                       beta=self._lw(l, "norm1.bias", "p"), W=self._lw(l, "spatial_attn.qkv.weight"), ldw=256, M=M, N=768,
-                       K=256, epi=EPI_BF16, Cp=qkv_s, ldc=768, bias=qb("spatial_attn"))
-            pl.add("hma_attn_spatial_fwd", qkv_s, o_s, lse_s, Fr, SA, self.scale)
-            pl.gemm_nt(A=o_s, lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else x2b, ldc2=256)
-            # action modulation: x += Lin(LN0(x) (1 + scale) + shift)   st_mask_git.py:66-76
-            if use_mod:
-                xhm, xm, rstdm = dp(ws["xhm"], s, M * 256), dp(ws["xm"], s, M * 256), dp(ws["rstdm"], s, M)
-                ap = f"decoder.layers.{l}.action_projectors.{domain}"
-                pl.add("hma_modln_fwd", x, dp(ws["ss"], l, Fr * 512), xhm, xm, rstdm, Fr, SA, 1e-6)
-                pl.gemm_nt(A=xm, lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
-                           epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=x2b, ldc2=256)
-            # temporal (causal, un-normed input)                st_transformer.py:111
-            pl.gemm_nt(A=x2b, lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768, K=256,
-                       epi=EPI_BF16, Cp=qkv_t, ldc=768, bias=qb("temporal_attn"))
-            pl.add("hma_attn_temporal_fwd", qkv_t, o_t, B, T, SA, self.scale)
-            pl.gemm_nt(A=o_t, lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"))
-            # MLP                                               st_transformer.py:112
-            pl.add("hma_ln_fwd", x, xh2, rstd2, M, 1e-5)
-            pl.gemm_nt(A=xh2, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
-                       beta=self._lw(l, "norm2.bias", "p"), W=self._lw(l, "mlp.fc1.weight"), ldw=256, M=M, N=1024, K=256,
-                       epi=EPI_GELU2, Cp=u, ldc=1024, C2=hg, ldc2=1024,
-                       bias=self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None)
-            pl.gemm_nt(A=hg, lda=1024, a_kind=A_BF16, W=self._lw(l, "mlp.fc2.weight"), ldw=1024, M=M, N=256, K=1024,
-                       epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None)
+            bufs = {k: dp(ws[k], s, ws[k][0].numel()) for k in ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t",
+                                                                 "xh2", "rstd2", "u", "hg")}
+            if A > 0 and self.modulate:
+                bufs.update({k: dp(ws[k], s, ws[k][0].numel()) for k in ("xhm", "xm", "rstdm")})
+                bufs["ss"] = dp(ws["ss"], l, Fr * 512)
+            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l))
         # readout on the image tokens only                      st_mask_git.py:681-683
         if readout:
           pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,
@@ -520,14 +542,138 @@ class STEngine:
         return ws["x"].view(B, T, SA, D).clone()
 
     def maskgit_step(self, prompt_BTS: torch.Tensor, unmasked: torch.Tensor, out_t: int, n_mask: int, last: bool,
-                     conf_override: Optional[torch.Tensor] = None, conf_out: Optional[torch.Tensor] = None) -> None:
+                     conf_override: Optional[torch.Tensor] = None, conf_out: Optional[torch.Tensor] = None,
+                     logits_T: int = 0, logits_t: int = 0, logits: Optional[torch.Tensor] = None) -> None:
         """One sampling step on the logits of the last forward (st_mask_git.py:397-453); updates in place."""
         B, T, S = prompt_BTS.shape
         assert prompt_BTS.is_contiguous() and prompt_BTS.dtype == torch.int64 and unmasked.dtype == torch.uint8
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.call("hma_maskgit_step", stream, self._ws["logits"].data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(),
+        lg = self._ws["logits"] if logits is None else logits
+        _lib.call("hma_maskgit_step", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(),
                   None if conf_override is None else conf_override.data_ptr(), None if conf_out is None else conf_out.data_ptr(),
-                  B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size)
+                  B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
+
+    # ------------------------------------------------------------------------------ incremental decode
+    # Frame t of the trunk depends on frames <= t only (spatial attention, modulation, MLP, positions and the
+    # action tokens are per frame; temporal attention is causal), so per-layer temporal K/V of finished frames
+    # are constants of the rollout: only the 320 rows of the frame being decoded flow through the layers.
+    def decode_begin(self, B: int, T_total: int, S: int, A: int) -> Dict[str, torch.Tensor]:
+        key = (B, T_total, S, A)
+        if getattr(self, "_dws_key", None) == key:
+            return self._dws
+        self._dws, self._dplans = {}, {}
+        L = self.cfg.num_layers
+        SA, M1 = S + A, B * (S + A)
+        dev = self.device
+        d: Dict[str, torch.Tensor] = {}
+
+        def buf(name, shape, dtype):
+            d[name] = torch.empty(shape, dtype=dtype, device=dev)
+
+        buf("ids", (B, 1, S), torch.int64)
+        buf("x", (M1, 256), F32)
+        for nm in ("xh1", "o_s", "x2b", "o_t", "xh2", "xhm", "xm"):
+            buf(nm, (M1, 256), BF16)
+        buf("qkv_s", (M1, 768), BF16)
+        buf("lse_s", (M1, 8), F32)
+        for nm in ("rstd1", "rstd2", "rstdm"):
+            buf(nm, (M1,), F32)
+        buf("u", (M1, 1024), BF16)
+        buf("hg", (M1, 1024), BF16)
+        buf("logits", (B * S, 1024), F32)
+        buf("cache", (L, B * T_total * SA, 768), BF16)
+        if A > 0:
+            buf("actions", (B * self.max_d_a,), F32)
+            buf("an", (B * self.max_d_a,), F32)
+            buf("sxhat", (B, 256), F32)
+            buf("srstd", (B,), F32)
+            buf("sh", (B, 256), F32)
+            buf("a_emb", (B, 256), F32)
+            buf("ada_pre", (L, B, 256), BF16)
+            buf("ada_act", (L, B, 256), BF16)
+            buf("ss", (L, B, 512), F32)
+        self._dws, self._dws_key = d, key
+        return d
+
+    def _decode_plan(self, B: int, T_total: int, S: int, A: int, domain: Optional[str], t: int, readout: bool) -> Plan:
+        key = (B, T_total, S, A, domain, t, readout, self._skip_norm)
+        if key in self._dplans:
+            return self._dplans[key]
+        cfg, d = self.cfg, self._dws
+        L = cfg.num_layers
+        SA, M1 = S + A, B * (S + A)
+        pl = Plan()
+        use_mod = A > 0 and self.modulate
+        if A > 0:
+            am = f"action_mlp.{domain}.model"
+            pl.add("hma_action_stem_fwd", d["actions"].data_ptr(), self.buffers[domain][0].data_ptr(),
+                   self.buffers[domain][1].data_ptr(), self.action_dims[domain], self._p(f"{am}.0.weight"), self._p(f"{am}.0.bias"),
+                   self._p(f"{am}.1.weight"), self._p(f"{am}.1.bias"), self._p(f"{am}.3.weight"), self._p(f"{am}.3.bias"),
+                   d["an"].data_ptr(), d["sxhat"].data_ptr(), d["srstd"].data_ptr(), d["sh"].data_ptr(), d["a_emb"].data_ptr(), B,
+                   self.d_actions[domain], self._skip_norm)
+            if use_mod:
+                ap = f"decoder.layers.0.action_projectors.{domain}"
+                pl.gemm_nt(A=d["a_emb"].data_ptr(), lda=256, a_kind=A_F32, W=self._wb(f"{ap}.adaLN_modulation.0.weight"), ldw=256,
+                           M=B, N=256, K=256, epi=EPI_SILU2, Cp=d["ada_pre"].data_ptr(), ldc=256,
+                           bias=self._p(f"{ap}.adaLN_modulation.0.bias"), C2=d["ada_act"].data_ptr(), ldc2=256, batch=L, sA=0,
+                           sW=256 * 256, sBias=256, sC=B * 256, sC2=B * 256)
+                pl.gemm_nt(A=d["ada_act"].data_ptr(), lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.adaLN_modulation.2.weight"),
+                           ldw=256, M=B, N=512, K=256, epi=EPI_F32, Cp=d["ss"].data_ptr(), ldc=512,
+                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=B * 256, sW=512 * 256, sBias=512, sC=B * 512)
+        pfr = cfg.S + cfg.action_token_size
+        pl.add("hma_embed_fwd", d["ids"].data_ptr(), self._p("token_embed.factored_embeds.0.weight"),
+               self._p("token_embed.factored_embeds.1.weight"), self._p("token_embed.mask_token_embed"),
+               self._p("pos_embed_TSC") + 4 * t * pfr * 256, d["a_emb"].data_ptr() if A > 0 else None, d["x"].data_ptr(), B, 1, S, A,
+               pfr, cfg.factored_vocab_size, cfg.image_vocab_size)
+        x = d["x"].data_ptr()
+        names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "o_t", "xh2", "rstd2", "u", "hg", "xhm", "xm", "rstdm")
+        for l in range(L):
+            bufs = {k: d[k].data_ptr() for k in names}
+            bufs["qkv_t"] = None
+            if use_mod:
+                bufs["ss"] = d["ss"].data_ptr() + l * B * 512 * 4
+            kv = {"cache": d["cache"][l].data_ptr(), "row_off": t * SA, "c_group": (SA, T_total * SA), "t_query": t,
+                  "T_cache": T_total}
+            self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv)
+        if readout:
+            pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=B * S, N=1024,
+                       K=256, epi=EPI_F32, Cp=d["logits"].data_ptr(), ldc=1024, bias=self._p("out_x_proj.bias"))
+        self._dplans[key] = pl
+        return pl
+
+    def decode_prefill(self, ids_BPS: torch.Tensor, actions: Optional[torch.Tensor], domain: Optional[str], T_total: int,
+                       skip_normalization: bool = False) -> None:
+        """Run the prompt frames through the trunk, filling the per-layer temporal qkv cache."""
+        B, P, S = ids_BPS.shape
+        A = self.cfg.action_token_size if actions is not None else 0
+        d = self.decode_begin(B, T_total, S, A)
+        skip = 1 if skip_normalization else 0
+        if skip != self._skip_norm:
+            self._skip_norm, self._plans, self._dplans = skip, {}, {}
+        ws = self._workspace(B, P, S, A, False)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(domain if actions is not None else None, stream)
+        ws["ids"].copy_(ids_BPS, non_blocking=True)
+        if actions is not None:
+            d_a = self.d_actions[domain]
+            ws["actions"][: B * P * d_a].copy_(actions[:, :P].reshape(-1), non_blocking=True)
+        self._forward_plan(B, P, S, A, False, domain if A > 0 else None, readout=False, kv_cache=d["cache"],
+                           T_cache=T_total).run(stream)
+
+    def decode_frame(self, ids_BS: torch.Tensor, actions_t: Optional[torch.Tensor], domain: Optional[str], t: int, T_total: int,
+                     readout: bool = True) -> torch.Tensor:
+        """One pass of frame t (tokens ids_BS, possibly partly masked) against the cached frames < t; refreshes
+        frame t's own cache rows.  Returns the (B*S, 1024) fp32 logits buffer of that frame."""
+        B, S = ids_BS.shape
+        A = self.cfg.action_token_size if actions_t is not None else 0
+        d = self.decode_begin(B, T_total, S, A)
+        stream = torch.cuda.current_stream().cuda_stream
+        d["ids"].view(B, S).copy_(ids_BS, non_blocking=True)
+        if actions_t is not None:
+            d_a = self.d_actions[domain]
+            d["actions"][: B * d_a].copy_(actions_t.reshape(-1), non_blocking=True)
+        self._decode_plan(B, T_total, S, A, domain if A > 0 else None, t, readout).run(stream)
+        return d["logits"]
 
     def zero_grad(self, active_domains: Optional[Sequence[str]] = None) -> None:
         """Zero the whole gradient buffer, or only the ranges that can receive gradients this step."""

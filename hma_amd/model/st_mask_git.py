@@ -382,6 +382,49 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         return samples_HW, factored, None
 
     @torch.no_grad()
+    def _generate_cached(self, input_ids, num_new_frames, h, w, maskgit_steps, temperature, action_ids, domain, kwargs):
+        """`generate` with a per-layer temporal K/V cache: exactly the reference's arithmetic per frame (frame t's
+        logits depend on frames <= t only), but each MaskGIT iteration moves the 320 rows of ONE frame through the
+        trunk instead of the whole window; one extra pass per finished frame stores its final K/V."""
+        if temperature > 1e-8:
+            raise NotImplementedError("categorical sampling (temperature > 0) is not built")
+        unmask_mode = kwargs.pop("unmask_mode", "random")
+        rand_draws = kwargs.pop("rand_draws", None)
+        skip_norm = bool(kwargs.get("skip_normalization", False))
+        S = h * w
+        B = input_ids.size(0)
+        dev = input_ids.device
+        eng = self._get_engine(dev)
+        prompt = input_ids.reshape(B, -1, S).contiguous()
+        P = prompt.size(1)
+        T_total = P + num_new_frames
+        dom = self._domain_key(domain) if action_ids is not None else None
+        acts = None if action_ids is None else action_ids.float().contiguous()
+        eng.decode_prefill(prompt, acts, dom, T_total, skip_norm)
+        out = torch.cat([prompt, torch.full((B, num_new_frames, S), self.mask_token_id, dtype=torch.long, device=dev)], dim=1)
+        draw = 0
+        for t in range(P, T_total):
+            frame = out[:, t : t + 1].contiguous()  # (B, 1, S) view the sampling kernel updates in place
+            unmasked = torch.zeros(B, S, dtype=torch.uint8, device=dev)
+            a_t = None if acts is None else acts[:, t]
+            for step in range(maskgit_steps):
+                logits = eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total)
+                last = step == maskgit_steps - 1
+                n = 0 if last else math.ceil(cosine_schedule((step + 1) / maskgit_steps) * S)
+                override = None
+                if not last and unmask_mode == "random":
+                    if rand_draws is not None:
+                        override = rand_draws[draw].reshape(B, S).contiguous().float()
+                        draw += 1
+                    else:
+                        override = torch.rand(B, h, w, device=dev).reshape(B, S).contiguous()
+                eng.maskgit_step(frame, unmasked, 0, n, last, override, logits_T=1, logits_t=0, logits=logits)
+            out[:, t] = frame[:, 0]
+            if t + 1 < T_total:  # store the finished frame's K/V (its tokens changed after the last pass)
+                eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total, readout=False)
+        return out.reshape(B, -1)
+
+    @torch.no_grad()
     def generate(self, input_ids: torch.LongTensor, attention_mask: torch.LongTensor = None, max_new_tokens: int = 0,
                  min_new_tokens: int = None, return_logits: bool = False, return_with_actions: bool = False,
                  maskgit_steps: int = 1, temperature: float = 0.0, action_ids: torch.Tensor = None, domain: str = "default",
@@ -392,6 +435,9 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         S = h * w
         num_new_frames = max_new_tokens // S
         B = input_ids.size(0)
+        if kwargs.pop("use_cache", True) and not return_logits and num_new_frames > 0:
+            return self._generate_cached(input_ids, num_new_frames, h, w, maskgit_steps, temperature, action_ids, domain,
+                                         kwargs)
         inputs_THW = input_ids.clone().reshape(B, -1, h, w)
         masked = torch.cat([inputs_THW, torch.full((B, num_new_frames, h, w), self.mask_token_id, dtype=torch.long,
                                                    device=input_ids.device)], dim=1)

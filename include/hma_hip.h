@@ -109,6 +109,12 @@ int hma_attn_temporal_fwd(void* stream, const void* qkv, void* o, int64_t batch,
                           float scale);
 int hma_attn_temporal_bwd(void* stream, const void* qkv, const void* o, const void* d_o, void* dqkv,
                           int64_t batch, int32_t T, int32_t n_s, float scale);
+/* Temporal attention against a per-layer qkv cache laid out [batch, T_cache, n_s, 768] (incremental
+ * decode; exact because frame t depends on frames <= t only, st_transformer.py:83-111).
+ * t_query < 0: prefill -- frames 0..T-1 attend causally, o rows (b, t, s) with T frames per sample.
+ * t_query >= 0: only frame t_query is new -- o holds that frame, rows (b, s). */
+int hma_attn_temporal_cached(void* stream, const void* qkv_cache, void* o, int64_t batch, int32_t T,
+                             int32_t t_query, int32_t T_cache, int32_t n_s, float scale);
 
 /* Fused token + action + positional embedding, factorization_utils.py:31-54 +
  * st_mask_git.py:640-672: x[b,t,s,:] = (id == mask_id ? mask_embed : E0[id % V] + E1[id / V]) +
@@ -148,10 +154,13 @@ int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* input_ids, 
  * logits f32 [B, T, S, 1024] frame out_t; writes samples into prompt[b, out_t, :] (int64 [B,T,S]),
  * updates unmasked (uint8 [B,S]).  conf_override (f32 [B,S]) replaces the confidences when not
  * NULL ("random" unmask mode, the torch.rand_like draw of :435); conf_out (f32 [B,S], may be NULL)
- * receives the model confidences.  n_mask = tokens to re-mask (ignored when last != 0). S <= 256. */
+ * receives the model confidences.  n_mask = tokens to re-mask (ignored when last != 0). S <= 256.
+ * logits_T / logits_t: frame count / index of the logits buffer when it differs from the prompt's
+ * (incremental decode keeps one frame of logits); logits_T <= 0 means (T, out_t). */
 int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
                      const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
-                     int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id);
+                     int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id, int32_t logits_T,
+                     int32_t logits_t);
 
 /* sum of squares of g[0:n) accumulated into *out (fp32 atomic; zero it first) -- clip_grad_norm_,
  * train_multi.py:594 */

@@ -396,7 +396,7 @@ def test_maskgit_step_bit_exact():
         rnd = torch.rand(B, S, generator=gen) if step % 2 else None  # alternate greedy / "random" confidences
         rd = None if rnd is None else rnd.to(DEV)
         _lib.call("hma_maskgit_step", ops.stream_ptr(), ld.data_ptr(), pd.data_ptr(), ud.data_ptr(),
-                  None if rd is None else rd.data_ptr(), conf.data_ptr(), B, T, S, out_t, n, int(last), mask_id)
+                  None if rd is None else rd.data_ptr(), conf.data_ptr(), B, T, S, out_t, n, int(last), mask_id, 0, 0)
         # oracle: argmax ids are bit-exact; ranks use the kernel's own confidences (fp32 summation order differs from torch)
         fl = logits[:, out_t].reshape(B, S, 2, 512)
         a = fl.argmax(-1)

@@ -195,6 +195,41 @@ def test_maskgit_generate_against_golden():
     _note("generate.generate2.id_agreement", (toks.cpu() == g["generate2.tokens"]).float().mean().item())
 
 
+def test_cached_decode_equals_full_window_decode():
+    """Incremental decode (per-layer temporal K/V cache) reproduces the full-window recompute: same ids, and
+    the per-frame logits agree to fp32 rounding of the attention sums."""
+    g = golden("g7_generate")
+    m = build_model(train=False)
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    cfg = m.config
+    ids = inp["labels"].reshape(2, cfg.T, 256)[:, : cfg.T - 2].reshape(2, -1)
+    kw = dict(max_new_tokens=2 * 256, maskgit_steps=2, temperature=0.0, action_ids=inp["actions_domA"], domain=["domA"] * 2,
+              h=[16, 16], w=[16, 16], unmask_mode="greedy")
+    full = m.generate(ids, None, use_cache=False, **kw)
+    cached = m.generate(ids, None, use_cache=True, **kw)
+    agree = (full == cached).float().mean().item()
+    _note("generate.cached_vs_full_agreement", agree)
+    assert agree >= 0.995
+    assert (cached != cfg.image_vocab_size).all()
+    _note("generate.cached.golden_agreement", (cached.cpu() == g["generate2.tokens"]).float().mean().item())
+    # logits of one cached frame pass vs the full-window forward on the same tokens
+    eng = m._engine
+    toks = full.reshape(2, cfg.T, 256)
+    logits_full, _ = m.compute_logits(toks.reshape(2, cfg.T, 16, 16), action_ids=inp["actions_domA"], domain=["domA"] * 2)
+    ref_last = logits_full[:, :, cfg.T - 1].permute(0, 2, 3, 1).reshape(2 * 256, 1024).clone()
+    eng.decode_prefill(toks[:, : cfg.T - 1].contiguous(), inp["actions_domA"].float(), "domA", cfg.T)
+    lg = eng.decode_frame(toks[:, cfg.T - 1].contiguous(), inp["actions_domA"][:, cfg.T - 1].float(), "domA", cfg.T - 1, cfg.T)
+    e = rel_err(lg, ref_last)
+    _note("generate.cached_logits_rel_err", e)
+    assert e <= 1e-3
+    # without actions
+    kw2 = dict(max_new_tokens=256, maskgit_steps=3, temperature=0.0, h=[16, 16], w=[16, 16], unmask_mode="greedy")
+    ids2 = inp["labels"].reshape(2, cfg.T, 256)[:, : cfg.T - 1].reshape(2, -1)
+    a = m.generate(ids2, None, use_cache=False, **kw2)
+    b = m.generate(ids2, None, use_cache=True, **kw2)
+    assert (a == b).float().mean().item() >= 0.995
+
+
 def test_decode_ids_bit_exact_vs_oracle_on_same_logits():
     """Index path: given the engine's own fp32 logits, the sampled ids equal the oracle's argmax/rank rule."""
     m = build_model(train=False)
