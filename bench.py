@@ -107,6 +107,57 @@ def cpu_baseline(model, domain, d_a, T, budget_s=25.0):
                       f"median of {len(warm)} warm steps ({med:.2f} s/step)"}
 
 
+def decode_bench(args, dev):
+    """BASELINE.json configs[4]: MaskGIT iterative decode, T = 16, 4 prompt + 12 generated frames, 8 iterations,
+    batch 64 -> generated frames/s (replicas only: no exchange step).  `--steps` rollouts are timed."""
+    from hma_amd.model import STMaskGIT  # noqa: F401
+
+    B, T, P, iters = args.batch, args.frames, 4, 8
+    model, domains, d_actions = build_model(args.domains, T, args.layers)
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.randint(0, 8192, (B, P * 256), generator=g).to(dev)
+    acts = torch.randn(B, T, d_actions[0], generator=g).to(dev)
+    kw = dict(max_new_tokens=(T - P) * 256, maskgit_steps=iters, temperature=0.0, action_ids=acts, domain=[domains[0]] * B,
+              unmask_mode="random")
+    for _ in range(max(1, args.warmup)):
+        out = model.generate(prompt, None, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.generate(prompt, None, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    assert int((out == 262144).sum()) == 0
+    frames = B * (T - P)
+    flops_min = 2.97e12 * B * (args.layers / 32.0)  # minimal algorithmic count with frame-causal reuse, SURVEY.md 8d
+    res = {
+        "metric": "generated frames/sec (MaskGIT iterative decode, autoregressive rollout) HMA-base T=16 16x16",
+        "value": frames / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"HMA-base-disc L{args.layers}, prompt {P} + {T - P} generated frames, {iters} MaskGIT iterations, "
+                               f"batch {B}, per-layer temporal K/V cache (one 320-row frame per pass)", "global_batch": B,
+                   "parallelism": "dp1"},
+        "roofline": {"bound": "mfma", "kernel": "whole rollout (minimal algorithmic FLOPs)", "achieved": flops_min / dt / 1e12,
+                     "peak": 2500.0, "unit": "TFLOP/s", "frac": flops_min / dt / 2.5e15, "traffic": None},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import st_maskgit_ref as R
+        rc = R.RefConfig(num_layers=args.layers, num_heads=8, d_model=256, T=T, use_mup=True)
+        dom = domains[0]
+        keep = lambda k: (".action_projectors." not in k and not k.startswith("action_")) or f".{dom}." in k
+        sd = {k: v.detach().to("cpu", copy=True) for k, v in model.state_dict().items() if keep(k)}
+        p1 = torch.full((1, T, 16, 16), 262144, dtype=torch.long)
+        p1[:, :P] = prompt[:1].cpu().reshape(1, P, 16, 16)
+        t1 = time.perf_counter()
+        R.maskgit_generate(sd, rc, p1, P, 2, 0.0, "greedy", acts[:1].cpu(), [dom])
+        el = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": 1.0 / (el * iters / 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"CPU oracle, B=1, one frame, 2 of {iters} MaskGIT iterations timed ({el:.1f} s) and scaled"}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +169,7 @@ def main():
     ap.add_argument("--domains", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--mode", choices=["train", "decode"], default="train")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +183,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "decode":
+        if rank == 0:
+            decode_bench(args, dev)
+        return
 
     from hma_amd.engine import LaunchTimer
     from hma_amd.train import Trainer
