@@ -490,6 +490,390 @@ __device__ __forceinline__ void epilogue_oct(const hma_gemm_nt_t& p, int64_t bz,
   }
 }
 
+// ------------------------------------------------------------- NT, persistent, deferred epilogue
+// Same 8-wave, one-per-CU pipeline as gemm_nt_persist_kernel, with the epilogue as a template parameter,
+// 16-byte bf16 accesses (epilogue_oct) and the deferred, interleaved epilogue described inside.
+template <int AKIND, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int tiles_m, int tiles_n, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int KT = (int)(p.K / PK);
+  const int kc = tid & 7;
+
+  // XCD-aware virtual id: the workgroups of one XCD (b % 8) take a contiguous run of tiles
+  const int G = gridDim.x;
+  const int b = blockIdx.x;
+  const int per = G >> 3;
+  const int vid = ((G & 7) == 0) ? (b & 7) * per + (b >> 3) : b;
+  const int my_tiles = vid < total_tiles ? (total_tiles - vid + G - 1) / G : 0;
+  const int total_it = my_tiles * KT;
+  if (total_it == 0) return;
+
+  struct Cursor { int tile; int kt; int64_t a_off[2]; int64_t w_off; int64_t bz; };
+  auto decode = [&](Cursor& c) {
+    const int per_b = tiles_m * tiles_n;
+    c.bz = c.tile / per_b;
+    const int r = c.tile % per_b;
+    const int mt = r / tiles_n, nt = r % tiles_n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t gr = (int64_t)mt * PM + (tid >> 3) + i * 64;
+      c.a_off[i] = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
+    }
+    c.w_off = ((int64_t)nt * PN + (tid >> 3)) * p.ldw;
+  };
+  Cursor ld;
+  ld.tile = vid; ld.kt = 0;
+  decode(ld);
+
+  auto load = [&](PRegs<AKIND>& r) {
+    const int k0 = ld.kt * PK + kc * 8;
+    r.k0 = k0;
+    const char* Ab = reinterpret_cast<const char*>(p.A) + ld.bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + ld.bz * p.sW + ld.w_off + k0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.w[i] = *reinterpret_cast<const uint4*>(Wb + (int64_t)i * 64 * p.ldw);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      r.a_ok[i] = ld.a_off[i] >= 0;
+      if (r.a_ok[i]) {
+        if (AKIND == HMA_A_F32) {
+          const float* s = reinterpret_cast<const float*>(Ab) + ld.a_off[i] + k0;
+          r.a[i][0] = *reinterpret_cast<const uint4*>(s);
+          r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(s + 4);
+        } else {
+          r.a[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Ab) + ld.a_off[i] + k0);
+        }
+      } else {
+        r.a[i][0] = make_uint4(0, 0, 0, 0);
+        r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    if (++ld.kt == KT) {
+      ld.kt = 0;
+      ld.tile += G;
+      if (ld.tile < total_tiles) decode(ld);
+    }
+  };
+  auto store = [&](const PRegs<AKIND>& r, int buf) {
+    uint16_t* As = smem + buf * P_STAGE;
+    uint16_t* Ws = As + P_A;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&Ws[((tid >> 3) + i * 64) * LDT + kc * 8]) = r.w[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint4 v;
+      if (AKIND == HMA_A_F32) {
+        const float4 lo = __builtin_bit_cast(float4, r.a[i][0]);
+        const float4 hi = __builtin_bit_cast(float4, r.a[i][AKIND == HMA_A_F32 ? 1 : 0]);
+        v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
+        v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
+      } else if (AKIND == HMA_A_BF16_AFFINE) {
+        float f[8];
+        unpack8(r.a[i][0], f);
+        if (r.a_ok[i]) {
+          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + r.k0), g1 = *reinterpret_cast<const float4*>(p.gamma + r.k0 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(p.beta + r.k0), b1 = *reinterpret_cast<const float4*>(p.beta + r.k0 + 4);
+          f[0] = f[0] * g0.x + b0.x; f[1] = f[1] * g0.y + b0.y; f[2] = f[2] * g0.z + b0.z; f[3] = f[3] * g0.w + b0.w;
+          f[4] = f[4] * g1.x + b1.x; f[5] = f[5] * g1.y + b1.y; f[6] = f[6] * g1.z + b1.z; f[7] = f[7] * g1.w + b1.w;
+        }
+        v = pack8(f);
+      } else {
+        v = r.a[i][0];
+      }
+      *reinterpret_cast<uint4*>(&As[((tid >> 3) + i * 64) * LDT + kc * 8]) = v;
+    }
+  };
+
+  f32x16_t acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+  };
+  zero_acc();
+
+  int cur_tile = vid, cur_kt = 0;
+  // Deferred epilogue: a finished tile's accumulators move to `pacc` and are written out in four parts,
+  // one after the MFMAs of each of the next tile's first four K-steps, so the store (and residual-load)
+  // traffic interleaves with the main loop's loads instead of arriving as one burst that stalls every wave.
+  f32x16_t pacc[2][2];
+  int ptile = -1;
+  const int lr = lane & 31, lhi = lane >> 5;
+  auto emit_part = [&](auto mt_tag, auto nt_tag) __attribute__((always_inline)) {
+    constexpr int mt = decltype(mt_tag)::value, nt = decltype(nt_tag)::value;
+    const int per_b = tiles_m * tiles_n;
+    const int64_t bz = ptile / per_b;
+    const int rr = ptile % per_b;
+    const int64_t bm = (int64_t)(rr / tiles_n) * PM, bn = (int64_t)(rr % tiles_n) * PN;
+    const int64_t m = bm + wm * 64 + mt * 32 + lr;
+    if (m < p.M) {
+      const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+      const int64_t nq = bn + wn * 64 + nt * 32;
+      const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
+#pragma unroll
+      for (int g2 = 0; g2 < 4; g2 += 2) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = pacc[nt][mt][4 * g2 + e];
+          v1[e] = pacc[nt][mt][4 * g2 + 4 + e];
+        }
+        if (bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 4 * lhi);
+          const float4 b1 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 8 + 4 * lhi);
+          v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+          v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+        }
+        epilogue_oct<EPI>(p, bz, crow, nq, g2, lhi, v0, v1);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto emit_step = [&](int part) __attribute__((always_inline)) {
+    if (ptile < 0) return;
+    switch (part) {
+      case 0: emit_part(I0{}, I0{}); break;
+      case 1: emit_part(I0{}, I1{}); break;
+      case 2: emit_part(I1{}, I0{}); break;
+      case 3: emit_part(I1{}, I1{}); ptile = -1; break;
+      default: break;
+    }
+  };
+
+  PRegs<AKIND> r0, r1;
+  load(r0);
+  if (total_it > 1) load(r1);
+  store(r0, 0);
+  __syncthreads();
+  const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+  auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
+    // `mine` held step `it` (already in LDS) and is free: refill it with step it + 2
+    if (it + 2 < total_it && !(ablate & 2)) load(mine);
+    const uint16_t* As = smem + (it & 1) * P_STAGE;
+    if (!(ablate & 4)) mma_tile(As, As + P_A, acc, wm, wn, lane);
+    if (!(ablate & 1)) emit_step(cur_kt);
+    if (++cur_kt == KT) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pacc[a][c] = acc[a][c];
+      ptile = cur_tile;
+      zero_acc();
+      cur_kt = 0;
+      cur_tile += G;
+    }
+    if (it + 1 < total_it) store(other, (it + 1) & 1);
+    __syncthreads();
+  };
+  for (int it = 0; it < total_it; it += 2) {
+    step(it, r0, r1);
+    if (it + 1 < total_it) step(it + 1, r1, r0);
+  }
+  if (!(ablate & 1)) {  // the last tile's epilogue has no following main loop to hide behind
+    for (int part = 0; part < 4; ++part) emit_step(part);
+  }
+}
+
+
+// ---------------------------------------------------------------- NT, weight-stationary (K = 256)
+// Measured invariant of the variants above: whatever the schedule, a CU moves ~11-12 B/clk through its
+// vector-memory path, L2 hits included, so at K = 256 the 128 KB of W re-streamed per 128 x 256 tile
+// (twice the bytes of the A tile itself) sets the time.  Here a workgroup parks ONE 256 x 256 weight
+// slab in LDS (132 KB) for its whole life and streams only token rows: A tiles of 128 x 32 through a
+// 20 KB double buffer (loads two steps ahead), the deferred 16-byte epilogue of gemm_nt_p3_kernel.
+constexpr int SK = 256, SW_LD = SK + 8;
+constexpr int SBK = 32, SLD = SBK + 8;          // A K-step and padded stage row
+constexpr int S_W = 256 * SW_LD;                  // elements of the weight slab
+constexpr int S_A = PM * SLD;                     // one A stage: [128][32 + 8]
+constexpr int S_SMEM_BYTES = (S_W + 2 * S_A) * 2; // 155648 B
+
+template <int AKIND>
+struct SRegs {
+  uint4 a[AKIND == HMA_A_F32 ? 2 : 1];
+  bool ok;
+  int k0;
+};
+
+template <int AKIND, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(hma_gemm_nt_t p, int tiles_m, int groups, int per_group) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Wsl = smem;           // [256 n][SW_LD]
+  uint16_t* Ast = smem + S_W;     // [2][128][SLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lhi = lane >> 5;
+  constexpr int KT = SK / SBK;     // 8 steps of 32
+  const int kc = tid & 3, srow = tid >> 2;  // 128 rows x 4 chunks of 8 elements
+
+  // workgroup -> (group = (batch, n-tile), slot within the group); groups are interleaved over workgroup ids
+  const int b = blockIdx.x;
+  const int g = b % groups, slot = b / groups;
+  const int tiles_n = (int)(p.N / PN);
+  const int64_t bz = g / tiles_n;
+  const int nt_idx = g % tiles_n;
+  const int64_t bn = (int64_t)nt_idx * PN;
+  const int my_tiles = slot < tiles_m ? (tiles_m - slot + per_group - 1) / per_group : 0;
+  const int total_it = my_tiles * KT;
+  if (total_it == 0) return;
+
+  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+  {  // park the weight slab
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
+    for (int c = tid; c < 256 * (SK / 8); c += 512) {
+      const int row = c >> 5, ch = c & 31;
+      *reinterpret_cast<uint4*>(&Wsl[row * SW_LD + ch * 8]) = *reinterpret_cast<const uint4*>(Wb + (int64_t)row * p.ldw + ch * 8);
+    }
+  }
+
+  int ld_tile = slot, ld_kt = 0;
+  int64_t ld_off = -1;
+  auto decode = [&]() {
+    const int64_t gr = (int64_t)ld_tile * PM + srow;
+    ld_off = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
+  };
+  decode();
+  auto load = [&](SRegs<AKIND>& r) {
+    const int k0 = ld_kt * SBK + kc * 8;
+    r.k0 = k0;
+    r.ok = ld_off >= 0;
+    if (r.ok) {
+      if (AKIND == HMA_A_F32) {
+        const float* sp = reinterpret_cast<const float*>(Ab) + ld_off + k0;
+        r.a[0] = *reinterpret_cast<const uint4*>(sp);
+        r.a[AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(sp + 4);
+      } else {
+        r.a[0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Ab) + ld_off + k0);
+      }
+    } else {
+      r.a[0] = make_uint4(0, 0, 0, 0);
+      r.a[AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+    }
+    if (++ld_kt == KT) {
+      ld_kt = 0;
+      ld_tile += per_group;
+      if (ld_tile < tiles_m) decode();
+    }
+  };
+  auto store = [&](const SRegs<AKIND>& r, int buf) {
+    uint4 v;
+    if (AKIND == HMA_A_F32) {
+      const float4 lo = __builtin_bit_cast(float4, r.a[0]);
+      const float4 hi = __builtin_bit_cast(float4, r.a[AKIND == HMA_A_F32 ? 1 : 0]);
+      v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
+      v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
+    } else if (AKIND == HMA_A_BF16_AFFINE) {
+      float f[8];
+      unpack8(r.a[0], f);
+      if (r.ok) {
+        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + r.k0), g1 = *reinterpret_cast<const float4*>(p.gamma + r.k0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.beta + r.k0), b1 = *reinterpret_cast<const float4*>(p.beta + r.k0 + 4);
+        f[0] = f[0] * g0.x + b0.x; f[1] = f[1] * g0.y + b0.y; f[2] = f[2] * g0.z + b0.z; f[3] = f[3] * g0.w + b0.w;
+        f[4] = f[4] * g1.x + b1.x; f[5] = f[5] * g1.y + b1.y; f[6] = f[6] * g1.z + b1.z; f[7] = f[7] * g1.w + b1.w;
+      }
+      v = pack8(f);
+    } else {
+      v = r.a[0];
+    }
+    *reinterpret_cast<uint4*>(&Ast[buf * S_A + srow * SLD + kc * 8]) = v;
+  };
+
+  f32x16_t acc[2][2], pacc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+  };
+  zero_acc();
+  int cur_tile = slot, cur_kt = 0, ptile = -1;
+  auto emit_part = [&](auto mt_tag, auto nt_tag) __attribute__((always_inline)) {
+    constexpr int mt = decltype(mt_tag)::value, nt = decltype(nt_tag)::value;
+    const int64_t m = (int64_t)ptile * PM + wm * 64 + mt * 32 + lr;
+    if (m < p.M) {
+      const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+      const int64_t nq = bn + wn * 64 + nt * 32;
+      const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
+#pragma unroll
+      for (int g2 = 0; g2 < 4; g2 += 2) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = pacc[nt][mt][4 * g2 + e];
+          v1[e] = pacc[nt][mt][4 * g2 + 4 + e];
+        }
+        if (bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 4 * lhi);
+          const float4 b1 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 8 + 4 * lhi);
+          v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+          v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+        }
+        epilogue_oct<EPI>(p, bz, crow, nq, g2, lhi, v0, v1);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto emit_step = [&](int part) __attribute__((always_inline)) {
+    if (ptile < 0) return;
+    switch (part) {
+      case 0: emit_part(I0{}, I0{}); break;
+      case 2: emit_part(I0{}, I1{}); break;
+      case 4: emit_part(I1{}, I0{}); break;
+      case 6: emit_part(I1{}, I1{}); ptile = -1; break;
+      default: break;
+    }
+  };
+
+  SRegs<AKIND> r0, r1;
+  load(r0);
+  if (total_it > 1) load(r1);
+  store(r0, 0);
+  __syncthreads();
+  auto step = [&](int it, SRegs<AKIND>& mine, SRegs<AKIND>& other) {
+    if (it + 2 < total_it) load(mine);
+    const uint16_t* As = Ast + (it & 1) * S_A;
+#pragma unroll
+    for (int kk = 0; kk < SBK / 16; ++kk) {
+      bf16x8_t wf[2], tf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wf[i] = *reinterpret_cast<const bf16x8_t*>(&Wsl[(wn * 64 + i * 32 + lr) * SW_LD + cur_kt * SBK + kk * 16 + lhi * 8]);
+        tf[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 64 + i * 32 + lr) * SLD + kk * 16 + lhi * 8]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mfma32(wf[nt], tf[mt], acc[nt][mt]);
+    }
+    emit_step(cur_kt);
+    if (++cur_kt == KT) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pacc[a][c] = acc[a][c];
+      ptile = cur_tile;
+      zero_acc();
+      cur_kt = 0;
+      cur_tile += per_group;
+    }
+    if (it + 1 < total_it) store(other, (it + 1) & 1);
+    __syncthreads();
+  };
+  for (int it = 0; it < total_it; it += 2) {
+    step(it, r0, r1);
+    if (it + 1 < total_it) step(it + 1, r1, r0);
+  }
+  for (int part = 0; part < 8; part += 2) emit_step(part);
+}
+
 // --------------------------------------------------------------------- NT, persistent, 2 per CU
 // Measured on MI355X (tools/ablate.sh): with one 8-wave workgroup per CU the epilogue of a tile (its
 // HBM stores, at ~5 TB/s aggregate, plus the GELU VALU work) and the MFMA main loop (~1 PFLOP/s without
@@ -1094,6 +1478,44 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
     static const bool use_p1 = getenv("HMA_GEMM_NT_P1") != nullptr;
     hma_gemm_nt_t pa = *p;
     pa._pad2 = ablate;
+    static const bool use_p2 = getenv("HMA_GEMM_NT_P2") != nullptr;
+    static const bool no_ws = getenv("HMA_GEMM_NT_NOWS") != nullptr;
+    // (measured per shape, profiles/gemm_shapes_r1.txt: it only wins for the N = K = 256 residual projections)
+    if (!use_p1 && !use_p2 && !no_ws && p->K == SK && p->N == PN && p->a_kind == HMA_A_BF16 && p->epi == HMA_EPI_RESID && !p->C2) {
+      // weight-stationary: one (batch, n-tile) group per workgroup, the groups dealt round-robin over the grid
+      const int groups = tiles_n * (p->batch > 0 ? p->batch : 1);
+      int per_group = n_cu / groups;
+      if (per_group < 1) per_group = 1;
+      if (per_group > tiles_m) per_group = tiles_m;
+      const dim3 sgrid((unsigned)(groups * per_group));
+#define HMA_NTS_CASE(AK, EP)                                                                          \
+  if (p->a_kind == AK && p->epi == EP) {                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_ws_kernel<AK, EP>>(S_SMEM_BYTES))) return rc;                    \
+    hipLaunchKernelGGL((gemm_nt_ws_kernel<AK, EP>), sgrid, dim3(512), S_SMEM_BYTES, s, pa, tiles_m, groups, per_group); \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+      HMA_NTS_CASE(HMA_A_BF16, HMA_EPI_RESID)
+    }
+    const bool valu_epi = p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2 || p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU;
+    const bool wide_bf16 = p->epi == HMA_EPI_BF16 && p->K == 256 && p->N >= 768 && p->a_kind == HMA_A_BF16;
+    if (!use_p1 && !use_p2 && !valu_epi && !wide_bf16 && p->K % PK == 0) {
+      const dim3 p3grid((unsigned)(total < n_cu ? total : n_cu));
+#define HMA_NT3_CASE(AK, EP)                                                                          \
+  if (p->a_kind == AK && p->epi == EP) {                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_p3_kernel<AK, EP>>(P_SMEM_BYTES))) return rc;                    \
+    hipLaunchKernelGGL((gemm_nt_p3_kernel<AK, EP>), p3grid, dim3(512), P_SMEM_BYTES, s, pa, tiles_m, tiles_n, total); \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+#define HMA_NT3_ALL(AK)                                                                               \
+  HMA_NT3_CASE(AK, HMA_EPI_BF16) HMA_NT3_CASE(AK, HMA_EPI_F32) HMA_NT3_CASE(AK, HMA_EPI_RESID)        \
+  HMA_NT3_CASE(AK, HMA_EPI_ATOMIC_F32)
+      HMA_NT3_ALL(HMA_A_BF16)
+      HMA_NT3_ALL(HMA_A_F32)
+      HMA_NT3_ALL(HMA_A_BF16_AFFINE)
+      return HMA_EINVAL;
+    }
     if (!use_p1 && p->K % QK == 0) {
       const dim3 qgrid((unsigned)(total < 2 * n_cu ? total : 2 * n_cu));
 #define HMA_NTQ_CASE(AK, EP)                                                                          \
