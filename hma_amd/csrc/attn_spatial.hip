@@ -224,65 +224,92 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 }
 
 // ------------------------------------------------------------------------------------- dK, dV
+// Q / dO (row-major for the score products, transposed for the gradient products) are staged in TWO
+// halves of n/2 query rows, so a workgroup needs 47 KB of LDS instead of 95 KB and two to three are
+// resident per CU: with one (measured: 487 us per layer) the staging of a (frame, head) and its MFMA
+// phase could not overlap with anything.  Each wave owns up to three 32-key tiles and keeps their dK / dV
+// accumulators in registers across both halves.
 template <int NT>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               uint16_t* __restrict__ dqkv, int64_t frames, float c_log2,
                                                               float scale) {
-  constexpr int N = NT * 32, LDV = N + 4;
+  constexpr int N = NT * 32;
+  constexpr int NQ = NT / 2;          // query tiles per half
+  constexpr int NR = NQ * 32;         // query rows per half
+  constexpr int LDV = NR + 4;
+  constexpr int KPW = (NT + 3) / 4;   // key tiles per wave (<= 3)
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* Qs = smem;                  // [N][LDR]
-  uint16_t* Gs = Qs + N * LDR;          // dO, [N][LDR]
-  uint16_t* Qt = Gs + N * LDR;          // [32][LDV]
+  uint16_t* Qs = smem;                  // [NR][LDR]
+  uint16_t* Gs = Qs + NR * LDR;         // dO, [NR][LDR]
+  uint16_t* Qt = Gs + NR * LDR;         // [32][LDV]
   uint16_t* Gt = Qt + 32 * LDV;         // [32][LDV]
-  float* L2s = reinterpret_cast<float*>(Gt + 32 * LDV);  // [N]
-  float* Dls = L2s + N;                                   // [N]
+  float* L2s = reinterpret_cast<float*>(Gt + 32 * LDV);  // [NR]
+  float* Dls = L2s + NR;                                  // [NR]
   int64_t frame; int head;
   decode_block(blockIdx.x, frames, frame, head);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5;
   const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
   const uint16_t* gbase = d_o + frame * N * DM + head * HD;
-  stage_rows(Qs, base, QKV_LD, N, tid, 256);
-  stage_rows(Gs, gbase, DM, N, tid, 256);
-  stage_cols(Qt, LDV, base, QKV_LD, N, tid, 256);
-  stage_cols(Gt, LDV, gbase, DM, N, tid, 256);
-  for (int i = tid; i < N; i += 256) {
-    L2s[i] = lse[(frame * N + i) * NH + head];
-    Dls[i] = delta[(frame * N + i) * NH + head];
-  }
-  __syncthreads();
 
-  const int hi = lane >> 5;
-  for (int kt = wave; kt < NT; kt += 4) {
-    const uint16_t* kb = base + DM + (int64_t)kt * 32 * QKV_LD;
-    const uint16_t* vb = base + 2 * DM + (int64_t)kt * 32 * QKV_LD;
-    const bf16x8_t k0 = frag_global(kb, QKV_LD, 0, lane), k1 = frag_global(kb, QKV_LD, 1, lane);
-    const bf16x8_t v0 = frag_global(vb, QKV_LD, 0, lane), v1 = frag_global(vb, QKV_LD, 1, lane);
-    f32x16_t dk = zero16(), dv = zero16();
-#pragma unroll 2
-    for (int qt = 0; qt < NT; ++qt) {
-      // S[q][key]: lane = key, rows = q
-      f32x16_t s = mfma32(frag_rows(Qs, qt * 32, 0, lane), k0, zero16());
-      s = mfma32(frag_rows(Qs, qt * 32, 1, lane), k1, s);
-      f32x16_t dp = mfma32(frag_rows(Gs, qt * 32, 0, lane), v0, zero16());
-      dp = mfma32(frag_rows(Gs, qt * 32, 1, lane), v1, dp);
-      f32x16_t ds;
+  f32x16_t dk[KPW], dv[KPW];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int q = qt * 32 + mfma32_row(e, hi);
-        const float p = fast_exp2(s[e] * c_log2 - L2s[q]);
-        s[e] = p;
-        ds[e] = p * (dp[e] - Dls[q]);
-      }
+  for (int j = 0; j < KPW; ++j) { dk[j] = zero16(); dv[j] = zero16(); }
+
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int q0 = half * NR;
+    if (half) __syncthreads();  // everyone is done reading the first half
+    stage_rows(Qs, base + (int64_t)q0 * QKV_LD, QKV_LD, NR, tid, 256);
+    stage_rows(Gs, gbase + (int64_t)q0 * DM, DM, NR, tid, 256);
+    stage_cols(Qt, LDV, base + (int64_t)q0 * QKV_LD, QKV_LD, NR, tid, 256);
+    stage_cols(Gt, LDV, gbase + (int64_t)q0 * DM, DM, NR, tid, 256);
+    for (int i = tid; i < NR; i += 256) {
+      L2s[i] = lse[(frame * N + q0 + i) * NH + head];
+      Dls[i] = delta[(frame * N + q0 + i) * NH + head];
+    }
+    __syncthreads();
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        dv = mfma32(frag_cols(Gt, LDV, qt * 32, s2, lane), pack_acc_half(s, s2), dv);
-        dk = mfma32(frag_cols(Qt, LDV, qt * 32, s2, lane), pack_acc_half(ds, s2), dk);
+    for (int j = 0; j < KPW; ++j) {
+      const int kt = wave + 4 * j;
+      if (kt < NT) {
+        const uint16_t* kb = base + DM + (int64_t)kt * 32 * QKV_LD;
+        const uint16_t* vb = base + 2 * DM + (int64_t)kt * 32 * QKV_LD;
+        const bf16x8_t k0 = frag_global(kb, QKV_LD, 0, lane), k1 = frag_global(kb, QKV_LD, 1, lane);
+        const bf16x8_t v0 = frag_global(vb, QKV_LD, 0, lane), v1 = frag_global(vb, QKV_LD, 1, lane);
+#pragma unroll 1
+        for (int qt = 0; qt < NQ; ++qt) {
+          // S[q][key]: lane = key, rows = q
+          f32x16_t sc = mfma32(frag_rows(Qs, qt * 32, 0, lane), k0, zero16());
+          sc = mfma32(frag_rows(Qs, qt * 32, 1, lane), k1, sc);
+          f32x16_t dp = mfma32(frag_rows(Gs, qt * 32, 0, lane), v0, zero16());
+          dp = mfma32(frag_rows(Gs, qt * 32, 1, lane), v1, dp);
+          f32x16_t ds;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int q = qt * 32 + mfma32_row(e, hi);
+            const float pr = fast_exp2(sc[e] * c_log2 - L2s[q]);
+            sc[e] = pr;
+            ds[e] = pr * (dp[e] - Dls[q]);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            dv[j] = mfma32(frag_cols(Gt, LDV, qt * 32, s2, lane), pack_acc_half(sc, s2), dv[j]);
+            dk[j] = mfma32(frag_cols(Qt, LDV, qt * 32, s2, lane), pack_acc_half(ds, s2), dk[j]);
+          }
+        }
       }
     }
-    const int64_t row0 = frame * N + kt * 32;
-    store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk, scale, lane);
-    store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv, 1.0f, lane);
+  }
+#pragma unroll
+  for (int j = 0; j < KPW; ++j) {
+    const int kt = wave + 4 * j;
+    if (kt < NT) {
+      const int64_t row0 = frame * N + kt * 32;
+      store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[j], scale, lane);
+      store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv[j], 1.0f, lane);
+    }
   }
 }
 
@@ -316,7 +343,8 @@ int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, c
                void* dqkv, int64_t frames, float scale) {
   constexpr int N = NT * 32, LDV = N + 4;
   constexpr int bytes_dq = (2 * N * LDR + 32 * LDV) * 2;
-  constexpr int bytes_dkv = (2 * N * LDR + 2 * 32 * LDV) * 2 + 2 * N * 4;
+  constexpr int NRh = N / 2;
+  constexpr int bytes_dkv = (2 * NRh * LDR + 2 * 32 * (NRh + 4)) * 2 + 2 * NRh * 4;
   int rc = set_lds<attn_bwd_dq_kernel<NT>>(bytes_dq);
   if (rc) return rc;
   rc = set_lds<attn_bwd_dkv_kernel<NT>>(bytes_dkv);

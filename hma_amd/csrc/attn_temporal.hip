@@ -92,7 +92,7 @@ __device__ __forceinline__ void causal_softmax(float (&s)[TM], int t, int T) {
   for (int tp = 0; tp < TM; ++tp) s[tp] *= inv;
 }
 
-__global__ __launch_bounds__(128) void attn_t_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int T,
+__global__ __launch_bounds__(128, 3) void attn_t_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int T,
                                                          int n_s, float c_log2, int64_t qkv_batch_rows) {
   __shared__ __attribute__((aligned(16))) uint16_t sm[TM * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
