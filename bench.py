@@ -209,14 +209,21 @@ def main():
         ids, labels, act = batches[di]
         return trainer.step(ids, labels, act, [domains[di]] * B)
 
+    # untimed preparation: every (shape, domain) pair of the schedule is run until its launch plan is captured
+    # as a hipGraph (N = 1 path), so the timed steps replay graphs only -- the analogue of a compiler warm-up
+    prepare_steps = 0
+    if world == 1:
+        for di in sorted(set(mine)):
+            ids, labels, act = batches[di]
+            for _ in range(3):
+                trainer.step(ids, labels, act, [domains[di]] * B)
+                prepare_steps += 1
     for k in range(args.warmup):
         ws = one(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if not args.no_kernel_timing:
-        eng.timer = LaunchTimer(["hma_gemm_nt"])
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
         ws = one(k)
@@ -225,7 +232,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timer, eng.timer = eng.timer, None
+    timer = None
+    if not args.no_kernel_timing:
+        # per-launch HIP events need eager launches: an instrumented pass of the same steps right after the timed
+        # region (the timed region itself replays hipGraphs on the N = 1 path)
+        eng.timer = LaunchTimer(["hma_gemm_nt"])
+        for k in range(args.warmup, min(total, args.warmup + 3)):
+            one(k)
+        torch.cuda.synchronize()
+        timer, eng.timer = eng.timer, None
+        timed_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer.pairs)
+        inst_steps = min(total, args.warmup + 3) - args.warmup
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -257,7 +274,10 @@ def main():
                                    "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                                    "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
                                    "flops_per_launch": s["flops"] / s["launches"],
-                                   "share_of_step_time": s["ms"] / (1e3 * dt)}
+                                   "share_of_step_time": (s["ms"] / inst_steps) / (1e3 * dt / args.steps),
+                                   "measured": f"HIP events around every hma_gemm_nt launch of {inst_steps} eager steps run "
+                                               "right after the timed region"}
+            out["config"]["prepare_steps"] = prepare_steps
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, domains[mine[0]], d_actions[mine[0]], T)
         print(json.dumps(out), flush=True)

@@ -215,6 +215,7 @@ class STEngine:
         if self._ws_key == key:
             return self._ws
         self._ws, self._plans = {}, {}
+        self.ws_generation = getattr(self, "ws_generation", 0) + 1  # captured graphs point into the old buffers
         torch.cuda.empty_cache()
         L = self.cfg.num_layers
         Ls = L if train else 1

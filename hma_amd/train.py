@@ -114,6 +114,11 @@ class Trainer:
         self.completed = 0
         self._micro = 0
         self._active: List[str] = []
+        # hipGraph replay of (zero-grad, forward, loss, backward) per (shape, domain): ~1500 launches per step
+        # become one graph launch.  Single-GPU fast path only; the N > 1 path interleaves all-reduces eagerly.
+        self.use_graphs = True
+        self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
+        self._seen: Dict[tuple, int] = {}
 
     def micro_step(self, input_ids, labels, action_ids=None, domain=None) -> Dict[str, torch.Tensor]:
         """forward + backward of one micro-batch; gradients accumulate in the flat buffer."""
@@ -129,6 +134,10 @@ class Trainer:
         T = self.model.config.T
         eng.grad_scale.value = 1.0 / (self.accum * red.world)
         eng.gscale.fill_(1.0)
+        if self.use_graphs and red.world == 1 and self.accum == 1 and eng.timer is None:
+            ws = self._graphed_micro_step(input_ids.reshape(B, T, -1), labels, action_ids, dom)
+            self._micro += 1
+            return ws
         ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True)
         if last and red.world > 1:
             red.begin()
@@ -137,6 +146,50 @@ class Trainer:
         else:
             eng.backward(eng.grad_scale.value)
         self._micro += 1
+        return ws
+
+    def _graphed_micro_step(self, ids_BTS, labels, action_ids, dom):
+        """forward + loss + backward through a captured hipGraph (built on the third use of a (shape, domain))."""
+        eng = self.engine
+        B, T, S = ids_BTS.shape
+        if getattr(self, "_graph_gen", None) != getattr(eng, "ws_generation", 0):
+            self._graphs, self._seen = {}, {}
+        key = (B, T, S, dom, action_ids is not None)
+        graph = self._graphs.get(key)
+        if graph is None:
+            n = self._seen.get(key, 0) + 1
+            self._seen[key] = n
+            ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True)
+            eng.backward(eng.grad_scale.value)
+            if n >= 2:  # buffers, plans and lazily-initialised kernel attributes exist now: capture for next time
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                Bq, Tq, Sq, A, domq = eng._last
+                with torch.cuda.graph(g):
+                    stream = torch.cuda.current_stream().cuda_stream
+                    eng._forward_plan(Bq, Tq, Sq, A, True, domq).run(stream)
+                    eng._ws["stats"].zero_()
+                    eng._loss_plan(Bq, Tq, Sq, True).run(stream)
+                    eng._ws["dx"].zero_()
+                    if A > 0:
+                        eng._ws["da_emb"].zero_()
+                    eng._backward_plan(Bq, Tq, Sq, A, domq).run(stream)
+                # the capture re-ran nothing (capture only records), gradients of this step are already in G
+                self._graphs[key] = g
+                self._graph_gen = eng.ws_generation
+            return ws
+        # replay: stage the inputs exactly as STEngine.forward does, then one graph launch
+        A = eng.cfg.action_token_size if action_ids is not None else 0
+        ws = eng._workspace(B, T, S, A, True)
+        stream = torch.cuda.current_stream().cuda_stream
+        eng.refresh_weights(dom if action_ids is not None else None, stream)
+        ws["ids"].copy_(ids_BTS, non_blocking=True)
+        ws["labels"].copy_(labels.reshape(B, T * S), non_blocking=True)
+        if action_ids is not None:
+            d_a = eng.d_actions[dom]
+            ws["actions"][: B * T * d_a].copy_(action_ids[:, :T].reshape(-1), non_blocking=True)
+        eng._last = (B, T, S, A, dom if A > 0 else None)
+        graph.replay()
         return ws
 
     def optimizer_step(self) -> None:
