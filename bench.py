@@ -211,13 +211,16 @@ def main():
 
     # untimed preparation: every (shape, domain) pair of the schedule is run until its launch plan is captured
     # as a hipGraph (N = 1 path), so the timed steps replay graphs only -- the analogue of a compiler warm-up
+    # (every rank runs the same NUMBER of steps per slot so the collectives stay matched)
     prepare_steps = 0
-    if world == 1:
-        for di in sorted(set(mine)):
-            ids, labels, act = batches[di]
-            for _ in range(3):
-                trainer.step(ids, labels, act, [domains[di]] * B)
-                prepare_steps += 1
+    for rnd in range(3):
+        for k in range(total):
+            first = mine.index(mine[k]) == k
+            ids, labels, act = batches[mine[k]]
+            if world == 1 and not first:
+                continue
+            trainer.step(ids, labels, act, [domains[mine[k]]] * B)
+            prepare_steps += 1
     for k in range(args.warmup):
         ws = one(k)
     torch.cuda.synchronize()

@@ -134,7 +134,7 @@ class Trainer:
         T = self.model.config.T
         eng.grad_scale.value = 1.0 / (self.accum * red.world)
         eng.gscale.fill_(1.0)
-        if self.use_graphs and red.world == 1 and self.accum == 1 and eng.timer is None:
+        if self.use_graphs and self.accum == 1 and eng.timer is None and eng.device.type == "cuda":
             ws = self._graphed_micro_step(input_ids.reshape(B, T, -1), labels, action_ids, dom)
             self._micro += 1
             return ws
@@ -148,37 +148,65 @@ class Trainer:
         self._micro += 1
         return ws
 
+    def _segments(self, pl) -> List[Tuple[int, Optional[int], Optional[str]]]:
+        """(start, stop, label) slices of the backward plan: one per gradient bucket when data-parallel."""
+        L = self.model.config.num_layers
+        if self.reducer.world == 1 and not getattr(self, "force_segments", False):
+            return [(0, None, None)]
+        out, start = [], 0
+        for l in reversed(range(L)):
+            if (L - l) % self.layers_per_bucket == 0 or l == 0:
+                stop = pl.marks[f"layer{l}"]
+                out.append((start, stop, f"layer{l}"))
+                start = stop
+        out.append((start, None, "end"))
+        return out
+
     def _graphed_micro_step(self, ids_BTS, labels, action_ids, dom):
-        """forward + loss + backward through a captured hipGraph (built on the third use of a (shape, domain))."""
-        eng = self.engine
+        """forward + loss + backward replayed from captured hipGraphs (built on the second use of a (shape, domain)):
+        ~1500 launches per step become one graph launch per gradient bucket; the all-reduce of a bucket is issued
+        between two graph launches exactly where the eager path issues it."""
+        eng, red = self.engine, self.reducer
         B, T, S = ids_BTS.shape
-        if getattr(self, "_graph_gen", None) != getattr(eng, "ws_generation", 0):
+        A_now = eng.cfg.action_token_size if action_ids is not None else 0
+        eng._workspace(B, T, S, A_now, True)  # (re)allocates only when the shape changed
+        if getattr(self, "_graph_gen", None) != eng.ws_generation:  # captured graphs point into the old buffers
             self._graphs, self._seen = {}, {}
+            self._graph_gen = eng.ws_generation
         key = (B, T, S, dom, action_ids is not None)
-        graph = self._graphs.get(key)
-        if graph is None:
+        graphs = self._graphs.get(key)
+        if graphs is None:
             n = self._seen.get(key, 0) + 1
             self._seen[key] = n
             ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True)
-            eng.backward(eng.grad_scale.value)
+            if red.world > 1:
+                red.begin()
+                eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
+                red.finish(self._active)
+            else:
+                eng.backward(eng.grad_scale.value)
             if n >= 2:  # buffers, plans and lazily-initialised kernel attributes exist now: capture for next time
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
                 Bq, Tq, Sq, A, domq = eng._last
-                with torch.cuda.graph(g):
-                    stream = torch.cuda.current_stream().cuda_stream
-                    eng._forward_plan(Bq, Tq, Sq, A, True, domq).run(stream)
-                    eng._ws["stats"].zero_()
-                    eng._loss_plan(Bq, Tq, Sq, True).run(stream)
-                    eng._ws["dx"].zero_()
-                    if A > 0:
-                        eng._ws["da_emb"].zero_()
-                    eng._backward_plan(Bq, Tq, Sq, A, domq).run(stream)
-                # the capture re-ran nothing (capture only records), gradients of this step are already in G
-                self._graphs[key] = g
-                self._graph_gen = eng.ws_generation
+                bwd = eng._backward_plan(Bq, Tq, Sq, A, domq)
+                graphs = []
+                for i, (start, stop, label) in enumerate(self._segments(bwd)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        stream = torch.cuda.current_stream().cuda_stream
+                        if i == 0:
+                            eng._forward_plan(Bq, Tq, Sq, A, True, domq).run(stream)
+                            eng._ws["stats"].zero_()
+                            eng._loss_plan(Bq, Tq, Sq, True).run(stream)
+                            eng._ws["dx"].zero_()
+                            if A > 0:
+                                eng._ws["da_emb"].zero_()
+                        bwd.run(stream, start, stop)
+                    graphs.append((g, label))
+                # capture only records: the gradients of this step are already in G
+                self._graphs[key] = graphs
             return ws
-        # replay: stage the inputs exactly as STEngine.forward does, then one graph launch
+        # replay: stage the inputs exactly as STEngine.forward does, then one graph launch per bucket
         A = eng.cfg.action_token_size if action_ids is not None else 0
         ws = eng._workspace(B, T, S, A, True)
         stream = torch.cuda.current_stream().cuda_stream
@@ -189,7 +217,14 @@ class Trainer:
             d_a = eng.d_actions[dom]
             ws["actions"][: B * T * d_a].copy_(action_ids[:, :T].reshape(-1), non_blocking=True)
         eng._last = (B, T, S, A, dom if A > 0 else None)
-        graph.replay()
+        if red.world > 1:
+            red.begin()
+        for g, label in graphs:
+            g.replay()
+            if label is not None:
+                red.on_segment(label)
+        if red.world > 1:
+            red.finish(self._active)
         return ws
 
     def optimizer_step(self) -> None:
