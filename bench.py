@@ -70,6 +70,26 @@ def domain_sequence(n_domains, n_draws, seed=0):
     return torch.multinomial(w / w.sum(), n_draws, replacement=True, generator=g).tolist()
 
 
+def pmc_traffic_per_launch(kernel_substr="gemm_nt"):
+    """HBM bytes per launch of the NT GEMM kernels from the committed rocprofv3 PMC passes (profiles/pmc_hbm_r1.json:
+    separate FETCH_SIZE / WRITE_SIZE runs of this bench on an 8-layer model; counters are in KB and, on gfx950,
+    FETCH_SIZE reports half of a wide coalesced read -- MI355X_MICROARCH.md section HBM -- so it is doubled)."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_r1.json")
+    try:
+        d = json.load(open(path))
+        tot, launches = 0.0, 0
+        for name, v in d["fetch"].items():
+            if kernel_substr in name:
+                tot += 2.0 * v["counter_sum_kb"] * 1024.0
+                launches += v["launches"]
+        for name, v in d["write"].items():
+            if kernel_substr in name:
+                tot += v["counter_sum_kb"] * 1024.0
+        return tot / launches if launches else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(model, domain, d_a, T, budget_s=25.0):
     """The CPU oracle (a port of the reference path, oracle/st_maskgit_ref.py) on the host cores: B = 1
     fwd + bwd + clip + AdamW, timed for a bounded number of steps."""
@@ -274,7 +294,8 @@ def main():
             if s:
                 ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (hma_gemm_nt)", "achieved": ach, "peak": 2500.0,
-                                   "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                                   "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic_per_launch(),
+                                   "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/pmc_hbm_r1.json",
                                    "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
                                    "flops_per_launch": s["flops"] / s["launches"],
                                    "share_of_step_time": (s["ms"] / inst_steps) / (1e3 * dt / args.steps),
