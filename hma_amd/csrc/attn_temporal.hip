@@ -1,10 +1,10 @@
 // Causal temporal attention over the T (<= 16) frames of one (b, s) token column, 8 heads of 32.
 //
-// The whole problem per column is 16 x 16 scores per head: far below an MFMA tile's worth of
-// reuse, and the kernel is bound by streaming qkv (1536 B per token row, rows T apart by n_s rows)
-// so it is written on the VALU with packed-bf16 dot products (v_dot2c_f32_bf16): one workgroup =
-// one column, one thread = one (t, head) row; the column's 16 x 1536 B of qkv are staged in LDS
-// with fully coalesced 1536-B row reads and K/V rows are broadcast-read by the 16 lanes of a head.
+// The whole problem per column is 16 x 16 scores per head, and the kernel should be bound by
+// streaming qkv (1536 B per token row, rows of a column n_s rows apart): one workgroup = one
+// column, whose 16 x 1536 B of qkv are staged in LDS with fully coalesced 1536-B row reads; each of
+// its two waves then walks four heads with 16x16 MFMAs (see the note above the kernels).  Only the
+// single-query decode kernel stays on the VALU (v_dot2c_f32_bf16), where there is no tile to form.
 //
 // Reference: BasicSelfAttention.forward, hma/model/attention.py:37-61 with causal=True (mask fill
 // -finfo.max, :52-56) as called at hma/model/st_transformer.py:111 on the "(B S) T C" view of the
@@ -56,14 +56,6 @@ __device__ __forceinline__ void st32(uint16_t* p, const float (&y)[32], float mu
 }
 
 // rows of the column: global row (b*T + t) * n_s + s
-__device__ __forceinline__ void load_column(uint16_t* dst, int dst_ld, const uint16_t* src, int64_t src_ld, int chunks_per_row,
-                                            int64_t row0, int64_t row_stride, int T, int tid) {
-  for (int c = tid; c < T * chunks_per_row; c += 128) {
-    const int t = c / chunks_per_row, ch = c % chunks_per_row;
-    *reinterpret_cast<uint4*>(dst + t * dst_ld + ch * 8) =
-        *reinterpret_cast<const uint4*>(src + (row0 + t * row_stride) * src_ld + ch * 8);
-  }
-}
 __device__ __forceinline__ void store_column(uint16_t* dst, int64_t dst_ld, const uint16_t* src, int src_ld, int src_col0,
                                              int chunks_per_row, int64_t row0, int64_t row_stride, int T, int tid) {
   for (int c = tid; c < T * chunks_per_row; c += 128) {
@@ -92,132 +84,203 @@ __device__ __forceinline__ void causal_softmax(float (&s)[TM], int t, int T) {
   for (int tp = 0; tp < TM; ++tp) s[tp] *= inv;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MFMA formulation.  One column and head is exactly one v_mfma_f32_16x16x32_bf16: S^T = K Q^T contracts the
+// 32 head channels and yields the 16 x 16 score tile with lane&15 = query t, registers = keys tp = 4*(lane>>4)+r,
+// so the causal softmax is 4 registers + two cross-group shuffles per lane.  Products that contract over time
+// (P V, dS K, dS^T Q, P^T dO) use v_mfma_f32_16x16x16_bf16 with the probability tile as the B operand straight
+// from those registers and the [time][channel] matrix gathered from LDS as A (4 x ds_read_u16 per 16 channels);
+// they are computed transposed (channels x time) so each lane ends up with 4 consecutive channels of one token
+// row -> 8-byte LDS writes into the slab, which leaves the CU through the same coalesced 1536-B row stores.
+// The VALU version of this kernel was instruction-bound (~3600 VALU ops per lane and column in backward).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int QLD = LD + 8;   // padded LDS rows (16-B aligned, breaks the 1536-B bank period)
+constexpr int GLD = DM + 8;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ f32x4_t mfma16k32(const bf16x8_t& a, const bf16x8_t& b) {
+  const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, z, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma16k16(const s16x4_t& a, const s16x4_t& b) {
+  const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, z, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4_t pack4(float a, float b, float c, float d) {
+  const uint2 v = make_uint2(pack_bf16(a, b), pack_bf16(c, d));
+  return __builtin_bit_cast(s16x4_t, v);
+}
+// A operand of a time-contracting product: element (m = channel c, k = time 4g + j) of a [time][channel] slab
+__device__ __forceinline__ s16x4_t gather_time(const uint16_t* base, int ld) {
+  s16x4_t r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = (short)base[j * ld];
+  return r;
+}
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// stage T rows of CHUNKS 16-B pieces into a padded slab, zero-filling rows T..15 (they feed MFMAs);
+// all of a thread's loads are issued before the first LDS write so that the column is in flight at once
+template <int CHUNKS>
+__device__ __forceinline__ void stage_rows(uint16_t* dst, int dst_ld, const uint16_t* src, int64_t src_ld, int64_t row0,
+                                           int64_t row_stride, int T, int tid) {
+  constexpr int N = TM * CHUNKS / 128;
+  uint4 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * 128;
+    const int t = c / CHUNKS, ch = c % CHUNKS;
+    v[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < T) v[i] = *reinterpret_cast<const uint4*>(src + (row0 + t * row_stride) * src_ld + ch * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * 128;
+    const int t = c / CHUNKS, ch = c % CHUNKS;
+    *reinterpret_cast<uint4*>(dst + t * dst_ld + ch * 8) = v[i];
+  }
+}
+
 __global__ __launch_bounds__(128, 3) void attn_t_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int T,
                                                          int n_s, float c_log2, int64_t qkv_batch_rows) {
-  __shared__ __attribute__((aligned(16))) uint16_t sm[TM * LD];
+  __shared__ __attribute__((aligned(16))) uint16_t sm[TM * QLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = lane & 15, h = wave * 4 + (lane >> 4);
+  const int c = lane & 15, g = lane >> 4;
   const int64_t col = blockIdx.x;  // b * n_s + s
   const int64_t b = col / n_s, s_idx = col % n_s;
   const int64_t row0 = b * T * n_s + s_idx;
-  load_column(sm, LD, qkv, LD, LD / 8, b * qkv_batch_rows + s_idx, n_s, T, tid);
+  stage_rows<LD / 8>(sm, QLD, qkv, LD, b * qkv_batch_rows + s_idx, n_s, T, tid);
   __syncthreads();
-  float out[32];
+#pragma unroll 1
+  for (int hh = 0; hh < 4; ++hh) {
+    const int h = wave * 4 + hh;
+    const uint16_t* qh = sm + c * QLD + h * 32 + 8 * g;
+    const bf16x8_t aQ = *reinterpret_cast<const bf16x8_t*>(qh);
+    const bf16x8_t aK = *reinterpret_cast<const bf16x8_t*>(qh + DM);
+    f32x4_t st = mfma16k32(aK, aQ);  // [tp = 4g + r][t = c]
+    float m = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) out[i] = 0.f;
-  if (t < T) {
-    uint32_t q[16];
-    ld16(sm + t * LD + h * 32, q);
-    float s[TM];
-#pragma unroll
-    for (int tp = 0; tp < TM; ++tp) {
-      s[tp] = 0.f;
-      if (tp < T) {
-        uint32_t k[16];
-        ld16(sm + tp * LD + DM + h * 32, k);
-        s[tp] = dot32(q, k) * c_log2;
-      }
+    for (int r = 0; r < 4; ++r) {
+      st[r] = (4 * g + r <= c) ? st[r] * c_log2 : -INFINITY;
+      m = fmaxf(m, st[r]);
     }
-    causal_softmax(s, t, T);
+    m = group_max(m);
+    float l = 0.f;
 #pragma unroll
-    for (int tp = 0; tp < TM; ++tp) {
-      if (tp < T) {
-        uint32_t v[16];
-        ld16(sm + tp * LD + 2 * DM + h * 32, v);
-        axpy32(out, s[tp], v);
-      }
+    for (int r = 0; r < 4; ++r) {
+      st[r] = __builtin_amdgcn_exp2f(st[r] - m);
+      l += st[r];
     }
+    const float inv = 1.0f / group_sum(l);
+    const s16x4_t pT = pack4(st[0] * inv, st[1] * inv, st[2] * inv, st[3] * inv);  // B: k = tp, n = t
+    f32x4_t ot[2];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      const s16x4_t vT = gather_time(sm + (4 * g) * QLD + 2 * DM + h * 32 + 16 * dd + c, QLD);
+      ot[dd] = mfma16k16(vT, pT);  // [d = 16dd + 4g + r][t = c]
+    }
+    __builtin_amdgcn_wave_barrier();  // this wave's reads of head h are done; its q slot becomes the output
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+      *reinterpret_cast<uint2*>(sm + c * QLD + h * 32 + 16 * dd + 4 * g) =
+          make_uint2(pack_bf16(ot[dd][0], ot[dd][1]), pack_bf16(ot[dd][2], ot[dd][3]));
   }
-  // each thread overwrites only its own q slot, which no other thread reads
-  if (t < T) st32(sm + t * LD + h * 32, out, 1.0f);
   __syncthreads();
-  store_column(o, DM, sm, LD, 0, DM / 8, row0, n_s, T, tid);
+  store_column(o, DM, sm, QLD, 0, DM / 8, row0, n_s, T, tid);
 }
 
-__global__ __launch_bounds__(128) void attn_t_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
-                                                         const uint16_t* __restrict__ d_o, uint16_t* __restrict__ dqkv,
-                                                         int T, int n_s, float c_log2, float scale) {
-  __shared__ __attribute__((aligned(16))) uint16_t sm[TM * LD];     // qkv, later dq|dk|dv
-  __shared__ __attribute__((aligned(16))) uint16_t sg[TM * DM];     // dO
-  __shared__ __attribute__((aligned(16))) float sp[8 * TM * TM];    // P[h][t][tp]
-  __shared__ __attribute__((aligned(16))) float sd[8 * TM * TM];    // dS[h][t][tp]
+__global__ __launch_bounds__(128, 2) void attn_t_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                         uint16_t* __restrict__ dqkv, int T, int n_s, float c_log2,
+                                                         float scale) {
+  __shared__ __attribute__((aligned(16))) uint16_t sm[TM * QLD];   // qkv, later dq|dk|dv
+  __shared__ __attribute__((aligned(16))) uint16_t sg[TM * GLD];   // dO
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = lane & 15, h = wave * 4 + (lane >> 4);
+  const int c = lane & 15, g = lane >> 4;
   const int64_t col = blockIdx.x;
   const int64_t b = col / n_s, s_idx = col % n_s;
   const int64_t row0 = b * T * n_s + s_idx;
-  load_column(sm, LD, qkv, LD, LD / 8, row0, n_s, T, tid);
-  load_column(sg, DM, d_o, DM, DM / 8, row0, n_s, T, tid);
+  stage_rows<LD / 8>(sm, QLD, qkv, LD, row0, n_s, T, tid);
+  stage_rows<DM / 8>(sg, GLD, d_o, DM, row0, n_s, T, tid);
   __syncthreads();
-
-  float dq[32];
+#pragma unroll 1
+  for (int hh = 0; hh < 4; ++hh) {
+    const int h = wave * 4 + hh;
+    const uint16_t* qh = sm + c * QLD + h * 32 + 8 * g;
+    const bf16x8_t aQ = *reinterpret_cast<const bf16x8_t*>(qh);
+    const bf16x8_t aK = *reinterpret_cast<const bf16x8_t*>(qh + DM);
+    const bf16x8_t aV = *reinterpret_cast<const bf16x8_t*>(qh + 2 * DM);
+    const bf16x8_t aG = *reinterpret_cast<const bf16x8_t*>(sg + c * GLD + h * 32 + 8 * g);
+    // orientation 1: lane = query t (c), registers = keys tp = 4g + r
+    f32x4_t st = mfma16k32(aK, aQ);
+    const f32x4_t dpt = mfma16k32(aV, aG);
+    float m = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) dq[i] = 0.f;
-  float p[TM], ds[TM];
-#pragma unroll
-  for (int tp = 0; tp < TM; ++tp) { p[tp] = 0.f; ds[tp] = 0.f; }
-  if (t < T) {
-    uint32_t q[16], g[16], oo[16];
-    ld16(sm + t * LD + h * 32, q);
-    ld16(sg + t * DM + h * 32, g);
-    ld16(o + (row0 + (int64_t)t * n_s) * DM + h * 32, oo);
-    const float delta = dot32(g, oo);
-#pragma unroll
-    for (int tp = 0; tp < TM; ++tp) {
-      if (tp < T) {
-        uint32_t k[16];
-        ld16(sm + tp * LD + DM + h * 32, k);
-        p[tp] = dot32(q, k) * c_log2;
-      }
+    for (int r = 0; r < 4; ++r) {
+      st[r] = (4 * g + r <= c) ? st[r] * c_log2 : -INFINITY;
+      m = fmaxf(m, st[r]);
     }
-    causal_softmax(p, t, T);
+    m = group_max(m);
+    float l = 0.f;
 #pragma unroll
-    for (int tp = 0; tp < TM; ++tp) {
-      if (tp < T) {
-        uint32_t v[16], k[16];
-        ld16(sm + tp * LD + 2 * DM + h * 32, v);
-        ds[tp] = p[tp] * (dot32(g, v) - delta);
-        ld16(sm + tp * LD + DM + h * 32, k);
-        axpy32(dq, ds[tp], k);
-      }
+    for (int r = 0; r < 4; ++r) {
+      st[r] = __builtin_amdgcn_exp2f(st[r] - m);
+      l += st[r];
     }
-  }
-  {
-    float* pp = sp + (h * TM + t) * TM;
-    float* dd = sd + (h * TM + t) * TM;
+    const float inv = 1.0f / group_sum(l);
+    float delta = 0.f;  // sum_tp P dP  ( = dO . O, the softmax-backward row term)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(pp + 4 * i) = make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
-      *reinterpret_cast<float4*>(dd + 4 * i) = make_float4(ds[4 * i], ds[4 * i + 1], ds[4 * i + 2], ds[4 * i + 3]);
+    for (int r = 0; r < 4; ++r) {
+      st[r] *= inv;
+      delta += st[r] * dpt[r];
+    }
+    delta = group_sum(delta);
+    const s16x4_t dsT = pack4(st[0] * (dpt[0] - delta), st[1] * (dpt[1] - delta), st[2] * (dpt[2] - delta),
+                              st[3] * (dpt[3] - delta));  // B: k = tp, n = t
+    // orientation 2: lane = key tp (c), registers = queries t = 4g + r
+    const f32x4_t s2 = mfma16k32(aQ, aK);
+    const f32x4_t dp2 = mfma16k32(aG, aV);
+    float p2[4], ds2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tq = 4 * g + r;
+      const float mq = __shfl(m, tq, 64), iq = __shfl(inv, tq, 64), dq_ = __shfl(delta, tq, 64);
+      p2[r] = (c <= tq) ? __builtin_amdgcn_exp2f(s2[r] * c_log2 - mq) * iq : 0.f;
+      ds2[r] = p2[r] * (dp2[r] - dq_);
+    }
+    const s16x4_t pB = pack4(p2[0], p2[1], p2[2], p2[3]);       // B: k = t, n = tp
+    const s16x4_t dsB = pack4(ds2[0], ds2[1], ds2[2], ds2[3]);
+    f32x4_t dq[2], dk[2], dv[2];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      const int off = (4 * g) * QLD + h * 32 + 16 * dd + c;
+      const s16x4_t qT = gather_time(sm + off, QLD);
+      const s16x4_t kT = gather_time(sm + off + DM, QLD);
+      const s16x4_t gT = gather_time(sg + (4 * g) * GLD + h * 32 + 16 * dd + c, GLD);
+      dq[dd] = mfma16k16(kT, dsT);  // dQ^T [d][t = c]
+      dk[dd] = mfma16k16(qT, dsB);  // dK^T [d][tp = c]
+      dv[dd] = mfma16k16(gT, pB);   // dV^T [d][tp = c]
+    }
+    __builtin_amdgcn_wave_barrier();  // every read of head h by this wave is done: reuse its slots for the gradients
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+      uint16_t* dst = sm + c * QLD + h * 32 + 16 * dd + 4 * g;
+      *reinterpret_cast<uint2*>(dst) =
+          make_uint2(pack_bf16(dq[dd][0] * scale, dq[dd][1] * scale), pack_bf16(dq[dd][2] * scale, dq[dd][3] * scale));
+      *reinterpret_cast<uint2*>(dst + DM) =
+          make_uint2(pack_bf16(dk[dd][0] * scale, dk[dd][1] * scale), pack_bf16(dk[dd][2] * scale, dk[dd][3] * scale));
+      *reinterpret_cast<uint2*>(dst + 2 * DM) = make_uint2(pack_bf16(dv[dd][0], dv[dd][1]), pack_bf16(dv[dd][2], dv[dd][3]));
     }
   }
   __syncthreads();
-  // pass 2: this thread now owns key/value row tp = t
-  float dk[32], dv[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
-  if (t < T) {
-#pragma unroll
-    for (int tq = 0; tq < TM; ++tq) {
-      if (tq < T) {
-        const float pv = sp[(h * TM + tq) * TM + t];
-        const float dsv = sd[(h * TM + tq) * TM + t];
-        uint32_t q[16], g[16];
-        ld16(sm + tq * LD + h * 32, q);
-        ld16(sg + tq * DM + h * 32, g);
-        axpy32(dk, dsv, q);
-        axpy32(dv, pv, g);
-      }
-    }
-  }
-  __syncthreads();  // every read of q/k/v is done: reuse the slab for the gradients
-  if (t < T) {
-    st32(sm + t * LD + h * 32, dq, scale);
-    st32(sm + t * LD + DM + h * 32, dk, scale);
-    st32(sm + t * LD + 2 * DM + h * 32, dv, 1.0f);
-  }
-  __syncthreads();
-  store_column(dqkv, LD, sm, LD, 0, LD / 8, row0, n_s, T, tid);
+  store_column(dqkv, LD, sm, QLD, 0, LD / 8, row0, n_s, T, tid);
 }
 
 // Incremental decode: only frame t_query is new.  One lane per (column, head): q from the cache row of frame
@@ -244,6 +307,8 @@ __global__ __launch_bounds__(64) void attn_t_decode_kernel(const uint16_t* __res
     }
   }
   causal_softmax(s, t_query, t_query + 1);
+#pragma unroll
+  for (int tp = 0; tp < TM; ++tp) s[tp] = from_bf16(to_bf16(s[tp]));  // P enters the PV product as bf16, as in the MFMA kernels
   float out[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) out[i] = 0.f;
@@ -298,8 +363,7 @@ extern "C" int hma_attn_temporal_bwd(void* stream, const void* qkv, const void* 
   if (T < 1 || T > TM || n_s < 1) return HMA_EINVAL;
   if (batch <= 0) return 0;
   hipLaunchKernelGGL(attn_t_bwd_kernel, dim3((unsigned)(batch * n_s)), dim3(128), 0, (hipStream_t)stream,
-                     (const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)d_o, (uint16_t*)dqkv, (int)T, (int)n_s,
-                     scale * LOG2E, scale);
+                     (const uint16_t*)qkv, (const uint16_t*)d_o, (uint16_t*)dqkv, (int)T, (int)n_s, scale * LOG2E, scale);
   HMA_CHECK_LAUNCH();
   return 0;
 }
