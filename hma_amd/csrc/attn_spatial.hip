@@ -41,28 +41,78 @@ __device__ __forceinline__ void decode_block(int64_t b, int64_t frames, int64_t&
   }
 }
 
-// row-major stage: dst[row][LDR] <- src[row * ld + 0..31] (bf16), n rows
-__device__ __forceinline__ void stage_rows(uint16_t* dst, const uint16_t* src, int64_t ld, int n, int tid, int nthr) {
-  for (int c = tid; c < n * 4; c += nthr) {
-    const int row = c >> 2, ch = c & 3;
-    *reinterpret_cast<uint4*>(&dst[row * LDR + ch * 8]) = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
-  }
-}
-// transposed stage: dst[d][ldv] (d = 0..31, token contiguous) <- src[token * ld + d]
-__device__ __forceinline__ void stage_cols(uint16_t* dst, int ldv, const uint16_t* src, int64_t ld, int n, int tid,
-                                           int nthr) {
-  for (int c = tid; c < n * 2; c += nthr) {
-    const int kp = c >> 2, ch = c & 3;
-    const uint4 a = *reinterpret_cast<const uint4*>(src + (int64_t)(2 * kp) * ld + ch * 8);
-    const uint4 b = *reinterpret_cast<const uint4*>(src + (int64_t)(2 * kp + 1) * ld + ch * 8);
-    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+// Staging is split into "issue every global load" and "write LDS" so that the whole (frame, head) slab is in
+// flight at once: with one load per loop trip the kernels spent most of their time in ten-odd serialized
+// HBM round trips per workgroup (dkv: ~30 us of staging latency around ~7 us of MFMA work).
+//
+// RowStage: ROWS rows of 64 B -> row-major [row][LDR].
+// Items past the end are clamped to the last one (its owner writes the same bytes), which keeps both phases
+// free of branches: a guarded load makes the compiler wait for it inside the guard.
+template <int ROWS>
+struct RowStage {
+  static constexpr int ITEMS = ROWS * 4, R = (ITEMS + 255) / 256;
+  uint4 v[R];
+  static __device__ __forceinline__ int item(int tid, int i) { return min(tid + i * 256, ITEMS - 1); }
+  __device__ __forceinline__ void load(const uint16_t* src, int64_t ld, int tid) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t x = (j & 1) ? ((aw[j >> 1] >> 16) | (bw[j >> 1] & 0xffff0000u))
-                                 : ((aw[j >> 1] & 0xffffu) | (bw[j >> 1] << 16));
-      *reinterpret_cast<uint32_t*>(&dst[(ch * 8 + j) * ldv + 2 * kp]) = x;
+    for (int i = 0; i < R; ++i) {
+      const int c = item(tid, i);
+      v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(c >> 2) * ld + (c & 3) * 8);
     }
   }
+  __device__ __forceinline__ void store(uint16_t* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int c = item(tid, i);
+      *reinterpret_cast<uint4*>(&dst[(c >> 2) * LDR + (c & 3) * 8]) = v[i];
+    }
+  }
+};
+// PairStage: ROWS rows handled as row pairs, written row-major ([row][LDR]) and/or transposed
+// ([d][ldv], token contiguous, two tokens per 4-byte write).
+template <int ROWS>
+struct PairStage {
+  static constexpr int ITEMS = ROWS * 2, R = (ITEMS + 255) / 256;
+  uint4 a[R], b[R];
+  static __device__ __forceinline__ int item(int tid, int i) { return min(tid + i * 256, ITEMS - 1); }
+  __device__ __forceinline__ void load(const uint16_t* src, int64_t ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int c = item(tid, i);
+      const uint16_t* p = src + (int64_t)(2 * (c >> 2)) * ld + (c & 3) * 8;
+      a[i] = *reinterpret_cast<const uint4*>(p);
+      b[i] = *reinterpret_cast<const uint4*>(p + ld);
+    }
+  }
+  __device__ __forceinline__ void store_rows(uint16_t* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int c = item(tid, i);
+      uint16_t* q = &dst[(2 * (c >> 2)) * LDR + (c & 3) * 8];
+      *reinterpret_cast<uint4*>(q) = a[i];
+      *reinterpret_cast<uint4*>(q + LDR) = b[i];
+    }
+  }
+  __device__ __forceinline__ void store_cols(uint16_t* dst, int ldv, int tid) const {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int c = item(tid, i);
+      const int kp = c >> 2, ch = c & 3;
+      const uint32_t aw[4] = {a[i].x, a[i].y, a[i].z, a[i].w}, bw[4] = {b[i].x, b[i].y, b[i].z, b[i].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t x = (j & 1) ? ((aw[j >> 1] >> 16) | (bw[j >> 1] & 0xffff0000u))
+                                   : ((aw[j >> 1] & 0xffffu) | (bw[j >> 1] << 16));
+        *reinterpret_cast<uint32_t*>(&dst[(ch * 8 + j) * ldv + 2 * kp]) = x;
+      }
+    }
+  }
+};
+// The n/32 tiles of a (frame, head) do not divide over 4 waves (10 -> 3,3,2,2): rotate which waves get the
+// extra tile from workgroup to workgroup so that no SIMD is always the loaded one.
+__device__ __forceinline__ int wave_rot(int wave) {
+  const unsigned r = blockIdx.x >> 3;
+  return (int)((wave + r + (r >> 5)) & 3);
 }
 
 // A operand from a row-major tile: lane (row = l & 31, hi) reads dims 16*s + 8*hi .. +8
@@ -119,13 +169,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   decode_block(blockIdx.x, frames, frame, head);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
-  stage_rows(Ks, base + DM, QKV_LD, N, tid, 256);
-  stage_cols(Vt, LDV, base + 2 * DM, QKV_LD, N, tid, 256);
+  {
+    RowStage<N> ks;
+    PairStage<N> vs;
+    ks.load(base + DM, QKV_LD, tid);
+    vs.load(base + 2 * DM, QKV_LD, tid);
+    ks.store(Ks, tid);
+    vs.store_cols(Vt, LDV, tid);
+  }
   __syncthreads();
 
-  for (int qt = wave; qt < NT; qt += 4) {
-    const uint16_t* qb = base + (int64_t)qt * 32 * QKV_LD;
-    const bf16x8_t q0 = frag_global(qb, QKV_LD, 0, lane), q1 = frag_global(qb, QKV_LD, 1, lane);
+  // the query tile of the NEXT trip is fetched while this one is computed (clamped re-load on the last trip)
+  const int qt0 = wave_rot(wave);
+  bf16x8_t nq0 = frag_global(base + (int64_t)min(qt0, NT - 1) * 32 * QKV_LD, QKV_LD, 0, lane);
+  bf16x8_t nq1 = frag_global(base + (int64_t)min(qt0, NT - 1) * 32 * QKV_LD, QKV_LD, 1, lane);
+  for (int qt = qt0; qt < NT; qt += 4) {
+    const bf16x8_t q0 = nq0, q1 = nq1;
+    {
+      const uint16_t* qn = base + (int64_t)min(qt + 4, NT - 1) * 32 * QKV_LD;
+      nq0 = frag_global(qn, QKV_LD, 0, lane);
+      nq1 = frag_global(qn, QKV_LD, 1, lane);
+    }
     // two key chunks of NT/2 tiles with one online-softmax merge: keeps the live scores at 80 VGPRs
     constexpr int NC = NT / 2;
     float m = -INFINITY, l = 0.f;
@@ -188,24 +252,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
   decode_block(blockIdx.x, frames, frame, head);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
-  stage_rows(Ks, base + DM, QKV_LD, N, tid, 256);
-  stage_rows(Vs, base + 2 * DM, QKV_LD, N, tid, 256);
-  stage_cols(Kt, LDV, base + DM, QKV_LD, N, tid, 256);
+  {
+    PairStage<N> ks;
+    RowStage<N> vs;
+    ks.load(base + DM, QKV_LD, tid);
+    vs.load(base + 2 * DM, QKV_LD, tid);
+    ks.store_rows(Ks, tid);
+    ks.store_cols(Kt, LDV, tid);
+    vs.store(Vs, tid);
+  }
   __syncthreads();
 
-  for (int qt = wave; qt < NT; qt += 4) {
-    const int64_t row0 = frame * N + qt * 32;
+  // operands of the NEXT query tile are fetched while this one is computed (clamped re-load on the last trip)
+  struct QTile { bf16x8_t q0, q1, g0, g1, o0, o1; float L2; };
+  auto fetch = [&](int qt) {
+    const int64_t r0 = frame * N + qt * 32;
     const uint16_t* qb = base + (int64_t)qt * 32 * QKV_LD;
-    const bf16x8_t q0 = frag_global(qb, QKV_LD, 0, lane), q1 = frag_global(qb, QKV_LD, 1, lane);
-    const uint16_t* dob = d_o + row0 * DM + head * HD;
-    const uint16_t* ob = o + row0 * DM + head * HD;
-    const bf16x8_t g0 = frag_global(dob, DM, 0, lane), g1 = frag_global(dob, DM, 1, lane);
-    const bf16x8_t o0 = frag_global(ob, DM, 0, lane), o1 = frag_global(ob, DM, 1, lane);
+    const uint16_t* dob = d_o + r0 * DM + head * HD;
+    const uint16_t* ob = o + r0 * DM + head * HD;
+    QTile t;
+    t.q0 = frag_global(qb, QKV_LD, 0, lane); t.q1 = frag_global(qb, QKV_LD, 1, lane);
+    t.g0 = frag_global(dob, DM, 0, lane);    t.g1 = frag_global(dob, DM, 1, lane);
+    t.o0 = frag_global(ob, DM, 0, lane);     t.o1 = frag_global(ob, DM, 1, lane);
+    t.L2 = lse[(r0 + (lane & 31)) * NH + head];
+    return t;
+  };
+  const int qt0 = wave_rot(wave);
+  QTile nxt = fetch(min(qt0, NT - 1));
+  for (int qt = qt0; qt < NT; qt += 4) {
+    const int64_t row0 = frame * N + qt * 32;
+    const QTile cur = nxt;
+    nxt = fetch(min(qt + 4, NT - 1));
+    const bf16x8_t q0 = cur.q0, q1 = cur.q1, g0 = cur.g0, g1 = cur.g1;
     float dl = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dl += (float)g0[j] * (float)o0[j] + (float)g1[j] * (float)o1[j];
+    for (int j = 0; j < 8; ++j) dl += (float)g0[j] * (float)cur.o0[j] + (float)g1[j] * (float)cur.o1[j];
     dl += __shfl_xor(dl, 32, 64);
-    const float L2 = lse[(row0 + (lane & 31)) * NH + head];
+    const float L2 = cur.L2;
     if (lane < 32) delta[(row0 + lane) * NH + head] = dl;
     f32x16_t acc = zero16();
 #pragma unroll 2
@@ -249,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   int64_t frame; int head;
   decode_block(blockIdx.x, frames, frame, head);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5;
+  const int hi = lane >> 5, wrot = wave_rot(wave);
   const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
   const uint16_t* gbase = d_o + frame * N * DM + head * HD;
 
@@ -260,19 +343,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     const int q0 = half * NR;
-    if (half) __syncthreads();  // everyone is done reading the first half
-    stage_rows(Qs, base + (int64_t)q0 * QKV_LD, QKV_LD, NR, tid, 256);
-    stage_rows(Gs, gbase + (int64_t)q0 * DM, DM, NR, tid, 256);
-    stage_cols(Qt, LDV, base + (int64_t)q0 * QKV_LD, QKV_LD, NR, tid, 256);
-    stage_cols(Gt, LDV, gbase + (int64_t)q0 * DM, DM, NR, tid, 256);
-    for (int i = tid; i < NR; i += 256) {
-      L2s[i] = lse[(frame * N + q0 + i) * NH + head];
-      Dls[i] = delta[(frame * N + q0 + i) * NH + head];
+    {
+      static_assert(NR <= 256, "one lse / delta row per thread");
+      PairStage<NR> qs, gs;
+      qs.load(base + (int64_t)q0 * QKV_LD, QKV_LD, tid);
+      gs.load(gbase + (int64_t)q0 * DM, DM, tid);
+      const int lr = min(tid, NR - 1);
+      const float l2 = lse[(frame * N + q0 + lr) * NH + head];
+      const float dl = delta[(frame * N + q0 + lr) * NH + head];
+      if (half) __syncthreads();  // everyone is done reading the first half
+      qs.store_rows(Qs, tid);
+      qs.store_cols(Qt, LDV, tid);
+      gs.store_rows(Gs, tid);
+      gs.store_cols(Gt, LDV, tid);
+      L2s[lr] = l2;
+      Dls[lr] = dl;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
-      const int kt = wave + 4 * j;
+      const int kt = wrot + 4 * j;
       if (kt < NT) {
         const uint16_t* kb = base + DM + (int64_t)kt * 32 * QKV_LD;
         const uint16_t* vb = base + 2 * DM + (int64_t)kt * 32 * QKV_LD;
@@ -304,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   }
 #pragma unroll
   for (int j = 0; j < KPW; ++j) {
-    const int kt = wave + 4 * j;
+    const int kt = wrot + 4 * j;
     if (kt < NT) {
       const int64_t row0 = frame * N + kt * 32;
       store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[j], scale, lane);
