@@ -21,6 +21,18 @@ using namespace hma;
 
 namespace {
 
+// Debug-only phase timers (-DHMA_PROF, tools/phase_prof.py): per-wave s_memtime deltas summed per phase.
+#ifdef HMA_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL unsigned long long pt_ = __builtin_readcyclecounter(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PROF_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_prof[i_], pacc_[i_]); atomicAdd(&g_prof[8], 1ull); } } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH()
+#endif
+
 constexpr int BM = 128;  // token rows per tile (NT) / k-columns of dW per tile (TN)
 constexpr int BN = 128;  // weight rows per tile
 constexpr int BK = 64;   // contraction step
@@ -652,12 +664,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
   store(r0, 0);
   __syncthreads();
   const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+  PROF_DECL;
   auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
+    PROF_MARK(0);
     // `mine` held step `it` (already in LDS) and is free: refill it with step it + 2
     if (it + 2 < total_it && !(ablate & 2)) load(mine);
+    PROF_MARK(1);
     const uint16_t* As = smem + (it & 1) * P_STAGE;
     if (!(ablate & 4)) mma_tile(As, As + P_A, acc, wm, wn, lane);
+    PROF_MARK(2);
     if (!(ablate & 1)) emit_step(cur_kt);
+    PROF_MARK(3);
     if (++cur_kt == KT) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -668,8 +685,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
       cur_kt = 0;
       cur_tile += G;
     }
+    PROF_MARK(6);
     if (it + 1 < total_it) store(other, (it + 1) & 1);
+    PROF_MARK(4);
     __syncthreads();
+    PROF_MARK(5);
   };
   for (int it = 0; it < total_it; it += 2) {
     step(it, r0, r1);
@@ -678,6 +698,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
   if (!(ablate & 1)) {  // the last tile's epilogue has no following main loop to hide behind
     for (int part = 0; part < 4; ++part) emit_step(part);
   }
+  PROF_MARK(3);
+  PROF_FLUSH();
 }
 
 
@@ -1032,8 +1054,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
   if (total_it > 1) load(r1);
   store(r0, 0);
   __syncthreads();
+  PROF_DECL;
   auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
+    PROF_MARK(0);
     if (it + 2 < total_it && !(ablate & 2)) load(mine);
+    PROF_MARK(1);
     const uint16_t* As = smem + (it & 1) * Q_STAGE;
     const uint16_t* Ws = As + Q_A;
     if (!(ablate & 4)) {
@@ -1052,18 +1077,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
           for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mfma32(wf[nt], tf[mt], acc[nt][mt]);
       }
     }
+    PROF_MARK(2);
     if (++cur_kt == KT) {
       if (!(ablate & 1)) finish_tile();
       cur_kt = 0;
       cur_tile += G;
     }
+    PROF_MARK(3);
     if (it + 1 < total_it) store(other, (it + 1) & 1);
+    PROF_MARK(4);
     __syncthreads();
+    PROF_MARK(5);
   };
   for (int it = 0; it < total_it; it += 2) {
     step(it, r0, r1);
     if (it + 1 < total_it) step(it + 1, r1, r0);
   }
+  PROF_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------ TN
@@ -1633,3 +1663,13 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   HMA_TN_CASE(HMA_A_F32, HMA_A_BF16_AFFINE)
   return HMA_EINVAL;
 }
+
+#ifdef HMA_PROF
+// debug build only (never part of the shipped ABI): read and clear the phase timers
+extern "C" int hma_debug_prof(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
