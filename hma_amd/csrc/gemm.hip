@@ -1351,13 +1351,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
 
   const int iters = (int)((m_end - m_begin + 63) / 64);
   const int r = lane & 31, hi = lane >> 5;
+  PROF_DECL;
   load(m_begin);
   store(0, m_begin);
   __syncthreads();
+  PROF_MARK(0);
   for (int it = 0; it < iters; ++it) {
     const int cur = it & 1;
     const int64_t m_next = m_begin + (int64_t)(it + 1) * 64;
     if (it + 1 < iters) load(m_next);
+    PROF_MARK(1);
     const uint16_t* Ys = Yt + cur * W_TILE;
     const uint16_t* As = At + cur * W_TILE;
 #pragma unroll
@@ -1372,49 +1375,56 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(yf[i], af[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[j], yf[i], acc[i][j]);  // D rows = k, D cols = n
     }
+    PROF_MARK(2);
     if (it + 1 < iters) store(cur ^ 1, m_next);
+    PROF_MARK(4);
     __syncthreads();
+    PROF_MARK(5);
   }
 
-  // D rows = n, D cols = k.
+  // D rows = k, D cols = n: a lane owns one n and, per accumulator, four runs of 4 consecutive k -> 16-byte
+  // stores (the phase timers showed 40-70 % of this kernel's wave time in an epilogue of 4-byte stores).
+  const bool bias_ws = p.ws && p.ws_elems >= (int64_t)gridDim.x * (WT * WT + WT);
   if (p.ws) {
-    // two-stage reduction: plain coalesced stores of this workgroup's 256 x 256 partial; tn_reduce_kernel
-    // sums the splits.  (Device-scope fp32 atomics from 256 workgroups onto the same 64 K addresses cost
-    // more than the whole main loop for the d_model-sized layers.)
+    // two-stage reduction: plain stores of this workgroup's 256 x 256 partial; tn_reduce_kernel sums the
+    // splits.  (Device-scope fp32 atomics from 256 workgroups onto the same 64 K addresses cost more than
+    // the whole main loop for the d_model-sized layers.)
     float* part = p.ws + (int64_t)vid * (WT * WT);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int kl = wk4 * 64 + j * 32 + r;
+        float* row = part + (wn2 * 128 + i * 32 + r) * WT + wk4 * 64 + j * 32 + 4 * hi;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) part[(wn2 * 128 + i * 32 + mfma32_row(e, hi)) * WT + kl] = acc[i][j][e];
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(row + 8 * q) =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
       }
   } else {
-  // Rotate the tile order by the split index so concurrent workgroups hit different addresses with
-  // their atomics.
-  float* dW = p.dW + bz * p.sdW;
+    // Rotate the tile order by the split index so concurrent workgroups hit different addresses with
+    // their atomics.
+    float* dW = p.dW + bz * p.sdW;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int qq = (q + split) & 7;
-    const int i = qq >> 1, j = qq & 1;
-    const int64_t k = k0 + wk4 * 64 + j * 32 + r;
-    f32x16_t v;
-    // static indexing of the accumulator array (a dynamic index would spill it to scratch)
-    switch (qq) {
-      case 0: v = acc[0][0]; break; case 1: v = acc[0][1]; break;
-      case 2: v = acc[1][0]; break; case 3: v = acc[1][1]; break;
-      case 4: v = acc[2][0]; break; case 5: v = acc[2][1]; break;
-      case 6: v = acc[3][0]; break; default: v = acc[3][1]; break;
-    }
+    for (int q = 0; q < 8; ++q) {
+      const int qq = (q + split) & 7;
+      const int i = qq >> 1, j = qq & 1;
+      const int64_t n = n0 + wn2 * 128 + i * 32 + r;
+      f32x16_t v;
+      // static indexing of the accumulator array (a dynamic index would spill it to scratch)
+      switch (qq) {
+        case 0: v = acc[0][0]; break; case 1: v = acc[0][1]; break;
+        case 2: v = acc[1][0]; break; case 3: v = acc[1][1]; break;
+        case 4: v = acc[2][0]; break; case 5: v = acc[2][1]; break;
+        case 6: v = acc[3][0]; break; default: v = acc[3][1]; break;
+      }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t n = n0 + wn2 * 128 + i * 32 + mfma32_row(e, hi);
-      atomicAdd(dW + n * p.lddw + k, v[e]);
+      for (int e = 0; e < 16; ++e) {
+        const int64_t kk = k0 + wk4 * 64 + j * 32 + mfma32_row(e, hi);
+        atomicAdd(dW + n * p.lddw + kk, v[e]);
+      }
     }
-  }
   }
   if (do_bias) {
 #pragma unroll
@@ -1424,9 +1434,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
       sj += __shfl_xor(sj, 2, 64);
       sj += __shfl_xor(sj, 4, 64);
       sj += __shfl_xor(sj, 8, 64);
-      if ((lane & 15) == 0) atomicAdd(p.dBias + bz * p.sdBias + n0 + wave * 32 + ci * 8 + j, sj);
+      if ((lane & 15) == 0) {
+        if (bias_ws)  // per-workgroup partial, summed by tn_reduce_kernel (no contended atomics)
+          p.ws[(int64_t)gridDim.x * (WT * WT) + (int64_t)vid * WT + wave * 32 + ci * 8 + j] = sj;
+        else
+          atomicAdd(p.dBias + bz * p.sdBias + n0 + wave * 32 + ci * 8 + j, sj);
+      }
     }
   }
+  PROF_MARK(3);
+  PROF_FLUSH();
 }
 
 // dW[bz][n0 + nl][k0 + kl] += sum over splits of ws[((bz * splits + s) * groups + g)][nl][kl]
@@ -1456,6 +1473,20 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int gro
     o.x += acc.x + a1.x + a2.x + a3.x; o.y += acc.y + a1.y + a2.y + a3.y;
     o.z += acc.z + a1.z + a2.z + a3.z; o.w += acc.w + a1.w + a2.w + a3.w;
     *dst = o;
+  }
+  // bias partials (written when the workspace has room for them): one block per group sums them
+  const int64_t nblocks = (int64_t)p.splits * groups * (p.batch > 0 ? p.batch : 1);
+  if (p.dBias && k0 == 0 && blockIdx.x < 4 && p.ws_elems >= nblocks * (WT * WT + WT)) {
+    // block x sums columns 64 x .. 64 x + 63; its 4 waves take every 4th split (independent loads), then LDS
+    __syncthreads();
+    const int col = blockIdx.x * 64 + lane;
+    const float* bp = p.ws + nblocks * (WT * WT) + (bz * p.splits * groups + g) * (int64_t)WT + col;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int sp = w; sp < p.splits; sp += 4) sum += bp[(int64_t)sp * groups * WT];
+    red[w][lane].x = sum;
+    __syncthreads();
+    if (w == 0) p.dBias[bz * p.sdBias + n0 + col] += red[0][lane].x + red[1][lane].x + red[2][lane].x + red[3][lane].x;
   }
 }
 
@@ -1625,6 +1656,8 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     int splits = 256 / (gn * gk * nb);  // one resident workgroup per CU
     if (splits < 1) splits = 1;
     if (splits > slabs) splits = (int)slabs;
+    // every split must own at least one 64-row slab (the two-stage reduction reads every partial)
+    while (splits > 1 && ((slabs + splits - 1) / splits) * (splits - 1) >= slabs) --splits;
     q.splits = splits;
     const int nblocks = gn * gk * nb * splits;
     const dim3 wgrid((unsigned)nblocks);

@@ -156,7 +156,7 @@ class STEngine:
         self.grad_scale = C.c_float(1.0)
         self.timer: Optional[LaunchTimer] = None
         if Plan.tn_workspace is None or Plan.tn_workspace.device != self.device:
-            Plan.tn_workspace = torch.empty(256 * 65536, dtype=F32, device=self.device)  # 64 MB
+            Plan.tn_workspace = torch.empty(256 * (65536 + 256), dtype=F32, device=self.device)  # 64 MB of tiles + bias partials
 
     # ------------------------------------------------------------------------------ pointers
     def _p(self, name: str) -> int:

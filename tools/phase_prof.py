@@ -60,8 +60,17 @@ case("dqkv", lambda i: ops.linear(qkv[i], wk768, None, epi=EPI_RESID, out=x32[i]
 case("dprj", lambda i: ops.linear(x32[i], w256, None, epi=EPI_BF16, out=o256[i]), 2.0 * M * 256 * 256)
 case("modlin", lambda i: ops.linear(xh[i], w256, b256, epi=EPI_RESID, out=x32[i], out2=o256[i]), 2.0 * M * 256 * 256)
 
+WS = torch.empty(256 * 65536, device=dev)
+def tn(dy, x, N, K, bias=True, gamma=None, beta=None):
+    dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev) if bias else None
+    return lambda i: ops.linear_wgrad(dy[i], x[i], dW, db, gamma=gamma, beta=beta, ws=WS)
+case("w_proj", tn(x32, xh, 256, 256), 2.0 * M * 256 * 256)
+case("w_fc2", tn(x32, h, 256, 1024), 2.0 * M * 256 * 1024)
+case("w_fc1", tn(u, xh, 1024, 256, gamma=g, beta=b), 2.0 * M * 256 * 1024)
+case("w_qkv", tn(qkv, xh, 768, 256, bias=False), 2.0 * M * 256 * 768)
+
 names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(cases)
-PH = ["loop", "issue-loads", "lds+mfma", "epilogue", "wait+lds-store", "barrier", "acc-copy", "-"]
+PH = ["loop/prologue", "issue-loads", "lds+mfma", "epilogue", "wait+lds-store", "barrier", "acc-copy", "-"]
 out = (C.c_ulonglong * 16)()
 for n in names:
     fn, fl = cases[n]
