@@ -1391,16 +1391,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
     // two-stage reduction: plain stores of this workgroup's 256 x 256 partial; tn_reduce_kernel sums the
     // splits.  (Device-scope fp32 atomics from 256 workgroups onto the same 64 K addresses cost more than
     // the whole main loop for the d_model-sized layers.)
-    float* part = p.ws + (int64_t)vid * (WT * WT);
+    // Partials are bf16 (the fp32 sum over splits is formed by tn_reduce_kernel): the reference's autocast
+    // backward returns the whole weight gradient in bf16, and the partial round trip (write + re-read of
+    // 256 x 64 K values per call) is otherwise half as many bytes again as the operands themselves.
+    uint16_t* part = reinterpret_cast<uint16_t*>(p.ws) + (int64_t)vid * (WT * WT);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float* row = part + (wn2 * 128 + i * 32 + r) * WT + wk4 * 64 + j * 32 + 4 * hi;
+        uint16_t* row = part + (wn2 * 128 + i * 32 + r) * WT + wk4 * 64 + j * 32;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(row + 8 * q) =
-              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        for (int q = 0; q < 4; q += 2) {
+          const float v0[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          const float v1[4] = {acc[i][j][4 * q + 4], acc[i][j][4 * q + 5], acc[i][j][4 * q + 6], acc[i][j][4 * q + 7]};
+          store_bf16_oct(row, q, hi, v0, v1);
+        }
       }
   } else {
     // Rotate the tile order by the split index so concurrent workgroups hit different addresses with
@@ -1458,11 +1463,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int gro
   const int idx = (blockIdx.x * 64 + lane) * 4;  // 4 consecutive k of one n row
   const int nl = idx / WT, kl = idx % WT;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* base = p.ws + (bz * p.splits * groups + g) * (int64_t)(WT * WT) + idx;
+  const uint16_t* base = reinterpret_cast<const uint16_t*>(p.ws) + (bz * p.splits * groups + g) * (int64_t)(WT * WT) + idx;
 #pragma unroll 4
   for (int sp = w; sp < p.splits; sp += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)sp * groups * (WT * WT));
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const uint2 v = *reinterpret_cast<const uint2*>(base + (int64_t)sp * groups * (WT * WT));
+    acc.x += bf16_lo(v.x); acc.y += bf16_hi(v.x); acc.z += bf16_lo(v.y); acc.w += bf16_hi(v.y);
   }
   red[w][lane] = acc;
   __syncthreads();

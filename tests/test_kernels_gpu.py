@@ -154,12 +154,20 @@ def test_gemm_tn(M, N, K, splits):
     dW.zero_()
     ops.linear_wgrad(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), dW, None, gamma=gam.to(DEV), beta=bet.to(DEV), splits=splits)
     close(dW, dy.t() @ rb(x * gam + bet), 2e-5, "dW affine")
-    # two-stage (workspace) reduction instead of atomics
-    ws = torch.full((256 * 65536,), float("nan"), device=DEV)
+    # two-stage (workspace) reduction instead of atomics: the per-workgroup partials are bf16 (summed in fp32),
+    # the precision class of the reference's autocast backward, which returns the whole dW in bf16
+    # (F.linear under torch.autocast, hma/train_multi.py mixed_precision="bf16"); bias partials stay fp32
+    ws = torch.full((256 * (65536 + 256),), float("nan"), device=DEV)
     dW.fill_(1.0); db.fill_(1.0)
     ops.linear_wgrad(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), dW, db, ws=ws)
-    close(dW, 1 + dy.t() @ x, 2e-5, "dW via workspace")
+    close(dW, 1 + dy.t() @ x, BF, "dW via workspace")
     close(db, 1 + dy.sum(0), 2e-5, "dbias via workspace")
+    # a workspace without room for the bias partials falls back to atomics for them
+    ws2 = torch.full((256 * 65536,), float("nan"), device=DEV)
+    dW.fill_(1.0); db.fill_(1.0)
+    ops.linear_wgrad(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), dW, db, ws=ws2)
+    close(dW, 1 + dy.t() @ x, BF, "dW via small workspace")
+    close(db, 1 + dy.sum(0), 2e-5, "dbias via small workspace")
 
 
 def test_gemm_tn_remap_and_batch():
