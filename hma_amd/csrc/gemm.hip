@@ -1096,6 +1096,190 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
   PROF_FLUSH();
 }
 
+// ------------------------------------------------------------- NT, streaming waves (K = 256)
+// The kernels above are one (or two) workgroups per CU marching in lock step: a barrier per K-step, every
+// wave in the same phase, and -- by the phase timers -- 50-80 % of the wave time spent in the epilogue or
+// waiting for operand loads.  At K = 256 these GEMMs are HBM-bound streams (bytes / 5.5 TB/s is 2-2.4x
+// below the measured times), so this variant is organised like a streaming kernel instead:
+//   * a workgroup parks one 256-column weight slab in LDS (132 KB) once; after that its 8 waves never
+//     synchronise again;
+//   * a wave owns whole 16-token row tiles: it loads the tile's A rows straight into MFMA B-operand
+//     registers (lane = token, 8 x 16 B spread over the row), multiplies against all 256 columns with
+//     v_mfma_f32_16x16x32_bf16 (weights as the A operand from LDS), and writes its own outputs; the next
+//     tile's A rows are in flight while it computes;
+//   * the contraction index and the weight rows are permuted (free: both are only LDS addressing) so that a
+//     lane loads full 16-byte chunks and ends up with 8 CONSECUTIVE output columns of its token per pair of
+//     16-column MFMA tiles -- 16-byte bf16 / 32-byte fp32 accesses without any cross-lane exchange.
+// k permutation: lane (tok, g = lane >> 4) holds chunks c = 4 j + g (j = 0..7) of its row, MFMA step j
+// contracts k = 8 c .. 8 c + 7.  Row permutation: tile 2p + o, MFMA row i  <->  n = 32 p + 8 (i >> 2) + (i & 3) + 4 o.
+constexpr int TW_LD = 256 + 8;                       // padded weight-slab row (elements)
+constexpr int TW_SMEM_BYTES = 256 * TW_LD * 2 + 2 * 256 * 4;  // slab + gamma/beta
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_run8(const hma_gemm_nt_t& p, int64_t bz, int64_t crow, int64_t n8, float (&v)[8]) {
+  // v = 8 consecutive columns n8 .. n8 + 7 of output row crow
+  if (EPI == HMA_EPI_BF16) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n8) = pack8(v);
+  } else if (EPI == HMA_EPI_F32) {
+    float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + n8;
+    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else if (EPI == HMA_EPI_GELU2 || EPI == HMA_EPI_SILU2) {
+    float u[8], a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      u[e] = from_bf16(to_bf16(v[e]));  // activate the ROUNDED pre-activation (what backward will read)
+      a[e] = EPI == HMA_EPI_GELU2 ? gelu_f(u[e]) : silu_f(u[e]);
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n8) = pack8(u);
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + n8) = pack8(a);
+  } else if (EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) {
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.U) + bz * p.sU + crow * p.ldu + n8);
+    float u[8];
+    unpack8(q, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= (EPI == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + n8) = pack8(v);
+  }
+}
+
+template <int AKIND, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Wsl = smem;                                             // [256 n][TW_LD], chunk-swizzled
+  float* gb = reinterpret_cast<float*>(smem + 256 * TW_LD);         // gamma[256] | beta[256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tok = lane & 15, g = lane >> 4;
+
+  const int b = blockIdx.x;
+  const int slab_id = b % nslabs, slot = b / nslabs;  // slab_id = (batch, n-slab)
+  const int slabs_n = (int)(p.N / 256);
+  const int64_t bz = slab_id / slabs_n;
+  const int64_t bn = (int64_t)(slab_id % slabs_n) * 256;
+
+  {  // park the weight slab: chunk ch of row n goes to position ch ^ (4 * ((n >> 4) & 1))  (bank spread, see below)
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
+    for (int c = tid; c < 256 * 32; c += 512) {
+      const int n = c >> 5, ch = c & 31;
+      *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) =
+          *reinterpret_cast<const uint4*>(Wb + (int64_t)n * p.ldw + ch * 8);
+    }
+    if (AKIND == HMA_A_BF16_AFFINE) {
+      for (int c = tid; c < 256; c += 512) { gb[c] = p.gamma[c]; gb[256 + c] = p.beta[c]; }
+    }
+  }
+  __syncthreads();  // the only barrier
+
+  const int64_t tiles = (p.M + 15) / 16;
+  const int64_t gw = (int64_t)slot * 8 + wave, nw = (int64_t)per_slab * 8;
+  if (gw >= tiles) return;
+
+  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+  // A rows of one tile as MFMA B operands: a[j] = chunk 4 j + g of token row (tile * 16 + tok)
+  auto load_a = [&](int64_t tile, bf16x8_t (&a)[8]) __attribute__((always_inline)) {
+    int64_t m = tile * 16 + tok;
+    m = m < p.M ? m : p.M - 1;
+    const int64_t off = remap_row(m, p.a_group_rows, p.a_group_stride) * p.lda;
+    if (AKIND == HMA_A_F32) {
+      const float* row = reinterpret_cast<const float*>(Ab) + off;
+      float4 lo[8], hi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lo[j] = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8);
+        hi[j] = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8 + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint4 v = make_uint4(pack_bf16(lo[j].x, lo[j].y), pack_bf16(lo[j].z, lo[j].w), pack_bf16(hi[j].x, hi[j].y),
+                                   pack_bf16(hi[j].z, hi[j].w));
+        a[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    } else {
+      const uint16_t* row = reinterpret_cast<const uint16_t*>(Ab) + off;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(row + (4 * j + g) * 8));
+    }
+  };
+  auto affine_a = [&](bf16x8_t (&a)[8]) __attribute__((always_inline)) {
+    if (AKIND == HMA_A_BF16_AFFINE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f[8];
+        unpack8(__builtin_bit_cast(uint4, a[j]), f);
+        const float* gm = gb + (4 * j + g) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * gm[e] + gm[256 + e];
+        a[j] = __builtin_bit_cast(bf16x8_t, pack8(f));
+      }
+    }
+  };
+
+  // lane constants of the weight-fragment address: MFMA row i = lane & 15 of tile (p, o) is
+  // n = 32 p + 8 (i >> 2) + (i & 3) + 4 o; logical chunk 4 j + g sits at 4 (j ^ ((i >> 3) & 1)) + g.
+  // Bank check (row stride 528 B = 33 x 16-B slots): a 16-lane group reads rows {0-3, 8-11, 16-19, 24-27} (+4 o);
+  // rows 16 apart would share a slot, the chunk swizzle moves them 4 slots on.
+  const int i16 = lane & 15;
+  const uint16_t* wbase = Wsl + (8 * (i16 >> 2) + (i16 & 3)) * TW_LD + g * 8;
+  const int jsw = (i16 >> 3) & 1;
+  const float* bias = p.bias ? p.bias + bz * p.sBias + bn : nullptr;
+
+  bf16x8_t a[8], an[8];
+  load_a(gw, an);
+  for (int64_t tile = gw; tile < tiles; tile += nw) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = an[j];
+    {
+      const int64_t nxt = tile + nw < tiles ? tile + nw : tile;  // clamped re-load on the last trip
+      load_a(nxt, an);
+    }
+    affine_a(a);
+    f32x4v_t acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint16_t* wj = wbase + ((j ^ jsw) << 5);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wj + (32 * (t >> 1) + 4 * (t & 1)) * TW_LD);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a[j], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 128 fragment reads (it spills)
+    }
+    const int64_t m = tile * 16 + tok;
+    if (m < p.M) {
+      const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const int64_t nl = 32 * pr + 8 * g;  // this lane's 8 consecutive columns of the slab
+        float v[8] = {acc[2 * pr][0], acc[2 * pr][1], acc[2 * pr][2], acc[2 * pr][3],
+                      acc[2 * pr + 1][0], acc[2 * pr + 1][1], acc[2 * pr + 1][2], acc[2 * pr + 1][3]};
+        if (bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(bias + nl), b1 = *reinterpret_cast<const float4*>(bias + nl + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (EPI == HMA_EPI_RESID) {
+          float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl;
+          float4 x0 = *reinterpret_cast<float4*>(C), x1 = *reinterpret_cast<float4*>(C + 4);
+          x0.x += v[0]; x0.y += v[1]; x0.z += v[2]; x0.w += v[3];
+          x1.x += v[4]; x1.y += v[5]; x1.z += v[6]; x1.w += v[7];
+          *reinterpret_cast<float4*>(C) = x0;
+          *reinterpret_cast<float4*>(C + 4) = x1;
+          if (p.C2) {
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(xs);
+          }
+        } else {
+          epilogue_run8<EPI>(p, bz, crow, bn + nl, v);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ TN
 // Stage a 64(m) x 128(col) slab of a row-major matrix TRANSPOSED into LDS as [128 col][64 m].
 // Thread task: rows 4*mi..4*mi+3, columns w*32 + ci*8 .. +8 (mi = lane & 15, ci = lane >> 4):
@@ -1546,6 +1730,31 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
     pa._pad2 = ablate;
     static const bool use_p2 = getenv("HMA_GEMM_NT_P2") != nullptr;
     static const bool no_ws = getenv("HMA_GEMM_NT_NOWS") != nullptr;
+    static const int use_sw = getenv("HMA_GEMM_NT_SW") ? atoi(getenv("HMA_GEMM_NT_SW")) : 0;
+    if (use_sw && !use_p1 && !use_p2 && p->K == 256 && p->epi != HMA_EPI_ATOMIC_F32 &&
+        ((use_sw & 1) || p->epi != HMA_EPI_RESID) && ((use_sw & 2) || p->N > 256)) {
+      // streaming waves: blocks dealt round-robin over the (batch, n-slab) pairs
+      const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
+      int per_slab = n_cu / nslabs;
+      if (per_slab < 1) per_slab = 1;
+      const int64_t tiles16 = (p->M + 15) / 16;
+      if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
+      const dim3 tgrid((unsigned)(nslabs * per_slab));
+#define HMA_NTW_CASE(AK, EP)                                                                          \
+  if (p->a_kind == AK && p->epi == EP) {                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_sw_kernel<AK, EP>>(TW_SMEM_BYTES))) return rc;                   \
+    hipLaunchKernelGGL((gemm_nt_sw_kernel<AK, EP>), tgrid, dim3(512), TW_SMEM_BYTES, s, pa, nslabs, per_slab); \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+#define HMA_NTW_ALL(AK)                                                                               \
+  HMA_NTW_CASE(AK, HMA_EPI_BF16) HMA_NTW_CASE(AK, HMA_EPI_F32) HMA_NTW_CASE(AK, HMA_EPI_RESID)        \
+  HMA_NTW_CASE(AK, HMA_EPI_GELU2) HMA_NTW_CASE(AK, HMA_EPI_SILU2) HMA_NTW_CASE(AK, HMA_EPI_DGELU)     \
+  HMA_NTW_CASE(AK, HMA_EPI_DSILU)
+      HMA_NTW_ALL(HMA_A_BF16)
+      HMA_NTW_ALL(HMA_A_F32)
+      HMA_NTW_ALL(HMA_A_BF16_AFFINE)
+    }
     // (measured per shape, profiles/gemm_shapes_r1.txt: it only wins for the N = K = 256 residual projections)
     if (!use_p1 && !use_p2 && !no_ws && p->K == SK && p->N == PN && p->a_kind == HMA_A_BF16 && p->epi == HMA_EPI_RESID && !p->C2) {
       // weight-stationary: one (batch, n-tile) group per workgroup, the groups dealt round-robin over the grid
