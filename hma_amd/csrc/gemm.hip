@@ -1145,8 +1145,10 @@ __device__ __forceinline__ void epilogue_run8(const hma_gemm_nt_t& p, int64_t bz
   }
 }
 
-template <int AKIND, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
+// NWAVES = 12 (3 per SIMD, <= 168 VGPRs) where the registers allow it, else 8: waves are independent, so more of
+// them is more loads in flight and more overlap of one wave's VALU/store epilogue with another's MFMAs.
+template <int AKIND, int EPI, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Wsl = smem;                                             // [256 n][TW_LD], chunk-swizzled
   float* gb = reinterpret_cast<float*>(smem + 256 * TW_LD);         // gamma[256] | beta[256]
@@ -1161,19 +1163,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int
 
   {  // park the weight slab: chunk ch of row n goes to position ch ^ (4 * ((n >> 4) & 1))  (bank spread, see below)
     const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
-    for (int c = tid; c < 256 * 32; c += 512) {
+    for (int c = tid; c < 256 * 32; c += 64 * NWAVES) {
       const int n = c >> 5, ch = c & 31;
       *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) =
           *reinterpret_cast<const uint4*>(Wb + (int64_t)n * p.ldw + ch * 8);
     }
     if (AKIND == HMA_A_BF16_AFFINE) {
-      for (int c = tid; c < 256; c += 512) { gb[c] = p.gamma[c]; gb[256 + c] = p.beta[c]; }
+      for (int c = tid; c < 256; c += 64 * NWAVES) { gb[c] = p.gamma[c]; gb[256 + c] = p.beta[c]; }
     }
   }
   __syncthreads();  // the only barrier
 
   const int64_t tiles = (p.M + 15) / 16;
-  const int64_t gw = (int64_t)slot * 8 + wave, nw = (int64_t)per_slab * 8;
+  const int64_t gw = (int64_t)slot * NWAVES + wave, nw = (int64_t)per_slab * NWAVES;
   if (gw >= tiles) return;
 
   const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
@@ -1235,6 +1237,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int
       load_a(nxt, an);
     }
     affine_a(a);
+    // epilogue operands (residual rows / saved pre-activation) are fetched BEFORE the 128 MFMAs that hide them
+    const int64_t m = tile * 16 + tok;
+    const int64_t crow = remap_row(m < p.M ? m : p.M - 1, p.c_group_rows, p.c_group_stride);
+    float4 rx[EPI == HMA_EPI_RESID ? 16 : 1];
+    uint4 ru[(EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) ? 8 : 1];
+    if (EPI == HMA_EPI_RESID) {
+      const float* C = reinterpret_cast<const float*>(p.C) + bz * p.sC + crow * p.ldc + bn + 8 * g;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        rx[2 * pr] = *reinterpret_cast<const float4*>(C + 32 * pr);
+        rx[2 * pr + 1] = *reinterpret_cast<const float4*>(C + 32 * pr + 4);
+      }
+    }
+    if (EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) {
+      const uint16_t* U = reinterpret_cast<const uint16_t*>(p.U) + bz * p.sU + crow * p.ldu + bn + 8 * g;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) ru[pr] = *reinterpret_cast<const uint4*>(U + 32 * pr);
+    }
     f32x4v_t acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
@@ -1248,9 +1268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 128 fragment reads (it spills)
     }
-    const int64_t m = tile * 16 + tok;
     if (m < p.M) {
-      const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         const int64_t nl = 32 * pr + 8 * g;  // this lane's 8 consecutive columns of the slab
@@ -1263,7 +1281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int
         }
         if (EPI == HMA_EPI_RESID) {
           float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl;
-          float4 x0 = *reinterpret_cast<float4*>(C), x1 = *reinterpret_cast<float4*>(C + 4);
+          float4 x0 = rx[2 * pr], x1 = rx[2 * pr + 1];
           x0.x += v[0]; x0.y += v[1]; x0.z += v[2]; x0.w += v[3];
           x1.x += v[4]; x1.y += v[5]; x1.z += v[6]; x1.w += v[7];
           *reinterpret_cast<float4*>(C) = x0;
@@ -1272,6 +1290,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int
             const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(xs);
           }
+        } else if (EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) {
+          float u[8];
+          unpack8(ru[pr], u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= (EPI == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl) = pack8(v);
         } else {
           epilogue_run8<EPI>(p, bz, crow, bn + nl, v);
         }
@@ -1730,20 +1754,23 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
     pa._pad2 = ablate;
     static const bool use_p2 = getenv("HMA_GEMM_NT_P2") != nullptr;
     static const bool no_ws = getenv("HMA_GEMM_NT_NOWS") != nullptr;
-    static const int use_sw = getenv("HMA_GEMM_NT_SW") ? atoi(getenv("HMA_GEMM_NT_SW")) : 0;
-    if (use_sw && !use_p1 && !use_p2 && p->K == 256 && p->epi != HMA_EPI_ATOMIC_F32 &&
-        ((use_sw & 1) || p->epi != HMA_EPI_RESID) && ((use_sw & 2) || p->N > 256)) {
+    // K = 256 (every forward GEMM but fc2, and the dgrads of proj / fc2): streaming waves.  Measured in situ
+    // (rocprofv3, bench.py): qkv 148 -> 105 us, temporal qkv 131 -> 105, fc1 308 -> 262, dfc2 287 -> 216,
+    // residual projections 102 -> 90 us against the lock-step kernels below (HMA_GEMM_NT_NOSW=1 restores them).
+    static const bool no_sw = getenv("HMA_GEMM_NT_NOSW") != nullptr;
+    if (!no_sw && !use_p1 && !use_p2 && p->K == 256 && p->epi != HMA_EPI_ATOMIC_F32) {
       // streaming waves: blocks dealt round-robin over the (batch, n-slab) pairs
       const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
-      int per_slab = n_cu / nslabs;
-      if (per_slab < 1) per_slab = 1;
       const int64_t tiles16 = (p->M + 15) / 16;
-      if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
-      const dim3 tgrid((unsigned)(nslabs * per_slab));
 #define HMA_NTW_CASE(AK, EP)                                                                          \
   if (p->a_kind == AK && p->epi == EP) {                                                              \
-    if ((rc = set_smem_bytes<gemm_nt_sw_kernel<AK, EP>>(TW_SMEM_BYTES))) return rc;                   \
-    hipLaunchKernelGGL((gemm_nt_sw_kernel<AK, EP>), tgrid, dim3(512), TW_SMEM_BYTES, s, pa, nslabs, per_slab); \
+    constexpr int NWV = 8; /* 12 waves (168 VGPRs) spill and measured 1.05-2.7x slower */                           \
+    int per_slab = n_cu / nslabs;                                                                     \
+    if (per_slab < 1) per_slab = 1;                                                                   \
+    if ((int64_t)per_slab * NWV > tiles16) per_slab = (int)((tiles16 + NWV - 1) / NWV);               \
+    if ((rc = set_smem_bytes<gemm_nt_sw_kernel<AK, EP, NWV>>(TW_SMEM_BYTES))) return rc;              \
+    hipLaunchKernelGGL((gemm_nt_sw_kernel<AK, EP, NWV>), dim3((unsigned)(nslabs * per_slab)), dim3(64 * NWV), TW_SMEM_BYTES, s, pa, \
+                       nslabs, per_slab);                                                             \
     HMA_CHECK_LAUNCH();                                                                               \
     return 0;                                                                                         \
   }
