@@ -50,9 +50,9 @@ _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
     "hma_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32],
-    "hma_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64],
+    "hma_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hma_modln_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32],
-    "hma_modln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64],
+    "hma_modln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "hma_attn_spatial_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
     "hma_attn_spatial_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
     "hma_attn_temporal_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32],

@@ -1535,8 +1535,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
   for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
   const bool do_bias = (p.dBias != nullptr) && (k0 == 0);
 
-  SlabRegs<YKIND> ry;
-  SlabRegs<AKIND> ra;
+  // Register stages of the operand prefetch.  Ablation (HMA_GEMM_TN_ABLATE, tools/gemm_bench.py) shows the loads,
+  // the transposing LDS writes, the MFMAs and the epilogue of this one-stage loop adding up almost serially; a
+  // second stage (loads of slab it + 2 in flight during slab it) was measured and is WORSE: 128 accumulator +
+  // 64 staging registers spill inside the loop (bf16 dY: 110 -> 169 us, affine: 124 -> 351 us in situ).
+  constexpr int NSETS = 1;
+  SlabRegs<YKIND> ry[NSETS];
+  SlabRegs<AKIND> ra[NSETS];
   f32x16_t acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -1545,32 +1550,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
-  auto load = [&](int64_t m0) {
-    slab_load<YKIND>(ry, Yb, p.ldy, m0, m_end, p.y_group_rows, p.y_group_stride, n0, lane, wave);
-    slab_load<AKIND>(ra, Ab, p.lda, m0, m_end, p.a_group_rows, p.a_group_stride, k0, lane, wave);
+  auto load = [&](int set, int64_t m0) __attribute__((always_inline)) {
+    slab_load<YKIND>(ry[set], Yb, p.ldy, m0, m_end, p.y_group_rows, p.y_group_stride, n0, lane, wave);
+    slab_load<AKIND>(ra[set], Ab, p.lda, m0, m_end, p.a_group_rows, p.a_group_stride, k0, lane, wave);
   };
-  auto store = [&](int buf, int64_t m0) {
+  auto store = [&](int set, int buf, int64_t m0) __attribute__((always_inline)) {
     if (do_bias)
-      slab_store<YKIND, true>(ry, Yt + buf * W_TILE, lane, wave, nullptr, nullptr, colsum, m0, m_end);
+      slab_store<YKIND, true>(ry[set], Yt + buf * W_TILE, lane, wave, nullptr, nullptr, colsum, m0, m_end);
     else
-      slab_store<YKIND, false>(ry, Yt + buf * W_TILE, lane, wave, nullptr, nullptr, colsum, m0, m_end);
-    slab_store<AKIND, false>(ra, At + buf * W_TILE, lane, wave, gm, bt, nullptr, m0, m_end);
+      slab_store<YKIND, false>(ry[set], Yt + buf * W_TILE, lane, wave, nullptr, nullptr, colsum, m0, m_end);
+    slab_store<AKIND, false>(ra[set], At + buf * W_TILE, lane, wave, gm, bt, nullptr, m0, m_end);
   };
 
   const int iters = (int)((m_end - m_begin + 63) / 64);
   const int r = lane & 31, hi = lane >> 5;
   PROF_DECL;
-  load(m_begin);
-  store(0, m_begin);
-  __syncthreads();
-  PROF_MARK(0);
-  for (int it = 0; it < iters; ++it) {
-    const int cur = it & 1;
-    const int64_t m_next = m_begin + (int64_t)(it + 1) * 64;
-    if (it + 1 < iters) load(m_next);
-    PROF_MARK(1);
+  const int ablate = p._pad0;  // debug only (HMA_GEMM_TN_ABLATE): 1 = skip MFMA, 2 = skip LDS stores, 4 = skip loads, 8 = skip epilogue
+  auto mma = [&](int cur) __attribute__((always_inline)) {
     const uint16_t* Ys = Yt + cur * W_TILE;
     const uint16_t* As = At + cur * W_TILE;
+    if (!(ablate & 1))
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       bf16x8_t yf[4], af[2];
@@ -1585,17 +1584,49 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[j], yf[i], acc[i][j]);  // D rows = k, D cols = n
     }
-    PROF_MARK(2);
-    if (it + 1 < iters) store(cur ^ 1, m_next);
-    PROF_MARK(4);
-    __syncthreads();
-    PROF_MARK(5);
+  };
+  load(0, m_begin);
+  store(0, 0, m_begin);
+  if (NSETS == 2 && iters > 1) load(NSETS - 1, m_begin + 64);
+  __syncthreads();
+  PROF_MARK(0);
+  if constexpr (NSETS == 2) {
+    // step(it, set_free, set_next): set_free held slab it (already in LDS) -> refill with slab it + 2;
+    // set_next holds slab it + 1 (loaded during step it - 1) -> transposed into the other LDS buffer.
+    auto step = [&](int it, int set_free, int set_next) __attribute__((always_inline)) {
+      if (it + 2 < iters && !(ablate & 4)) load(set_free, m_begin + (int64_t)(it + 2) * 64);
+      PROF_MARK(1);
+      mma(it & 1);
+      PROF_MARK(2);
+      if (it + 1 < iters && !(ablate & 2)) store(set_next, (it & 1) ^ 1, m_begin + (int64_t)(it + 1) * 64);
+      PROF_MARK(4);
+      __syncthreads();
+      PROF_MARK(5);
+    };
+    for (int it = 0; it < iters; it += 2) {
+      step(it, 0, NSETS - 1);
+      if (it + 1 < iters) step(it + 1, NSETS - 1, 0);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+      const int cur = it & 1;
+      const int64_t m_next = m_begin + (int64_t)(it + 1) * 64;
+      if (it + 1 < iters && !(ablate & 4)) load(0, m_next);
+      PROF_MARK(1);
+      mma(cur);
+      PROF_MARK(2);
+      if (it + 1 < iters && !(ablate & 2)) store(0, cur ^ 1, m_next);
+      PROF_MARK(4);
+      __syncthreads();
+      PROF_MARK(5);
+    }
   }
 
   // D rows = k, D cols = n: a lane owns one n and, per accumulator, four runs of 4 consecutive k -> 16-byte
   // stores (the phase timers showed 40-70 % of this kernel's wave time in an epilogue of 4-byte stores).
   const bool bias_ws = p.ws && p.ws_elems >= (int64_t)gridDim.x * (WT * WT + WT);
-  if (p.ws) {
+  if (ablate & 8) {
+  } else if (p.ws) {
     // two-stage reduction: plain stores of this workgroup's 256 x 256 partial; tn_reduce_kernel sums the
     // splits.  (Device-scope fp32 atomics from 256 workgroups onto the same 64 K addresses cost more than
     // the whole main loop for the d_model-sized layers.)
@@ -1887,6 +1918,8 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   if (p->y_kind == HMA_A_BF16_AFFINE) return HMA_EINVAL;
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
   hma_gemm_tn_t q = *p;
+  static const int tn_ablate = getenv("HMA_GEMM_TN_ABLATE") ? atoi(getenv("HMA_GEMM_TN_ABLATE")) : 0;
+  q._pad0 = tn_ablate;
   const int64_t slabs = (q.M + 63) / 64;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dxn, const uint16_t* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      float* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows) {
+                                                     float* __restrict__ dbeta, uint16_t* __restrict__ dxb, int64_t rows) {
   __shared__ float red[2][4][D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
     o.z += rs * (g[2] - s1 - xh[2] * s2);
     o.w += rs * (g[3] - s1 - xh[3] * s2);
     *reinterpret_cast<float4*>(dx + row * D + lane * 4) = o;
+    if (dxb) *reinterpret_cast<uint2*>(dxb + row * D + lane * 4) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
   }
   if (gamma) {
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void modln_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void modln_bwd_kernel(const uint16_t* __restrict__ dxm, const uint16_t* __restrict__ xhat,
                                                         const float* __restrict__ rstd, const float* __restrict__ ss,
                                                         float* __restrict__ dx, float* __restrict__ dss,
-                                                        int64_t rows_per_frame) {
+                                                        uint16_t* __restrict__ dxb, int64_t rows_per_frame) {
   __shared__ float red[2][4][D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t f = blockIdx.x;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void modln_bwd_kernel(const uint16_t* __restri
     o.z += rs * (g[2] - s1 - xh[2] * s2);
     o.w += rs * (g[3] - s1 - xh[3] * s2);
     *reinterpret_cast<float4*>(dx + row * D + lane * 4) = o;
+    if (dxb) *reinterpret_cast<uint2*>(dxb + row * D + lane * 4) = make_uint2(pack_bf16(o.x, o.y), pack_bf16(o.z, o.w));
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -176,14 +178,14 @@ extern "C" int hma_ln_fwd(void* stream, const float* x, void* xhat, float* rstd,
 }
 
 extern "C" int hma_ln_bwd(void* stream, const void* dxn, const void* xhat, const float* rstd, const float* gamma,
-                          float* dx, float* dgamma, float* dbeta, int64_t rows) {
+                          float* dx, float* dgamma, float* dbeta, int64_t rows, void* dx_bf16) {
   if (!dxn || !xhat || !rstd || !dx) return HMA_EINVAL;
   if (gamma && (!dgamma || !dbeta)) return HMA_EINVAL;
   if (rows <= 0) return 0;
   int64_t b = (rows + 3) / 4;
   if (b > 1024) b = 1024;  // bounds the dgamma/dbeta atomics to 1024 x 512
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dxn,
-                     (const uint16_t*)xhat, rstd, gamma, dx, dgamma, dbeta, rows);
+                     (const uint16_t*)xhat, rstd, gamma, dx, dgamma, dbeta, (uint16_t*)dx_bf16, rows);
   HMA_CHECK_LAUNCH();
   return 0;
 }
@@ -199,11 +201,11 @@ extern "C" int hma_modln_fwd(void* stream, const float* x, const float* ss, void
 }
 
 extern "C" int hma_modln_bwd(void* stream, const void* dxm, const void* xhat, const float* rstd, const float* ss,
-                             float* dx, float* dss, int64_t frames, int64_t rows_per_frame) {
+                             float* dx, float* dss, int64_t frames, int64_t rows_per_frame, void* dx_bf16) {
   if (!dxm || !xhat || !rstd || !ss || !dx || !dss) return HMA_EINVAL;
   if (frames <= 0 || rows_per_frame <= 0) return 0;
   hipLaunchKernelGGL(modln_bwd_kernel, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)dxm, (const uint16_t*)xhat, rstd, ss, dx, dss, rows_per_frame);
+                     (const uint16_t*)dxm, (const uint16_t*)xhat, rstd, ss, dx, dss, (uint16_t*)dx_bf16, rows_per_frame);
   HMA_CHECK_LAUNCH();
   return 0;
 }

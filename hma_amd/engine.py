@@ -260,6 +260,7 @@ class STEngine:
         if train:
             buf("dlogits", (Mi, 1024), BF16)
             buf("dx", (M, 256), F32)
+            buf("dxb", (M, 256), BF16)  # bf16 copy of dx: operand of the dgrad / wgrad GEMMs that read it
             buf("t256", (M, 256), BF16)
             buf("dqkv", (M, 768), BF16)
             buf("delta", (M, 8), F32)
@@ -404,11 +405,15 @@ class STEngine:
         pl = Plan()
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
+        dxb = ws["dxb"].data_ptr()
         # readout
         pl.gemm_tn(dY=ws["dlogits"].data_ptr(), ldy=1024, y_kind=A_BF16, A=x, lda=256, a_kind=A_F32, a_group=(S, SA), M=Mi,
                    N=1024, K=256, dW=self._g("out_x_proj.weight"), lddw=256, dBias=self._g("out_x_proj.bias"))
         pl.gemm_nt(A=ws["dlogits"].data_ptr(), lda=1024, a_kind=A_BF16, W=self.WT["out"].data_ptr(), ldw=1024, M=Mi, N=256,
                    K=1024, epi=EPI_F32, Cp=dx, ldc=256, c_group=(S, SA))
+        # Every producer of dx below also writes its bf16 rounding (dxb): that is what autocast hands a linear's
+        # backward, and the GEMMs that consume it read half the bytes (the fp32 dx stays the accumulator).
+        pl.add("hma_cast_bf16", dx, dxb, M * 256)
         use_mod = A > 0 and self.modulate
         for l in reversed(range(L)):
             xh1, rstd1 = dp(ws["xh1"], l, M * 256), dp(ws["rstd1"], l, M)
@@ -421,42 +426,45 @@ class STEngine:
             gb = lambda suffix, on=True: self._lw(l, suffix, "g") if on else None
             wt = lambda k: dp(self.WT[k], l, self.WT[k][0].numel())
             # ---- MLP
-            pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024, dW=gw("mlp.fc2.weight"),
+            pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024, dW=gw("mlp.fc2.weight"),
                        lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias))
-            pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
+            pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
                        U=u, ldu=1024)  # dU overwrites u in place
             pl.gemm_tn(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
                        beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024, K=256, dW=gw("mlp.fc1.weight"), lddw=256,
                        dBias=gb("mlp.fc1.bias", cfg.mlp_bias))
             pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M)
+            pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
+                   dxb)
             # ---- temporal attention
-            pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+            pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                        dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias))
-            pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
+            pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale)
             pl.gemm_tn(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
                        dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias))
-            pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256)
+            pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
+                       C2=dxb, ldc2=256)
             # ---- action modulation
             if use_mod:
                 xhm, xm, rstdm = dp(ws["xhm"], l, M * 256), dp(ws["xm"], l, M * 256), dp(ws["rstdm"], l, M)
                 ap = f"decoder.layers.{l}.action_projectors.{domain}"
-                pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                            dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
-                pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=dp(self.WT[f"lin:{domain}"], l, 256 * 256), ldw=256, M=M, N=256, K=256,
+                pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=dp(self.WT[f"lin:{domain}"], l, 256 * 256), ldw=256, M=M, N=256, K=256,
                            epi=EPI_BF16, Cp=t256, ldc=256)
-                pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA)
+                pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
             # ---- spatial attention
-            pl.gemm_tn(dY=dx, ldy=256, y_kind=A_F32, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+            pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                        dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias))
-            pl.gemm_nt(A=dx, lda=256, a_kind=A_F32, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
+            pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale)
             pl.gemm_tn(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, a_kind=A_BF16_AFFINE,
                        gamma=self._lw(l, "norm1.weight", "p"), beta=self._lw(l, "norm1.bias", "p"), M=M, N=768, K=256,
                        dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias))
             pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M)
+            pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
+                   dxb)
             pl.mark(f"layer{l}")
         # ---- embedding, adaLN stacks, action stem
         pl.add("hma_embed_bwd", ws["ids"].data_ptr(), dx, self._g("token_embed.factored_embeds.0.weight"),

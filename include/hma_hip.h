@@ -82,16 +82,17 @@ int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p);
  * xhat = (x - mean) * rstd (bf16), rstd saved.  st_transformer.py:50,75,86,112 (eps 1e-5). */
 int hma_ln_fwd(void* stream, const float* x, void* xhat, float* rstd, int64_t rows, float eps);
 /* dx += LN-backward(dxn * gamma); dgamma += sum dxn*xhat; dbeta += sum dxn  (gamma may be NULL:
- * no affine, then dgamma/dbeta are untouched) */
+ * no affine, then dgamma/dbeta are untouched).  dx_bf16 (optional, may be NULL): bf16 copy of the updated dx,
+ * the operand the next linear's backward GEMMs read (autocast hands them grad_output in bf16). */
 int hma_ln_bwd(void* stream, const void* dxn, const void* xhat, const float* rstd, const float* gamma,
-               float* dx, float* dgamma, float* dbeta, int64_t rows);
+               float* dx, float* dgamma, float* dbeta, int64_t rows, void* dx_bf16);
 /* ModulateLayer prologue, st_mask_git.py:71-74: xhat = LN(x, eps 1e-6, no affine);
  * xm = xhat * (1 + scale[bt]) + shift[bt], ss = [shift | scale] (fp32, 512 per (b,t)). */
 int hma_modln_fwd(void* stream, const float* x, const float* ss, void* xhat, void* xm, float* rstd,
                   int64_t frames, int64_t rows_per_frame, float eps);
 /* backward of the above: dss[bt] = [sum_s dxm | sum_s dxm*xhat]; dx += LN-backward(dxm*(1+scale)) */
 int hma_modln_bwd(void* stream, const void* dxm, const void* xhat, const float* rstd, const float* ss,
-                  float* dx, float* dss, int64_t frames, int64_t rows_per_frame);
+                  float* dx, float* dss, int64_t frames, int64_t rows_per_frame, void* dx_bf16 /* optional, as hma_ln_bwd */);
 
 /* Bidirectional spatial self-attention on packed qkv rows, attention.py:37-61 with causal=False:
  * qkv (bf16) [frames * n, 3 * 256] = [q | k | v], heads of 32; o (bf16) [frames * n, 256];

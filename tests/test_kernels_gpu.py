@@ -210,9 +210,12 @@ def test_layernorm_fwd_bwd():
     dx = torch.ones(rows, 256, device=DEV)
     dg = torch.zeros(256, device=DEV)
     db = torch.zeros(256, device=DEV)
-    _lib.call("hma_ln_bwd", ops.stream_ptr(), dxn.to(DEV).bfloat16().data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
-              gam.to(DEV).data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows)
+    dxb = torch.empty(rows, 256, dtype=torch.bfloat16, device=DEV)
+    dxn_d, gam_d = dxn.to(DEV).bfloat16(), gam.to(DEV)  # kept alive: a temporary's block can be re-used by the next one
+    _lib.call("hma_ln_bwd", ops.stream_ptr(), dxn_d.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+              gam_d.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, dxb.data_ptr())
     close(dx, 1 + xr.grad, 2 * BF, "ln dx")
+    assert torch.equal(dxb, dx.bfloat16()), "bf16 copy of dx"
     close(dg, gr.grad, 2 * BF, "dgamma")
     close(db, br.grad, 1e-4, "dbeta")
 
@@ -236,9 +239,12 @@ def test_modulate_ln_fwd_bwd():
     y.backward(dxm.reshape(frames, rpf, 256))
     dx = torch.zeros(frames * rpf, 256, device=DEV)
     dss = torch.empty(frames, 512, device=DEV)
-    _lib.call("hma_modln_bwd", ops.stream_ptr(), dxm.to(DEV).bfloat16().data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
-              ssd.data_ptr(), dx.data_ptr(), dss.data_ptr(), frames, rpf)
+    dxb = torch.empty(frames * rpf, 256, dtype=torch.bfloat16, device=DEV)
+    dxm_d = dxm.to(DEV).bfloat16()
+    _lib.call("hma_modln_bwd", ops.stream_ptr(), dxm_d.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+              ssd.data_ptr(), dx.data_ptr(), dss.data_ptr(), frames, rpf, dxb.data_ptr())
     close(dx, xr.grad, 2 * BF, "modln dx")
+    assert torch.equal(dxb, dx.bfloat16()), "bf16 copy of dx"
     close(dss, sr.grad, 2 * BF, "dss")
 
 
