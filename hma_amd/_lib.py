@@ -28,6 +28,8 @@ class GemmNT(C.Structure):
         ("U", c_vp), ("ldu", c_i64),
         ("batch", c_i32), ("_pad2", c_i32),
         ("sA", c_i64), ("sW", c_i64), ("sBias", c_i64), ("sC", c_i64), ("sC2", c_i64), ("sU", c_i64),
+        ("ln_xhat", c_vp), ("ln_rstd", c_vp), ("ln_ss", c_vp), ("ln_xm", c_vp),
+        ("ln_eps", C.c_float), ("ln_rows_per_frame", c_i32),
     ]
 
 

@@ -1147,7 +1147,7 @@ __device__ __forceinline__ void epilogue_run8(const hma_gemm_nt_t& p, int64_t bz
 
 // NWAVES = 12 (3 per SIMD, <= 168 VGPRs) where the registers allow it, else 8: waves are independent, so more of
 // them is more loads in flight and more overlap of one wave's VALU/store epilogue with another's MFMAs.
-template <int AKIND, int EPI, int NWAVES>
+template <int AKIND, int EPI, int NWAVES, bool LNF = false>
 __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Wsl = smem;                                             // [256 n][TW_LD], chunk-swizzled
@@ -1290,6 +1290,10 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
             const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(xs);
           }
+          if (LNF) {  // kept for the fused LayerNorm below
+            rx[2 * pr] = x0;
+            rx[2 * pr + 1] = x1;
+          }
         } else if (EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) {
           float u[8];
           unpack8(ru[pr], u);
@@ -1299,6 +1303,44 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
         } else {
           epilogue_run8<EPI>(p, bz, crow, bn + nl, v);
         }
+      }
+    }
+    if constexpr (EPI == HMA_EPI_RESID && LNF) {  // (a separate instantiation: the plain residual epilogue stays lean)
+      // Fused LayerNorm of the new residual row (N = 256: the 4 lanes tok, tok+16, tok+32, tok+48 hold the whole
+      // row, 64 values each): same two-pass mean / variance as ln_fwd_kernel, reductions = 2 shuffles.
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += rx[q].x + rx[q].y + rx[q].z + rx[q].w;
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / 256.0f);
+      float sq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        rx[q].x -= mean; rx[q].y -= mean; rx[q].z -= mean; rx[q].w -= mean;
+        sq += rx[q].x * rx[q].x + rx[q].y * rx[q].y + rx[q].z * rx[q].z + rx[q].w * rx[q].w;
+      }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      const float rstd = rsqrtf(sq * (1.0f / 256.0f) + p.ln_eps);
+      if (m < p.M) {
+        uint16_t* xh = reinterpret_cast<uint16_t*>(p.ln_xhat) + crow * 256 + 8 * g;
+        const float* ssf = p.ln_ss ? p.ln_ss + (crow / p.ln_rows_per_frame) * 512 + 8 * g : nullptr;
+        uint16_t* xm = p.ln_ss ? reinterpret_cast<uint16_t*>(p.ln_xm) + crow * 256 + 8 * g : nullptr;
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+          float h[8] = {rx[2 * pr].x * rstd, rx[2 * pr].y * rstd, rx[2 * pr].z * rstd, rx[2 * pr].w * rstd,
+                        rx[2 * pr + 1].x * rstd, rx[2 * pr + 1].y * rstd, rx[2 * pr + 1].z * rstd, rx[2 * pr + 1].w * rstd};
+          *reinterpret_cast<uint4*>(xh + 32 * pr) = pack8(h);
+          if (ssf) {
+            const float4 sh0 = *reinterpret_cast<const float4*>(ssf + 32 * pr), sh1 = *reinterpret_cast<const float4*>(ssf + 32 * pr + 4);
+            const float4 sc0 = *reinterpret_cast<const float4*>(ssf + 256 + 32 * pr), sc1 = *reinterpret_cast<const float4*>(ssf + 256 + 32 * pr + 4);
+            float mm[8] = {h[0] * (1.f + sc0.x) + sh0.x, h[1] * (1.f + sc0.y) + sh0.y, h[2] * (1.f + sc0.z) + sh0.z, h[3] * (1.f + sc0.w) + sh0.w,
+                           h[4] * (1.f + sc1.x) + sh1.x, h[5] * (1.f + sc1.y) + sh1.y, h[6] * (1.f + sc1.z) + sh1.z, h[7] * (1.f + sc1.w) + sh1.w};
+            *reinterpret_cast<uint4*>(xm + 32 * pr) = pack8(mm);
+          }
+        }
+        if (g == 0) p.ln_rstd[crow] = rstd;
       }
     }
   }
@@ -1766,6 +1808,11 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2) && !p->C2) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU) && !p->U) return HMA_EINVAL;
+  if (p->ln_xhat) {  // fused LayerNorm: only on the streaming residual path
+    static const bool no_sw_ln = getenv("HMA_GEMM_NT_NOSW") != nullptr;
+    if (no_sw_ln || p->epi != HMA_EPI_RESID || p->N != 256 || p->K != 256 || p->batch > 1 || !p->ln_rstd) return HMA_EINVAL;
+    if (p->ln_ss && (!p->ln_xm || p->ln_rows_per_frame <= 0)) return HMA_EINVAL;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
   static const bool use_v1 = getenv("HMA_GEMM_NT_V1") != nullptr;
@@ -1793,6 +1840,22 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       // streaming waves: blocks dealt round-robin over the (batch, n-slab) pairs
       const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
       const int64_t tiles16 = (p->M + 15) / 16;
+      if (p->ln_xhat) {  // validated above: A bf16 or any kind, RESID, N = K = 256
+        int per_slab = n_cu;
+        if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
+#define HMA_NTW_LN_CASE(AK)                                                                           \
+  if (p->a_kind == AK) {                                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_sw_kernel<AK, HMA_EPI_RESID, 8, true>>(TW_SMEM_BYTES))) return rc; \
+    hipLaunchKernelGGL((gemm_nt_sw_kernel<AK, HMA_EPI_RESID, 8, true>), dim3((unsigned)per_slab), dim3(512), TW_SMEM_BYTES, s, pa, \
+                       1, per_slab);                                                                  \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+        HMA_NTW_LN_CASE(HMA_A_BF16)
+        HMA_NTW_LN_CASE(HMA_A_F32)
+        HMA_NTW_LN_CASE(HMA_A_BF16_AFFINE)
+        return HMA_EINVAL;
+      }
 #define HMA_NTW_CASE(AK, EP)                                                                          \
   if (p->a_kind == AK && p->epi == EP) {                                                              \
     constexpr int NWV = 8; /* 12 waves (168 VGPRs) spill and measured 1.05-2.7x slower */                           \

@@ -294,12 +294,13 @@ class STEngine:
                    beta=self._lw(l, "norm1.bias", "p"), W=self._lw(l, "spatial_attn.qkv.weight"), ldw=256, M=M, N=768, K=256,
                    epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=qb("spatial_attn"))
         pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale)
+        # (the LayerNorm / modulate prologue of the NEXT sub-block is fused into this projection's epilogue)
+        fuse = dict(ln_xhat=b["xhm"], ln_rstd=b["rstdm"], ln_eps=1e-6, ln_ss=b["ss"], ln_xm=b["xm"], ln_rows_per_frame=SA) if use_mod else {}
         pl.gemm_nt(A=b["o_s"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else b["x2b"], ldc2=256)
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else b["x2b"], ldc2=256, **fuse)
         # action modulation: x += Lin(LN0(x) (1 + scale) + shift)   st_mask_git.py:66-76
         if use_mod:
             ap = f"decoder.layers.{l}.action_projectors.{domain}"
-            pl.add("hma_modln_fwd", x, b["ss"], b["xhm"], b["xm"], b["rstdm"], Fr, SA, 1e-6)
             pl.gemm_nt(A=b["xm"], lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
                        epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=b["x2b"], ldc2=256)
         # temporal (causal, un-normed input)                st_transformer.py:111
@@ -313,9 +314,8 @@ class STEngine:
                        bias=qb("temporal_attn"))
             pl.add("hma_attn_temporal_cached", kv["cache"], b["o_t"], B, T, kv["t_query"], kv["T_cache"], SA, self.scale)
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"))
-        # MLP                                               st_transformer.py:112
-        pl.add("hma_ln_fwd", x, b["xh2"], b["rstd2"], M, 1e-5)
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
+        # MLP (its LayerNorm: fused above)                   st_transformer.py:112
         pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
                    beta=self._lw(l, "norm2.bias", "p"), W=self._lw(l, "mlp.fc1.weight"), ldw=256, M=M, N=1024, K=256,
                    epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024,

@@ -56,6 +56,14 @@ typedef struct {
   /* batching over blockIdx.z (per-layer adaLN stacks): element strides, 0 = shared */
   int32_t batch; int32_t _pad2;
   int64_t sA, sW, sBias, sC, sC2, sU;
+  /* Optional fused LayerNorm of the updated residual rows (HMA_EPI_RESID with N = K = 256, batch <= 1 only;
+   * anything else with ln_xhat set is HMA_EINVAL): after C += A' W^T + bias the kernel also writes
+   *   ln_xhat = LN(C row, ln_eps, no affine) (bf16, leading dimension 256, row index = C row) and ln_rstd,
+   * i.e. what hma_ln_fwd would produce from the new residual (st_transformer.py:112 norm2), and, when ln_ss is
+   * set, ln_xm = ln_xhat * (1 + scale[f]) + shift[f] with f = row / ln_rows_per_frame and ln_ss = [shift | scale]
+   * (fp32, 512 per frame), i.e. hma_modln_fwd (st_mask_git.py:71-74). */
+  void* ln_xhat; float* ln_rstd; const float* ln_ss; void* ln_xm;
+  float ln_eps; int32_t ln_rows_per_frame;
 } hma_gemm_nt_t;
 int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p);
 
