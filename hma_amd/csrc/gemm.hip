@@ -1113,7 +1113,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
 // k permutation: lane (tok, g = lane >> 4) holds chunks c = 4 j + g (j = 0..7) of its row, MFMA step j
 // contracts k = 8 c .. 8 c + 7.  Row permutation: tile 2p + o, MFMA row i  <->  n = 32 p + 8 (i >> 2) + (i & 3) + 4 o.
 constexpr int TW_LD = 256 + 8;                       // padded weight-slab row (elements)
-constexpr int TW_SMEM_BYTES = 256 * TW_LD * 2 + 2 * 256 * 4;  // slab + gamma/beta
+// exact-erf GELU by table: the activation's argument is a bf16 value, so Phi(u) (forward) or dgelu(u) (backward)
+// is a function of 16 bits; every |u| in [2^-16, 20) -- 2592 bf16 values per sign -- gets an fp32 entry in LDS
+// (20.7 KB, built per workgroup with erff at start-up), smaller |u| use the first entry (Phi = 0.5 to 6e-6), larger
+// the last (0 or 1).  ~9 instructions + one LDS read per element instead of ~23 (the epilogue was VALU-bound), and
+// the result is the correctly rounded fp32 gelu of the rounded pre-activation, as in the reference.
+constexpr int GT_A0 = 0x3780, GT_A1 = 0x41A0, GT_N = GT_A1 - GT_A0;  // bf16 bit patterns of 2^-16 and 20.0
+constexpr int TW_SMEM_BYTES = 256 * TW_LD * 2 + 2 * 256 * 4 + 2 * GT_N * 4;  // slab + gamma/beta + table
+__device__ __forceinline__ float gt_lookup(const float* tbl, uint32_t bits16) {
+  const uint32_t a = bits16 & 0x7fffu;
+  const uint32_t k = min(max(a, (uint32_t)GT_A0), (uint32_t)(GT_A1 - 1));  // -> v_med3_u32
+  return tbl[k + (bits16 >> 15) * GT_N];  // tbl points at entry -GT_A0
+}
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 
@@ -1152,6 +1163,8 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Wsl = smem;                                             // [256 n][TW_LD], chunk-swizzled
   float* gb = reinterpret_cast<float*>(smem + 256 * TW_LD);         // gamma[256] | beta[256]
+  float* gtab = gb + 512;                                           // Phi / dgelu table (see gt_lookup)
+  const float* gtl = gtab - GT_A0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tok = lane & 15, g = lane >> 4;
 
@@ -1170,6 +1183,14 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
     }
     if (AKIND == HMA_A_BF16_AFFINE) {
       for (int c = tid; c < 256; c += 64 * NWAVES) { gb[c] = p.gamma[c]; gb[256 + c] = p.beta[c]; }
+    }
+    if (EPI == HMA_EPI_GELU2 || EPI == HMA_EPI_DGELU) {
+      for (int c = tid; c < 2 * GT_N; c += 64 * NWAVES) {
+        const uint32_t bits = (uint32_t)(GT_A0 + (c % GT_N)) | (c >= GT_N ? 0x8000u : 0u);
+        const float u = __uint_as_float(bits << 16);
+        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+        gtab[c] = EPI == HMA_EPI_GELU2 ? cdf : cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+      }
     }
   }
   __syncthreads();  // the only barrier
@@ -1294,11 +1315,27 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
             rx[2 * pr] = x0;
             rx[2 * pr + 1] = x1;
           }
-        } else if (EPI == HMA_EPI_DGELU || EPI == HMA_EPI_DSILU) {
+        } else if (EPI == HMA_EPI_DGELU) {
+          const uint32_t w[4] = {ru[pr].x, ru[pr].y, ru[pr].z, ru[pr].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gt_lookup(gtl, (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl) = pack8(v);
+        } else if (EPI == HMA_EPI_GELU2) {
+          const uint4 uq = pack8(v);  // the saved pre-activation; the activation is applied to the ROUNDED value
+          const uint32_t w[4] = {uq.x, uq.y, uq.z, uq.w};
+          float h[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t bits = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            h[e] = __uint_as_float(bits << 16) * gt_lookup(gtl, bits);
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl) = uq;
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(h);
+        } else if (EPI == HMA_EPI_DSILU) {
           float u[8];
           unpack8(ru[pr], u);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= (EPI == HMA_EPI_DGELU ? dgelu_f(u[e]) : dsilu_f(u[e]));
+          for (int e = 0; e < 8; ++e) v[e] *= dsilu_f(u[e]);
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl) = pack8(v);
         } else {
           epilogue_run8<EPI>(p, bz, crow, bn + nl, v);
@@ -1341,6 +1378,146 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
           }
         }
         if (g == 0) p.ln_rstd[crow] = rstd;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------- NT, streaming waves, K = 256 * KC (KC = 2, 3, 4)
+// Same wave-owns-its-rows structure for the K = 768 / 1024 GEMMs (fc2, dfc1, dqkv, readout dgrad), whose weight
+// slab (256 x K) does not fit LDS: the slab is cycled through LDS in 256-wide K chunks under a workgroup barrier
+// (one per chunk, every ~128 MFMAs per wave instead of every 8), each wave keeps its tile's 64 accumulators across
+// the chunks, and the chunk order snakes (0..KC-1, KC-1..0, ...) so the chunk at every turn is reused.  A rows of
+// the next (tile, chunk) step are in flight in registers across the barriers; epilogue per wave as above.
+template <int AKIND, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Wsl = smem;  // [256 n][TW_LD]: one K chunk, chunk-swizzled
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tok = lane & 15, g = lane >> 4;
+  const int KC = (int)(p.K >> 8);
+
+  const int b = blockIdx.x;
+  const int slab_id = b % nslabs, slot = b / nslabs;
+  const int slabs_n = (int)(p.N / 256);
+  const int64_t bz = slab_id / slabs_n;
+  const int64_t bn = (int64_t)(slab_id % slabs_n) * 256;
+  const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
+
+  const int64_t tiles = (p.M + 15) / 16;
+  const int64_t nw = (int64_t)per_slab * 8;
+  const int64_t gw0 = (int64_t)slot * 8, gw = gw0 + wave;
+  const int trips = gw0 < tiles ? (int)((tiles - gw0 + nw - 1) / nw) : 0;  // of wave 0: every wave runs this many (barriers)
+
+  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
+  auto load_a = [&](int64_t tile, int chunk, bf16x8_t (&a)[8]) __attribute__((always_inline)) {
+    int64_t m = tile * 16 + tok;
+    m = m < p.M ? m : p.M - 1;
+    const int64_t off = remap_row(m, p.a_group_rows, p.a_group_stride) * p.lda + chunk * 256;
+    if (AKIND == HMA_A_F32) {
+      const float* row = reinterpret_cast<const float*>(Ab) + off;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 lo = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8 + 4);
+        const uint4 v = make_uint4(pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w));
+        a[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    } else {
+      const uint16_t* row = reinterpret_cast<const uint16_t*>(Ab) + off;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(row + (4 * j + g) * 8));
+    }
+  };
+  // step s = (trip, position in the snake) -> K chunk
+  auto chunk_of = [&](int trip, int cc) { return (trip & 1) ? KC - 1 - cc : cc; };
+
+  const int i16 = lane & 15;
+  const uint16_t* wbase = Wsl + (8 * (i16 >> 2) + (i16 & 3)) * TW_LD + g * 8;
+  const int jsw = (i16 >> 3) & 1;
+  const float* bias = p.bias ? p.bias + bz * p.sBias + bn : nullptr;
+
+  bf16x8_t a[8], an[8];
+  {
+    const int64_t t0 = gw < tiles ? gw : tiles - 1;
+    load_a(t0, 0, an);
+  }
+  int loaded = -1;
+  for (int trip = 0; trip < trips; ++trip) {
+    const int64_t tile = gw + (int64_t)trip * nw;
+    const bool active = tile < tiles;
+    const int64_t tile_c = active ? tile : tiles - 1;  // idle waves re-load a valid row and discard
+    const int64_t m = tile_c * 16 + tok;
+    const int64_t crow = remap_row(m < p.M ? m : p.M - 1, p.c_group_rows, p.c_group_stride);
+    float4 rx[EPI == HMA_EPI_RESID ? 16 : 1];
+    f32x4v_t acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < KC; ++cc) {
+      const int chunk = chunk_of(trip, cc);
+      if (chunk != loaded) {  // uniform over the workgroup
+        __syncthreads();      // everyone is done with the previous chunk
+        for (int c = tid; c < 256 * 32; c += 512) {
+          const int n = c >> 5, ch = c & 31;
+          *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) =
+              *reinterpret_cast<const uint4*>(Wb + (int64_t)n * p.ldw + chunk * 256 + ch * 8);
+        }
+        __syncthreads();
+        loaded = chunk;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = an[j];
+      {  // A rows of the next (tile, chunk) step
+        int ntrip = trip, ncc = cc + 1;
+        if (ncc == KC) { ncc = 0; ++ntrip; }
+        int64_t ntile = gw + (int64_t)ntrip * nw;
+        if (ntrip >= trips || ntile >= tiles) { ntile = tile_c; ntrip = trip; }
+        load_a(ntile, chunk_of(ntrip, ncc), an);
+      }
+      if (EPI == HMA_EPI_RESID && cc == 0) {  // residual rows: fetched a whole tile ahead of their use
+        const float* C = reinterpret_cast<const float*>(p.C) + bz * p.sC + crow * p.ldc + bn + 8 * g;
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+          rx[2 * pr] = *reinterpret_cast<const float4*>(C + 32 * pr);
+          rx[2 * pr + 1] = *reinterpret_cast<const float4*>(C + 32 * pr + 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint16_t* wj = wbase + ((j ^ jsw) << 5);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wj + (32 * (t >> 1) + 4 * (t & 1)) * TW_LD);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a[j], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (active && m < p.M) {
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const int64_t nl = 32 * pr + 8 * g;
+        float v[8] = {acc[2 * pr][0], acc[2 * pr][1], acc[2 * pr][2], acc[2 * pr][3],
+                      acc[2 * pr + 1][0], acc[2 * pr + 1][1], acc[2 * pr + 1][2], acc[2 * pr + 1][3]};
+        if (bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(bias + nl), b1 = *reinterpret_cast<const float4*>(bias + nl + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (EPI == HMA_EPI_RESID) {
+          float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl;
+          float4 x0 = rx[2 * pr], x1 = rx[2 * pr + 1];
+          x0.x += v[0]; x0.y += v[1]; x0.z += v[2]; x0.w += v[3];
+          x1.x += v[4]; x1.y += v[5]; x1.z += v[6]; x1.w += v[7];
+          *reinterpret_cast<float4*>(C) = x0;
+          *reinterpret_cast<float4*>(C + 4) = x1;
+          if (p.C2) {
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(xs);
+          }
+        } else {
+          epilogue_run8<EPI>(p, bz, crow, bn + nl, v);
+        }
       }
     }
   }
@@ -1875,6 +2052,28 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       HMA_NTW_ALL(HMA_A_BF16)
       HMA_NTW_ALL(HMA_A_F32)
       HMA_NTW_ALL(HMA_A_BF16_AFFINE)
+    }
+    // K-chunked streaming variant: measured SLOWER than the lock-step kernels in situ (fc2 / dqkv-resid 241 vs 182 us,
+    // dfc1 / dqkv 165 vs 110 us): the whole workgroup idles while a 132 KB weight chunk is re-parked, four times per
+    // 128 token rows.  Kept opt-in (HMA_GEMM_NT_SWK=1) as the base for a double-buffered version.
+    static const bool no_swk = getenv("HMA_GEMM_NT_SWK") == nullptr;
+    if (!no_sw && !no_swk && !use_p1 && !use_p2 && p->K > 256 && p->K <= 1024 && (p->K & 255) == 0 && p->a_kind != HMA_A_BF16_AFFINE &&
+        (p->epi == HMA_EPI_BF16 || p->epi == HMA_EPI_F32 || p->epi == HMA_EPI_RESID)) {
+      const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
+      const int64_t tiles16 = (p->M + 15) / 16;
+      int per_slab = n_cu / nslabs;
+      if (per_slab < 1) per_slab = 1;
+      if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
+#define HMA_NTK_CASE(AK, EP)                                                                          \
+  if (p->a_kind == AK && p->epi == EP) {                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_swk_kernel<AK, EP>>(TW_SMEM_BYTES))) return rc;                  \
+    hipLaunchKernelGGL((gemm_nt_swk_kernel<AK, EP>), dim3((unsigned)(nslabs * per_slab)), dim3(512), TW_SMEM_BYTES, s, pa, \
+                       nslabs, per_slab);                                                             \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+      HMA_NTK_CASE(HMA_A_BF16, HMA_EPI_BF16) HMA_NTK_CASE(HMA_A_BF16, HMA_EPI_F32) HMA_NTK_CASE(HMA_A_BF16, HMA_EPI_RESID)
+      HMA_NTK_CASE(HMA_A_F32, HMA_EPI_BF16) HMA_NTK_CASE(HMA_A_F32, HMA_EPI_F32) HMA_NTK_CASE(HMA_A_F32, HMA_EPI_RESID)
     }
     // (measured per shape, profiles/gemm_shapes_r1.txt: it only wins for the N = K = 256 residual projections)
     if (!use_p1 && !use_p2 && !no_ws && p->K == SK && p->N == PN && p->a_kind == HMA_A_BF16 && p->epi == HMA_EPI_RESID && !p->C2) {
