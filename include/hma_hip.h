@@ -184,6 +184,20 @@ int hma_adamw(void* stream, float* p, const float* g, float* m, float* v, void* 
               const float* sqnorm, float max_norm, const uint8_t* flags);
 /* dst(bf16) = src(f32) for n elements */
 int hma_cast_bf16(void* stream, const float* src, void* dst, int64_t n);
+
+/* MaskGIT training collator on device, hma/data.py:28-98 (get_maskgit_collator.collate_fn) on ids [B, T, HW]:
+ * factorise (num_factored sub-vocabularies of V: 2 x 512 for the shipped models), corruption where r_corrupt[.., k] < corrupt_thresh (data.py:42-49), non-MLM corruption of
+ * frames >= first_masked_frame where r_nonmlm[.., k] > correct_rate[t - fmf] (:51-64), cosine masking where
+ * r_mask < mask_prob[b, t - fmf] -> mask_id (:68-83).  Every random draw is an input tensor (device pointers:
+ * r_corrupt / random_values [B, T, HW, num_factored]; r_nonmlm [B, T - fmf, HW, num_factored]; correct_rate [T - fmf]; mask_prob
+ * [B, T - fmf]; r_mask [B, T - fmf, HW]; NULL = that stage is off; mask_prob NULL = ids pass through unchanged, as
+ * the reference does without dataloader_apply_mask).  any_masked (optional int32 flag) is OR-ed with 1 if any token
+ * was masked (the reference redraws until that is the case, :72).  Pure function: bit-exact given the same draws. */
+int hma_maskgit_collate(void* stream, const int64_t* ids, int64_t* out_ids, const float* r_corrupt, float corrupt_thresh,
+                        const int64_t* random_values, const float* r_nonmlm, const float* correct_rate,
+                        const float* mask_prob, const float* r_mask, int64_t B, int32_t T, int32_t HW,
+                        int32_t first_masked_frame, int32_t V, int32_t num_factored /* 1 | 2: last dim of the draws */,
+                        int64_t mask_id, int32_t* any_masked);
 /* dst[b][c][r] (bf16) = src[b][r][c] (f32): transposed bf16 copies of weights for the dgrad GEMMs */
 int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t rows, int32_t cols,
                             int32_t batch, int64_t src_stride, int64_t dst_stride);
