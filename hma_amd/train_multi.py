@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Multi-dataset training driver (SURVEY row a16 + (f) rows): `python -m hma_amd.train_multi --output_dir ...`.
+
+The reference's loop (hma/train_multi.py:556-599, 779-1030) without Accelerate: one `RawTokenDataset` per data
+directory (one action domain each), `MultiTaskBatchSampler` (one domain per batch, temperature 3), the device-side
+MaskGIT collator, and the fused `Trainer` step (forward + backward + sparse-by-domain all-reduce + clip + AdamW).
+Launched under `torch.distributed.run` it is one process per GPU: like the reference every process builds the SAME
+sampler (num_replicas=1, rank=0, `train_multi.py:928-932`) and rank r takes batches r, r + world, ... of it
+(Accelerate's BatchSamplerShard, `:939,990`).  Flags keep the reference's names; the ones that have no meaning here
+(`--no_compile`, `--mu_transfer`, ...) are accepted and ignored so existing launch scripts keep working.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import time
+from pathlib import Path
+from typing import List
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import ConcatDataset
+
+from .config import GenieConfig
+from .data import RawTokenDataset, get_maskgit_collator
+from .data_sampler import MultiTaskBatchSampler
+from .model.st_mask_git import STMaskGIT
+from .train import Trainer
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Train the spatial-temporal MaskGIT on tokenised video + action datasets.")
+    p.add_argument("--train_data_dir", type=str, nargs="+", required=True, help="One dataset directory per action domain.")
+    p.add_argument("--window_size", type=int, default=12)
+    p.add_argument("--stride", type=int, default=None)
+    p.add_argument("--filter_overlaps", action="store_true")
+    p.add_argument("--genie_config", type=str, required=True, help="GenieConfig JSON (e.g. magvit_n32_h8_d256_action.json).")
+    p.add_argument("--resume_from_checkpoint", type=str, default=None)
+    p.add_argument("--per_device_train_batch_size", type=int, default=4)
+    p.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    p.add_argument("--learning_rate", type=float, default=1e-4)
+    p.add_argument("--weight_decay", type=float, default=0.05)
+    p.add_argument("--num_train_epochs", type=int, default=2)
+    p.add_argument("--max_train_steps", type=int, default=None)
+    p.add_argument("--num_warmup_steps", type=int, default=500)
+    p.add_argument("--max_grad_norm", type=float, default=1.0)
+    p.add_argument("--adam_beta_1", type=float, default=0.9)
+    p.add_argument("--adam_beta_2", type=float, default=0.95)
+    p.add_argument("--adam_eps", type=float, default=1e-8)
+    p.add_argument("--output_dir", type=str, required=True)
+    p.add_argument("--checkpointing_steps", type=int, default=None)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--sampling_temperature", type=float, default=3.0, help="Dataset-mix temperature (train_multi.py:931).")
+    p.add_argument("--log_every", type=int, default=10)
+    for ignored in ("--no_compile", "--mu_transfer", "--pin_memory", "--overfit_first_batch"):
+        p.add_argument(ignored, action="store_true", help="accepted for script compatibility; no effect")
+    for ignored in ("--report_to", "--run_name", "--lr_scheduler_type", "--val_data_dir", "--domain", "--num_workers"):
+        p.add_argument(ignored, default=None, help="accepted for script compatibility; no effect")
+    return p.parse_args(argv)
+
+
+def build_datasets(args) -> List[RawTokenDataset]:
+    kw = dict(window_size=args.window_size, filter_overlaps=args.filter_overlaps, use_actions=True)
+    if args.stride is not None:
+        kw.update(stride=args.stride, compute_stride_from_freq_table=False)
+    return [RawTokenDataset(d, **kw) for d in args.train_data_dir]
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+
+    datasets = build_datasets(args)
+    domains = [d.name for d in datasets]
+    config = GenieConfig.from_pretrained(args.genie_config)
+    config.T = args.window_size
+    config.use_mup = True  # train_multi.py forces the muP attention scale (8 / head_dim)
+    if args.resume_from_checkpoint:
+        model = STMaskGIT.from_pretrained(args.resume_from_checkpoint)
+    else:
+        model = STMaskGIT(config)
+        model.init_action_projectors(domains, [d.n_action for d in datasets], [d.action_stat for d in datasets], config.action_network)
+    model = model.to("cuda")
+    trainer = Trainer(model, lr=args.learning_rate, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
+                      weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, warmup_steps=args.num_warmup_steps,
+                      grad_accum=args.gradient_accumulation_steps)
+
+    concat = ConcatDataset(datasets)
+    sampler = MultiTaskBatchSampler([len(d) for d in datasets], args.per_device_train_batch_size, args.sampling_temperature,
+                                    seed=args.seed)  # defaults num_replicas=1, rank=0: every process draws the same sequence
+    collate = get_maskgit_collator(config)
+    steps_per_epoch = max(len(sampler) // (world * args.gradient_accumulation_steps), 1)
+    max_steps = args.max_train_steps or args.num_train_epochs * steps_per_epoch
+    out_dir = Path(args.output_dir)
+    step, t0, tokens = 0, time.time(), 0
+    for epoch in range(10 ** 9):
+        sampler.set_epoch(epoch)
+        micro = 0
+        for k, indices in enumerate(sampler):
+            if k % world != rank:  # BatchSamplerShard: rank r takes every world-th batch
+                continue
+            batch = collate([concat[i] for i in indices])
+            ws = trainer.micro_step(batch["input_ids"], batch["labels"], batch.get("action_ids"), batch["domain"])
+            tokens += batch["input_ids"].numel()
+            micro += 1
+            if micro % args.gradient_accumulation_steps:
+                continue
+            trainer.optimizer_step()
+            step += 1
+            if rank == 0 and (step % args.log_every == 0 or step == max_steps):
+                loss, acc = trainer.loss_and_acc(ws)
+                dt = time.time() - t0
+                print(json.dumps({"step": step, "loss": float(loss), "acc": float(acc), "domain": batch["domain"][0],
+                                  "tokens_per_s_per_gpu": tokens / dt}), flush=True)
+            if rank == 0 and args.checkpointing_steps and step % args.checkpointing_steps == 0:
+                model.save_pretrained(out_dir / f"step_{step}")
+            if step >= max_steps:
+                break
+        if step >= max_steps:
+            break
+    if rank == 0:
+        model.save_pretrained(out_dir / f"step_{step}")
+    if world > 1:
+        dist.barrier()
+    return step
+
+
+if __name__ == "__main__":
+    main()

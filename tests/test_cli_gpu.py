@@ -1,0 +1,54 @@
+"""End-to-end plumbing on the GPU: synthetic on-disk datasets (two action domains) -> train_multi for a few optimizer
+steps (sampler + device collator + fused trainer) -> checkpoint -> generate.py rollout -> output files in the
+reference's format."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from hma_amd import generate as hgen
+from hma_amd import train_multi as htrain
+from hma_amd.data import RawTokenDataset, write_token_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(path, name, n, action_dim, seed):
+    rng = np.random.default_rng(seed)
+    tokens = rng.integers(0, 262144, size=(n, 16, 16), dtype=np.uint32)
+    seg = np.repeat(np.arange(n // 20 + 1), 20)[:n].astype(np.int32)
+    write_token_dataset(path / name, tokens, seg, rng.standard_normal((n, action_dim)).astype(np.float32), name=name)
+    return tokens
+
+
+def test_train_then_generate(tmp_path):
+    tok_a = _dataset(tmp_path, "domA", 80, 7, 0)
+    _dataset(tmp_path, "domB", 60, 5, 1)
+    cfg = {"num_layers": 2, "num_heads": 8, "use_actions": True, "d_model": 256, "T": 4, "S": 256, "image_vocab_size": 262144,
+           "use_mup": False, "action_network": "concat+modulate", "num_factored_vocabs": 2, "qkv_bias": False, "proj_bias": True,
+           "mlp_bias": True, "qk_norm": False, "attn_drop": 0.0, "mlp_ratio": 4.0, "mlp_drop": 0.0}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    steps = htrain.main(["--train_data_dir", str(tmp_path / "domA"), str(tmp_path / "domB"), "--genie_config", str(tmp_path / "cfg.json"),
+                         "--window_size", "4", "--stride", "1", "--per_device_train_batch_size", "2", "--max_train_steps", "4",
+                         "--num_warmup_steps", "2", "--output_dir", str(tmp_path / "out"), "--seed", "0", "--log_every", "2"])
+    assert steps == 4
+    ckpt = tmp_path / "out" / "step_4"
+    assert (ckpt / "config.json").exists() and (ckpt / "model.safetensors").exists()
+    saved = json.load(open(ckpt / "config.json"))
+    assert saved["action_domains"] == ["domA", "domB"] and saved["d_actions"] == [7, 5]
+
+    out = hgen.main(["--val_data_dir", str(tmp_path / "domA"), "--checkpoint_dir", str(ckpt), "--output_dir", str(tmp_path / "gen"),
+                     "--num_prompt_frames", "2", "--window_size", "4", "--maskgit_steps", "2", "--batch_size", "2", "--max_example", "2",
+                     "--add_action_input"])
+    # [prompt (2) | generated (2) | ground truth (2)] frames per example
+    assert out.shape[1:] == (6, 16, 16)
+    meta = json.load(open(tmp_path / "gen" / "metadata.json"))
+    assert meta["num_images"] == 6 and meta["t"] == 4 and meta["trained_steps"] == 4 and meta["token_dtype"] == "uint32"
+    raw = np.fromfile(tmp_path / "gen" / "video.bin", dtype=np.uint32).reshape(-1, 6, 16, 16)
+    assert raw.shape[0] == out.shape[0]
+    first = RawTokenDataset(tmp_path / "domA", window_size=4, compute_stride_from_freq_table=False)[0]["input_ids"].reshape(4, 16, 16)
+    assert np.array_equal(raw[0, :2], first[:2].numpy().astype(np.uint32))        # prompt frames kept
+    assert np.array_equal(raw[0, 4:], first[2:].numpy().astype(np.uint32))        # ground truth appended
+    assert (raw[:, 2:4] < 262144).all()                                           # generated ids are real tokens
+    assert np.array_equal(tok_a[:2], raw[0, :2])
