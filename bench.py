@@ -293,8 +293,14 @@ def main():
             s = timer.summary().get("hma_gemm_nt")
             if s:
                 ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (hma_gemm_nt)", "achieved": ach, "peak": 2500.0,
-                                   "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic_per_launch(),
+                traffic = pmc_traffic_per_launch()
+                avg_s = 1e-3 * s["ms"] / s["launches"]
+                out["roofline"] = {"bound": "mfma", "kernel": "hma_gemm_nt (gemm_nt_sw_kernel at K = 256, gemm_nt_p3_kernel above)",
+                                   "achieved": ach, "peak": 2500.0,
+                                   "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
+                                   # the same launches against the HBM roofline (they are output-dominated streams at K = 256)
+                                   "hbm": None if not traffic else {"achieved": traffic / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                                    "frac": traffic / avg_s / 8e12},
                                    "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/pmc_hbm_r1.json",
                                    "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
                                    "flops_per_launch": s["flops"] / s["launches"],
