@@ -1127,6 +1127,7 @@ __device__ __forceinline__ float gt_lookup(const float* tbl, uint32_t bits16) {
 }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_run8(const hma_gemm_nt_t& p, int64_t bz, int64_t crow, int64_t n8, float (&v)[8]) {
@@ -1383,19 +1384,24 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   }
 }
 
-// ------------------------------------------------- NT, streaming waves, K = 256 * KC (KC = 2, 3, 4)
+// ------------------------------------------------- NT, streaming waves, K = 128 * KH (K = 512 .. 1024)
 // Same wave-owns-its-rows structure for the K = 768 / 1024 GEMMs (fc2, dfc1, dqkv, readout dgrad), whose weight
-// slab (256 x K) does not fit LDS: the slab is cycled through LDS in 256-wide K chunks under a workgroup barrier
-// (one per chunk, every ~128 MFMAs per wave instead of every 8), each wave keeps its tile's 64 accumulators across
-// the chunks, and the chunk order snakes (0..KC-1, KC-1..0, ...) so the chunk at every turn is reused.  A rows of
-// the next (tile, chunk) step are in flight in registers across the barriers; epilogue per wave as above.
+// slab (256 x K) does not fit LDS: it is streamed through two 256 x 128 LDS buffers.  Per step (one 128-wide K
+// piece of one tile round) every thread fetches its share of the NEXT piece into registers, the waves multiply
+// the current piece (64 MFMAs each, accumulators kept across the pieces of a tile), the registers are written to
+// the other buffer, one barrier.  A rows of the next step are in flight in registers too; epilogue per wave.
+// (A first version that re-parked whole 256-wide chunks between two barriers with nothing overlapping was
+// 1.3-1.5x SLOWER than the lock-step kernel; see profiles/.)
+constexpr int TH_LD = 128 + 8;                          // padded half-slab row (elements): 17 x 16-B slots
+constexpr int TH_BUF = 256 * TH_LD;                     // one buffer (elements)
+constexpr int TH_SMEM_BYTES = 2 * TH_BUF * 2;           // 139264 B
+
 template <int AKIND, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* Wsl = smem;  // [256 n][TW_LD]: one K chunk, chunk-swizzled
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tok = lane & 15, g = lane >> 4;
-  const int KC = (int)(p.K >> 8);
+  const int KH = (int)(p.K >> 7);  // 128-wide pieces
 
   const int b = blockIdx.x;
   const int slab_id = b % nslabs, slot = b / nslabs;
@@ -1408,16 +1414,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, in
   const int64_t nw = (int64_t)per_slab * 8;
   const int64_t gw0 = (int64_t)slot * 8, gw = gw0 + wave;
   const int trips = gw0 < tiles ? (int)((tiles - gw0 + nw - 1) / nw) : 0;  // of wave 0: every wave runs this many (barriers)
+  const int total = trips * KH;
+  if (total == 0) return;
 
   const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
-  auto load_a = [&](int64_t tile, int chunk, bf16x8_t (&a)[8]) __attribute__((always_inline)) {
+  auto load_a = [&](int64_t tile, int piece, bf16x8_t (&a)[4]) __attribute__((always_inline)) {
     int64_t m = tile * 16 + tok;
     m = m < p.M ? m : p.M - 1;
-    const int64_t off = remap_row(m, p.a_group_rows, p.a_group_stride) * p.lda + chunk * 256;
+    const int64_t off = remap_row(m, p.a_group_rows, p.a_group_stride) * p.lda + piece * 128;
     if (AKIND == HMA_A_F32) {
       const float* row = reinterpret_cast<const float*>(Ab) + off;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const float4 lo = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8);
         const float4 hi = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8 + 4);
         const uint4 v = make_uint4(pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w));
@@ -1426,23 +1434,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, in
     } else {
       const uint16_t* row = reinterpret_cast<const uint16_t*>(Ab) + off;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(row + (4 * j + g) * 8));
+      for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(row + (4 * j + g) * 8));
     }
   };
-  // step s = (trip, position in the snake) -> K chunk
-  auto chunk_of = [&](int trip, int cc) { return (trip & 1) ? KC - 1 - cc : cc; };
-
+  // this thread's 8 chunks of a weight piece: chunk c = tid + 512 i -> row c >> 4, 16-B chunk c & 15 (swizzled as in sw).
+  // (Written inline below: passed through a lambda the 8-register array stayed in scratch memory.)
+  const uint16_t* wsrc = Wb + (int64_t)(tid >> 4) * p.ldw + (tid & 15) * 8;  // chunk i: + 32 i rows
+#define HMA_SWK_LOAD_W(piece_)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
+    wq[i] = *reinterpret_cast<const u32x4_t*>(wsrc + (int64_t)(32 * i) * p.ldw + (piece_) * 128);
+#define HMA_SWK_STORE_W(buf_)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                      \
+    const int n = (tid >> 4) + 32 * i, ch = tid & 15;                                                  \
+    *reinterpret_cast<u32x4_t*>(&(buf_)[n * TH_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) = wq[i];      \
+  }
   const int i16 = lane & 15;
-  const uint16_t* wbase = Wsl + (8 * (i16 >> 2) + (i16 & 3)) * TW_LD + g * 8;
+  const int wofs = (8 * (i16 >> 2) + (i16 & 3)) * TH_LD + g * 8;
   const int jsw = (i16 >> 3) & 1;
   const float* bias = p.bias ? p.bias + bz * p.sBias + bn : nullptr;
 
-  bf16x8_t a[8], an[8];
-  {
-    const int64_t t0 = gw < tiles ? gw : tiles - 1;
-    load_a(t0, 0, an);
-  }
-  int loaded = -1;
+  bf16x8_t a[4], an[4];
+  u32x4_t wq[8];
+  HMA_SWK_LOAD_W(0)
+  load_a(gw < tiles ? gw : tiles - 1, 0, an);
+  HMA_SWK_STORE_W(smem)
+  __syncthreads();
+
+  int step = 0;
   for (int trip = 0; trip < trips; ++trip) {
     const int64_t tile = gw + (int64_t)trip * nw;
     const bool active = tile < tiles;
@@ -1453,28 +1471,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, in
     f32x4v_t acc[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < KC; ++cc) {
-      const int chunk = chunk_of(trip, cc);
-      if (chunk != loaded) {  // uniform over the workgroup
-        __syncthreads();      // everyone is done with the previous chunk
-        for (int c = tid; c < 256 * 32; c += 512) {
-          const int n = c >> 5, ch = c & 31;
-          *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) =
-              *reinterpret_cast<const uint4*>(Wb + (int64_t)n * p.ldw + chunk * 256 + ch * 8);
-        }
-        __syncthreads();
-        loaded = chunk;
-      }
+    for (int piece = 0; piece < KH; ++piece, ++step) {
+      const uint16_t* cur = smem + (step & 1) * TH_BUF;
+      const bool more = step + 1 < total;
+      int npiece = piece + 1, ntrip = trip;
+      if (npiece == KH) { npiece = 0; ++ntrip; }
+      const int wpiece = more ? npiece : piece;  // unconditional: the last prefetch is unused
+      HMA_SWK_LOAD_W(wpiece)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = an[j];
-      {  // A rows of the next (tile, chunk) step
-        int ntrip = trip, ncc = cc + 1;
-        if (ncc == KC) { ncc = 0; ++ntrip; }
+      for (int j = 0; j < 4; ++j) a[j] = an[j];
+      {
         int64_t ntile = gw + (int64_t)ntrip * nw;
-        if (ntrip >= trips || ntile >= tiles) { ntile = tile_c; ntrip = trip; }
-        load_a(ntile, chunk_of(ntrip, ncc), an);
+        if (!more || ntile >= tiles) ntile = tile_c;
+        load_a(ntile, more ? npiece : piece, an);
       }
-      if (EPI == HMA_EPI_RESID && cc == 0) {  // residual rows: fetched a whole tile ahead of their use
+      if (EPI == HMA_EPI_RESID && piece == 0) {  // residual rows: fetched a whole tile ahead of their use
         const float* C = reinterpret_cast<const float*>(p.C) + bz * p.sC + crow * p.ldc + bn + 8 * g;
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) {
@@ -1483,15 +1494,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, in
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint16_t* wj = wbase + ((j ^ jsw) << 5);
+      for (int j = 0; j < 4; ++j) {
+        const uint16_t* wj = cur + wofs + ((j ^ jsw) << 5);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wj + (32 * (t >> 1) + 4 * (t & 1)) * TW_LD);
+          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wj + (32 * (t >> 1) + 4 * (t & 1)) * TH_LD);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a[j], acc[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      {
+        uint16_t* nbuf = smem + ((step + 1) & 1) * TH_BUF;
+        HMA_SWK_STORE_W(nbuf)
+      }
+      __syncthreads();
     }
     if (active && m < p.M) {
 #pragma unroll
@@ -2053,11 +2069,11 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       HMA_NTW_ALL(HMA_A_F32)
       HMA_NTW_ALL(HMA_A_BF16_AFFINE)
     }
-    // K-chunked streaming variant: measured SLOWER than the lock-step kernels in situ (fc2 / dqkv-resid 241 vs 182 us,
-    // dfc1 / dqkv 165 vs 110 us): the whole workgroup idles while a 132 KB weight chunk is re-parked, four times per
-    // 128 token rows.  Kept opt-in (HMA_GEMM_NT_SWK=1) as the base for a double-buffered version.
+    // K > 256 streaming variant (weights double-buffered through LDS in 128-wide pieces): measured EQUAL to the
+    // lock-step kernel in situ (fc2 / dqkv-resid 177 vs 182 us, dfc1 / dqkv 109 vs 110 us; 113.5 ms/step both ways) --
+    // both re-stream the 256 x K weight slab once per 128 token rows.  Opt-in (HMA_GEMM_NT_SWK=1).
     static const bool no_swk = getenv("HMA_GEMM_NT_SWK") == nullptr;
-    if (!no_sw && !no_swk && !use_p1 && !use_p2 && p->K > 256 && p->K <= 1024 && (p->K & 255) == 0 && p->a_kind != HMA_A_BF16_AFFINE &&
+    if (!no_sw && !no_swk && !use_p1 && !use_p2 && p->K > 256 && p->K <= 1024 && (p->K & 127) == 0 && p->a_kind != HMA_A_BF16_AFFINE &&
         (p->epi == HMA_EPI_BF16 || p->epi == HMA_EPI_F32 || p->epi == HMA_EPI_RESID)) {
       const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
       const int64_t tiles16 = (p->M + 15) / 16;
@@ -2066,8 +2082,8 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
 #define HMA_NTK_CASE(AK, EP)                                                                          \
   if (p->a_kind == AK && p->epi == EP) {                                                              \
-    if ((rc = set_smem_bytes<gemm_nt_swk_kernel<AK, EP>>(TW_SMEM_BYTES))) return rc;                  \
-    hipLaunchKernelGGL((gemm_nt_swk_kernel<AK, EP>), dim3((unsigned)(nslabs * per_slab)), dim3(512), TW_SMEM_BYTES, s, pa, \
+    if ((rc = set_smem_bytes<gemm_nt_swk_kernel<AK, EP>>(TH_SMEM_BYTES))) return rc;                  \
+    hipLaunchKernelGGL((gemm_nt_swk_kernel<AK, EP>), dim3((unsigned)(nslabs * per_slab)), dim3(512), TH_SMEM_BYTES, s, pa, \
                        nslabs, per_slab);                                                             \
     HMA_CHECK_LAUNCH();                                                                               \
     return 0;                                                                                         \
