@@ -197,12 +197,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Debug only: HMA_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 with the gloo backend, so the N > 1 trainer path
+    # (domain all-gather, bucketed all-reduce on the side stream between per-bucket hipGraphs) can be exercised on a
+    # one-GPU box.  The numbers of such a run mean nothing.
+    one_device = os.environ.get("HMA_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.mode == "decode":
         if rank == 0:
