@@ -148,13 +148,24 @@ __device__ __forceinline__ f32x16_t zero16() {
   for (int e = 0; e < 16; ++e) z[e] = 0.f;
   return z;
 }
-// store a [d x token] accumulator (lane = token, rows = d) as bf16 into row-major [token][ld] at column col0
+// store a [d x token] accumulator (lane = token, rows = d) as bf16 into row-major [token][ld] at column col0.
+// A lane holds d = 8 g + 4 hi + {0..3} for g = 0..3: the two half-waves trade quads (v_permlane32_swap) so that lane
+// (r, hi = 0) owns d = 16 q .. 16 q + 7 and lane (r, hi = 1) d = 16 q + 8 .. + 15 -> 16-byte stores (8-byte scattered
+// stores reach about half the HBM write rate of 16-byte ones, tools/probes/store_pattern.hip).
 __device__ __forceinline__ void store_dt(uint16_t* base, int64_t ld, const f32x16_t& a, float mul, int lane) {
-  uint16_t* row = base + (int64_t)(lane & 31) * ld + 4 * (lane >> 5);
+  const int hi = lane >> 5;
+  uint16_t* row = base + (int64_t)(lane & 31) * ld;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<uint2*>(row + 8 * g) =
-        make_uint2(pack_bf16(a[4 * g] * mul, a[4 * g + 1] * mul), pack_bf16(a[4 * g + 2] * mul, a[4 * g + 3] * mul));
+  for (int q = 0; q < 2; ++q) {
+    const int g = 2 * q;
+    uint32_t ax = pack_bf16(a[4 * g] * mul, a[4 * g + 1] * mul), ay = pack_bf16(a[4 * g + 2] * mul, a[4 * g + 3] * mul);
+    uint32_t bx = pack_bf16(a[4 * g + 4] * mul, a[4 * g + 5] * mul), by = pack_bf16(a[4 * g + 6] * mul, a[4 * g + 7] * mul);
+    // before: hi = 0 lanes hold d = 8g .. 8g+3 (a*) and 8g+8 .. 8g+11 (b*); hi = 1 lanes hold 8g+4 .. +7 and 8g+12 .. +15
+    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+    // v_permlane32_swap exchanges the first operand's upper half-wave with the second operand's lower half-wave
+    *reinterpret_cast<uint4*>(row + 16 * q + 8 * hi) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  }
 }
 
 // ------------------------------------------------------------------------------------- forward
