@@ -213,15 +213,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         s[kt] = mfma32(frag_rows(Ks, (c * NC + kt) * 32, 0, lane), q0, zero16());
         s[kt] = mfma32(frag_rows(Ks, (c * NC + kt) * 32, 1, lane), q1, s[kt]);
       }
-      float mc = -INFINITY;
+      float mc = -INFINITY;  // max of the RAW scores; the scale (> 0) is folded into the exp2 argument below
 #pragma unroll
       for (int kt = 0; kt < NC; ++kt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          s[kt][e] *= c_log2;
-          mc = fmaxf(mc, s[kt][e]);
-        }
-      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+        for (int e = 0; e < 16; ++e) mc = fmaxf(mc, s[kt][e]);
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64)) * c_log2;
       const float m_new = fmaxf(m, mc);
       const float alpha = fast_exp2(m - m_new);  // 0 on the first chunk
       l *= alpha;
@@ -231,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
       for (int kt = 0; kt < NC; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          s[kt][e] = fast_exp2(s[kt][e] - m_new);
+          s[kt][e] = fast_exp2(fmaf(s[kt][e], c_log2, -m_new));
           l += s[kt][e];
         }
 #pragma unroll
