@@ -1926,31 +1926,36 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
 }
 
 // dW[bz][n0 + nl][k0 + kl] += sum over splits of ws[((bz * splits + s) * groups + g)][nl][kl]
-// 256 workgroups per 256 x 256 block: 64 lanes x float4 = 256 outputs each, the splits dealt over the 4 waves.
+// 128 workgroups per 256 x 256 block: 64 lanes x 8 outputs each, the splits dealt over the 4 waves.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int groups_n, int groups_k) {
-  __shared__ float4 red[4][64];
+  __shared__ float4 red[4][64][2];
   const int groups = groups_n * groups_k;
   const int g = blockIdx.y % groups;
   const int64_t bz = blockIdx.y / groups;
   const int64_t n0 = (int64_t)(g / groups_k) * WT, k0 = (int64_t)(g % groups_k) * WT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int idx = (blockIdx.x * 64 + lane) * 4;  // 4 consecutive k of one n row
+  const int idx = (blockIdx.x * 64 + lane) * 8;  // 8 consecutive k of one n row: one 16-byte bf16 load per split
   const int nl = idx / WT, kl = idx % WT;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const uint16_t* base = reinterpret_cast<const uint16_t*>(p.ws) + (bz * p.splits * groups + g) * (int64_t)(WT * WT) + idx;
-#pragma unroll 4
+#pragma unroll 8
   for (int sp = w; sp < p.splits; sp += 4) {
-    const uint2 v = *reinterpret_cast<const uint2*>(base + (int64_t)sp * groups * (WT * WT));
-    acc.x += bf16_lo(v.x); acc.y += bf16_hi(v.x); acc.z += bf16_lo(v.y); acc.w += bf16_hi(v.y);
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(base + (int64_t)sp * groups * (WT * WT)), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
   }
-  red[w][lane] = acc;
+  red[w][lane][0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  red[w][lane][1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
   __syncthreads();
-  if (w == 0) {
-    const float4 a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
-    float4* dst = reinterpret_cast<float4*>(p.dW + bz * p.sdW + (n0 + nl) * p.lddw + k0 + kl);
+  if (w < 2) {  // wave 0 finishes k .. k+3, wave 1 k+4 .. k+7
+    float4* dst = reinterpret_cast<float4*>(p.dW + bz * p.sdW + (n0 + nl) * p.lddw + k0 + kl + 4 * w);
     float4 o = *dst;
-    o.x += acc.x + a1.x + a2.x + a3.x; o.y += acc.y + a1.y + a2.y + a3.y;
-    o.z += acc.z + a1.z + a2.z + a3.z; o.w += acc.w + a1.w + a2.w + a3.w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = red[q][lane][w];
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
     *dst = o;
   }
   // bias partials (written when the workspace has room for them): one block per group sums them
@@ -1963,9 +1968,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int gro
     float sum = 0.f;
 #pragma unroll 8
     for (int sp = w; sp < p.splits; sp += 4) sum += bp[(int64_t)sp * groups * WT];
-    red[w][lane].x = sum;
+    red[w][lane][0].x = sum;
     __syncthreads();
-    if (w == 0) p.dBias[bz * p.sdBias + n0 + col] += red[0][lane].x + red[1][lane].x + red[2][lane].x + red[3][lane].x;
+    if (w == 0) p.dBias[bz * p.sdBias + n0 + col] += red[0][lane][0].x + red[1][lane][0].x + red[2][lane][0].x + red[3][lane][0].x;
   }
 }
 
@@ -2217,7 +2222,7 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     // XCD remap leaves in (batch, split, group) order
     const int64_t per = (slabs + splits - 1) / splits;
     if (q.ws && (q.ws_elems < (int64_t)nblocks * WT * WT || per * (splits - 1) >= slabs || splits == 1)) q.ws = nullptr;
-    const dim3 rgrid((unsigned)(WT * WT / 256), (unsigned)(gn * gk * nb));
+    const dim3 rgrid((unsigned)(WT * WT / 512), (unsigned)(gn * gk * nb));
 #define HMA_TNW_CASE(YK, AK)                                                                        \
   if (q.y_kind == YK && q.a_kind == AK) {                                                            \
     if ((rc = set_smem_bytes<gemm_tn_wide_kernel<YK, AK>>(W_SMEM_BYTES))) return rc;                 \
