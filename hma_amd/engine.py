@@ -32,6 +32,7 @@ class Plan:
     """A recorded sequence of C-ABI launches with fixed arguments; `run` replays it on a stream."""
 
     tn_workspace: Optional[torch.Tensor] = None  # scratch for the two-stage weight-gradient reduction
+    _tn_workspaces: Dict[int, torch.Tensor] = {}
 
     def __init__(self):
         self.calls: List[Tuple[Callable, str, tuple]] = []
@@ -124,6 +125,7 @@ class STEngine:
         self.flags = self.layout.decay_flags().to(self.device)
         self.sqnorm = torch.zeros(1, dtype=F32, device=self.device)
         self.opt_step = 0
+        self.dom_steps: Dict[str, int] = {}  # per-domain Adam step counts (a head is only stepped when its domain had a gradient)
         L, d = cfg.num_layers, cfg.d_model
         hid = int(d * cfg.mlp_ratio)
         mk = lambda *s: torch.zeros(*s, dtype=BF16, device=self.device)
@@ -155,8 +157,14 @@ class STEngine:
         self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
         self.grad_scale = C.c_float(1.0)
         self.timer: Optional[LaunchTimer] = None
-        if Plan.tn_workspace is None or Plan.tn_workspace.device != self.device:
-            Plan.tn_workspace = torch.empty(256 * (65536 + 256), dtype=F32, device=self.device)  # 64 MB of tiles + bias partials
+        # One workspace per GPU for the life of the process: recorded plans (and captured graphs) of EVERY engine hold
+        # its raw pointer, so it must never be re-allocated.  (It used to be when `device` came without an index --
+        # torch.device("cuda") != tensor.device -- and a second engine's creation then freed the block under the first
+        # engine's plans, whose wgrad partials landed in whatever the allocator put there next.)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if idx not in Plan._tn_workspaces:
+            Plan._tn_workspaces[idx] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))  # 64 MB + bias partials
+        Plan.tn_workspace = Plan._tn_workspaces[idx]
 
     # ------------------------------------------------------------------------------ pointers
     def _p(self, name: str) -> int:
@@ -754,17 +762,26 @@ class STEngine:
             self.V = torch.zeros_like(self.P)
         stream = torch.cuda.current_stream().cuda_stream
         ranges = self.layout.trainable_ranges(active_domains)
+        # Adam's bias correction uses the number of updates EACH parameter has received (torch.optim.AdamW keeps
+        # `state["step"]` per parameter and skips parameters whose grad is None): the dense range is stepped every
+        # time, a domain's block only when that domain was active on some rank.
         self.opt_step += 1
+        steps = [self.opt_step]
+        for dom in self.layout.domains:
+            if dom in active_domains:
+                self.dom_steps[dom] = self.dom_steps.get(dom, 0) + 1
+                steps.append(self.dom_steps[dom])
+        assert len(steps) == len(ranges)
         sq = None
         if max_norm is not None and max_norm > 0:
             self.sqnorm.zero_()
             for a, b in ranges:
                 _lib.call("hma_sqnorm", stream, self.G.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr())
             sq = self.sqnorm.data_ptr()
-        for a, b in ranges:
+        for (a, b), step in zip(ranges, steps):
             _lib.call("hma_adamw", stream, self.P.data_ptr() + 4 * a, self.G.data_ptr() + 4 * a, self.M.data_ptr() + 4 * a,
                       self.V.data_ptr() + 4 * a, self.Wb.data_ptr() + 2 * a, b - a, lr, betas[0], betas[1], eps, weight_decay,
-                      self.opt_step, sq, float(max_norm or 0.0), self.flags.data_ptr() + a // ALIGN)
+                      step, sq, float(max_norm or 0.0), self.flags.data_ptr() + a // ALIGN)
         # bf16 copies were emitted by the update itself; only the transposed copies are stale
         self._wt_ok = False
         self._dom_fresh = set()

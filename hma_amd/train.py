@@ -239,6 +239,48 @@ class Trainer:
         self.optimizer_step()
         return ws
 
+    # ------------------------------------------------------------------ resume (SURVEY (f) row 4)
+    STATE_FILE = "trainer_state.safetensors"
+
+    def save_state(self, directory) -> None:
+        """Model (`config.json` + `model.safetensors`, as `save_pretrained`) plus the optimizer state needed to resume:
+        Adam moments per named parameter, the optimizer-step counts (global and per action domain) -- the role of
+        Accelerate's `optimizer.bin` / `scheduler.bin` (hma/train_multi.py:310-321; the lr schedule is a pure function
+        of the step count here).  Own format: torch's per-parameter AdamW state dict is not reproduced."""
+        import json
+        import os
+        from safetensors.torch import save_file
+        eng = self.engine
+        self.model.save_pretrained(directory)
+        tensors = {}
+        if eng.M is not None:
+            for name, e in eng.layout.entries.items():
+                tensors[f"m.{name}"] = eng.M[e.offset:e.offset + e.numel].detach().cpu().clone()
+                tensors[f"v.{name}"] = eng.V[e.offset:e.offset + e.numel].detach().cpu().clone()
+        meta = {"completed": str(self.completed), "opt_step": str(eng.opt_step), "dom_steps": json.dumps(eng.dom_steps)}
+        tensors["_"] = torch.zeros(1)
+        save_file(tensors, os.path.join(str(directory), self.STATE_FILE), metadata=meta)
+
+    def load_state(self, directory) -> None:
+        """Inverse of `save_state` for a Trainer built on a model loaded from the same directory."""
+        import json
+        import os
+        from safetensors import safe_open
+        eng = self.engine
+        with safe_open(os.path.join(str(directory), self.STATE_FILE), framework="pt") as f:
+            meta = f.metadata()
+            names = set(f.keys())
+            if any(k.startswith("m.") for k in names):
+                if eng.M is None:
+                    eng.M, eng.V = torch.zeros_like(eng.P), torch.zeros_like(eng.P)
+                for name, e in eng.layout.entries.items():
+                    if f"m.{name}" in names:
+                        eng.M[e.offset:e.offset + e.numel].copy_(f.get_tensor(f"m.{name}"))
+                        eng.V[e.offset:e.offset + e.numel].copy_(f.get_tensor(f"v.{name}"))
+        self.completed = int(meta["completed"])
+        eng.opt_step = int(meta["opt_step"])
+        eng.dom_steps = {k: int(v) for k, v in json.loads(meta["dom_steps"]).items()}
+
     def loss_and_acc(self, ws) -> Tuple[torch.Tensor, torch.Tensor]:
         st = ws["stats"]
         return st[0] / st[2], st[1] / st[2]

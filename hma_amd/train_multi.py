@@ -95,6 +95,10 @@ def main(argv=None):
     trainer = Trainer(model, lr=args.learning_rate, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
                       weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, warmup_steps=args.num_warmup_steps,
                       grad_accum=args.gradient_accumulation_steps)
+    start_step = 0
+    if args.resume_from_checkpoint and os.path.exists(os.path.join(args.resume_from_checkpoint, Trainer.STATE_FILE)):
+        trainer.load_state(args.resume_from_checkpoint)  # Adam moments + step counts (train_multi.py:484-533)
+        start_step = trainer.completed
 
     concat = ConcatDataset(datasets)
     sampler = MultiTaskBatchSampler([len(d) for d in datasets], args.per_device_train_batch_size, args.sampling_temperature,
@@ -103,7 +107,7 @@ def main(argv=None):
     steps_per_epoch = max(len(sampler) // (world * args.gradient_accumulation_steps), 1)
     max_steps = args.max_train_steps or args.num_train_epochs * steps_per_epoch
     out_dir = Path(args.output_dir)
-    step, t0, tokens = 0, time.time(), 0
+    step, t0, tokens = start_step, time.time(), 0
     for epoch in range(10 ** 9):
         sampler.set_epoch(epoch)
         micro = 0
@@ -124,13 +128,13 @@ def main(argv=None):
                 print(json.dumps({"step": step, "loss": float(loss), "acc": float(acc), "domain": batch["domain"][0],
                                   "tokens_per_s_per_gpu": tokens / dt}), flush=True)
             if rank == 0 and args.checkpointing_steps and step % args.checkpointing_steps == 0:
-                model.save_pretrained(out_dir / f"step_{step}")
+                trainer.save_state(out_dir / f"step_{step}")
             if step >= max_steps:
                 break
         if step >= max_steps:
             break
     if rank == 0:
-        model.save_pretrained(out_dir / f"step_{step}")
+        trainer.save_state(out_dir / f"step_{step}")
     if world > 1:
         dist.barrier()
     return step
