@@ -71,6 +71,15 @@ _PROTOS = {
     "hma_sqnorm": [c_vp, c_vp, c_i64, c_vp],
     "hma_adamw": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp],
     "hma_cast_bf16": [c_vp, c_vp, c_vp, c_i64],
+    "hma_diff_prepare": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
+    "hma_silu_cast": [c_vp, c_vp, c_vp, c_i64],
+    "hma_silu_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64],
+    "hma_adaln_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_i64, c_i32],
+    "hma_adaln_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32],
+    "hma_gate_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32],
+    "hma_gate_bwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32],
+    "hma_diff_loss": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i32],
+    "hma_diff_p_sample": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64, c_i32],
     "hma_maskgit_collate": [c_vp, c_vp, c_vp, c_vp, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp],
     "hma_transpose_cast_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64],
     "hma_abi_version": [],

@@ -185,6 +185,44 @@ int hma_adamw(void* stream, float* p, const float* g, float* m, float* v, void* 
 /* dst(bf16) = src(f32) for n elements */
 int hma_cast_bf16(void* stream, const float* src, void* dst, int64_t n);
 
+/* ---- Diffusion head (DiffLoss / SimpleMLPAdaLN, hma/model/diffloss.py; hma/diffusion/gaussian_diffusion.py) --------
+ * The head's Linear layers run through hma_gemm_nt / hma_gemm_tn; these are the row kernels around them.  Hidden
+ * width W: multiple of 256, <= 2048.  `mod` tensors are the bf16 outputs of the adaLN_modulation Linears
+ * ([rows, ldm], shift | scale | gate at the given column offsets).  Schedule tables are fp32 device arrays.
+ *
+ * hma_diff_prepare: x_t = sqrt_ac[t] x0 + sqrt_1mac[t] noise (gaussian_diffusion.py:203-219; noise NULL: x_t = x0, the
+ *   sampler's input), also as bf16 zero-padded to `pad` columns (the input_proj GEMM operand), and the sinusoidal
+ *   timestep embedding of tmap[t] (tmap NULL: t) as bf16 [rows, 256] (diffloss.py:79-90). */
+int hma_diff_prepare(void* stream, const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
+                     const float* sqrt_1mac, const int32_t* tmap, float* xt, void* xt_pad, void* tfreq, int64_t n,
+                     int32_t C, int32_t pad);
+/* sy = bf16(SiLU(y)) -- the nn.SiLU in front of every adaLN_modulation (diffloss.py:120,142); dy = dsy * SiLU'(y) */
+int hma_silu_cast(void* stream, const float* y, void* sy, int64_t n);
+int hma_silu_bwd(void* stream, const float* y, const float* dsy, float* dy, int64_t n);
+/* out = bf16(LN(x; gamma, beta | no affine, eps) * (1 + scale) + shift)   ResBlock / FinalLayer, diffloss.py:116-124,140-149.
+ * backward: dx += LN-backward, dmod[shift] = dout, dmod[scale] = dout * LN(x), dgamma / dbeta += (atomics). */
+int hma_adaln_fwd(void* stream, const float* x, const void* mod, int64_t ldm, int32_t off_shift, int32_t off_scale,
+                  const float* gamma, const float* beta, float eps, void* out, int64_t n, int32_t W);
+int hma_adaln_bwd(void* stream, const void* dout, const float* x, const void* mod, int64_t ldm, int32_t off_shift,
+                  int32_t off_scale, const float* gamma, const float* beta, float eps, float* dx, void* dmod,
+                  float* dgamma, float* dbeta, int64_t n, int32_t W);
+/* x += gate * h (diffloss.py:124); backward: dh = dx * gate, dmod[gate] = dx * h (dx is also the identity branch's grad) */
+int hma_gate_fwd(void* stream, float* x, const void* mod, int64_t ldm, int32_t off_gate, const void* h, int64_t n, int32_t W);
+int hma_gate_bwd(void* stream, const float* dx, const void* mod, int64_t ldm, int32_t off_gate, const void* h, void* dh,
+                 void* dmod, int64_t n, int32_t W);
+/* Per-row training loss mean_c (noise - eps)^2 + vb (LossType.MSE + ModelVarType.LEARNED_RANGE with the mean frozen:
+ * KL to the true posterior, or the discretised-Gaussian decoder NLL at t == 0; gaussian_diffusion.py:650-745) from the
+ * network output out [rows, ldo] = [eps | v | padding]; stats[0] += sum_rows loss * mask; rows_out (optional) = per-row
+ * loss; dout (optional, [rows, ldo], only the 2C used columns are written) = d loss / d out * grad_scale * mask / *denom.
+ * tables6 = [sqrt_recip_ac | sqrt_recipm1_ac | posterior_mean_coef1 | coef2 | posterior_log_variance_clipped |
+ * log(betas)], n_steps each. */
+int hma_diff_loss(void* stream, const float* out, int64_t ldo, const float* x0, const float* xt, const float* noise,
+                  const int64_t* t, const float* tables6, int32_t n_steps, const float* mask, const float* denom,
+                  float grad_scale, float* stats, float* rows_out, float* dout, int64_t n, int32_t C);
+/* One reverse step x <- mean(x, out) + [step != 0] exp(logvar / 2) noise temperature  (p_sample, :358-394) */
+int hma_diff_p_sample(void* stream, const float* out, int64_t ldo, float* x, const float* noise, const float* tables6,
+                      int32_t n_steps, int32_t step, float temperature, int32_t clip_denoised, int64_t n, int32_t C);
+
 /* MaskGIT training collator on device, hma/data.py:28-98 (get_maskgit_collator.collate_fn) on ids [B, T, HW]:
  * factorise (num_factored sub-vocabularies of V: 2 x 512 for the shipped models), corruption where r_corrupt[.., k] < corrupt_thresh (data.py:42-49), non-MLM corruption of
  * frames >= first_masked_frame where r_nonmlm[.., k] > correct_rate[t - fmf] (:51-64), cosine masking where
