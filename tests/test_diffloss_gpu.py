@@ -33,15 +33,15 @@ def test_training_loss_and_gradients():
     z = G["z"].to(DEV).requires_grad_(True)
     loss = m(G["target"].to(DEV), z, G["mask"].to(DEV), t=G["t"].to(DEV), noise=G["noise"].to(DEV))
     # bf16 GEMM operands, fp32 accumulation / statistics: network output within 1 % (rms), loss within 1 %
-    assert rel(m.last_net_out, G["net_out"]) < 1.5e-2
-    assert abs(loss.item() - G["loss"].item()) <= 1e-2 * abs(G["loss"].item()), (loss.item(), G["loss"].item())
+    assert rel(m.last_net_out, G["net_out"]) < 1e-2          # measured 5.7e-3
+    assert abs(loss.item() - G["loss"].item()) <= 2e-3 * abs(G["loss"].item()), (loss.item(), G["loss"].item())  # measured 3.4e-4
     loss.backward()
-    assert rel(z.grad, G["dz"]) < 3e-2
+    assert rel(z.grad, G["dz"]) < 2e-2                           # measured 8.8e-3
     worst = 0.0
     for n, p in m.named_parameters():
         r = rel(p.grad, G[f"grad.{n}"])
         worst = max(worst, r)
-        assert r < 4e-2, (n, r)
+        assert r < 2.5e-2, (n, r)                                # worst measured 1.0e-2
     # a second call accumulates into .grad like autograd does
     g0 = m.net.cond_embed.weight.grad.clone()
     m(G["target"].to(DEV), z, G["mask"].to(DEV), t=G["t"].to(DEV), noise=G["noise"].to(DEV)).backward()
@@ -60,4 +60,4 @@ def test_sampling_chain():
     m = build()
     x = m.sample(G["s.z"].to(DEV), temperature=0.9, noise0=G["s.noise0"].to(DEV), step_noises=G["s.draws"].to(DEV))
     assert x.shape == G["s.sample"].shape
-    assert rel(x, G["s.sample"]) < 3e-2
+    assert rel(x, G["s.sample"]) < 1.5e-2                        # measured 4.6e-3 after 10 reverse steps
