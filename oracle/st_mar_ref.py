@@ -1,0 +1,51 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (plain PyTorch fp32) of STMAR's training forward.
+
+Follows /root/reference/hma/model/st_mar.py: patchify :199-207, forward :219-275 (mask-latent fill :245, patch mask
+:260), compute_latents :146-197 (token_embed Linear, action tokens, pos_embed, z_proj_ln, trunk, out_x_proj +
+decoder_norm + diffusion_pos_embed), compute_video_loss_and_acc :131-144 (DiffLoss on every patch row with the patch
+mask).  The trunk is oracle/st_maskgit_ref.py's, the head oracle/diffloss_ref.py's.  Pinned by
+tests/golden/g11_stmar.safetensors (tests/golden/make_golden_stmar.py).  Only tests may import this.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import diffloss_ref as DR
+from . import st_maskgit_ref as R
+
+
+def patchify(x, p):
+    """(B, T, H, W, C) -> (B, T, H/p, W/p, p*p*C), channel order (p, q, c)  (st_mar.py:199-207)."""
+    B, T, H, W, C = x.shape
+    x = x.reshape(B, T, H // p, p, W // p, p, C)
+    return torch.einsum("nthpwqc->nthwpqc", x).reshape(B, T, H // p, W // p, C * p * p)
+
+
+def compute_latents(sd, cfg, x_patches, action_ids, domain):
+    """x_patches (B, T, h, w, 16) -> z (B, T, h*w, d)."""
+    B, T, h, w, _ = x_patches.shape
+    x = F.linear(x_patches.reshape(B, T, h * w, -1).float(), sd["token_embed.weight"])
+    a_emb = R.action_stem(sd, cfg, action_ids, domain[0])
+    x = torch.cat([x, a_emb[:, :T, None].expand(B, T, cfg.action_token_size, cfg.d_model)], dim=2)
+    x = x + sd["pos_embed_TSC"][:, :T, : x.shape[2]]
+    x = F.layer_norm(x, (cfg.d_model,), sd["z_proj_ln.weight"], sd["z_proj_ln.bias"], 1e-6)
+    for l in range(cfg.num_layers):
+        x = R.st_block(sd, cfg, l, x, a_emb, domain[0])
+    x = x[:, :, : h * w]
+    y = F.linear(x, sd["out_x_proj.weight"], sd["out_x_proj.bias"])
+    y = F.layer_norm(y, (cfg.d_model,), sd["decoder_norm.weight"], sd["decoder_norm.bias"], 1e-6)
+    return y + sd["diffusion_pos_embed_learned"].view(1, -1, h * w, cfg.d_model)[:, :T]
+
+
+def forward(sd, cfg, input_ids, labels, action_ids, domain, masked, t, noise, patch_size, H, W, diff_depth):
+    """STMAR.forward loss with the diffusion draws (t, noise) passed in.  input_ids / labels (B, T*H*W, C) float."""
+    B = input_ids.shape[0]
+    T = cfg.T
+    x = input_ids.reshape(B, T, H, W, -1).clone()
+    x[masked] = sd["mask_token"].reshape(-1)
+    z = compute_latents(sd, cfg, patchify(x, patch_size), action_ids, domain)
+    target = patchify(labels.reshape(B, T, H, W, -1), patch_size)
+    pmask = patchify(masked[..., None].float(), patch_size).sum(-1) > 0
+    n = B * T * z.shape[2]
+    P = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
+    loss, _ = DR.diffloss_forward(P, target.reshape(n, -1).float(), z.reshape(n, -1), pmask.reshape(n).float(), t, noise, diff_depth)
+    return loss, z

@@ -1,0 +1,46 @@
+"""STMAR training forward on CPU: oracle/st_mar_ref.py against the reference's loss, latents and
+gradients (tests/golden/make_golden_stmar.py; the state dict is regenerated from a seed on both sides)."""
+import os
+
+import torch
+from safetensors.torch import load_file
+
+from oracle import st_mar_ref as M
+from oracle import st_maskgit_ref as R
+from tests.golden.stmar_cfg import CFG, inputs, seeded_state
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = load_file(os.path.join(HERE, "golden", "g11_stmar.safetensors"))
+
+
+def template():
+    out = {}
+    for line in open(os.path.join(HERE, "golden", "g11_stmar_keys.txt")):
+        name, shape = line.split(" ", 1)
+        out[name] = torch.zeros(eval(shape))
+    # buffers keep their constructor values (action statistics)
+    from tests.golden.stmar_cfg import STATS, DOMAINS
+    for dom, st in zip(DOMAINS, STATS):
+        out[f"action_preprocessor.{dom}.mean"] = torch.tensor(st[0])
+        out[f"action_preprocessor.{dom}.std"] = torch.tensor(st[1])
+    return out
+
+
+def ref_cfg():
+    return R.RefConfig(num_layers=2, num_heads=8, d_model=256, T=3, S=1024, use_mup=True, qkv_bias=True, mlp_bias=False)
+
+
+def test_stmar_forward_and_gradients_match_reference():
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not (k.endswith(".mean") or k.endswith(".std")) else v)
+          for k, v in seeded_state(template()).items()}
+    inp = inputs()
+    loss, z = M.forward(sd, ref_cfg(), inp["latents"], inp["latents"], inp["actions_domA"], ["domA"] * 2, inp["masked"], inp["t"],
+                        inp["noise"], 2, 32, 32, CFG["diffloss_d"])
+    assert torch.allclose(z, G["z"], rtol=1e-3, atol=2e-4)
+    assert abs(loss.item() - G["loss"].item()) <= 1e-4 * abs(G["loss"].item())
+    loss.backward()
+    for k in G:
+        if k.startswith("grad.") :
+            want, got = G[k], sd[k[5:]].grad
+            assert torch.allclose(got, want, rtol=5e-3, atol=2e-5 * want.abs().max().item() + 1e-9), k
+    assert G["grad_is_none.domB"].item() == 1.0 and sd["action_mlp.domB.model.0.weight"].grad is None
