@@ -80,6 +80,12 @@ _PROTOS = {
     "hma_gate_bwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32],
     "hma_diff_loss": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i32],
     "hma_diff_p_sample": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64, c_i32],
+    "hma_mar_patchify": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32],
+    "hma_mar_mask_token_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32],
+    "hma_mar_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32],
+    "hma_mar_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32],
+    "hma_mar_readout_fwd": [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
+    "hma_mar_readout_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
     "hma_maskgit_collate": [c_vp, c_vp, c_vp, c_vp, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp],
     "hma_transpose_cast_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64],
     "hma_abi_version": [],

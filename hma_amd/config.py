@@ -86,3 +86,34 @@ class GenieConfig:
 
     def shallow_copy(self) -> "GenieConfig":
         return type(self)(**vars(self))
+
+
+@dataclasses.dataclass
+class DiffusionGenieConfig(GenieConfig):
+    """Mirror of hma/config.py:84-117 (the continuous-latent / diffusion-head model, STMAR)."""
+
+    Diffusion: bool = True
+    dim: int = 512
+    dataloader_apply_mask: bool = True
+    dataloader_apply_corruption: bool = False
+    dataloader_mask_ratio_min: float = 0.1
+    vae_stride: int = 1
+    patch_size: int = 1
+    vae_embed_dim: int = 4
+    mask_ratio_min: float = 0.7
+    attn_dropout: float = 0.1
+    proj_dropout: float = 0.1
+    buffer_size: int = 64
+    diffloss_d: int = 4
+    diffloss_w: int = 1024
+    num_sampling_steps: str = "100"
+    diffusion_batch_mul: int = 1
+    grad_checkpointing: bool = False
+    use_actions: bool = True
+    jointly_predict_actions: bool = False
+    jointly_predict_states: bool = True
+    action_token_size: int = 64
+    label_drop_prob: float = 0.5
+    action_loss_weight: float = 1.0
+    predict_unmask: bool = False
+    maskgit_steps: int = 16

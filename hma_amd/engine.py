@@ -421,6 +421,7 @@ class STEngine:
                    K=1024, epi=EPI_F32, Cp=dx, ldc=256, c_group=(S, SA))
         # Every producer of dx below also writes its bf16 rounding (dxb): that is what autocast hands a linear's
         # backward, and the GEMMs that consume it read half the bytes (the fp32 dx stays the accumulator).
+        pl.mark("post_readout")  # (STMAR drives its own readout and enters the plan here)
         pl.add("hma_cast_bf16", dx, dxb, M * 256)
         use_mod = A > 0 and self.modulate
         for l in reversed(range(L)):
@@ -475,10 +476,12 @@ class STEngine:
                    dxb)
             pl.mark(f"layer{l}")
         # ---- embedding, adaLN stacks, action stem
+        pl.mark("embed")
         pl.add("hma_embed_bwd", ws["ids"].data_ptr(), dx, self._g("token_embed.factored_embeds.0.weight"),
                self._g("token_embed.factored_embeds.1.weight"), self._g("token_embed.mask_token_embed"), self._g("pos_embed_TSC"),
                ws["da_emb"].data_ptr() if A > 0 else None, B, T, S, A, cfg.S + cfg.action_token_size, cfg.factored_vocab_size,
                cfg.image_vocab_size)
+        pl.mark("post_embed")
         if A > 0:
             dom = domain
             if self.modulate:
@@ -543,6 +546,44 @@ class STEngine:
             ws["stats"].zero_()
             self._loss_plan(B, T, S, train and loss_grad).run(stream)
         return ws
+
+    # ------------------------------------------------------------------------------ trunk-only training (STMAR)
+    def trunk_train_forward(self, B: int, T: int, S: int, actions: torch.Tensor, domain: str, build_x: Callable[[dict], None]) -> dict:
+        """Action stem -> `build_x(ws)` writes the residual stream ws["x"] ([B*T*(S+A), 256] fp32, may read ws["a_emb"])
+        -> the L ST-blocks with every activation saved.  No token embedding, readout or loss: the caller owns those
+        (hma/model/st_mar.py keeps the trunk of st_mask_git.py and replaces what is around it)."""
+        A = self.cfg.action_token_size
+        d_a = self.d_actions[domain]
+        if actions.shape[-1] != d_a:
+            raise ValueError(f"action_ids last dim {actions.shape[-1]} != d_action {d_a} of domain {domain}")
+        ws = self._workspace(B, T, S, A, True)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(domain, stream)
+        ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
+        am = f"action_mlp.{domain}.model"
+        _lib.call("hma_action_stem_fwd", stream, ws["actions"].data_ptr(), self.buffers[domain][0].data_ptr(),
+                  self.buffers[domain][1].data_ptr(), self.action_dims[domain], self._p(f"{am}.0.weight"), self._p(f"{am}.0.bias"),
+                  self._p(f"{am}.1.weight"), self._p(f"{am}.1.bias"), self._p(f"{am}.3.weight"), self._p(f"{am}.3.bias"),
+                  ws["an"].data_ptr(), ws["sxhat"].data_ptr(), ws["srstd"].data_ptr(), ws["sh"].data_ptr(), ws["a_emb"].data_ptr(),
+                  B * T, d_a, self._skip_norm)
+        build_x(ws)
+        self._forward_plan(B, T, S, A, True, domain, embed=False, readout=False).run(stream, timer=self.timer)
+        self._last = (B, T, S, A, domain)
+        return ws
+
+    def trunk_train_backward(self, fill_dx: Callable[[dict], None], embed_bwd: Callable[[dict], None]) -> None:
+        """`fill_dx(ws)` writes d loss / d x_out into ws["dx"] (zeroed before) -> backward of the ST-blocks -> `embed_bwd(ws)`
+        consumes ws["dx"] (= d loss / d x_in) and adds the action rows' sum into ws["da_emb"] -> adaLN stacks and action stem."""
+        B, T, S, A, domain = self._last
+        ws = self._ws
+        stream = torch.cuda.current_stream().cuda_stream
+        ws["dx"].zero_()
+        ws["da_emb"].zero_()
+        fill_dx(ws)
+        pl = self._backward_plan(B, T, S, A, domain)
+        pl.run(stream, pl.marks["post_readout"], pl.marks["embed"], timer=self.timer)
+        embed_bwd(ws)
+        pl.run(stream, pl.marks["post_embed"], None, timer=self.timer)
 
     def run_trunk(self, x_BTSD: torch.Tensor, a_emb: Optional[torch.Tensor], domain: Optional[str], l0: int = 0,
                   l1: Optional[int] = None) -> torch.Tensor:

@@ -1,0 +1,264 @@
+"""Spatial-temporal MAR: the continuous-latent model with a diffusion head, `STMAR`.
+
+Mirror of hma/model/st_mar.py for training: same constructor (`DiffusionGenieConfig`), parameter names / shapes
+(`mask_token`, `token_embed.weight (d, p*p*c)`, `z_proj_ln`, `decoder.*`, `out_x_proj (d, d)`, `decoder_norm`,
+`diffusion_pos_embed_learned`, `pos_embed_TSC`, `diffloss.net.*`, per-domain `action_*`), `init_action_projectors`,
+and `forward(input_ids, labels, action_ids, domain, masked_tokens_indicator=..., h=, w=) -> ModelOutput(loss, acc, logits)`.
+
+Execution: the ST-transformer trunk, action stems and per-layer modulation are the discrete model's engine (the decoder
+modules and their parameters are shared with an internal `STMaskGIT` whose flat buffers they live in); around it
+`hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
+`DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
+Not built: `jointly_predict_actions`, `generate` (MAR decoding), dropout (`mlp_drop` must be 0), diffusion_batch_mul > 1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+from huggingface_hub import PyTorchModelHubMixin
+from transformers.utils import ModelOutput
+
+from .. import _lib
+from .._lib import A_BF16, A_F32, EPI_F32
+from ..config import DiffusionGenieConfig, GenieConfig
+from ..ops import make_gemm_nt, make_gemm_tn, ptr
+from .diffloss import DiffLoss
+from .st_mask_git import FixedMuReadout, STMaskGIT
+
+BF16, F32 = torch.bfloat16, torch.float32
+_PAD = 128
+
+
+class _MarLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, owner, value):
+        ctx.owner = owner
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.owner._backward(g)
+        return None, None, None
+
+
+class STMAR(nn.Module, PyTorchModelHubMixin):
+    """Spatial-Time MAR with VisionTransformer backbone (st_mar.py:36-78)."""
+
+    def __init__(self, config: DiffusionGenieConfig):
+        super().__init__()
+        if isinstance(config, dict):
+            config = DiffusionGenieConfig.from_dict(config)
+        if config.mlp_drop != 0.0:
+            raise NotImplementedError("dropout inside the MLP blocks (mlp_drop > 0) is not built")
+        if config.jointly_predict_actions:
+            raise NotImplementedError("jointly_predict_actions is not built")
+        if config.diffusion_batch_mul != 1:
+            raise NotImplementedError("diffusion_batch_mul > 1 is not built")
+        self.config = config
+        self.patch_size, self.vae_embed_dim = config.patch_size, config.vae_embed_dim
+        self.h = self.w = math.isqrt(config.S)
+        assert self.h ** 2 == config.S, "Expected S to be square"
+        self.seq_len = config.S // (config.patch_size ** 2)          # patch tokens per frame
+        d, T, pc = config.d_model, config.T, config.vae_embed_dim * config.patch_size ** 2
+        if pc > 64:
+            raise NotImplementedError("patch channels > 64")
+        # the trunk (+ action stems / modulation) of the discrete model, on the patch-token grid
+        core_cfg = GenieConfig.from_dict({**config.to_dict(), "S": self.seq_len, "jointly_predict_actions": False, "init_actions": False,
+                                          "action_domains": None, "d_actions": None, "action_stats": None})
+        object.__setattr__(self, "_core_box", [STMaskGIT(core_cfg)])  # not a registered sub-module: only shared pieces are exposed
+        core = self._core
+        self.decoder = core.decoder
+        self.action_mask_tokens = core.action_mask_tokens
+        self.pos_embed_TSC = nn.Parameter(torch.zeros(1, T, config.S + config.action_token_size, d))
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, config.vae_embed_dim))
+        self.token_embed = nn.Linear(pc, d, bias=False)
+        cls = FixedMuReadout if config.use_mup else nn.Linear
+        self.out_x_proj = cls(d, d)
+        self.decoder_norm = nn.LayerNorm(d, eps=1e-6)
+        self.z_proj_ln = nn.LayerNorm(d, eps=1e-6)
+        self.diffusion_pos_embed_learned = nn.Parameter(torch.zeros(1, self.seq_len * T, d))
+        self.diffloss = DiffLoss(target_channels=pc, z_channels=d, width=config.diffloss_w, depth=config.diffloss_d,
+                                 num_sampling_steps=config.num_sampling_steps, grad_checkpointing=config.grad_checkpointing)
+        self.diffusion_batch_mul = config.diffusion_batch_mul
+        torch.nn.init.normal_(self.diffusion_pos_embed_learned, std=0.02)
+        self._anchor: Optional[torch.Tensor] = None
+        self._saved = None
+        self._grads_live = False
+        if (config.init_actions or config.use_actions) and config.action_domains is not None:
+            self.init_action_projectors(config.action_domains, config.d_actions, config.action_stats, config.action_network)
+
+    @property
+    def _core(self) -> STMaskGIT:
+        return self._core_box[0]
+
+    def init_action_projectors(self, domains: List[str], d_actions: List[int], action_stats, action_network: str = "mlp"):
+        """st_mar.py:80-99: the discrete model's per-domain stems / projectors plus one DiffLoss head per domain."""
+        core = self._core
+        core.init_action_projectors(domains, d_actions, action_stats, action_network)  # (its unused action_out_projectors stay internal)
+        self.config.init_actions = True
+        self.config.action_domains, self.config.d_actions, self.config.action_stats = list(domains), list(d_actions), action_stats
+        self.action_preprocessor = core.action_preprocessor
+        self.action_mlp = core.action_mlp
+        self.action_diff_losses = nn.ModuleDict()
+        for dom, da in zip(domains, d_actions):
+            self.action_diff_losses[dom] = DiffLoss(target_channels=da, z_channels=self.config.d_model, width=self.config.diffloss_w,
+                                                    depth=self.config.diffloss_d, num_sampling_steps=self.config.num_sampling_steps)
+
+    # ------------------------------------------------------------------------------------------ helpers
+    @staticmethod
+    def _cast(stream, w: torch.Tensor, rows: int, cols: int, transpose: bool):
+        """bf16 copy of a weight zero-padded to (rows, cols); optionally its transpose."""
+        wp = torch.zeros(rows, cols, dtype=F32, device=w.device)
+        wp[: w.shape[0], : w.shape[1]] = w.detach()
+        wb = torch.empty(rows, cols, dtype=BF16, device=w.device)
+        _lib.call("hma_cast_bf16", stream, ptr(wp), ptr(wb), wp.numel())
+        wt = None
+        if transpose:
+            wt = torch.empty(cols, rows, dtype=BF16, device=w.device)
+            _lib.call("hma_transpose_cast_bf16", stream, ptr(wp), ptr(wt), rows, cols, 1, 0, 0)
+        return wb, wt
+
+    @staticmethod
+    def _nt(stream, **kw):
+        g = make_gemm_nt(**kw)
+        _lib.call("hma_gemm_nt", stream, C.byref(g))
+
+    @staticmethod
+    def _tn(stream, **kw):
+        g = make_gemm_tn(**kw)
+        _lib.call("hma_gemm_tn", stream, C.byref(g))
+
+    def _engine(self, dev):
+        core = self._core
+        eng = core._get_engine(dev)
+        ver = tuple(p._version for p in (self.decoder.layers[0].mlp.fc1.weight, self.decoder.layers[-1].norm1.weight))
+        if ver != getattr(self, "_seen_versions", None):  # load_state_dict / an optimizer wrote through the named parameters
+            self._seen_versions = ver
+            eng.weights_changed()
+        return eng
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, input_ids, labels, action_ids=None, domain="default", **kwargs):
+        assert "masked_tokens_indicator" in kwargs
+        if action_ids is None:
+            raise NotImplementedError("STMAR without action conditioning is not built")
+        cfg = self.config
+        masked = kwargs["masked_tokens_indicator"]
+        T, H, W = cfg.T, self.h, self.w
+        if "h" in kwargs:
+            H, W = int(kwargs["h"][0]), int(kwargs["w"][0])
+        dev = input_ids.device
+        B, Cc, p = input_ids.shape[0], cfg.vae_embed_dim, cfg.patch_size
+        h_, w_ = H // p, W // p
+        S, A, d = h_ * w_, cfg.action_token_size, cfg.d_model
+        if S != self.seq_len:
+            raise ValueError(f"{H}x{W} latents give {S} patch tokens per frame, the model was built for {self.seq_len}")
+        SA, Fr, Mi, M, pc = S + A, B * T, B * T * S, B * T * (S + A), Cc * p * p
+        dom = domain if isinstance(domain, str) else domain[0]
+        train = torch.is_grad_enabled() and self.training
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        lat = input_ids.detach().reshape(Fr, H, W, Cc).to(F32).contiguous()
+        lab = labels.detach().reshape(Fr, H, W, Cc).to(F32).contiguous()
+        mk = masked.reshape(Fr, H, W).to(torch.uint8).contiguous()
+        patches, target, pmask = e(Mi, _PAD, dt=BF16), e(Mi, pc), e(Mi)
+        _lib.call("hma_mar_patchify", stream, ptr(lat), ptr(mk), ptr(self.mask_token), ptr(patches), _PAD, None, ptr(pmask), Fr, H, W, Cc, p)
+        _lib.call("hma_mar_patchify", stream, ptr(lab), None, None, None, 0, ptr(target), None, Fr, H, W, Cc, p)
+        wtok, wtok_t = self._cast(stream, self.token_embed.weight, d, _PAD, train)
+        wout, wout_t = self._cast(stream, self.out_x_proj.weight, d, d, train)
+        eng = self._engine(dev)
+        xtok, xhat_e, rstd_e = e(Mi, d), e(M, d, dt=BF16), e(M)
+        pos_stride = self.pos_embed_TSC.shape[2] * d
+
+        def build_x(ws):
+            self._nt(stream, A=ptr(patches), lda=_PAD, a_kind=A_BF16, W=ptr(wtok), ldw=_PAD, M=Mi, N=d, K=_PAD, epi=EPI_F32, Cp=ptr(xtok), ldc=d)
+            _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr(), ptr(self.pos_embed_TSC), pos_stride,
+                      ptr(self.z_proj_ln.weight), ptr(self.z_proj_ln.bias), 1e-6, ws["x"].data_ptr(), ptr(xhat_e), ptr(rstd_e), Fr, T, S, A)
+
+        ws = eng.trunk_train_forward(B, T, S, action_ids.to(dev, F32), dom, build_x)
+        y, z, yhat, rstd_r = e(Mi, d), e(Mi, d), e(Mi, d, dt=BF16), e(Mi)
+        self._nt(stream, A=ws["x"].data_ptr(), lda=d, a_kind=A_F32, a_group=(S, SA), W=ptr(wout), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
+                 Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))
+        _lib.call("hma_mar_readout_fwd", stream, ptr(y), ptr(self.decoder_norm.weight), ptr(self.decoder_norm.bias), 1e-6,
+                  ptr(self.diffusion_pos_embed_learned), ptr(z), ptr(yhat), ptr(rstd_r), Mi, T, S)
+        zl = z.detach().requires_grad_(train)
+        inner = self.diffloss(target, zl, pmask, t=kwargs.get("diffusion_t"), noise=kwargs.get("diffusion_noise"))
+        logits = z.view(B, T, h_, w_, d).permute(0, 4, 1, 2, 3)
+        acc = torch.zeros((), device=dev)
+        if not train:
+            return ModelOutput(loss=inner.detach(), acc=acc, logits=logits)
+        self._saved = dict(inner=inner, zl=zl, yhat=yhat, rstd_r=rstd_r, xhat_e=xhat_e, rstd_e=rstd_e, patches=patches, mk=mk, wtok_t=wtok_t,
+                           wout_t=wout_t, dims=(B, T, H, W, Cc, p, S, A, dom), pos_stride=pos_stride)
+        if self._anchor is None or self._anchor.device != dev:
+            self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        return ModelOutput(loss=_MarLoss.apply(self._anchor, self, inner.detach()), acc=acc, logits=logits)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _accum(self, p: nn.Parameter, g: torch.Tensor):
+        g = g.reshape(p.shape)
+        p.grad = g if p.grad is None else p.grad + g
+
+    def _backward(self, grad_out: torch.Tensor):
+        sv = self._saved
+        B, T, H, W, Cc, p, S, A, dom = sv["dims"]
+        d, SA, Fr, Mi, pc = self.config.d_model, S + A, B * T, B * T * S, Cc * p * p
+        dev = sv["zl"].device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        eng = self._core._engine
+        z0 = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        sv["inner"].backward(grad_out)                       # DiffLoss: parameter grads + d loss / d z
+        dz = sv["zl"].grad.contiguous()
+        dy, dpos2, dg_n, db_n = z0(Mi, d), z0(self.diffusion_pos_embed_learned.shape), z0(d), z0(d)
+        _lib.call("hma_mar_readout_bwd", stream, ptr(dz), ptr(sv["yhat"]), ptr(sv["rstd_r"]), ptr(self.decoder_norm.weight), ptr(dy), ptr(dpos2),
+                  ptr(dg_n), ptr(db_n), Mi, T, S)
+        dWo, dBo = z0(d, d), z0(d)
+        if not self._grads_live:
+            eng.zero_grad()
+
+        def fill_dx(ws):
+            self._tn(stream, dY=ptr(dy), ldy=d, y_kind=A_F32, A=ws["x"].data_ptr(), lda=d, a_kind=A_F32, a_group=(S, SA), M=Mi, N=d, K=d,
+                     dW=ptr(dWo), lddw=d, dBias=ptr(dBo))
+            self._nt(stream, A=ptr(dy), lda=d, a_kind=A_F32, W=ptr(sv["wout_t"]), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
+                     Cp=ws["dx"].data_ptr(), ldc=d, c_group=(S, SA))
+
+        dxtok, dpos, dg_z, db_z = z0(Mi, d), z0(self.pos_embed_TSC.shape), z0(d), z0(d)
+        dWt, dpatch, dmask_tok = z0(d, _PAD), z0(Mi, _PAD), z0(8)
+
+        def embed_bwd(ws):
+            _lib.call("hma_mar_embed_bwd", stream, ws["dx"].data_ptr(), ptr(sv["xhat_e"]), ptr(sv["rstd_e"]), ptr(self.z_proj_ln.weight), ptr(dxtok),
+                      ws["da_emb"].data_ptr(), ptr(dpos), sv["pos_stride"], ptr(dg_z), ptr(db_z), Fr, T, S, A)
+            self._tn(stream, dY=ptr(dxtok), ldy=d, y_kind=A_F32, A=ptr(sv["patches"]), lda=_PAD, a_kind=A_BF16, M=Mi, N=d, K=_PAD, dW=ptr(dWt),
+                     lddw=_PAD)
+            self._nt(stream, A=ptr(dxtok), lda=d, a_kind=A_F32, W=ptr(sv["wtok_t"]), ldw=d, M=Mi, N=_PAD, K=d, epi=EPI_F32, Cp=ptr(dpatch), ldc=_PAD)
+            _lib.call("hma_mar_mask_token_bwd", stream, ptr(dpatch), _PAD, ptr(sv["mk"]), ptr(dmask_tok), Fr, H, W, Cc, p)
+
+        eng.trunk_train_backward(fill_dx, embed_bwd)
+        self._grads_live = True
+        with torch.no_grad():
+            self._accum(self.out_x_proj.weight, dWo)
+            self._accum(self.out_x_proj.bias, dBo)
+            self._accum(self.decoder_norm.weight, dg_n)
+            self._accum(self.decoder_norm.bias, db_n)
+            self._accum(self.diffusion_pos_embed_learned, dpos2)
+            self._accum(self.z_proj_ln.weight, dg_z)
+            self._accum(self.z_proj_ln.bias, db_z)
+            self._accum(self.pos_embed_TSC, dpos)
+            self._accum(self.token_embed.weight, dWt[:, :pc].contiguous())
+            self._accum(self.mask_token, dmask_tok[:Cc].clone())
+            core = self._core
+            active = set(eng.layout.regions) - {"frozen", "head", "tail"} - {f"dom:{x}" for x in eng.domains if x != dom}
+            for name, prm in core.named_parameters():  # trunk / action parameters: views into the engine's gradient buffer
+                if eng.layout.entries[name].region in active:
+                    prm.grad = eng.view(name, eng.G)
+        self._saved = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        for prm in self.parameters():
+            prm.grad = None
+        if self._core._engine is not None:
+            self._core._engine.zero_grad()
+        self._grads_live = False

@@ -223,6 +223,33 @@ int hma_diff_loss(void* stream, const float* out, int64_t ldo, const float* x0, 
 int hma_diff_p_sample(void* stream, const float* out, int64_t ldo, float* x, const float* noise, const float* tables6,
                       int32_t n_steps, int32_t step, float temperature, int32_t clip_denoised, int64_t n, int32_t C);
 
+/* ---- STMAR (continuous latents, hma/model/st_mar.py) input / output stages around the ST-transformer trunk --------------
+ * hma_mar_patchify: latents [frames, H, W, C] -> patches [frames * H/p * W/p, p*p*C] in (p, q, c) channel order
+ *   (st_mar.py:199-207); pixels flagged in `masked` (uint8, optional) are replaced by mask_token[c] first (:245);
+ *   out_bf16 (zero-padded to `pad` columns: the token_embed GEMM operand) and / or out_f32; patch_mask (optional) = 1
+ *   where any pixel of the patch is masked (:260). */
+int hma_mar_patchify(void* stream, const float* latents, const uint8_t* masked, const float* mask_token, void* out_bf16,
+                     int32_t pad, float* out_f32, float* patch_mask, int64_t frames, int32_t H, int32_t W, int32_t C,
+                     int32_t patch);
+/* dmask_token[c] += sum over masked pixels of d patches[row, (p, q, c)]  (backward of the mask-latent fill) */
+int hma_mar_mask_token_bwd(void* stream, const float* dpatches, int64_t ld, const uint8_t* masked, float* dmask_token,
+                           int64_t frames, int32_t H, int32_t W, int32_t C, int32_t patch);
+/* x = z_proj_ln(concat(xtok rows, a_emb repeated A times) + pos_embed_TSC[t, s])  (st_mar.py:155-178; eps 1e-6, affine);
+ * pos rows of frame t start at pos + t * pos_frame_stride.  backward: dxtok = d(image rows), da_emb[f] += sum over
+ * the action rows, dpos / dgamma / dbeta += (atomics). */
+int hma_mar_embed_fwd(void* stream, const float* xtok, const float* a_emb, const float* pos, int64_t pos_frame_stride,
+                      const float* gamma, const float* beta, float eps, float* x, void* xhat, float* rstd, int64_t frames,
+                      int32_t T, int32_t S, int32_t A);
+int hma_mar_embed_bwd(void* stream, const float* dx, const void* xhat, const float* rstd, const float* gamma, float* dxtok,
+                      float* da_emb, float* dpos, int64_t pos_frame_stride, float* dgamma, float* dbeta, int64_t frames,
+                      int32_t T, int32_t S, int32_t A);
+/* z = decoder_norm(y) + diffusion_pos_embed_learned[t * S + s]  (st_mar.py:192-194; rows (b, t, s)); backward:
+ * dy = LN-backward(dz * gamma), dpos2 / dgamma / dbeta += (atomics). */
+int hma_mar_readout_fwd(void* stream, const float* y, const float* gamma, const float* beta, float eps, const float* pos2,
+                        float* z, void* yhat, float* rstd, int64_t rows, int32_t T, int32_t S);
+int hma_mar_readout_bwd(void* stream, const float* dz, const void* yhat, const float* rstd, const float* gamma, float* dy,
+                        float* dpos2, float* dgamma, float* dbeta, int64_t rows, int32_t T, int32_t S);
+
 /* MaskGIT training collator on device, hma/data.py:28-98 (get_maskgit_collator.collate_fn) on ids [B, T, HW]:
  * factorise (num_factored sub-vocabularies of V: 2 x 512 for the shipped models), corruption where r_corrupt[.., k] < corrupt_thresh (data.py:42-49), non-MLM corruption of
  * frames >= first_masked_frame where r_nonmlm[.., k] > correct_rate[t - fmf] (:51-64), cosine masking where

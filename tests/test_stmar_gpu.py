@@ -1,0 +1,57 @@
+"""STMAR training forward / backward on the GPU against the reference's golden vectors (G11)."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from hma_amd.config import DiffusionGenieConfig
+from hma_amd.model.st_mar import STMAR
+from tests.golden.stmar_cfg import CFG, DOMAINS, D_ACTIONS, STATS, inputs, seeded_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = load_file(os.path.join(HERE, "golden", "g11_stmar.safetensors"))
+
+
+def build():
+    m = STMAR(DiffusionGenieConfig(**CFG))
+    m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, CFG["action_network"])
+    return m
+
+
+def rel(a, b):
+    return ((a.float().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def test_state_dict_matches_reference_names_and_shapes():
+    want = {}
+    for line in open(os.path.join(HERE, "golden", "g11_stmar_keys.txt")):
+        name, shape = line.split(" ", 1)
+        want[name] = tuple(eval(shape))
+    got = {k: tuple(v.shape) for k, v in build().state_dict().items()}
+    assert got == want, sorted(set(got) ^ set(want))[:10]
+
+
+def test_forward_backward_match_reference():
+    m = build()
+    m.load_state_dict(seeded_state(m.state_dict()))
+    m = m.to(DEV).train()
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    out = m(input_ids=inp["latents"].clone(), labels=inp["latents"].clone(), action_ids=inp["actions_domA"], domain=["domA"] * 2,
+            masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=inp["t"], diffusion_noise=inp["noise"])
+    z = out.logits.permute(0, 2, 3, 4, 1).reshape(2, 3, 256, 256)
+    assert rel(z, G["z"]) < 1e-2                                         # measured 3.7e-3
+    assert abs(out.loss.item() - G["loss"].item()) <= 2e-3 * abs(G["loss"].item()), (out.loss.item(), G["loss"].item())  # measured 1e-4
+    out.loss.backward()
+    params = dict(m.named_parameters())
+    worst = {}
+    for k in G:
+        if k.startswith("grad."):
+            g = params[k[5:]].grad
+            assert g is not None, k
+            worst[k] = rel(g, G[k])
+    bad = {k: v for k, v in worst.items() if v > 2e-2}              # worst measured 6.8e-3 (rms, relative)
+    assert not bad, bad
+    assert params["action_mlp.domB.model.0.weight"].grad is None  # the other domain's head is untouched
