@@ -796,7 +796,7 @@ class STEngine:
         on_segment("end")
 
     def optimizer_step(self, lr: float, active_domains: Sequence[str], betas=(0.9, 0.95), eps: float = 1e-8,
-                       weight_decay: float = 0.05, max_norm: Optional[float] = 1.0) -> None:
+                       weight_decay: float = 0.05, max_norm: Optional[float] = 1.0, extra_grads: Sequence[torch.Tensor] = ()) -> None:
         """Global-norm clip + AdamW over the ranges that received gradients (hma/train_multi.py:593-598)."""
         if self.M is None:
             self.M = torch.zeros_like(self.P)
@@ -818,6 +818,8 @@ class STEngine:
             self.sqnorm.zero_()
             for a, b in ranges:
                 _lib.call("hma_sqnorm", stream, self.G.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr())
+            for g in extra_grads:  # gradients held outside the flat buffer (STMAR's head) count towards the global norm
+                _lib.call("hma_sqnorm", stream, g.data_ptr(), g.numel(), self.sqnorm.data_ptr())
             sq = self.sqnorm.data_ptr()
         for (a, b), step in zip(ranges, steps):
             _lib.call("hma_adamw", stream, self.P.data_ptr() + 4 * a, self.G.data_ptr() + 4 * a, self.M.data_ptr() + 4 * a,

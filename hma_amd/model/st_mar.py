@@ -256,6 +256,29 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                     prm.grad = eng.view(name, eng.G)
         self._saved = None
 
+    # ------------------------------------------------------------------------------------------ optimizer
+    def optimizer_step(self, lr: float, domain: str, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
+                       max_norm: Optional[float] = 1.0) -> None:
+        """Global-norm clip + AdamW over everything that received a gradient (train_multi.py:593-598): the trunk and the active
+        domain's block through the engine's flat ranges, the parameters this class owns (input / output stages, DiffLoss head)
+        tensor by tensor with the same `hma_adamw` kernel and the same clip coefficient.  Biases and 1-D tensors are not decayed."""
+        eng = self._core._engine
+        own = [(n, p) for n, p in self.named_parameters() if p.grad is not None and not n.startswith(("decoder.", "action_mlp.")) and
+               n != "action_mask_tokens"]
+        grads = [p.grad.contiguous() for _, p in own]
+        eng.optimizer_step(lr, [domain], betas, eps, weight_decay, max_norm, extra_grads=grads)
+        stream = torch.cuda.current_stream().cuda_stream
+        st = self.__dict__.setdefault("_opt_state", {})
+        sq = eng.sqnorm.data_ptr() if max_norm else None
+        for (n, p), g in zip(own, grads):
+            if n not in st:
+                st[n] = [torch.zeros_like(p.data), torch.zeros_like(p.data), 0]
+            st[n][2] += 1
+            wd = weight_decay if (p.dim() >= 2 and not n.endswith(".bias")) else 0.0
+            _lib.call("hma_adamw", stream, ptr(p.data), ptr(g), ptr(st[n][0]), ptr(st[n][1]), None, p.numel(), lr, betas[0], betas[1], eps, wd,
+                      st[n][2], sq, float(max_norm or 0.0), None)
+            p._version  # (in-place through the kernel: the engine-side caches hold no copy of these tensors)
+
     def zero_grad(self, set_to_none: bool = True):
         for prm in self.parameters():
             prm.grad = None

@@ -55,3 +55,25 @@ def test_forward_backward_match_reference():
     bad = {k: v for k, v in worst.items() if v > 2e-2}              # worst measured 6.8e-3 (rms, relative)
     assert not bad, bad
     assert params["action_mlp.domB.model.0.weight"].grad is None  # the other domain's head is untouched
+
+
+def test_train_steps_reduce_the_loss():
+    """forward + backward + clip + AdamW (engine ranges for the trunk / active domain, per-tensor for the head) on a fixed batch."""
+    m = build()
+    m.load_state_dict(seeded_state(m.state_dict()))
+    m = m.to(DEV).train()
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    losses = []
+    for _ in range(5):
+        m.zero_grad()
+        out = m(input_ids=inp["latents"].clone(), labels=inp["latents"].clone(), action_ids=inp["actions_domA"], domain=["domA"] * 2,
+                masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=inp["t"], diffusion_noise=inp["noise"])
+        out.loss.backward()
+        m.optimizer_step(2e-3, "domA")
+        losses.append(out.loss.item())
+    assert losses[-1] < 0.9 * losses[0], losses
+    moved = {n for n, p in m.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert {"token_embed.weight", "mask_token", "out_x_proj.weight", "diffloss.net.cond_embed.weight", "decoder.layers.0.mlp.fc1.weight",
+            "action_mlp.domA.model.0.weight", "pos_embed_TSC"} <= moved
+    assert not any("domB" in n for n in moved) and "action_mask_tokens" not in moved
