@@ -548,7 +548,8 @@ class STEngine:
         return ws
 
     # ------------------------------------------------------------------------------ trunk-only training (STMAR)
-    def trunk_train_forward(self, B: int, T: int, S: int, actions: torch.Tensor, domain: str, build_x: Callable[[dict], None]) -> dict:
+    def trunk_train_forward(self, B: int, T: int, S: int, actions: torch.Tensor, domain: str, build_x: Callable[[dict], None],
+                            train: bool = True) -> dict:
         """Action stem -> `build_x(ws)` writes the residual stream ws["x"] ([B*T*(S+A), 256] fp32, may read ws["a_emb"])
         -> the L ST-blocks with every activation saved.  No token embedding, readout or loss: the caller owns those
         (hma/model/st_mar.py keeps the trunk of st_mask_git.py and replaces what is around it)."""
@@ -556,7 +557,7 @@ class STEngine:
         d_a = self.d_actions[domain]
         if actions.shape[-1] != d_a:
             raise ValueError(f"action_ids last dim {actions.shape[-1]} != d_action {d_a} of domain {domain}")
-        ws = self._workspace(B, T, S, A, True)
+        ws = self._workspace(B, T, S, A, train)
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh_weights(domain, stream)
         ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
@@ -567,8 +568,9 @@ class STEngine:
                   ws["an"].data_ptr(), ws["sxhat"].data_ptr(), ws["srstd"].data_ptr(), ws["sh"].data_ptr(), ws["a_emb"].data_ptr(),
                   B * T, d_a, self._skip_norm)
         build_x(ws)
-        self._forward_plan(B, T, S, A, True, domain, embed=False, readout=False).run(stream, timer=self.timer)
-        self._last = (B, T, S, A, domain)
+        self._forward_plan(B, T, S, A, train, domain, embed=False, readout=False).run(stream, timer=self.timer)
+        if train:
+            self._last = (B, T, S, A, domain)
         return ws
 
     def trunk_train_backward(self, fill_dx: Callable[[dict], None], embed_bwd: Callable[[dict], None]) -> None:

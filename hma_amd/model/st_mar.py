@@ -9,7 +9,8 @@ Execution: the ST-transformer trunk, action stems and per-layer modulation are t
 modules and their parameters are shared with an internal `STMaskGIT` whose flat buffers they live in); around it
 `hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
 `DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
-Not built: `jointly_predict_actions`, `generate` (MAR decoding), dropout (`mlp_drop` must be 0), diffusion_batch_mul > 1.
+`maskgit_generate` / `generate` are the MAR decode (st_mar.py:277-452) with `DiffLoss.sample`.
+Not built: `jointly_predict_actions`, classifier-free guidance (cfg != 1), dropout (`mlp_drop` must be 0), diffusion_batch_mul > 1.
 """
 from __future__ import annotations
 
@@ -196,6 +197,119 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         if self._anchor is None or self._anchor.device != dev:
             self._anchor = torch.zeros((), device=dev, requires_grad=True)
         return ModelOutput(loss=_MarLoss.apply(self._anchor, self, inner.detach()), acc=acc, logits=logits)
+
+    # ------------------------------------------------------------------------------------------ generation (MAR decode)
+    @torch.no_grad()
+    def compute_latents(self, x_patches: torch.Tensor, action_ids: torch.Tensor = None, domain=None, **kwargs):
+        """st_mar.py:146-197 on already patchified latents (B, T, h, w, p*p*c) -> (decoded_states (B, d, T, h, w), None)."""
+        if action_ids is None:
+            raise NotImplementedError("STMAR without action conditioning is not built")
+        cfg = self.config
+        B, T, h_, w_, pc = x_patches.shape
+        dev = x_patches.device
+        S, A, d = h_ * w_, cfg.action_token_size, cfg.d_model
+        Fr, Mi, M = B * T, B * T * S, B * T * (S + A)
+        dom = domain if isinstance(domain, str) else domain[0]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        patches = torch.zeros(Mi, _PAD, dtype=BF16, device=dev)
+        patches[:, :pc] = x_patches.reshape(Mi, pc)          # layout + dtype only
+        wtok, _ = self._cast(stream, self.token_embed.weight, d, _PAD, False)
+        wout, _ = self._cast(stream, self.out_x_proj.weight, d, d, False)
+        eng = self._engine(dev)
+        xtok, xhat_e, rstd_e = e(Mi, d), e(M, d, dt=BF16), e(M)
+        pos_stride = self.pos_embed_TSC.shape[2] * d
+
+        def build_x(ws):
+            self._nt(stream, A=ptr(patches), lda=_PAD, a_kind=A_BF16, W=ptr(wtok), ldw=_PAD, M=Mi, N=d, K=_PAD, epi=EPI_F32, Cp=ptr(xtok), ldc=d)
+            _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr(), ptr(self.pos_embed_TSC), pos_stride,
+                      ptr(self.z_proj_ln.weight), ptr(self.z_proj_ln.bias), 1e-6, ws["x"].data_ptr(), ptr(xhat_e), ptr(rstd_e), Fr, T, S, A)
+
+        ws = eng.trunk_train_forward(B, T, S, action_ids.to(dev, F32), dom, build_x, train=False)
+        y, z, yhat, rstd_r = e(Mi, d), e(Mi, d), e(Mi, d, dt=BF16), e(Mi)
+        self._nt(stream, A=ws["x"].data_ptr(), lda=d, a_kind=A_F32, a_group=(S, S + A), W=ptr(wout), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
+                 Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))
+        _lib.call("hma_mar_readout_fwd", stream, ptr(y), ptr(self.decoder_norm.weight), ptr(self.decoder_norm.bias), 1e-6,
+                  ptr(self.diffusion_pos_embed_learned), ptr(z), ptr(yhat), ptr(rstd_r), Mi, T, S)
+        return z.view(B, T, h_, w_, d).permute(0, 4, 1, 2, 3), None
+
+    def patchify(self, x):
+        """(B, T, H, W, C) -> (B, T, H/p, W/p, p*p*C) through the patchify kernel (st_mar.py:199-207)."""
+        B, T, H, W, Cc = x.shape
+        p = self.patch_size
+        out = torch.empty(B * T * (H // p) * (W // p), Cc * p * p, dtype=F32, device=x.device)
+        _lib.call("hma_mar_patchify", torch.cuda.current_stream(x.device).cuda_stream, ptr(x.to(F32).contiguous()), None, None, None, 0, ptr(out),
+                  None, B * T, H, W, Cc, p)
+        return out.view(B, T, H // p, W // p, Cc * p * p)
+
+    def unpatchify(self, x):
+        """(B, T, h, w, p*p*C) -> (B, T, h*p, w*p, C): a pure re-layout (st_mar.py:209-217)."""
+        p, c = self.patch_size, self.vae_embed_dim
+        B, T, h_, w_, _ = x.shape
+        return x.reshape(B, T, h_, w_, p, p, c).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, T, h_ * p, w_ * p, c)
+
+    def sample_orders(self, bsz):
+        """A random generation order per sample (st_mar.py:351-360; numpy's global RNG like the reference)."""
+        import numpy as np
+        return torch.stack([torch.from_numpy(np.random.permutation(self.seq_len)) for _ in range(bsz)]).long()
+
+    @torch.no_grad()
+    def maskgit_generate(self, prompt_THW, out_t: int, unmask_mode: str = "random", action_ids=None, domain="default", maskgit_steps=8,
+                         cfg=1.0, temperature=1.0, cfg_schedule="linear", action_only: bool = False, state_only: bool = False,
+                         orders: Optional[torch.Tensor] = None, draws=None, **kwargs):
+        """MAR decode of frame `out_t` (st_mar.py:362-452; cfg must be 1).  Returns (frame (B, H, W, C), the first pass's latents
+        (B, d, h, w), None).  `orders` / `draws` replay the random order and the Gaussian draws of each DiffLoss.sample call
+        ([(noise0, step_noises), ...]).  Like the reference, `unmasked` is never updated: every step re-predicts all tokens outside
+        the first `mask_len` entries of the order, the last step all of them."""
+        import numpy as np
+        assert out_t, "maskgit_generate requires out_t > 0"
+        if cfg != 1.0:
+            raise NotImplementedError("classifier-free guidance (cfg != 1) is not built")
+        dev = prompt_THW.device
+        x = self.patchify(prompt_THW).clone()
+        B, T, h_, w_, pc = x.shape
+        S = h_ * w_
+        orders = (self.sample_orders(B) if orders is None else orders).to(dev)
+        z = self.compute_latents(x, action_ids=action_ids, domain=domain)[0][:, :, out_t]
+        orig = z.clone()
+        for step in range(maskgit_steps):
+            if step > 0:
+                z = self.compute_latents(x, action_ids=action_ids, domain=domain)[0][:, :, out_t]
+            mask_len = max(1, min(S - 1, int(np.floor(self.seq_len * np.cos(math.pi / 2.0 * (step + 1) / maskgit_steps)))))
+            mask_next = torch.zeros(B, S, device=dev).scatter(-1, orders[:, :mask_len], torch.ones(B, S, device=dev)).bool()
+            to_pred = torch.ones(B, S, dtype=torch.bool, device=dev) if step >= maskgit_steps - 1 else ~mask_next
+            rows = z.reshape(B, -1, S).permute(0, 2, 1)[to_pred].contiguous()          # (n, d): gather of the rows to sample
+            kw = {} if draws is None else dict(noise0=draws[step][0], step_noises=draws[step][1])
+            smp = self.diffloss.sample(rows, temperature, 1.0, clip_denoised=True, **kw)
+            xt = x[:, out_t].reshape(B, S, pc)
+            xt[to_pred] = smp
+            x[:, out_t] = xt.reshape(B, h_, w_, pc)
+        return self.unpatchify(x)[:, out_t], orig, None
+
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask=None, max_new_tokens: int = 0, min_new_tokens: int = None, return_logits: bool = False,
+                 return_with_actions: bool = False, temperature: float = 1.0, action_ids=None, domain="default", action_only: bool = False,
+                 state_only: bool = False, **kwargs):
+        """Frame-by-frame rollout (st_mar.py:277-349): input_ids (B, T0*H*W, C) latents -> (B, (T0 + new)*H*W, C)."""
+        assert min_new_tokens in (None, max_new_tokens), "Expecting `min_new_tokens`, if specified, to match `max_new_tokens`."
+        if return_with_actions:
+            raise NotImplementedError("action prediction (jointly_predict_actions) is not built")
+        h, w, c = self.h, self.w, self.vae_embed_dim
+        if "h" in kwargs:
+            h, w = int(kwargs["h"][0]), int(kwargs["w"][0])
+        S = h * w
+        new = max_new_tokens // S
+        B = input_ids.shape[0]
+        x = input_ids.reshape(B, -1, h, w, c).clone()
+        x = torch.cat([x, self.mask_token.detach()[None, None].to(x).expand(B, new, h, w, c)], dim=1).contiguous()
+        firsts = []
+        for t in range(x.shape[1] - new, x.shape[1]):
+            frame, first, _ = self.maskgit_generate(x, t, maskgit_steps=self.config.maskgit_steps, temperature=temperature,
+                                                    action_ids=action_ids, domain=domain)
+            x[:, t] = frame
+            firsts.append(first)
+        tokens = x.reshape(B, -1, c)
+        return (tokens, torch.stack(firsts, dim=2)) if return_logits else tokens
 
     # ------------------------------------------------------------------------------------------ backward
     def _accum(self, p: nn.Parameter, g: torch.Tensor):

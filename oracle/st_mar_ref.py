@@ -49,3 +49,39 @@ def forward(sd, cfg, input_ids, labels, action_ids, domain, masked, t, noise, pa
     P = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
     loss, _ = DR.diffloss_forward(P, target.reshape(n, -1).float(), z.reshape(n, -1), pmask.reshape(n).float(), t, noise, diff_depth)
     return loss, z
+
+
+def unpatchify(x, p, c):
+    """(B, T, h, w, p*p*c) -> (B, T, h*p, w*p, c)  (st_mar.py:209-217)."""
+    B, T, h, w, _ = x.shape
+    return torch.einsum("nthwpqc->nthpwqc", x.reshape(B, T, h, w, p, p, c)).reshape(B, T, h * p, w * p, c)
+
+
+@torch.no_grad()
+def maskgit_generate(sd, cfg, prompt_THWC, out_t, maskgit_steps, temperature, action_ids, domain, orders, draws, patch_size, diff_depth,
+                     num_sampling_steps):
+    """STMAR.maskgit_generate (st_mar.py:362-452, cfg = 1) with the random order and every Gaussian draw passed in:
+    draws[k] = (noise0, step_noises) of the k-th DiffLoss.sample call.  NB the reference never updates `unmasked`, so
+    every step re-predicts all tokens outside the first mask_len entries of the order, and the last step all of them."""
+    import math
+    import numpy as np
+    x = patchify(prompt_THWC, patch_size).clone()
+    B, T, h, w, pc = x.shape
+    S = h * w
+    P = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
+    z = compute_latents(sd, cfg, x, action_ids, domain)[:, out_t]
+    orig = z.clone()
+    for step in range(maskgit_steps):
+        if step > 0:
+            z = compute_latents(sd, cfg, x, action_ids, domain)[:, out_t]
+        mask_len = max(1, min(S - 1, int(np.floor(S * np.cos(math.pi / 2.0 * (step + 1) / maskgit_steps)))))
+        mask_next = torch.zeros(B, S).scatter(-1, orders[:, :mask_len], torch.ones(B, S)).bool()
+        to_pred = torch.ones(B, S, dtype=torch.bool) if step >= maskgit_steps - 1 else ~mask_next
+        rows = z[to_pred]
+        noise0, step_noises = draws[step]
+        smp = DR.diffloss_sample(P, rows, noise0, list(step_noises), diff_depth, temperature, num_sampling_steps, clip_denoised=True)
+        xt = x[:, out_t].reshape(B, S, pc)
+        xt[to_pred] = smp
+        x[:, out_t] = xt.reshape(B, h, w, pc)
+    c = pc // (patch_size ** 2)
+    return unpatchify(x, patch_size, c)[:, out_t], orig

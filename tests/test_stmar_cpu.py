@@ -44,3 +44,15 @@ def test_stmar_forward_and_gradients_match_reference():
             want, got = G[k], sd[k[5:]].grad
             assert torch.allclose(got, want, rtol=5e-3, atol=2e-5 * want.abs().max().item() + 1e-9), k
     assert G["grad_is_none.domB"].item() == 1.0 and sd["action_mlp.domB.model.0.weight"].grad is None
+
+
+def test_mar_decode_matches_reference():
+    """maskgit_generate of one frame (2 MaskGIT steps x 10 diffusion steps) with the reference's order and Gaussian draws."""
+    D = load_file(os.path.join(HERE, "golden", "g12_stmar_decode.safetensors"))
+    sd = seeded_state(template())
+    inp = inputs()
+    draws = [(D[f"noise0.{k}"], D[f"steps.{k}"]) for k in range(2)]
+    frame, orig = M.maskgit_generate(sd, ref_cfg(), D["prompt"], 2, 2, 0.9, inp["actions_domA"], ["domA"] * 2, D["orders"], draws, 2,
+                                     CFG["diffloss_d"], CFG["num_sampling_steps"])
+    assert torch.allclose(orig.permute(0, 2, 1).reshape(2, 256, 16, 16), D["orig_latents"], rtol=1e-3, atol=2e-4)
+    assert torch.allclose(frame, D["frame"], rtol=1e-3, atol=1e-3)
