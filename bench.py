@@ -127,6 +127,54 @@ def cpu_baseline(model, domain, d_a, T, budget_s=25.0):
                       f"median of {len(warm)} warm steps ({med:.2f} s/step)"}
 
 
+def mar_bench(args, dev):
+    """BASELINE.json configs[3] on ONE GPU (its 8-GPU form shards samples exactly like the headline config): STMAR (continuous
+    VAE latents 32x32x4 -> 256 patch tokens + 64 action tokens per frame, T = 16, diffusion head width 1024 / depth 4), batch 16,
+    forward + backward + clip + AdamW.  Not the headline metric: a measured line for the C4 row."""
+    import time
+    from hma_amd.config import DiffusionGenieConfig
+    from hma_amd.model.st_mar import STMAR
+
+    B, T = (args.batch if args.batch != 32 else 16), args.frames
+    cfg = DiffusionGenieConfig(num_layers=args.layers, num_heads=8, d_model=256, T=T, S=1024, use_mup=True, action_network="concat+modulate",
+                               num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.0, mlp_bias=False,
+                               patch_size=2, vae_embed_dim=4, diffloss_w=1024, diffloss_d=4, num_sampling_steps="100", attn_drop=0.0)
+    m = STMAR(cfg)
+    m.init_action_projectors(["dom0", "dom1"], [14, 7], [[[0.0] * 7, [1.0] * 7]] * 2, cfg.action_network)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
+                p_.normal_(0, 0.02)
+    m = m.to(dev).train()
+    g = torch.Generator(device=dev).manual_seed(0)
+    lat = torch.randn(B, T * 1024, 4, device=dev, generator=g) * 0.7
+    masked = torch.rand(B, T, 32, 32, device=dev, generator=g) < 0.6
+    act = torch.randn(B, T, 14, device=dev, generator=g)
+
+    def step():
+        m.zero_grad()
+        out = m(input_ids=lat, labels=lat, action_ids=act, domain=["dom0"] * B, masked_tokens_indicator=masked, h=[32] * B, w=[32] * B)
+        out.loss.backward()
+        m.optimizer_step(1e-4, "dom0")
+        return out.loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({
+        "metric": "patch-tokens/sec (STMAR train step: fwd+bwd+clip+AdamW) HMA-MAR T=16 32x32x4 latents", "value": B * T * 256 / dt,
+        "unit": "patch-tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"HMA-MAR d256/h8/L{args.layers}, diffusion head 1024x4, synthetic latents T={T} 32x32x4 (+64 action "
+                               f"tokens/frame), batch {B}/GPU, eager launches (no hipGraph)", "global_batch": B, "parallelism": "dp1"},
+        "final_loss": float(loss)}), flush=True)
+
+
 def decode_bench(args, dev):
     """BASELINE.json configs[4]: MaskGIT iterative decode, T = 16, 4 prompt + 12 generated frames, 8 iterations,
     batch 64 -> generated frames/s (replicas only: no exchange step).  `--steps` rollouts are timed."""
@@ -189,7 +237,7 @@ def main():
     ap.add_argument("--domains", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--mode", choices=["train", "decode"], default="train")
+    ap.add_argument("--mode", choices=["train", "decode", "mar"], default="train")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,6 +264,10 @@ def main():
     if args.mode == "decode":
         if rank == 0:
             decode_bench(args, dev)
+        return
+    if args.mode == "mar":
+        if rank == 0:
+            mar_bench(args, dev)
         return
 
     from hma_amd.engine import LaunchTimer
