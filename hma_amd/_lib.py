@@ -30,6 +30,7 @@ class GemmNT(C.Structure):
         ("sA", c_i64), ("sW", c_i64), ("sBias", c_i64), ("sC", c_i64), ("sC2", c_i64), ("sU", c_i64),
         ("ln_xhat", c_vp), ("ln_rstd", c_vp), ("ln_ss", c_vp), ("ln_xm", c_vp),
         ("ln_eps", C.c_float), ("ln_rows_per_frame", c_i32),
+        ("drop_p", C.c_float), ("drop_salt", c_i32), ("drop_seed", c_vp),
     ]
 
 
@@ -87,6 +88,7 @@ _PROTOS = {
     "hma_mar_readout_fwd": [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
     "hma_mar_readout_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
     "hma_maskgit_collate": [c_vp, c_vp, c_vp, c_vp, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp],
+    "hma_dropout_bf16": [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_i32],
     "hma_transpose_cast_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64],
     "hma_abi_version": [],
 }

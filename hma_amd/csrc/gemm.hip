@@ -462,6 +462,16 @@ __device__ __forceinline__ void epilogue_oct(const hma_gemm_nt_t& p, int64_t bz,
     *reinterpret_cast<float4*>(C + 8) = make_float4(v1[0], v1[1], v1[2], v1[3]);
   } else if (EPI == HMA_EPI_RESID) {
     float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + nq + 8 * g2 + 4 * hi;
+    if (p.drop_p > 0.f) {  // Dropout on the branch output before the residual add (st_transformer.py:26)
+      const uint32_t seed = *p.drop_seed, th = drop_thresh(p.drop_p);
+      const float sc = 1.0f / (1.0f - p.drop_p);
+      const int64_t e0 = crow * p.ldc + nq + 8 * g2 + 4 * hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = drop_keep(seed, p.drop_salt, e0 + e, th) ? v0[e] * sc : 0.f;
+        v1[e] = drop_keep(seed, p.drop_salt, e0 + 8 + e, th) ? v1[e] * sc : 0.f;
+      }
+    }
     float4 x0 = *reinterpret_cast<float4*>(C), x1 = *reinterpret_cast<float4*>(C + 8);
     x0.x += v0[0]; x0.y += v0[1]; x0.z += v0[2]; x0.w += v0[3];
     x1.x += v1[0]; x1.y += v1[1]; x1.z += v1[2]; x1.w += v1[3];
@@ -1320,6 +1330,12 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
           const uint32_t w[4] = {ru[pr].x, ru[pr].y, ru[pr].z, ru[pr].w};
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= gt_lookup(gtl, (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+          if (p.drop_p > 0.f) {  // the forward's mask on gelu(u): same seed, salt and element index
+            const uint32_t seed = *p.drop_seed, th = drop_thresh(p.drop_p);
+            const float sc = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = drop_keep(seed, p.drop_salt, crow * p.ldc + bn + nl + e, th) ? v[e] * sc : 0.f;
+          }
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl) = pack8(v);
         } else if (EPI == HMA_EPI_GELU2) {
           const uint4 uq = pack8(v);  // the saved pre-activation; the activation is applied to the ROUNDED value
@@ -1329,6 +1345,12 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
           for (int e = 0; e < 8; ++e) {
             const uint32_t bits = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
             h[e] = __uint_as_float(bits << 16) * gt_lookup(gtl, bits);
+          }
+          if (p.drop_p > 0.f) {  // Dropout on the activation (st_transformer.py:25); u itself is saved undropped
+            const uint32_t seed = *p.drop_seed, th = drop_thresh(p.drop_p);
+            const float sc = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = drop_keep(seed, p.drop_salt, crow * p.ldc2 + bn + nl + e, th) ? h[e] * sc : 0.f;
           }
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl) = uq;
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(h);
@@ -2006,6 +2028,15 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2) && !p->C2) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU) && !p->U) return HMA_EINVAL;
+  if (p->drop_p != 0.f) {  // dropout: streaming GELU2 / DGELU, persistent RESID
+    static const bool no_sw_d = getenv("HMA_GEMM_NT_NOSW") != nullptr;
+    if (!(p->drop_p > 0.f && p->drop_p < 1.f) || !p->drop_seed || (p->batch > 1)) return HMA_EINVAL;
+    const bool act = (p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_DGELU) && p->K == 256 && !no_sw_d;
+    const bool res = p->epi == HMA_EPI_RESID && p->K > 256 && p->K % 64 == 0 && p->N % 256 == 0 && !p->ln_xhat &&
+                     getenv("HMA_GEMM_NT_V1") == nullptr && getenv("HMA_GEMM_NT_P1") == nullptr && getenv("HMA_GEMM_NT_SWK") == nullptr;
+    if (!act && !res) return HMA_EINVAL;
+    if (p->epi == HMA_EPI_DGELU && p->ldc != p->ldu) return HMA_EINVAL;  // the mask is indexed like the forward's C2
+  }
   if (p->ln_xhat) {  // fused LayerNorm: only on the streaming residual path
     static const bool no_sw_ln = getenv("HMA_GEMM_NT_NOSW") != nullptr;
     if (no_sw_ln || p->epi != HMA_EPI_RESID || p->N != 256 || p->K != 256 || p->batch > 1 || !p->ln_rstd) return HMA_EINVAL;

@@ -93,6 +93,16 @@ __device__ __forceinline__ float dsilu_f(float u) {
   return s * (1.0f + u * (1.0f - s));
 }
 
+// Counter-based dropout mask: keep iff hash(seed, salt, element index) >= p * 2^32 (murmur3 finaliser over the mixed
+// index); forward and backward call it with the same arguments instead of storing the mask.
+__device__ __forceinline__ bool drop_keep(uint32_t seed, int salt, int64_t idx, uint32_t thresh) {
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)((uint64_t)idx >> 32) * 0x9E3779B9u);
+  x ^= seed + 0x7F4A7C15u * (uint32_t)(salt + 1);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x >= thresh;
+}
+__device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
+
 __device__ __forceinline__ f32x16_t mfma32(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }

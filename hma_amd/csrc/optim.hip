@@ -84,6 +84,15 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n,
+                                                           float p, const uint32_t* __restrict__ seed_dev, int salt) {
+  const uint32_t seed = *seed_dev, th = drop_thresh(p);
+  const float sc = 1.0f / (1.0f - p);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    dst[i] = to_bf16(drop_keep(seed, salt, i, th) ? src[i] * sc : 0.f);
+}
+
 inline unsigned flat_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -138,3 +147,13 @@ extern "C" int hma_transpose_cast_bf16(void* stream, const float* src, void* dst
 }
 
 extern "C" int hma_abi_version(void) { return 0x484d4101; }
+
+extern "C" int hma_dropout_bf16(void* stream, const float* src, void* dst, int64_t rows, int32_t cols, float p, const uint32_t* seed_dev,
+                                int32_t salt) {
+  if (!src || !dst || !seed_dev || !(p > 0.f && p < 1.f) || cols < 1) return HMA_EINVAL;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(flat_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, rows * cols, p,
+                     seed_dev, (int)salt);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}

@@ -125,6 +125,8 @@ class STEngine:
         self.flags = self.layout.decay_flags().to(self.device)
         self.sqnorm = torch.zeros(1, dtype=F32, device=self.device)
         self.opt_step = 0
+        self.drop_seed = torch.zeros(1, dtype=torch.int32, device=self.device)  # bumped per training forward (dropout masks)
+        self._drop_counter = 0
         self.dom_steps: Dict[str, int] = {}  # per-domain Adam step counts (a head is only stepped when its domain had a gradient)
         L, d = cfg.num_layers, cfg.d_model
         hid = int(d * cfg.mlp_ratio)
@@ -269,6 +271,8 @@ class STEngine:
             buf("dlogits", (Mi, 1024), BF16)
             buf("dx", (M, 256), F32)
             buf("dxb", (M, 256), BF16)  # bf16 copy of dx: operand of the dgrad / wgrad GEMMs that read it
+            if float(getattr(self.cfg, "mlp_drop", 0.0) or 0.0) > 0.0:
+                buf("dxm", (M, 256), BF16)  # dx behind the Dropout that follows fc2
             buf("t256", (M, 256), BF16)
             buf("dqkv", (M, 768), BF16)
             buf("delta", (M, 8), F32)
@@ -289,7 +293,7 @@ class STEngine:
         return name in self.layout.entries
 
     def _emit_layer(self, pl: Plan, l: int, x: int, b: Dict[str, int], M: int, Fr: int, B: int, T: int, SA: int,
-                    use_mod: bool, domain: Optional[str], kv: Optional[dict] = None) -> None:
+                    use_mod: bool, domain: Optional[str], kv: Optional[dict] = None, train: bool = False) -> None:
         """One STBlock forward (st_transformer.py:79-114) on M rows = Fr frames of SA tokens.  `kv` redirects the
         temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
         "t_query": -1 | t, "T_cache": frames}."""
@@ -327,9 +331,23 @@ class STEngine:
         pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
                    beta=self._lw(l, "norm2.bias", "p"), W=self._lw(l, "mlp.fc1.weight"), ldw=256, M=M, N=1024, K=256,
                    epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024,
-                   bias=self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None)
+                   bias=self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None, **self._drop(train, l, 0))
         pl.gemm_nt(A=b["hg"], lda=1024, a_kind=A_BF16, W=self._lw(l, "mlp.fc2.weight"), ldw=1024, M=M, N=256, K=1024,
-                   epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None)
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
+                   **self._drop(train, l, 1))
+
+    def bump_dropout(self) -> None:
+        """New dropout masks for the next training forward + backward (a device-side seed: plans / graphs stay valid)."""
+        if float(getattr(self.cfg, "mlp_drop", 0.0) or 0.0) > 0.0:
+            self._drop_counter += 1
+            self.drop_seed.fill_((self._drop_counter * 2654435761) % (1 << 31))
+
+    def _drop(self, train: bool, l: int, which: int) -> dict:
+        """Dropout arguments of the MLP's two nn.Dropout sites (st_transformer.py:24-27): training only, mlp_drop > 0."""
+        p = float(getattr(self.cfg, "mlp_drop", 0.0) or 0.0)
+        if not train or p <= 0.0:
+            return {}
+        return dict(drop_p=p, drop_salt=2 * l + which, drop_seed=self.drop_seed.data_ptr())
 
     def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True, kv_cache=None,
                       T_cache=0) -> Plan:
@@ -382,7 +400,7 @@ class STEngine:
             if A > 0 and self.modulate:
                 bufs.update({k: dp(ws[k], s, ws[k][0].numel()) for k in ("xhm", "xm", "rstdm")})
                 bufs["ss"] = dp(ws["ss"], l, Fr * 512)
-            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l))
+            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train)
         # readout on the image tokens only                      st_mask_git.py:681-683
         if readout:
           pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,
@@ -434,11 +452,15 @@ class STEngine:
             gw = lambda suffix: self._lw(l, suffix, "g")
             gb = lambda suffix, on=True: self._lw(l, suffix, "g") if on else None
             wt = lambda k: dp(self.WT[k], l, self.WT[k][0].numel())
-            # ---- MLP
-            pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024, dW=gw("mlp.fc2.weight"),
+            # ---- MLP (with mlp_drop: the gradient first passes the Dropout behind fc2, then the one behind the GELU)
+            dmlp = dxb
+            if self._drop(True, l, 1):
+                dmlp = ws["dxm"].data_ptr()
+                pl.add("hma_dropout_bf16", dx, dmlp, M, 256, float(cfg.mlp_drop), self.drop_seed.data_ptr(), 2 * l + 1)
+            pl.gemm_tn(dY=dmlp, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024, dW=gw("mlp.fc2.weight"),
                        lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias))
-            pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
-                       U=u, ldu=1024)  # dU overwrites u in place
+            pl.gemm_nt(A=dmlp, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
+                       U=u, ldu=1024, **self._drop(True, l, 0))  # dU overwrites u in place
             pl.gemm_tn(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
                        beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024, K=256, dW=gw("mlp.fc1.weight"), lddw=256,
                        dBias=gb("mlp.fc1.bias", cfg.mlp_bias))
@@ -539,6 +561,8 @@ class STEngine:
             if actions.shape[-1] != d_a:
                 raise ValueError(f"action_ids last dim {actions.shape[-1]} != d_action {d_a} of domain {domain}")
             ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
+        if train:
+            self.bump_dropout()
         self._forward_plan(B, T, S, A, train, domain if A > 0 else None).run(stream, timer=self.timer)
         self._last = (B, T, S, A, domain if A > 0 else None)
         if labels is not None:
@@ -568,6 +592,8 @@ class STEngine:
                   ws["an"].data_ptr(), ws["sxhat"].data_ptr(), ws["srstd"].data_ptr(), ws["sh"].data_ptr(), ws["a_emb"].data_ptr(),
                   B * T, d_a, self._skip_norm)
         build_x(ws)
+        if train:
+            self.bump_dropout()
         self._forward_plan(B, T, S, A, train, domain, embed=False, readout=False).run(stream, timer=self.timer)
         if train:
             self._last = (B, T, S, A, domain)

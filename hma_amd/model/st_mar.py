@@ -10,7 +10,7 @@ modules and their parameters are shared with an internal `STMaskGIT` whose flat 
 `hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
 `DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
 `maskgit_generate` / `generate` are the MAR decode (st_mar.py:277-452) with `DiffLoss.sample`.
-Not built: `jointly_predict_actions`, classifier-free guidance (cfg != 1), dropout (`mlp_drop` must be 0), diffusion_batch_mul > 1.
+Not built: `jointly_predict_actions`, classifier-free guidance (cfg != 1), diffusion_batch_mul > 1.
 """
 from __future__ import annotations
 
@@ -53,8 +53,6 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         super().__init__()
         if isinstance(config, dict):
             config = DiffusionGenieConfig.from_dict(config)
-        if config.mlp_drop != 0.0:
-            raise NotImplementedError("dropout inside the MLP blocks (mlp_drop > 0) is not built")
         if config.jointly_predict_actions:
             raise NotImplementedError("jointly_predict_actions is not built")
         if config.diffusion_batch_mul != 1:
@@ -180,7 +178,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
             _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr(), ptr(self.pos_embed_TSC), pos_stride,
                       ptr(self.z_proj_ln.weight), ptr(self.z_proj_ln.bias), 1e-6, ws["x"].data_ptr(), ptr(xhat_e), ptr(rstd_e), Fr, T, S, A)
 
-        ws = eng.trunk_train_forward(B, T, S, action_ids.to(dev, F32), dom, build_x)
+        ws = eng.trunk_train_forward(B, T, S, action_ids.to(dev, F32), dom, build_x, train=train)
         y, z, yhat, rstd_r = e(Mi, d), e(Mi, d), e(Mi, d, dt=BF16), e(Mi)
         self._nt(stream, A=ws["x"].data_ptr(), lda=d, a_kind=A_F32, a_group=(S, SA), W=ptr(wout), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
                  Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))

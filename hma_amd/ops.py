@@ -40,7 +40,8 @@ def make_gemm_nt(*, A: int, lda: int, a_kind: int, W: int, ldw: int, M: int, N: 
                  a_group=(0, 0), c_group=(0, 0), C2: Optional[int] = None, ldc2: int = 0, U: Optional[int] = None,
                  ldu: int = 0, batch: int = 1, sA: int = 0, sW: int = 0, sBias: int = 0, sC: int = 0, sC2: int = 0,
                  sU: int = 0, ln_xhat: Optional[int] = None, ln_rstd: Optional[int] = None, ln_eps: float = 0.0,
-                 ln_ss: Optional[int] = None, ln_xm: Optional[int] = None, ln_rows_per_frame: int = 0) -> GemmNT:
+                 ln_ss: Optional[int] = None, ln_xm: Optional[int] = None, ln_rows_per_frame: int = 0, drop_p: float = 0.0,
+                 drop_salt: int = 0, drop_seed: Optional[int] = None) -> GemmNT:
     g = GemmNT()
     g.A, g.lda, g.a_kind = A, lda, a_kind
     g.a_group_rows, g.a_group_stride = a_group
@@ -54,6 +55,7 @@ def make_gemm_nt(*, A: int, lda: int, a_kind: int, W: int, ldw: int, M: int, N: 
     g.batch, g.sA, g.sW, g.sBias, g.sC, g.sC2, g.sU = batch, sA, sW, sBias, sC, sC2, sU
     g.ln_xhat, g.ln_rstd, g.ln_ss, g.ln_xm = ln_xhat, ln_rstd, ln_ss, ln_xm
     g.ln_eps, g.ln_rows_per_frame = ln_eps, ln_rows_per_frame
+    g.drop_p, g.drop_salt, g.drop_seed = drop_p, drop_salt, drop_seed
     return g
 
 

@@ -167,6 +167,7 @@ class Trainer:
         ~1500 launches per step become one graph launch per gradient bucket; the all-reduce of a bucket is issued
         between two graph launches exactly where the eager path issues it."""
         eng, red = self.engine, self.reducer
+        eng.bump_dropout()
         B, T, S = ids_BTS.shape
         A_now = eng.cfg.action_token_size if action_ids is not None else 0
         eng._workspace(B, T, S, A_now, True)  # (re)allocates only when the shape changed

@@ -64,6 +64,15 @@ typedef struct {
    * (fp32, 512 per frame), i.e. hma_modln_fwd (st_mask_git.py:71-74). */
   void* ln_xhat; float* ln_rstd; const float* ln_ss; void* ln_xm;
   float ln_eps; int32_t ln_rows_per_frame;
+  /* Optional inverted dropout (nn.Dropout in Mlp, st_transformer.py:24-27; training only), drop_p in (0, 1):
+   *   HMA_EPI_GELU2: C2 = GELU(u) * keep / (1 - p)         (C, the saved pre-activation, is not dropped)
+   *   HMA_EPI_DGELU: C  = acc * GELU'(U) * keep / (1 - p)   (the same mask: same seed, salt and element index)
+   *   HMA_EPI_RESID: C += (acc + bias) * keep / (1 - p)
+   * keep = hash(*drop_seed, drop_salt, row * ldc + column) >= p * 2^32 (counter-based, hma_dropout_bf16 uses the same
+   * function), so backward regenerates the mask instead of storing it.  drop_seed is a DEVICE pointer (one uint32 the
+   * host bumps per step: recorded launches and captured graphs stay valid).  Supported on the streaming K = 256 kernel
+   * (GELU2 / DGELU) and the persistent kernel (RESID); otherwise HMA_EINVAL. */
+  float drop_p; int32_t drop_salt; const uint32_t* drop_seed;
 } hma_gemm_nt_t;
 int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p);
 
@@ -263,6 +272,10 @@ int hma_maskgit_collate(void* stream, const int64_t* ids, int64_t* out_ids, cons
                         const float* mask_prob, const float* r_mask, int64_t B, int32_t T, int32_t HW,
                         int32_t first_masked_frame, int32_t V, int32_t num_factored /* 1 | 2: last dim of the draws */,
                         int64_t mask_id, int32_t* any_masked);
+/* dst (bf16, [rows, cols]) = src (fp32) * keep / (1 - p) with the mask of hma_gemm_nt_t's dropout (element index row * cols
+ * + col): the gradient that flows back through the Dropout after fc2 (st_transformer.py:26). */
+int hma_dropout_bf16(void* stream, const float* src, void* dst, int64_t rows, int32_t cols, float p, const uint32_t* seed_dev,
+                     int32_t salt);
 /* dst[b][c][r] (bf16) = src[b][r][c] (f32): transposed bf16 copies of weights for the dgrad GEMMs */
 int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t rows, int32_t cols,
                             int32_t batch, int64_t src_stride, int64_t dst_stride);

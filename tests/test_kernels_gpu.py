@@ -452,3 +452,59 @@ def test_sqnorm_adamw_cast_transpose():
     dst = torch.empty(3, 70, 40, dtype=torch.bfloat16, device=DEV)
     _lib.call("hma_transpose_cast_bf16", ops.stream_ptr(), src.data_ptr(), dst.data_ptr(), 40, 70, 3, 40 * 70, 40 * 70)
     assert torch.equal(dst.cpu(), src.cpu().transpose(1, 2).bfloat16())
+
+
+# ------------------------------------------------------------------------------------------ dropout in the GEMM epilogues
+def test_gemm_dropout_masks_are_consistent_between_forward_and_backward():
+    """nn.Dropout of the MLP (st_transformer.py:24-27) inside the epilogues: GELU2 drops the activation (not the saved
+    pre-activation), DGELU re-creates the same mask, RESID drops the branch output, hma_dropout_bf16 the gradient behind it."""
+    M, p = 1000, 0.25
+    x = rb(torch.randn(M, 256, generator=g(70)))
+    w1 = rb(torch.randn(1024, 256, generator=g(71)) * 0.1)
+    seed = torch.tensor([12345], dtype=torch.int32, device=DEV)
+    xd, w1d = x.to(DEV).bfloat16(), w1.to(DEV).bfloat16()
+    u, h = (torch.empty(M, 1024, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    gm = ops.make_gemm_nt(A=xd.data_ptr(), lda=256, a_kind=A_BF16, W=w1d.data_ptr(), ldw=256, M=M, N=1024, K=256, epi=EPI_GELU2,
+                          Cp=u.data_ptr(), ldc=1024, C2=h.data_ptr(), ldc2=1024, drop_p=p, drop_salt=3, drop_seed=seed.data_ptr())
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gm))
+    uf = x @ w1.t()
+    close(u, uf, BF, "u is not dropped")
+    ref = F.gelu(u.float().cpu())
+    keep = h.float().cpu() != 0
+    frac = 1 - keep.float().mean().item()
+    assert abs(frac - p) < 0.01, frac
+    close(h.float().cpu()[keep], (ref / (1 - p))[keep], 2 * BF, "kept activations are scaled by 1 / (1 - p)")
+    # backward: dh * gelu'(u) * mask / (1 - p), same seed / salt / indices
+    dh = rb(torch.randn(M, 256, generator=g(72)))
+    w2t = rb(torch.randn(1024, 256, generator=g(73)) * 0.1)   # [N = 1024, K = 256]: dgrad weight of fc2
+    du = torch.empty(M, 1024, dtype=torch.bfloat16, device=DEV)
+    dhd, w2d = dh.to(DEV).bfloat16(), w2t.to(DEV).bfloat16()
+    gd = ops.make_gemm_nt(A=dhd.data_ptr(), lda=256, a_kind=A_BF16, W=w2d.data_ptr(), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU,
+                          Cp=du.data_ptr(), ldc=1024, U=u.data_ptr(), ldu=1024, drop_p=p, drop_salt=3, drop_seed=seed.data_ptr())
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gd))
+    uu = u.float().cpu().requires_grad_(True)
+    F.gelu(uu).backward(torch.ones_like(uu))
+    want = (dh @ w2t.t()) * uu.grad * keep.float() / (1 - p)
+    close(du, want, 2 * BF, "du with the forward's mask")
+    assert torch.equal(du.float().cpu() != 0, keep & (want != 0)) or ((du.float().cpu() != 0) ^ keep).float().mean().item() < 1e-3
+    # a different seed gives a different mask
+    seed.fill_(777)
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gm))
+    assert ((h.float().cpu() != 0) ^ keep).float().mean().item() > 0.2
+    # RESID (K = 1024) drops the branch output; hma_dropout_bf16 re-creates that mask on a gradient
+    hh = rb(torch.randn(M, 1024, generator=g(74)) * 0.3)
+    w2 = rb(torch.randn(256, 1024, generator=g(75)) * 0.05)
+    xres = torch.zeros(M, 256, device=DEV)
+    hd, w2b = hh.to(DEV).bfloat16(), w2.to(DEV).bfloat16()
+    gr = ops.make_gemm_nt(A=hd.data_ptr(), lda=1024, a_kind=A_BF16, W=w2b.data_ptr(), ldw=1024, M=M, N=256, K=1024, epi=EPI_RESID,
+                          Cp=xres.data_ptr(), ldc=256, drop_p=p, drop_salt=8, drop_seed=seed.data_ptr())
+    _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gr))
+    y = hh @ w2.t()
+    k2 = xres.cpu() != 0
+    assert abs(1 - k2.float().mean().item() - p) < 0.01
+    close(xres.cpu()[k2], (y / (1 - p))[k2], 1e-4, "kept branch outputs")
+    gsrc = torch.randn(M, 256, generator=g(76))
+    gdst = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
+    _lib.call("hma_dropout_bf16", ops.stream_ptr(), gsrc.to(DEV).data_ptr(), gdst.data_ptr(), M, 256, p, seed.data_ptr(), 8)
+    assert torch.equal(gdst.float().cpu() != 0, k2 & (rb(gsrc / (1 - p)) != 0))
+    close(gdst, gsrc * k2.float() / (1 - p), BF, "masked gradient")

@@ -101,3 +101,35 @@ def test_mar_decode_matches_reference():
                      domain=["domA"] * 2, temperature=0.9)
     assert out.shape == (2, 3 * 1024, 4) and torch.isfinite(out).all()
     assert torch.equal(out[:, :1024].cpu(), D["prompt"][:, 0].reshape(2, 1024, 4))
+
+
+def test_mlp_dropout_trains_and_eval_is_deterministic():
+    """The shipped MAR config trains with mlp_drop = 0.05 (hma/configs/mar_n32_h8_d256_action.json): masks change per step in
+    training, nothing is dropped in eval, and the fixed-batch loss still falls."""
+    cfg = dict(CFG, mlp_drop=0.05)
+    m = STMAR(DiffusionGenieConfig(**cfg))
+    m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, CFG["action_network"])
+    m.load_state_dict(seeded_state(m.state_dict()))
+    m = m.to(DEV)
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    kw = dict(input_ids=inp["latents"], labels=inp["latents"], action_ids=inp["actions_domA"], domain=["domA"] * 2,
+              masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=inp["t"], diffusion_noise=inp["noise"])
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(**kw).loss.item(), m(**kw).loss.item()
+    # eval: no dropout -> the reference's (no-drop) value, repeatable up to the fp32 atomics order of the loss reduction
+    assert abs(e1 - e2) <= 2e-6 * abs(e1) and abs(e1 - G["loss"].item()) <= 2e-3 * abs(G["loss"].item())
+    m.train()
+    with torch.no_grad():
+        pass
+    l1 = m(**kw).loss.item()
+    l2 = m(**kw).loss.item()
+    assert abs(l1 - l2) > 1e-4 * abs(l1) and abs(l1 - e1) < 0.2 * abs(e1)       # different masks per forward, same ballpark
+    losses = []
+    for _ in range(6):
+        m.zero_grad()
+        out = m(**kw)
+        out.loss.backward()
+        m.optimizer_step(2e-3, "domA")
+        losses.append(out.loss.item())
+    assert min(losses[-2:]) < 0.9 * losses[0], losses
