@@ -1947,6 +1947,304 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
   PROF_FLUSH();
 }
 
+// ------------------------------------------------------------------------------- TN, LDS-DMA ring
+// bf16 x bf16 weight gradient whose operand tiles never pass through registers: `global_load_lds` (16 bytes per
+// lane, 1 KB per wave instruction) fills a ring of four 32-token stages ([32][256] bf16 of dY, then of A: 32 KB),
+// three stages in flight ahead of the MFMAs across raw s_barriers with counted vmcnt waits.  The register-staged
+// kernel above keeps one 64-token stage (64 KB per CU) in flight and exposes most of the HBM latency each iteration
+// (its time did not move when the staging transposes were replaced by row-major LDS tiles + 2-byte gathers).  The MFMA fragments
+// (8 tokens of one column per lane) come out of the row-major image with ds_read_b64_tr_b16 (TR) or eight 2-byte
+// reads (!TR, the reference gather).  LDS image of a tile: row r, 16-byte chunk c lives at chunk c ^ ((r & 3) << 2)
+// (the DMA writes lane-linear, so the permutation is applied to each lane's SOURCE address and again on the read):
+// the four rows of a transposing read then fall in four different 64-byte bank groups.
+// The LayerNorm affine of A is not applied here: tn_reduce_kernel finishes dW = gamma * (dY^T xhat) + colsum(dY) beta^T.
+constexpr int DM_ROWS = 32;
+constexpr int DM_TILE_BYTES = DM_ROWS * 512;
+constexpr int DM_STAGE_BYTES = 2 * DM_TILE_BYTES;
+#ifndef DM_STAGES_N
+#define DM_STAGES_N 4
+#endif
+constexpr int DM_STAGES = DM_STAGES_N;  // 4 x 32 KB (5 slots, the whole LDS, measured the same)
+constexpr int DM_SMEM_BYTES = DM_STAGES * DM_STAGE_BYTES;
+
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+#define HMA_LDS(T) __attribute__((address_space(3))) T
+
+__device__ __forceinline__ int dm_off(int row, int col) {  // byte offset of element (row, col) in a swizzled tile
+  return row * 512 + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + ((col & 7) << 1);
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from each lane's `src` to LDS bytes [dst, dst + 1024) in lane order.  Issued
+// from inline asm so that hipcc does not count it: with the builtin the compiler drains vmcnt(0) before the next LDS
+// read and nothing stays in flight.  The waits are the counted `s_waitcnt vmcnt(N)` in the loop below.
+__device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(dst)
+      : "memory");
+}
+
+// ABL (debug build only): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no partial stores, 16 no barrier
+template <bool TR, bool COLSUM, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(hma_gemm_tn_t p, int groups_n, int groups_k) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn2 = wave >> 2, wk4 = wave & 3;
+
+  const int G = gridDim.x;
+  const int b = blockIdx.x;
+  // workgroup b runs on XCD b & 7: give every XCD one contiguous run of virtual ids, so that the workgroups of one split
+  // (consecutive ids: the n / k groups that re-read the same rows of A or dY) share an L2 -- for any G
+  const int vid = (b & 7) * (G >> 3) + min(b & 7, G & 7) + (b >> 3);
+  const int groups = groups_n * groups_k;
+  const int per_batch = groups * p.splits;
+  const int64_t bz = vid / per_batch;
+  const int r0 = vid % per_batch;
+  const int split = r0 / groups, g = r0 % groups;
+  const int64_t n0 = (int64_t)(g / groups_k) * WT, k0 = (int64_t)(g % groups_k) * WT;
+
+  const int64_t slabs = (p.M + 63) / 64;
+  const int64_t per = (slabs + p.splits - 1) / p.splits;
+  const int64_t m_begin = (int64_t)split * per * 64;
+  int64_t m_end = m_begin + per * 64;
+  if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int nst = (int)((m_end - m_begin) / DM_ROWS);  // host guarantees M % 32 == 0
+
+  const uint16_t* Yb = reinterpret_cast<const uint16_t*>(p.dY) + bz * p.sY + n0;
+  const uint16_t* Ab = reinterpret_cast<const uint16_t*>(p.A) + bz * p.sA + k0;
+  float colsum = 0.f;
+  constexpr int ablate = ABL;
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+
+  // wave w fills rows 4 w .. 4 w + 3 of both tiles of a stage: two 1 KB pieces (two rows each) per tile
+  auto issue = [&](int st, int slot) __attribute__((always_inline)) {
+    if (ablate & 1) return;
+    const int64_t m0 = m_begin + (int64_t)st * DM_ROWS;
+    const uint32_t slot_b = lds_b + slot * DM_STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int rl = q * 2 + (lane >> 5);                 // row & 3 (4 w is a multiple of 4)
+      const int lc = (lane & 31) ^ (rl << 2);             // logical chunk that lands in this lane's slot
+      const int64_t m = m0 + wave * 4 + rl;
+      const uint16_t* ys = Yb + m * p.ldy + lc * 8;  // host: no row groups on this path
+      const uint16_t* as = Ab + m * p.lda + lc * 8;
+      glds16(ys, slot_b + (wave * 4 + q * 2) * 512);
+      glds16(as, slot_b + DM_TILE_BYTES + (wave * 4 + q * 2) * 512);
+    }
+  };
+
+  const int r = lane & 31, hi = lane >> 5;
+  const int i16 = lane & 15, g16 = lane >> 4;
+  // fragment: tokens 16 kk + 8 hi .. + 7 of column c0 + r of the tile at `tile`
+  auto frag = [&](HMA_LDS(char)* tile, int c0, int kk) __attribute__((always_inline)) {
+    if (ablate & 4) return __builtin_bit_cast(bf16x8_t, make_uint4(c0, kk, c0, kk));
+    if (TR) {
+      // a 16-lane group reads a [4 token][16 column] block: lane i supplies row i >> 2, columns 4 (i & 3) .. + 3 and
+      // receives column i of the block's 4 rows (tools/probes/tr_read_dma.hip)
+      const int col = c0 + 16 * (g16 & 1) + 4 * (i16 & 3);
+      const int row = kk * 16 + 8 * hi + (i16 >> 2);
+      const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + dm_off(row, col)));
+      const v4s16_t hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + dm_off(row + 4, col)));
+      typedef short v8s16_t __attribute__((ext_vector_type(8)));
+      const v8s16_t v = __builtin_shufflevector(lo, hv, 0, 1, 2, 3, 4, 5, 6, 7);
+      return __builtin_bit_cast(bf16x8_t, v);
+    } else {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const uint32_t x0 = *(HMA_LDS(uint16_t)*)(tile + dm_off(kk * 16 + 8 * hi + e, c0 + r));
+        const uint32_t x1 = *(HMA_LDS(uint16_t)*)(tile + dm_off(kk * 16 + 8 * hi + e + 1, c0 + r));
+        w[e >> 1] = x0 | (x1 << 16);
+      }
+      return __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+  };
+
+  struct Frags {
+    bf16x8_t y[4], a[2];
+  };
+  auto read_frags = [&](Frags& f, int slot, int kk) __attribute__((always_inline)) {
+    HMA_LDS(char)* Ys = lds + slot * DM_STAGE_BYTES;
+    HMA_LDS(char)* As = Ys + DM_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.y[i] = frag(Ys, wn2 * 128 + i * 32, kk);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.a[j] = frag(As, wk4 * 64 + j * 32, kk);
+  };
+  auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+    if (COLSUM) {
+      // the four waves of a wn2 half hold the same dY fragments: wave wk4 sums fragment wk4 (columns 32 wk4 + r)
+      uint4 ys = __builtin_bit_cast(uint4, f.y[0]);
+#pragma unroll
+      for (int i = 1; i < 4; ++i) {
+        const uint4 yi = __builtin_bit_cast(uint4, f.y[i]);
+        ys.x = wk4 == i ? yi.x : ys.x; ys.y = wk4 == i ? yi.y : ys.y;
+        ys.z = wk4 == i ? yi.z : ys.z; ys.w = wk4 == i ? yi.w : ys.w;
+      }
+      float v[8];
+      unpack8(ys, v);
+      colsum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (ablate & 2)
+          acc[i][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f.a[j]).x ^ __builtin_bit_cast(uint4, f.y[i]).y);
+        else
+          acc[i][j] = mfma32(f.a[j], f.y[i], acc[i][j]);  // D rows = k, D cols = n
+      }
+  };
+  // wait until this wave's pieces of stage st have landed: the pieces of the later stages issued so far (4 per stage, at
+  // most `behind` stages) may stay outstanding
+  auto wait_stage = [&](int st, int behind) __attribute__((always_inline)) {
+    int later = nst - 1 - st;
+    later = later < behind ? later : behind;
+    if (later >= 3)
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // (A software-pipelined variant -- fragments read half a stage ahead, barrier in the middle of the stage -- measured
+  // 10 % slower: it needs stage st + 1 landed half a stage earlier, and the DMA depth is what this loop lives on.)
+#pragma unroll
+  for (int st = 0; st < DM_STAGES - 1; ++st)
+    if (st < nst) issue(st, st);
+  Frags f0, f1;
+  int slot = 0;
+  for (int st = 0; st < nst; ++st) {
+    wait_stage(st, DM_STAGES - 2);
+    // every wave's pieces of stage st are in LDS, and every wave is done reading stage st - 1 (its slot is refilled next)
+    if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
+    read_frags(f0, slot, 0);
+    read_frags(f1, slot, 1);
+    mma(f0);
+    // the refill goes behind the first eight MFMAs: its address generation and issue overlap the matrix pipe
+    if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
+    mma(f1);
+    slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
+  }
+  // bf16 partial of this workgroup's 256 x 256 block, in the order the accumulators sit in the waves: piece
+  // ((wave * 8 + i * 2 + j) * 2 + h) * 64 + lane is the lane's 8 values e = 8 h .. 8 h + 7 of acc[i][j], i.e. row
+  // n = 128 wn2 + 32 i + r, columns k = 64 wk4 + 32 j + 16 h + 4 hi + {0..3} and the same + 8 (tn_reduce_native_kernel
+  // decodes this).  Every store instruction writes 1 KB contiguous; the row-major layout of the register-staged
+  // kernels (32 rows x 32 B per instruction) cost 17-22 us per call for these 32 MB (ablation in profiles/).
+  uint16_t* part = reinterpret_cast<uint16_t*>(p.ws) + (int64_t)vid * (WT * WT);
+  if (!(ablate & 8))
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x16_t& v = acc[i][j];
+          const uint4 o = make_uint4(pack_bf16(v[8 * h], v[8 * h + 1]), pack_bf16(v[8 * h + 2], v[8 * h + 3]),
+                                     pack_bf16(v[8 * h + 4], v[8 * h + 5]), pack_bf16(v[8 * h + 6], v[8 * h + 7]));
+          *reinterpret_cast<uint4*>(part + ((((wave * 8 + i * 2 + j) * 2 + h) * 64 + lane) << 3)) = o;
+        }
+  if (COLSUM && k0 == 0) {
+    colsum += __shfl_xor(colsum, 32);
+    if (hi == 0) p.ws[(int64_t)gridDim.x * (WT * WT) + (int64_t)vid * WT + wn2 * 128 + wk4 * 32 + r] = colsum;
+  }
+}
+
+// Sum of the LDS-DMA kernel's partials (layout: see its epilogue) into dW.  One block per 32 pieces (512 B of every
+// split's partial): the 8 half-waves take every 8th split, 16 bytes per lane; 256 blocks per 256 x 256 output block.
+// affine != 0: dW += gamma[k] * P[n][k] + beta[k] * colsum(dY)[n] (the LayerNorm affine of A, which the DMA kernel cannot
+// apply on the way into LDS); colsum comes from the bias partials of the n-block's k0 == 0 group.
+__global__ __launch_bounds__(256) void tn_reduce_native_kernel(hma_gemm_tn_t p, int groups_n, int groups_k, int affine) {
+  __shared__ float red[8][32][8];
+  __shared__ float csum[8][32];
+  const int groups = groups_n * groups_k;
+  const int g = blockIdx.y % groups;
+  const int64_t bz = blockIdx.y / groups;
+  const int64_t n0 = (int64_t)(g / groups_k) * WT, k0 = (int64_t)(g % groups_k) * WT;
+  const int tid = threadIdx.x, r = tid & 31, sl = tid >> 5;  // sl: split lane 0..7
+  const int grp = blockIdx.x >> 1, hi = blockIdx.x & 1;      // 1 KB group of 64 pieces, and which half of it
+  const int h = grp & 1, j = (grp >> 1) & 1, i = (grp >> 2) & 3, wave = grp >> 4;
+  const int wn2 = wave >> 2, wk4 = wave & 3;
+  const int nl = wn2 * 128 + i * 32 + r;
+  const int kl = wk4 * 64 + j * 32 + 16 * h + 4 * hi;  // this piece: columns kl .. kl + 3 and kl + 8 .. kl + 11
+  const int64_t nblocks = (int64_t)p.splits * groups * (p.batch > 0 ? p.batch : 1);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint16_t* base = reinterpret_cast<const uint16_t*>(p.ws) + (bz * p.splits * groups + g) * (int64_t)(WT * WT) +
+                         ((grp * 64 + hi * 32 + r) << 3);
+#pragma unroll 8
+  for (int sp = sl; sp < p.splits; sp += 8) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(base + (int64_t)sp * groups * (WT * WT)), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[sl][r][e] = acc[e];
+  if (affine) {
+    const int g0 = (g / groups_k) * groups_k;
+    const float* bp = p.ws + nblocks * (WT * WT) + (bz * p.splits * groups + g0) * (int64_t)WT + nl;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int sp = sl; sp < p.splits; sp += 8) sum += bp[(int64_t)sp * groups * WT];
+    csum[sl][r] = sum;
+  }
+  __syncthreads();
+  if (tid < 64) {  // lanes 0-31 finish columns kl .. kl + 3, lanes 32-63 kl + 8 .. kl + 11
+    const int qd = tid >> 5;
+    const int kk = kl + 8 * qd;
+    float4* dst = reinterpret_cast<float4*>(p.dW + bz * p.sdW + (n0 + nl) * p.lddw + k0 + kk);
+    float4 o = *dst;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      t.x += red[q][r][4 * qd]; t.y += red[q][r][4 * qd + 1]; t.z += red[q][r][4 * qd + 2]; t.w += red[q][r][4 * qd + 3];
+    }
+    if (affine) {
+      const float4 gm = *reinterpret_cast<const float4*>(p.gamma + k0 + kk);
+      const float4 bt = *reinterpret_cast<const float4*>(p.beta + k0 + kk);
+      float cs = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cs += csum[q][r];
+      t.x = gm.x * t.x + bt.x * cs; t.y = gm.y * t.y + bt.y * cs; t.z = gm.z * t.z + bt.z * cs; t.w = gm.w * t.w + bt.w * cs;
+    }
+    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    *dst = o;
+  }
+  // bias gradient: blocks 0..7 of a k0 == 0 group sum the column-sum partials of columns 32 x .. 32 x + 31
+  if (p.dBias && k0 == 0 && blockIdx.x < 8) {
+    __syncthreads();
+    const int col = blockIdx.x * 32 + r;
+    const float* bp = p.ws + nblocks * (WT * WT) + (bz * p.splits * groups + g) * (int64_t)WT + col;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int sp = sl; sp < p.splits; sp += 8) sum += bp[(int64_t)sp * groups * WT];
+    csum[sl][r] = sum;
+    __syncthreads();
+    if (tid < 32) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tot += csum[q][r];
+      p.dBias[bz * p.sdBias + n0 + col] += tot;
+    }
+  }
+}
+
 // dW[bz][n0 + nl][k0 + kl] += sum over splits of ws[((bz * splits + s) * groups + g)][nl][kl]
 // 128 workgroups per 256 x 256 block: 64 lanes x 8 outputs each, the splits dealt over the 4 waves.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int groups_n, int groups_k) {
@@ -1980,8 +2278,8 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int gro
     }
     *dst = o;
   }
-  // bias partials (written when the workspace has room for them): one block per group sums them
   const int64_t nblocks = (int64_t)p.splits * groups * (p.batch > 0 ? p.batch : 1);
+  // bias partials (written when the workspace has room for them): one block per group sums them
   if (p.dBias && k0 == 0 && blockIdx.x < 4 && p.ws_elems >= nblocks * (WT * WT + WT)) {
     // block x sums columns 64 x .. 64 x + 63; its 4 waves take every 4th split (independent loads), then LDS
     __syncthreads();
@@ -2254,6 +2552,46 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     const int64_t per = (slabs + splits - 1) / splits;
     if (q.ws && (q.ws_elems < (int64_t)nblocks * WT * WT || per * (splits - 1) >= slabs || splits == 1)) q.ws = nullptr;
     const dim3 rgrid((unsigned)(WT * WT / 512), (unsigned)(gn * gk * nb));
+    // bf16 x bf16 with a workspace: the LDS-DMA ring kernel (HMA_GEMM_TN_DMA=0 falls back to the register-staged kernel,
+    // =u16 selects the 2-byte reference gather instead of the transposing LDS read)
+    static const char* tn_dma_env = getenv("HMA_GEMM_TN_DMA");
+    static const char* tn_dma = tn_dma_env ? tn_dma_env : "tr";
+    const bool bias_room = q.ws && q.ws_elems >= (int64_t)nblocks * (WT * WT + WT);
+    if (tn_dma[0] != '0' && q.ws && q.y_kind == HMA_A_BF16 && (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE) &&
+        q.M % DM_ROWS == 0 && q.y_group_rows <= 0 && q.a_group_rows <= 0 && q.ldy % 8 == 0 && q.lda % 8 == 0 && q.sY % 8 == 0 && q.sA % 8 == 0 &&
+        (reinterpret_cast<uintptr_t>(q.dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.A) & 15) == 0 &&
+        (bias_room || (!q.dBias && q.a_kind == HMA_A_BF16))) {
+      const int affine = q.a_kind == HMA_A_BF16_AFFINE;
+      const int want_colsum = (q.dBias != nullptr) || affine;
+#define HMA_TND_LAUNCH(TR, CS)                                                                       \
+  {                                                                                                   \
+    if ((rc = set_smem_bytes<gemm_tn_dma_kernel<TR, CS>>(DM_SMEM_BYTES))) return rc;                  \
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<TR, CS>), wgrid, dim3(512), DM_SMEM_BYTES, s, q, gn, gk);  \
+  }
+#ifdef HMA_PROF
+#define HMA_TND_ABL(A)                                                                                        \
+  case A:                                                                                                     \
+    if ((rc = set_smem_bytes<gemm_tn_dma_kernel<true, true, A>>(DM_SMEM_BYTES))) return rc;                   \
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<true, true, A>), wgrid, dim3(512), DM_SMEM_BYTES, s, q, gn, gk);   \
+    break;
+      if (tn_ablate) {
+        switch (tn_ablate) {
+          HMA_TND_ABL(1) HMA_TND_ABL(2) HMA_TND_ABL(4) HMA_TND_ABL(8) HMA_TND_ABL(16) HMA_TND_ABL(6) HMA_TND_ABL(7) HMA_TND_ABL(15)
+          HMA_TND_ABL(3) HMA_TND_ABL(9) HMA_TND_ABL(24)
+          default: return HMA_EINVAL;
+        }
+      } else
+#endif
+      if (tn_dma[0] == 'u') {
+        if (want_colsum) HMA_TND_LAUNCH(false, true) else HMA_TND_LAUNCH(false, false)
+      } else {
+        if (want_colsum) HMA_TND_LAUNCH(true, true) else HMA_TND_LAUNCH(true, false)
+      }
+      HMA_CHECK_LAUNCH();
+      hipLaunchKernelGGL(tn_reduce_native_kernel, dim3((unsigned)(WT * WT / 256), rgrid.y), dim3(256), 0, s, q, gn, gk, affine);
+      HMA_CHECK_LAUNCH();
+      return 0;
+    }
 #define HMA_TNW_CASE(YK, AK)                                                                        \
   if (q.y_kind == YK && q.a_kind == AK) {                                                            \
     if ((rc = set_smem_bytes<gemm_tn_wide_kernel<YK, AK>>(W_SMEM_BYTES))) return rc;                 \

@@ -170,6 +170,36 @@ def test_gemm_tn(M, N, K, splits):
     close(db, 1 + dy.sum(0), 2e-5, "dbias via small workspace")
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 256, 256), (96, 256, 256), (4096, 256, 256), (2080, 768, 256), (8192, 1024, 256),
+                                   (4000 * 32, 256, 1024), (16384, 256, 768)])
+def test_gemm_tn_ring(M, N, K):
+    """bf16 x bf16 wgrads with a workspace and M % 32 == 0 take the LDS-DMA ring kernel (gemm_tn_dma_kernel): plain,
+    with the bias gradient, and with the LayerNorm affine that the reduction kernel applies afterwards."""
+    dy = rb(torch.randn(M, N, generator=g(30)) * 0.5)
+    x = rb(torch.randn(M, K, generator=g(31)))
+    dyd, xd = dy.to(DEV).bfloat16(), x.to(DEV).bfloat16()
+    ws = torch.full((256 * (65536 + 256),), float("nan"), device=DEV)
+    ref = (dy.double().t() @ x.double()).float()
+    dW = torch.ones(N, K, device=DEV)
+    db = torch.ones(N, device=DEV)
+    ops.linear_wgrad(dyd, xd, dW, db, ws=ws)
+    close(dW, 1 + ref, BF, "dW ring")
+    close(db, 1 + dy.double().sum(0).float(), 2e-5, "dbias ring")
+    dW.fill_(-2.0)
+    ops.linear_wgrad(dyd, xd, dW, None, ws=ws)
+    close(dW, ref - 2, BF, "dW ring, no bias")
+    gam = torch.randn(K, generator=g(32)) * 0.2 + 1
+    bet = torch.randn(K, generator=g(33)) * 0.2
+    refa = (dy.double().t() @ (x.double() * gam.double() + bet.double())).float()
+    dW.fill_(0.5); db.fill_(0.25)
+    ops.linear_wgrad(dyd, xd, dW, db, gamma=gam.to(DEV), beta=bet.to(DEV), ws=ws)
+    close(dW, 0.5 + refa, BF, "dW ring affine")
+    close(db, 0.25 + dy.double().sum(0).float(), 2e-5, "dbias ring affine")
+    dW.fill_(0.5)
+    ops.linear_wgrad(dyd, xd, dW, None, gamma=gam.to(DEV), beta=bet.to(DEV), ws=ws)
+    close(dW, 0.5 + refa, BF, "dW ring affine, no bias")
+
+
 def test_gemm_tn_remap_and_batch():
     frames, S, SA, N, K = 3, 64, 80, 128, 256
     dy = rb(torch.randn(frames * S, N, generator=g(26)))

@@ -60,7 +60,7 @@ case("dqkv", lambda i: ops.linear(qkv[i], wk768, None, epi=EPI_RESID, out=x32[i]
 case("dprj", lambda i: ops.linear(x32[i], w256, None, epi=EPI_BF16, out=o256[i]), 2.0 * M * 256 * 256)
 case("modlin", lambda i: ops.linear(xh[i], w256, b256, epi=EPI_RESID, out=x32[i], out2=o256[i]), 2.0 * M * 256 * 256)
 
-WS = torch.empty(256 * 65536, device=dev)
+WS = torch.empty(256 * (65536 + 256), device=dev)
 def tn(dy, x, N, K, bias=True, gamma=None, beta=None):
     dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev) if bias else None
     return lambda i: ops.linear_wgrad(dy[i], x[i], dW, db, gamma=gamma, beta=beta, ws=WS)
@@ -68,6 +68,12 @@ case("w_proj", tn(x32, xh, 256, 256), 2.0 * M * 256 * 256)
 case("w_fc2", tn(x32, h, 256, 1024), 2.0 * M * 256 * 1024)
 case("w_fc1", tn(u, xh, 1024, 256, gamma=g, beta=b), 2.0 * M * 256 * 1024)
 case("w_qkv", tn(qkv, xh, 768, 256, bias=False), 2.0 * M * 256 * 768)
+# bf16 dY as the engine issues the layer wgrads (LDS-DMA ring kernel with HMA_GEMM_TN_DMA=tr: marks are
+# prologue / issue / reads+mfma / epilogue / vmcnt wait / barrier)
+case("wb_proj", tn(o256, xh, 256, 256), 2.0 * M * 256 * 256)
+case("wb_qkv", tn(qkv, xh, 768, 256, bias=False), 2.0 * M * 256 * 768)
+case("wb_fc1", tn(u, xh, 1024, 256, gamma=g, beta=b), 2.0 * M * 256 * 1024)
+case("wb_fc2", tn(o256, h, 256, 1024), 2.0 * M * 256 * 1024)
 
 names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(cases)
 PH = ["loop/prologue", "issue-loads", "lds+mfma", "epilogue", "wait+lds-store", "barrier", "acc-copy", "-"]
