@@ -2294,6 +2294,254 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int gro
   }
 }
 
+// ------------------------------------------------------------------------------- NT, LDS-DMA ring (K > 256, N = 256)
+// C[m][0..255] = A[m][:] . W[0..255][:]^T for the deep-K layer GEMMs (fc2, dfc1, dqkv: K = 768 / 1024).  The lock-step
+// kernel above re-streams the 256 x K weight slab through each CU's vector-memory path once per 128 token rows, and that
+// path (~11-12 B/clk per CU, L2 hits included) is what bounds it.  Here a workgroup owns a contiguous run of token rows
+// and works through it in 256-row tiles (half the weight re-reads per row), both operands arriving by LDS-DMA in 32-deep
+// K stages ([256][32] bf16 of A, then of W: 32 KB, four-slot ring, three stages in flight) that keep streaming across
+// tile boundaries, so the next tile's first stages land while this tile's epilogue runs.  Rows are 64 B in LDS; 16-byte
+// chunk c of row r sits at chunk c ^ ((r >> 2) & 3) (applied to the DMA source address and again on the read), which
+// makes the ds_read_b128 fragment reads conflict-free.  Accumulators and epilogue as gemm_nt_p3_kernel (a lane owns one
+// token row and runs of 4 output columns).
+constexpr int NR_TILE_BYTES = 256 * 64;           // one operand's K stage
+constexpr int NR_STAGE_BYTES = 2 * NR_TILE_BYTES;  // A then W
+constexpr int NR_STAGES = 4;
+constexpr int NR_SMEM_BYTES = NR_STAGES * NR_STAGE_BYTES;  // 128 KB
+
+// ABL (debug build only): 1 no A DMA, 2 no W DMA, 4 no epilogue memory traffic, 8 no MFMA
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, int64_t chunk) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int vid = (b & 7) * (G >> 3) + min(b & 7, G & 7) + (b >> 3);  // contiguous row runs per XCD
+  const int64_t m_begin = (int64_t)vid * chunk;
+  int64_t m_end = m_begin + chunk;
+  if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int KT = (int)(p.K >> 5);
+  // Every other workgroup starts with a 128-row tile: neighbouring CUs are then half a tile out of phase, and one's
+  // epilogue (residual read + write, HBM) overlaps the other's K loop instead of the whole chip alternating between the two.
+  const int64_t first = ((vid & 1) && m_end - m_begin > 128) ? 128 : 256;
+  const int64_t rest = m_end - m_begin - first;
+  const int ntiles = 1 + (rest > 0 ? (int)((rest + 255) >> 8) : 0);
+  const int nst = ntiles * KT;
+
+  const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A);
+  const uint16_t* W = reinterpret_cast<const uint16_t*>(p.W);
+  // DMA pieces of this wave: rows 32 wave + 16 q + (lane >> 2) of both tiles, q = 0, 1
+  const int prow = wave * 32 + (lane >> 2);
+  // issue cursor (runs three stages ahead of the compute cursor)
+  int i_kt = 0;
+  int64_t i_m0 = m_begin, i_end = m_begin + first < m_end ? m_begin + first : m_end;
+  const uint16_t* a_src[2];
+  const uint16_t* w_src[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = prow + 16 * q;
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    w_src[q] = W + (int64_t)row * p.ldw + c * 8;
+  }
+  auto set_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = prow + 16 * q;
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      int64_t m = i_m0 + row;
+      m = m < i_end ? m : i_end - 1;  // rows past the tile are clamped (their outputs are never stored)
+      a_src[q] = A + m * p.lda + c * 8;
+    }
+  };
+  set_tile();
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    const uint32_t sb = lds_b + slot * NR_STAGE_BYTES + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!(ABL & 1)) glds16(a_src[q] + i_kt * 32, sb + q * 1024);
+      if (!(ABL & 2)) glds16(w_src[q] + i_kt * 32, sb + NR_TILE_BYTES + q * 1024);
+    }
+    if (++i_kt == KT) {
+      i_kt = 0;
+      i_m0 = i_end;
+      i_end = i_m0 + 256 < m_end ? i_m0 + 256 : m_end;
+      if (i_m0 >= m_end) i_m0 = m_end - 1, i_end = m_end;  // (no tile follows: nothing more is issued)
+      set_tile();
+    }
+  };
+
+  f32x16_t acc[4][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+  };
+  zero_acc();
+
+  const int lr = lane & 31, lhi = lane >> 5;
+  // fragment of row `row` of a tile: k = 16 kk + 8 lhi .. + 7
+  auto frag = [&](HMA_LDS(char)* tile, int row, int kk) __attribute__((always_inline)) {
+    const int c = (kk * 2 + lhi) ^ ((row >> 2) & 3);
+    return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(uint4)*)(tile + row * 64 + c * 16));
+  };
+  auto wait_stage = [&](int st) __attribute__((always_inline)) {
+    const int later = nst - 1 - st;
+    if (later >= 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+#pragma unroll
+  for (int st = 0; st < NR_STAGES - 1; ++st)
+    if (st < nst) issue(st);
+  int kt = 0;
+  int64_t m0 = m_begin, t_end = m_begin + first < m_end ? m_begin + first : m_end;
+  for (int st = 0; st < nst; ++st) {
+    const int slot = st & (NR_STAGES - 1);
+    wait_stage(st);
+    // every wave's pieces of stage st are in LDS, and every wave is done reading stage st - 1 (its slot is refilled below)
+    __builtin_amdgcn_s_barrier();
+    HMA_LDS(char)* As = lds + slot * NR_STAGE_BYTES;
+    HMA_LDS(char)* Ws = As + NR_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[4], wf[2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = frag(As, wm * 128 + mt * 32 + lr, kk);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[nt] = frag(Ws, wn * 64 + nt * 32 + lr, kk);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (ABL & 8)
+            acc[mt][nt][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, wf[nt]).x ^ __builtin_bit_cast(uint4, af[mt]).y);
+          else
+            acc[mt][nt] = mfma32(wf[nt], af[mt], acc[mt][nt]);  // D rows = n, D cols = token
+        }
+      if (kk == 0 && st + NR_STAGES - 1 < nst) issue((st + NR_STAGES - 1) & (NR_STAGES - 1));
+    }
+    if (++kt == KT) {
+      // tile done: epilogue (the ring keeps filling with the next tile's stages meanwhile)
+      const float* bias = p.bias;
+      if (EPI == HMA_EPI_RESID) {
+        // The residual rows come from HBM: all 16 float4 loads of a 64-row half are issued before the first add (16 KB
+        // per wave in flight).  One 32-byte round trip per accumulator pair, as epilogue_oct does it, left the tile
+        // epilogue latency-bound: 70 us of fc2's 178 us (ablation in profiles/).
+        float* Cb = reinterpret_cast<float*>(p.C);
+        const uint32_t seed = p.drop_p > 0.f ? *p.drop_seed : 0u;
+        const uint32_t th = drop_thresh(p.drop_p);
+        const float sc = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float4 x[2][2][2][2];
+          int64_t off[2], crow[2];
+          bool ok[2];
+#pragma unroll
+          for (int ml = 0; ml < 2; ++ml) {
+            int64_t m = m0 + wm * 128 + (half * 2 + ml) * 32 + lr;
+            ok[ml] = m < t_end;
+            m = ok[ml] ? m : t_end - 1;  // clamped, never stored
+            crow[ml] = remap_row(m, p.c_group_rows, p.c_group_stride);
+            off[ml] = crow[ml] * p.ldc;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int gi = 0; gi < 2; ++gi) {
+                const float* c = Cb + off[ml] + wn * 64 + nt * 32 + 16 * gi + 4 * lhi;
+                x[ml][nt][gi][0] = *reinterpret_cast<const float4*>(c);
+                x[ml][nt][gi][1] = *reinterpret_cast<const float4*>(c + 8);
+              }
+          }
+#pragma unroll
+          for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int gi = 0; gi < 2; ++gi) {
+                const int mt = half * 2 + ml, g2 = 2 * gi;
+                const int64_t nq = wn * 64 + nt * 32;
+                float v0[4], v1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v0[e] = (ABL & 4) ? 0.f : acc[mt][nt][4 * g2 + e];
+                  v1[e] = (ABL & 4) ? 0.f : acc[mt][nt][4 * g2 + 4 + e];
+                }
+                if (bias) {
+                  const float4 b0 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 4 * lhi);
+                  const float4 b1 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 8 + 4 * lhi);
+                  v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+                  v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+                }
+                if (p.drop_p > 0.f) {  // Dropout on the branch output before the residual add (st_transformer.py:26)
+                  const int64_t e0 = off[ml] + nq + 8 * g2 + 4 * lhi;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    v0[e] = drop_keep(seed, p.drop_salt, e0 + e, th) ? v0[e] * sc : 0.f;
+                    v1[e] = drop_keep(seed, p.drop_salt, e0 + 8 + e, th) ? v1[e] * sc : 0.f;
+                  }
+                }
+                float4 x0 = x[ml][nt][gi][0], x1 = x[ml][nt][gi][1];
+                x0.x += v0[0]; x0.y += v0[1]; x0.z += v0[2]; x0.w += v0[3];
+                x1.x += v1[0]; x1.y += v1[1]; x1.z += v1[2]; x1.w += v1[3];
+                if (ok[ml] && !(ABL & 4)) {
+                  float* c = Cb + off[ml] + nq + 8 * g2 + 4 * lhi;
+                  *reinterpret_cast<float4*>(c) = x0;
+                  *reinterpret_cast<float4*>(c + 8) = x1;
+                  if (p.C2) {
+                    const float ca[4] = {x0.x, x0.y, x0.z, x0.w}, cb[4] = {x1.x, x1.y, x1.z, x1.w};
+                    store_bf16_oct(reinterpret_cast<uint16_t*>(p.C2) + crow[ml] * p.ldc2 + nq, g2, lhi, ca, cb);
+                  }
+                }
+              }
+        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int64_t m = m0 + wm * 128 + mt * 32 + lr;
+          if (m < t_end) {
+            const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int64_t nq = wn * 64 + nt * 32;
+#pragma unroll
+              for (int g2 = 0; g2 < 4; g2 += 2) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v0[e] = acc[mt][nt][4 * g2 + e];
+                  v1[e] = acc[mt][nt][4 * g2 + 4 + e];
+                }
+                if (bias) {
+                  const float4 b0 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 4 * lhi);
+                  const float4 b1 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 8 + 4 * lhi);
+                  v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+                  v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+                }
+                if (!(ABL & 4) || v0[0] + v1[3] == 1.2345e-30f) epilogue_oct<EPI>(p, 0, crow, nq, g2, lhi, v0, v1);
+              }
+            }
+          }
+        }
+      }
+      zero_acc();
+      kt = 0;
+      m0 = t_end;
+      t_end = m0 + 256 < m_end ? m0 + 256 : m_end;
+    }
+  }
+}
+
 template <auto Kern>
 int set_smem_bytes(int bytes) {
   static bool done = false;
@@ -2402,6 +2650,36 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       HMA_NTW_ALL(HMA_A_BF16)
       HMA_NTW_ALL(HMA_A_F32)
       HMA_NTW_ALL(HMA_A_BF16_AFFINE)
+    }
+    // deep-K, N = 256, plain bf16 operands: the LDS-DMA ring kernel (HMA_GEMM_NT_RING=0 disables)
+    static const bool nt_ring = !(getenv("HMA_GEMM_NT_RING") && getenv("HMA_GEMM_NT_RING")[0] == '0');
+    if (nt_ring && !use_p1 && !use_p2 && p->K > 256 && (p->K & 31) == 0 && p->N == 256 && p->a_kind == HMA_A_BF16 &&
+        (p->batch <= 1) && p->a_group_rows <= 0 && (p->epi == HMA_EPI_BF16 || p->epi == HMA_EPI_RESID) &&
+        (p->lda & 7) == 0 && (p->ldw & 7) == 0 && (reinterpret_cast<uintptr_t>(p->A) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(p->W) & 15) == 0 && p->M >= 256) {
+      int64_t chunk = (p->M + n_cu - 1) / n_cu;
+      chunk = (chunk + 31) & ~(int64_t)31;
+      const unsigned g = (unsigned)((p->M + chunk - 1) / chunk);
+#ifdef HMA_PROF
+#define HMA_NTR_ABL(EP, A)                                                                            \
+  if (p->epi == EP && ablate == A) {                                                                  \
+    if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP, A>>(NR_SMEM_BYTES))) return rc;                  \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<EP, A>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk); \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+#define HMA_NTR_ABLS(EP) HMA_NTR_ABL(EP, 1) HMA_NTR_ABL(EP, 2) HMA_NTR_ABL(EP, 3) HMA_NTR_ABL(EP, 4) HMA_NTR_ABL(EP, 8) \
+  HMA_NTR_ABL(EP, 7) HMA_NTR_ABL(EP, 12) HMA_NTR_ABL(EP, 11) HMA_NTR_ABL(EP, 15)
+      HMA_NTR_ABLS(HMA_EPI_BF16) HMA_NTR_ABLS(HMA_EPI_RESID)
+#endif
+#define HMA_NTR_CASE(EP)                                                                              \
+  if (p->epi == EP) {                                                                                 \
+    if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP>>(NR_SMEM_BYTES))) return rc;                     \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<EP>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk);   \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
+      HMA_NTR_CASE(HMA_EPI_BF16) HMA_NTR_CASE(HMA_EPI_RESID)
     }
     // K > 256 streaming variant (weights double-buffered through LDS in 128-wide pieces): measured EQUAL to the
     // lock-step kernel in situ (fc2 / dqkv-resid 177 vs 182 us, dfc1 / dqkv 109 vs 110 us; 113.5 ms/step both ways) --

@@ -100,6 +100,38 @@ def test_gemm_nt_epilogues():
     close(acc, 1 + (lin - b), 1e-5, "atomic")
 
 
+@pytest.mark.parametrize("M,K", [(256, 1024), (384, 768), (1000, 1024), (8192 + 40, 768), (70000, 512)])
+def test_gemm_nt_ring(M, K):
+    """Deep-K, N = 256 GEMMs with plain bf16 operands take the LDS-DMA ring kernel (gemm_nt_ring_kernel): bf16 output,
+    residual accumulate with bias, bf16 copy and a remapped output; partial tiles and uneven row runs."""
+    N = 256
+    x = rb(torch.randn(M, K, generator=g(40)))
+    w = rb(torch.randn(N, K, generator=g(41)) * 0.1)
+    b = torch.randn(N, generator=g(42))
+    xd, wd = x.to(DEV).bfloat16(), w.to(DEV).bfloat16()
+    lin = (x.double() @ w.double().t()).float()
+    y = ops.linear(xd, wd, None, epi=EPI_BF16)
+    close(y, lin, BF, "ring bf16 out")
+    assert (y.float().cpu() - lin).abs().max() < (y.float().cpu() - lin.flip(0)).abs().max()
+    res = torch.randn(M, N, generator=g(43))
+    out = res.to(DEV).clone()
+    out2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.linear(xd, wd, b.to(DEV), epi=EPI_RESID, out=out, out2=out2)
+    close(out, res + lin + b, 1e-5, "ring resid")
+    close(out2, res + lin + b, BF, "ring resid bf16 copy")
+    # output rows remapped into (S + A)-row frames
+    if M % 64 == 0:
+        S, SA = 64, 80
+        frames = M // S
+        outr = torch.zeros(frames * SA, N, device=DEV)
+        gm = ops.make_gemm_nt(A=xd.data_ptr(), lda=K, a_kind=A_BF16, W=wd.data_ptr(), ldw=K, M=M, N=N, K=K, epi=EPI_RESID,
+                              Cp=outr.data_ptr(), ldc=N, c_group=(S, SA))
+        _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(gm))
+        full = torch.zeros(frames, SA, N)
+        full[:, :S] = lin.reshape(frames, S, N)
+        close(outr, full.reshape(-1, N), 1e-5, "ring c remap")
+
+
 def test_gemm_nt_row_remap_and_batch():
     # A rows sliced out of (S + A)-row frames, C written back remapped
     frames, S, SA, K, N = 3, 64, 80, 256, 128

@@ -4,7 +4,10 @@ import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hma_amd import _lib, ops
+from hma_amd import _lib
+if os.environ.get("HMA_DEBUG_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["HMA_DEBUG_LIB"])
+from hma_amd import ops
 from hma_amd._lib import *
 
 dev = "cuda"
