@@ -90,6 +90,7 @@ _PROTOS = {
     "hma_maskgit_collate": [c_vp, c_vp, c_vp, c_vp, C.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp],
     "hma_dropout_bf16": [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_i32],
     "hma_transpose_cast_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64],
+    "hma_fold_ln_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64],
     "hma_abi_version": [],
 }
 

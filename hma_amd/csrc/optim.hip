@@ -146,6 +146,43 @@ extern "C" int hma_transpose_cast_bf16(void* stream, const float* src, void* dst
   return 0;
 }
 
+// One wave per weight row: Wf[n][:] = bf16(W[n][:] * gamma), bf[n] = bias[n] + W[n][:] . beta  (cols a multiple of 4)
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      uint16_t* __restrict__ Wf, float* __restrict__ bf, int rows, int cols,
+                                                      int64_t in_stride, int64_t wf_stride, int64_t bf_stride) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= rows) return;
+  const int64_t b = blockIdx.y;
+  const float* w = W + b * in_stride + (int64_t)n * cols;
+  const float* g = gamma + b * in_stride;
+  const float* be = beta + b * in_stride;
+  uint16_t* o = Wf + b * wf_stride + (int64_t)n * cols;
+  float dot = 0.f;
+  for (int k = lane * 4; k < cols; k += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(w + k);
+    const float4 gg = *reinterpret_cast<const float4*>(g + k);
+    const float4 bb = *reinterpret_cast<const float4*>(be + k);
+    dot += x.x * bb.x + x.y * bb.y + x.z * bb.z + x.w * bb.w;
+    *reinterpret_cast<uint2*>(o + k) = make_uint2(pack_bf16(x.x * gg.x, x.y * gg.y), pack_bf16(x.z * gg.z, x.w * gg.w));
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) dot += __shfl_xor(dot, s);
+  if (lane == 0) bf[b * bf_stride + n] = dot + (bias ? bias[b * in_stride + n] : 0.f);
+}
+
+extern "C" int hma_fold_ln_bf16(void* stream, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf,
+                                float* bf, int32_t rows, int32_t cols, int32_t batch, int64_t in_stride, int64_t wf_stride,
+                                int64_t bf_stride) {
+  if (!W || !gamma || !beta || !Wf || !bf || rows <= 0 || cols <= 0 || (cols & 3)) return HMA_EINVAL;
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)batch), dim3(256), 0, (hipStream_t)stream, W, gamma,
+                     beta, bias, (uint16_t*)Wf, bf, (int)rows, (int)cols, in_stride, wf_stride, bf_stride);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int hma_abi_version(void) { return 0x484d4101; }
 
 extern "C" int hma_dropout_bf16(void* stream, const float* src, void* dst, int64_t rows, int32_t cols, float p, const uint32_t* seed_dev,

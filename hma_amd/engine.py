@@ -134,6 +134,10 @@ class STEngine:
         # transposed bf16 weight copies for the input-gradient GEMMs
         self.WT = {"qkv_s": mk(L, d, 3 * d), "proj_s": mk(L, d, d), "qkv_t": mk(L, d, 3 * d), "proj_t": mk(L, d, d),
                    "fc1": mk(L, d, hid), "fc2": mk(L, hid, d), "out": mk(d, 1024)}
+        # forward weights of the two Linears that follow a LayerNorm, with the LayerNorm's affine folded in
+        # (hma_fold_ln_bf16): the forward GEMM then reads the saved xhat as a plain bf16 operand
+        self.WF = {"qkv_s": mk(L, 3 * d, d), "fc1": mk(L, hid, d)}
+        self.BF = {"qkv_s": torch.zeros(L, 3 * d, dtype=F32, device=self.device), "fc1": torch.zeros(L, hid, dtype=F32, device=self.device)}
         self.modulate = "modulate" in cfg.action_network
         if self.modulate:
             for dom in self.domains:
@@ -207,6 +211,12 @@ class STEngine:
                 _lib.call("hma_transpose_cast_bf16", stream, self._p(f"decoder.layers.{L - 1}.{suffix}"),
                           self.WT[key][L - 1].data_ptr(), rows, cols, L, ls, -rows * cols)
             _lib.call("hma_transpose_cast_bf16", stream, self._p("out_x_proj.weight"), self.WT["out"].data_ptr(), 1024, d, 1, 0, 0)
+            for key, lin, norm, rows, has_bias in (("qkv_s", "spatial_attn.qkv", "norm1", 3 * d, cfg.qkv_bias),
+                                                   ("fc1", "mlp.fc1", "norm2", hid, cfg.mlp_bias)):
+                pre = f"decoder.layers.{L - 1}."
+                _lib.call("hma_fold_ln_bf16", stream, self._p(pre + lin + ".weight"), self._p(pre + norm + ".weight"),
+                          self._p(pre + norm + ".bias"), self._p(pre + lin + ".bias") if has_bias else None,
+                          self.WF[key][L - 1].data_ptr(), self.BF[key][L - 1].data_ptr(), rows, d, L, ls, -rows * d, -rows)
             self._wt_ok = True
         if domain is not None and self.modulate and domain not in self._dom_fresh:
             pre = f"decoder.layers.0.action_projectors.{domain}"
@@ -302,9 +312,8 @@ class STEngine:
         pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
         # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
         pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
-        pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
-                   beta=self._lw(l, "norm1.bias", "p"), W=self._lw(l, "spatial_attn.qkv.weight"), ldw=256, M=M, N=768, K=256,
-                   epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=qb("spatial_attn"))
+        pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
+                   epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
         pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale)
         # (the LayerNorm / modulate prologue of the NEXT sub-block is fused into this projection's epilogue)
         fuse = dict(ln_xhat=b["xhm"], ln_rstd=b["rstdm"], ln_eps=1e-6, ln_ss=b["ss"], ln_xm=b["xm"], ln_rows_per_frame=SA) if use_mod else {}
@@ -328,10 +337,9 @@ class STEngine:
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
         # MLP (its LayerNorm: fused above)                   st_transformer.py:112
-        pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
-                   beta=self._lw(l, "norm2.bias", "p"), W=self._lw(l, "mlp.fc1.weight"), ldw=256, M=M, N=1024, K=256,
-                   epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024,
-                   bias=self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None, **self._drop(train, l, 0))
+        pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16, W=self.WF["fc1"][l].data_ptr(), ldw=256, M=M, N=1024, K=256,
+                   epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024, bias=self.BF["fc1"][l].data_ptr(),
+                   **self._drop(train, l, 0))  # norm2 folded into W / bias
         pl.gemm_nt(A=b["hg"], lda=1024, a_kind=A_BF16, W=self._lw(l, "mlp.fc2.weight"), ldw=1024, M=M, N=256, K=1024,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
                    **self._drop(train, l, 1))

@@ -279,6 +279,12 @@ int hma_dropout_bf16(void* stream, const float* src, void* dst, int64_t rows, in
 /* dst[b][c][r] (bf16) = src[b][r][c] (f32): transposed bf16 copies of weights for the dgrad GEMMs */
 int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t rows, int32_t cols,
                             int32_t batch, int64_t src_stride, int64_t dst_stride);
+/* A LayerNorm's affine folded into the Linear that consumes it (st_transformer.py:86 norm1 -> spatial qkv, :112 norm2 ->
+ * mlp.fc1): Linear(xhat * gamma + beta) = xhat @ (W * gamma)^T + (bias + W @ beta).  Wf[b][n][k] (bf16) = W[b][n][k] *
+ * gamma[b][k], bf[b][n] (f32) = (bias ? bias[b][n] : 0) + sum_k W[b][n][k] * beta[b][k]; W / gamma / beta / bias of batch b
+ * sit `in_stride` floats after those of batch b - 1 (the per-layer blocks of the flat parameter buffer). */
+int hma_fold_ln_bf16(void* stream, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* bf,
+                     int32_t rows, int32_t cols, int32_t batch, int64_t in_stride, int64_t wf_stride, int64_t bf_stride);
 /* out[r] = sum_{j<reps} in[(r / inner) * reps * inner + j * inner + r % inner] helper is not exported */
 
 /* library identity, for the loader: returns 0x484d4101 */

@@ -132,6 +132,28 @@ def test_gemm_nt_ring(M, K):
         close(outr, full.reshape(-1, N), 1e-5, "ring c remap")
 
 
+def test_fold_ln_into_linear():
+    """hma_fold_ln_bf16: Linear(xhat * gamma + beta) == xhat @ Wf^T + bf, batched over per-layer blocks of one flat buffer."""
+    L, N, K = 3, 768, 256
+    stride = N * K + 2 * K + N + 64                      # [W | gamma | beta | bias | pad] per layer, layers at a constant stride
+    flat = torch.randn(L * stride, generator=g(50))
+    flat_d = flat.to(DEV)
+    Wf = torch.zeros(L, N, K, dtype=torch.bfloat16, device=DEV)
+    bf = torch.zeros(L, N, device=DEV)
+    base = flat_d.data_ptr()
+    _lib.call("hma_fold_ln_bf16", ops.stream_ptr(), base, base + 4 * N * K, base + 4 * (N * K + K), base + 4 * (N * K + 2 * K),
+              Wf.data_ptr(), bf.data_ptr(), N, K, L, stride, N * K, N)
+    for l in range(L):
+        blk = flat[l * stride:(l + 1) * stride]
+        W, gam, bet, bias = blk[:N * K].view(N, K), blk[N * K:N * K + K], blk[N * K + K:N * K + 2 * K], blk[N * K + 2 * K:N * K + 2 * K + N]
+        close(Wf[l], W * gam, BF, "folded weight")
+        close(bf[l], bias + W @ bet, 1e-5, "folded bias")
+    bf.fill_(7.0)
+    _lib.call("hma_fold_ln_bf16", ops.stream_ptr(), base, base + 4 * N * K, base + 4 * (N * K + K), None,
+              Wf.data_ptr(), bf.data_ptr(), N, K, 1, 0, 0, 0)
+    close(bf[0], flat[:N * K].view(N, K) @ flat[N * K + K:N * K + 2 * K], 1e-5, "folded bias, no Linear bias")
+
+
 def test_gemm_nt_row_remap_and_batch():
     # A rows sliced out of (S + A)-row frames, C written back remapped
     frames, S, SA, K, N = 3, 64, 80, 256, 128
