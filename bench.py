@@ -356,7 +356,7 @@ def main():
                 ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
                 traffic = pmc_traffic_per_launch()
                 avg_s = 1e-3 * s["ms"] / s["launches"]
-                out["roofline"] = {"bound": "mfma", "kernel": "hma_gemm_nt (gemm_nt_sw_kernel at K = 256, gemm_nt_p3_kernel above)",
+                out["roofline"] = {"bound": "mfma", "kernel": "hma_gemm_nt (gemm_nt_sw_kernel at K = 256, gemm_nt_ring_kernel at K = 768 / 1024)",
                                    "achieved": ach, "peak": 2500.0,
                                    "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
                                    # the same launches against the HBM roofline (they are output-dominated streams at K = 256)

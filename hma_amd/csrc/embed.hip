@@ -88,6 +88,63 @@ __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const int64_t* __res
   atomicAdd(pm, macc.x); atomicAdd(pm + 1, macc.y); atomicAdd(pm + 2, macc.z); atomicAdd(pm + 3, macc.w);
 }
 
+// Same gradients with the atomics moved into LDS.  Both tables have only V (512) rows, so ~256 token rows land on every
+// table row and the global-atomic version above serialises on them (1.05 ms per step at the bench shape, 40x its HBM
+// time).  A workgroup takes one table, one 64-column slice (V x 64 fp32 = 128 KB of LDS) and one contiguous run of
+// token rows; a wave handles a token with one 256-byte load and one conflict-free ds_add_f32, and the slice is flushed
+// with one global atomic per non-zero entry at the end.  Mask-token rows are summed in registers (table 0 workgroups).
+__global__ __launch_bounds__(256) void embed_bwd_tok_lds_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+                                                                float* __restrict__ dE0, float* __restrict__ dE1,
+                                                                float* __restrict__ dmask, int64_t img_rows, int S, int SA, int V,
+                                                                int64_t mask_id, int64_t rows_per_group) {
+  extern __shared__ __attribute__((aligned(16))) float tbl[];  // [V][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int variant = blockIdx.x & 7, table = variant >> 2, cs = variant & 3;
+  const int64_t group = blockIdx.x >> 3;
+  for (int i = threadIdx.x; i < V * 64; i += 256) tbl[i] = 0.f;
+  __syncthreads();
+  const int64_t r_begin = group * rows_per_group;
+  int64_t r_end = r_begin + rows_per_group;
+  if (r_end > img_rows) r_end = img_rows;
+  float macc = 0.f;
+  // each wave walks 64-row chunks: lane i first fetches the id and the dx offset of row chunk + i, then the 64 rows are
+  // visited eight at a time (eight loads in flight, then eight LDS adds)
+  for (int64_t c0 = r_begin + wave * 64; c0 < r_end; c0 += 256) {
+    const bool mine = c0 + lane < r_end;
+    const int64_t rr = mine ? c0 + lane : r_end - 1;
+    const int64_t id = ids[rr];
+    int row = id == mask_id ? -1 : (int)(table == 0 ? id % V : (id / V) % V);
+    if (!mine) row = -2;  // past the run: loaded (clamped) but not added
+    const int64_t bt = rr / S;
+    const uint32_t off = (uint32_t)((bt * SA + (rr - bt * S)) * (D / 4));  // in 16-byte units (host: fits 32 bits)
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      float g[8];
+      int rj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rj[j] = __shfl(row, j0 + j);
+        const uint32_t oj = __shfl(off, j0 + j);
+        g[j] = dx[(int64_t)oj * 4 + cs * 64 + lane];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rj[j] >= 0)
+          atomicAdd(&tbl[rj[j] * 64 + lane], g[j]);  // ds_add_f32, 64 consecutive words
+        else if (rj[j] == -1 && table == 0)
+          macc += g[j];
+      }
+    }
+  }
+  __syncthreads();
+  float* dE = table == 0 ? dE0 : dE1;
+  for (int i = threadIdx.x; i < V * 64; i += 256) {
+    const float v = tbl[i];
+    if (v != 0.f) atomicAdd(dE + (int64_t)(i >> 6) * D + cs * 64 + (i & 63), v);
+  }
+  if (table == 0 && macc != 0.f) atomicAdd(dmask + cs * 64 + lane, macc);
+}
+
 // da_emb[bt][:] += sum over the A action-token rows of frame bt
 __global__ __launch_bounds__(256) void embed_bwd_act_kernel(const float* __restrict__ dx, float* __restrict__ da_emb, int S,
                                                             int A) {
@@ -238,10 +295,28 @@ extern "C" int hma_embed_bwd(void* stream, const int64_t* ids, const float* dx, 
                      (int)pos_frame_rows);
   HMA_CHECK_LAUNCH();
   const int64_t img_rows = B * T * S;
-  int64_t blocks = (img_rows + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ids, dx, dE0, dE1, dmask_embed, img_rows,
-                     (int)S, SA, (int)V, mask_id);
+  const size_t tbl_bytes = (size_t)V * 64 * sizeof(float);
+  if (tbl_bytes <= 144 * 1024 && img_rows >= 4096 && B * T * (int64_t)SA * (D / 4) < ((int64_t)1 << 32)) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_tok_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              144 * 1024) != hipSuccess)
+        return HMA_EINVAL;
+      attr_done = true;
+    }
+    // 8 (table, column slice) variants x token groups: one workgroup per CU, runs in multiples of 256 rows
+    int64_t groups = 32;
+    int64_t per = (img_rows + groups - 1) / groups;
+    per = (per + 255) & ~(int64_t)255;
+    groups = (img_rows + per - 1) / per;
+    hipLaunchKernelGGL(embed_bwd_tok_lds_kernel, dim3((unsigned)(groups * 8)), dim3(256), tbl_bytes, s, ids, dx, dE0, dE1,
+                       dmask_embed, img_rows, (int)S, SA, (int)V, mask_id, per);
+  } else {
+    int64_t blocks = (img_rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ids, dx, dE0, dE1, dmask_embed, img_rows,
+                       (int)S, SA, (int)V, mask_id);
+  }
   HMA_CHECK_LAUNCH();
   if (A > 0) {
     hipLaunchKernelGGL(embed_bwd_act_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, dx, da_emb, (int)S, (int)A);

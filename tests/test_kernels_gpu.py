@@ -377,10 +377,12 @@ def test_attn_temporal(B, T, n_s):
 
 
 # ------------------------------------------------------------------------------------------ embedding / stem
-def test_embed_fwd_bwd():
-    B, T, S, A, V = 2, 3, 256, 64, 512
+@pytest.mark.parametrize("B,T,id_range", [(2, 3, 512 * 512), (5, 7, 512 * 512), (9, 4, 8192)])
+def test_embed_fwd_bwd(B, T, id_range):
+    # (the larger cases take the LDS-atomic table-gradient kernel; ids < 8192 puts every token on 16 rows of table 1)
+    S, A, V = 256, 64, 512
     mask_id = V * V
-    ids = torch.randint(0, V * V, (B, T, S), generator=g(50))
+    ids = torch.randint(0, id_range, (B, T, S), generator=g(50))
     ids[torch.rand(B, T, S, generator=g(51)) < 0.4] = mask_id
     E0 = torch.randn(V, 256, generator=g(52)); E1 = torch.randn(V, 256, generator=g(53))
     me = torch.randn(1, 256, generator=g(54)); pos = torch.randn(T + 1, S + A, 256, generator=g(55))
