@@ -1179,7 +1179,11 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tok = lane & 15, g = lane >> 4;
 
-  const int b = blockIdx.x;
+  // Workgroup b runs on XCD b & 7.  Every XCD gets one contiguous run of virtual ids, and the n-slabs of one slot
+  // (consecutive ids: they stream the SAME token rows, in the same order) therefore share an L2: at N = 768 / 1024 the
+  // A rows otherwise cross the fabric once per slab.
+  const int G = gridDim.x;
+  const int b = (blockIdx.x & 7) * (G >> 3) + min((int)(blockIdx.x & 7), G & 7) + (blockIdx.x >> 3);
   const int slab_id = b % nslabs, slot = b / nslabs;  // slab_id = (batch, n-slab)
   const int slabs_n = (int)(p.N / 256);
   const int64_t bz = slab_id / slabs_n;
