@@ -2303,19 +2303,29 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(hma_gemm_tn_t p, int gro
 // kernel above re-streams the 256 x K weight slab through each CU's vector-memory path once per 128 token rows, and that
 // path (~11-12 B/clk per CU, L2 hits included) is what bounds it.  Here a workgroup owns a contiguous run of token rows
 // and works through it in 256-row tiles (half the weight re-reads per row), both operands arriving by LDS-DMA in 32-deep
-// K stages ([256][32] bf16 of A, then of W: 32 KB, four-slot ring, three stages in flight) that keep streaming across
-// tile boundaries, so the next tile's first stages land while this tile's epilogue runs.  Rows are 64 B in LDS; 16-byte
-// chunk c of row r sits at chunk c ^ ((r >> 2) & 3) (applied to the DMA source address and again on the read), which
-// makes the ds_read_b128 fragment reads conflict-free.  Accumulators and epilogue as gemm_nt_p3_kernel (a lane owns one
+// K stages ([256][32] bf16 of A, then of W: 32 KB, four-slot ring, three stages in flight; or 64-deep stages in two
+// slots) that keep streaming across tile boundaries, so the next tile's first stages land while this tile's epilogue
+// runs.  Rows are 64 (128) B in LDS; 16-byte chunk c of row r sits at chunk c ^ swz(r) (applied to the DMA source
+// address and again on the read), which makes the ds_read_b128 fragment reads conflict-free.  Accumulators and epilogue as gemm_nt_p3_kernel (a lane owns one
 // token row and runs of 4 output columns).
-constexpr int NR_TILE_BYTES = 256 * 64;           // one operand's K stage
-constexpr int NR_STAGE_BYTES = 2 * NR_TILE_BYTES;  // A then W
-constexpr int NR_STAGES = 4;
-constexpr int NR_SMEM_BYTES = NR_STAGES * NR_STAGE_BYTES;  // 128 KB
+constexpr int NR_SMEM_BYTES = 128 * 1024;  // NS slots x (A tile + W tile) x 256 rows x 2 KD bytes
 
 // ABL (debug build only): 1 no A DMA, 2 no W DMA, 4 no epilogue memory traffic, 8 no MFMA
-template <int EPI, int ABL = 0>
+// KD = K depth of a stage (32: 64-byte LDS rows, 4 slots, 3 stages in flight; 64: 128-byte rows = whole cache lines per
+// DMA row piece, 2 slots, 1 stage in flight), NS = slots.
+template <int EPI, int ABL = 0, int KD = 32, int NS = 4>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, int64_t chunk) {
+  constexpr int RB = KD * 2;                 // LDS row bytes
+  constexpr int NR_TILE_BYTES = 256 * RB;    // one operand's K stage
+  constexpr int NR_STAGE_BYTES = 2 * NR_TILE_BYTES;
+  constexpr int NR_STAGES = NS;
+  static_assert(NS * NR_STAGE_BYTES == NR_SMEM_BYTES, "ring size");
+  constexpr int LPR = RB / 16;               // lanes (16-byte chunks) per row
+  constexpr int RPP = 64 / LPR;              // rows per 1 KB DMA piece
+  constexpr int QN = 32 / RPP;               // pieces per wave, tile and stage (a wave fills rows 32 w .. 32 w + 31)
+  constexpr int KK = KD / 16;                // MFMA k-steps per stage
+  // chunk swizzle of a row (conflict-free ds_read_b128 fragments for both row sizes)
+  auto swz = [](int row) { return KD == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -2328,7 +2338,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
   int64_t m_end = m_begin + chunk;
   if (m_end > p.M) m_end = p.M;
   if (m_begin >= m_end) return;
-  const int KT = (int)(p.K >> 5);
+  const int KT = (int)(p.K / KD);
   // Every other workgroup starts with a 128-row tile: neighbouring CUs are then half a tile out of phase, and one's
   // epilogue (residual read + write, HBM) overlaps the other's K loop instead of the whole chip alternating between the two.
   const int64_t first = ((vid & 1) && m_end - m_begin > 128) ? 128 : 256;
@@ -2338,24 +2348,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
 
   const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A);
   const uint16_t* W = reinterpret_cast<const uint16_t*>(p.W);
-  // DMA pieces of this wave: rows 32 wave + 16 q + (lane >> 2) of both tiles, q = 0, 1
-  const int prow = wave * 32 + (lane >> 2);
+  // DMA pieces of this wave: rows 32 wave + RPP q + lane / LPR of both tiles, q = 0 .. QN - 1
+  const int prow = wave * 32 + lane / LPR;
   // issue cursor (runs three stages ahead of the compute cursor)
   int i_kt = 0;
   int64_t i_m0 = m_begin, i_end = m_begin + first < m_end ? m_begin + first : m_end;
-  const uint16_t* a_src[2];
-  const uint16_t* w_src[2];
+  const uint16_t* a_src[QN];
+  const uint16_t* w_src[QN];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = prow + 16 * q;
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
+  for (int q = 0; q < QN; ++q) {
+    const int row = prow + RPP * q;
+    const int c = (lane % LPR) ^ swz(row);
     w_src[q] = W + (int64_t)row * p.ldw + c * 8;
   }
   auto set_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = prow + 16 * q;
-      const int c = (lane & 3) ^ ((row >> 2) & 3);
+    for (int q = 0; q < QN; ++q) {
+      const int row = prow + RPP * q;
+      const int c = (lane % LPR) ^ swz(row);
       int64_t m = i_m0 + row;
       m = m < i_end ? m : i_end - 1;  // rows past the tile are clamped (their outputs are never stored)
       a_src[q] = A + m * p.lda + c * 8;
@@ -2363,11 +2373,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
   };
   set_tile();
   auto issue = [&](int slot) __attribute__((always_inline)) {
-    const uint32_t sb = lds_b + slot * NR_STAGE_BYTES + wave * 2048;
+    const uint32_t sb = lds_b + slot * NR_STAGE_BYTES + wave * 32 * RB;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (!(ABL & 1)) glds16(a_src[q] + i_kt * 32, sb + q * 1024);
-      if (!(ABL & 2)) glds16(w_src[q] + i_kt * 32, sb + NR_TILE_BYTES + q * 1024);
+    for (int q = 0; q < QN; ++q) {
+      if (!(ABL & 1)) glds16(a_src[q] + i_kt * KD, sb + q * 1024);
+      if (!(ABL & 2)) glds16(w_src[q] + i_kt * KD, sb + NR_TILE_BYTES + q * 1024);
     }
     if (++i_kt == KT) {
       i_kt = 0;
@@ -2392,14 +2402,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
   const int lr = lane & 31, lhi = lane >> 5;
   // fragment of row `row` of a tile: k = 16 kk + 8 lhi .. + 7
   auto frag = [&](HMA_LDS(char)* tile, int row, int kk) __attribute__((always_inline)) {
-    const int c = (kk * 2 + lhi) ^ ((row >> 2) & 3);
-    return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(uint4)*)(tile + row * 64 + c * 16));
+    const int c = (kk * 2 + lhi) ^ swz(row);
+    return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(uint4)*)(tile + row * RB + c * 16));
   };
   auto wait_stage = [&](int st) __attribute__((always_inline)) {
-    const int later = nst - 1 - st;
-    if (later >= 2)
+    int later = nst - 1 - st;  // stages issued behind st: at most NS - 2 at this point, 2 QN pieces each
+    later = later < NS - 2 ? later : NS - 2;
+    static_assert(2 * QN == 4 || NS == 2, "vmcnt immediates below: 4 pieces per stage and wave, or nothing in flight behind st");
+    if (NS > 2 && later >= 2)
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1)
+    else if (NS > 2 && later == 1)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2411,14 +2423,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
   int kt = 0;
   int64_t m0 = m_begin, t_end = m_begin + first < m_end ? m_begin + first : m_end;
   for (int st = 0; st < nst; ++st) {
-    const int slot = st & (NR_STAGES - 1);
+    const int slot = st % NR_STAGES;
     wait_stage(st);
     // every wave's pieces of stage st are in LDS, and every wave is done reading stage st - 1 (its slot is refilled below)
     __builtin_amdgcn_s_barrier();
     HMA_LDS(char)* As = lds + slot * NR_STAGE_BYTES;
     HMA_LDS(char)* Ws = As + NR_TILE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
       bf16x8_t af[4], wf[2];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) af[mt] = frag(As, wm * 128 + mt * 32 + lr, kk);
@@ -2433,7 +2445,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
           else
             acc[mt][nt] = mfma32(wf[nt], af[mt], acc[mt][nt]);  // D rows = n, D cols = token
         }
-      if (kk == 0 && st + NR_STAGES - 1 < nst) issue((st + NR_STAGES - 1) & (NR_STAGES - 1));
+      if (kk == 0 && st + NR_STAGES - 1 < nst) issue((st + NR_STAGES - 1) % NR_STAGES);
     }
     if (++kt == KT) {
       // tile done: epilogue (the ring keeps filling with the next tile's stages meanwhile)
@@ -2676,10 +2688,19 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
   HMA_NTR_ABL(EP, 7) HMA_NTR_ABL(EP, 12) HMA_NTR_ABL(EP, 11) HMA_NTR_ABL(EP, 15)
       HMA_NTR_ABLS(HMA_EPI_BF16) HMA_NTR_ABLS(HMA_EPI_RESID)
 #endif
+      // stage depth: 64 (two slots) measured 5 % faster for the bf16 epilogue, 0-3 % slower for the residual one (which is
+      // at the register cap with its batched epilogue); HMA_GEMM_NT_RING=32 / 64 forces one for both
+      static const char* ring_env = getenv("HMA_GEMM_NT_RING");
+      const bool ring64 = ring_env && ring_env[0] == '6' ? true : ring_env && ring_env[0] == '3' ? false : p->epi == HMA_EPI_BF16;
 #define HMA_NTR_CASE(EP)                                                                              \
   if (p->epi == EP) {                                                                                 \
-    if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP>>(NR_SMEM_BYTES))) return rc;                     \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<EP>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk);   \
+    if (ring64 && (p->K & 63) == 0) {                                                                 \
+      if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP, 0, 64, 2>>(NR_SMEM_BYTES))) return rc;         \
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EP, 0, 64, 2>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk); \
+    } else {                                                                                          \
+      if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP>>(NR_SMEM_BYTES))) return rc;                   \
+      hipLaunchKernelGGL((gemm_nt_ring_kernel<EP>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk); \
+    }                                                                                                 \
     HMA_CHECK_LAUNCH();                                                                               \
     return 0;                                                                                         \
   }
