@@ -385,11 +385,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
           dp = mfma32(frag_rows(Gs, qt * 32, 1, lane), v1, dp);
           f32x16_t ds;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int q = qt * 32 + mfma32_row(e, hi);
-            const float pr = fast_exp2(sc[e] * c_log2 - L2s[q]);
-            sc[e] = pr;
-            ds[e] = pr * (dp[e] - Dls[q]);
+          for (int g = 0; g < 4; ++g) {  // rows 8 g + 4 hi + {0..3}: one 16-byte LDS read each for lse and delta
+            const float4 l4 = *reinterpret_cast<const float4*>(&L2s[qt * 32 + 8 * g + 4 * hi]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&Dls[qt * 32 + 8 * g + 4 * hi]);
+            const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float pr = fast_exp2(sc[4 * g + e] * c_log2 - lq[e]);
+              sc[4 * g + e] = pr;
+              ds[4 * g + e] = pr * (dp[4 * g + e] - dq4[e]);
+            }
           }
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
