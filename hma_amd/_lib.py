@@ -52,6 +52,7 @@ class GemmTN(C.Structure):
 _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
+    "hma_gemm_tn_pair": [c_vp, C.POINTER(GemmTN), C.POINTER(GemmTN)],
     "hma_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32],
     "hma_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hma_modln_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32],

@@ -1991,8 +1991,24 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
 }
 
 // ABL (debug build only): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no partial stores, 16 no barrier
+// One launch serves up to TWO weight-gradient problems (hma_gemm_tn_pair): the 256 workgroups are divided between
+// them, so each is split over fewer M-slices and the fixed cost of a split-M wgrad -- 128 KB of partials per
+// workgroup, written and re-read -- is paid once per launch instead of once per problem.
+struct tn_prob {
+  const void* dY;
+  const void* A;
+  float* ws;         // this problem's partials (bf16 blocks, then fp32 column-sum partials)
+  int64_t M, ldy, lda, sY, sA;
+  int splits, gn, gk;
+  int nb;            // workgroups of this problem
+  int colsum;        // write the column-sum partials
+};
+struct tn_pair_args {
+  tn_prob q[2];      // problem 1's workgroup ids follow problem 0's (q[1].nb == 0: a single problem)
+};
+
 template <bool TR, bool COLSUM, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(hma_gemm_tn_t p, int groups_n, int groups_k) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -2004,7 +2020,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(hma_gemm_tn_t p, in
   const int b = blockIdx.x;
   // workgroup b runs on XCD b & 7: give every XCD one contiguous run of virtual ids, so that the workgroups of one split
   // (consecutive ids: the n / k groups that re-read the same rows of A or dY) share an L2 -- for any G
-  const int vid = (b & 7) * (G >> 3) + min(b & 7, G & 7) + (b >> 3);
+  const int gvid = (b & 7) * (G >> 3) + min(b & 7, G & 7) + (b >> 3);
+  const bool second = gvid >= args.q[0].nb;
+  const tn_prob p = second ? args.q[1] : args.q[0];
+  const int vid = gvid - (second ? args.q[0].nb : 0);
+  const int groups_n = p.gn, groups_k = p.gk;
   const int groups = groups_n * groups_k;
   const int per_batch = groups * p.splits;
   const int64_t bz = vid / per_batch;
@@ -2164,9 +2184,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(hma_gemm_tn_t p, in
                                      pack_bf16(v[8 * h + 4], v[8 * h + 5]), pack_bf16(v[8 * h + 6], v[8 * h + 7]));
           *reinterpret_cast<uint4*>(part + ((((wave * 8 + i * 2 + j) * 2 + h) * 64 + lane) << 3)) = o;
         }
-  if (COLSUM && k0 == 0) {
+  if (COLSUM && k0 == 0 && p.colsum) {
     colsum += __shfl_xor(colsum, 32);
-    if (hi == 0) p.ws[(int64_t)gridDim.x * (WT * WT) + (int64_t)vid * WT + wn2 * 128 + wk4 * 32 + r] = colsum;
+    if (hi == 0) p.ws[(int64_t)p.nb * (WT * WT) + (int64_t)vid * WT + wn2 * 128 + wk4 * 32 + r] = colsum;
   }
 }
 
@@ -2826,6 +2846,56 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
     return 0;                                                                             \
   }
 
+// ---- LDS-DMA ring weight gradients: eligibility, split planning and launch of one or two problems
+static bool tn_dma_eligible(const hma_gemm_tn_t& q) {
+  return q.N % WT == 0 && q.K % WT == 0 && q.y_kind == HMA_A_BF16 && (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE) &&
+         q.M > 0 && q.M % DM_ROWS == 0 && q.y_group_rows <= 0 && q.a_group_rows <= 0 && q.ldy % 8 == 0 && q.lda % 8 == 0 &&
+         q.sY % 8 == 0 && q.sA % 8 == 0 && (reinterpret_cast<uintptr_t>(q.dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.A) & 15) == 0;
+}
+// splits for a problem that may use at most `budget` workgroups; 0 if it cannot take the two-stage path
+static int tn_plan_splits(const hma_gemm_tn_t& q, int budget) {
+  const int64_t slabs = (q.M + 63) / 64;
+  const int groups = (int)(q.N / WT) * (int)(q.K / WT) * (q.batch > 0 ? q.batch : 1);
+  int splits = budget / groups;
+  if (splits < 1) splits = 1;
+  if (splits > slabs) splits = (int)slabs;
+  while (splits > 1 && ((slabs + splits - 1) / splits) * (splits - 1) >= slabs) --splits;
+  return splits > 1 ? splits : 0;
+}
+static tn_prob tn_make_prob(const hma_gemm_tn_t& q, float* ws, int splits) {
+  tn_prob t;
+  t.dY = q.dY; t.A = q.A; t.ws = ws;
+  t.M = q.M; t.ldy = q.ldy; t.lda = q.lda; t.sY = q.sY; t.sA = q.sA;
+  t.splits = splits; t.gn = (int)(q.N / WT); t.gk = (int)(q.K / WT);
+  t.nb = splits * t.gn * t.gk * (q.batch > 0 ? q.batch : 1);
+  t.colsum = (q.dBias != nullptr) || q.a_kind == HMA_A_BF16_AFFINE;
+  return t;
+}
+template <bool TR>
+static int tn_dma_launch(hipStream_t s, const tn_pair_args& a) {
+  const bool cs = a.q[0].colsum || (a.q[1].nb > 0 && a.q[1].colsum);
+  const dim3 grid((unsigned)(a.q[0].nb + a.q[1].nb));
+  int rc;
+  if (cs) {
+    if ((rc = set_smem_bytes<gemm_tn_dma_kernel<TR, true>>(DM_SMEM_BYTES))) return rc;
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<TR, true>), grid, dim3(512), DM_SMEM_BYTES, s, a);
+  } else {
+    if ((rc = set_smem_bytes<gemm_tn_dma_kernel<TR, false>>(DM_SMEM_BYTES))) return rc;
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<TR, false>), grid, dim3(512), DM_SMEM_BYTES, s, a);
+  }
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+static int tn_dma_reduce(hipStream_t s, hma_gemm_tn_t q, const tn_prob& t) {
+  q.splits = t.splits;
+  q.ws = t.ws;
+  const unsigned gy = (unsigned)(t.gn * t.gk * (q.batch > 0 ? q.batch : 1));
+  hipLaunchKernelGGL(tn_reduce_native_kernel, dim3((unsigned)(WT * WT / 256), gy), dim3(256), 0, s, q, t.gn, t.gk,
+                     (int)(q.a_kind == HMA_A_BF16_AFFINE));
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   if (!p || !p->dY || !p->A || !p->dW) return HMA_EINVAL;
   if (p->M <= 0) return 0;
@@ -2860,40 +2930,29 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     static const char* tn_dma_env = getenv("HMA_GEMM_TN_DMA");
     static const char* tn_dma = tn_dma_env ? tn_dma_env : "tr";
     const bool bias_room = q.ws && q.ws_elems >= (int64_t)nblocks * (WT * WT + WT);
-    if (tn_dma[0] != '0' && q.ws && q.y_kind == HMA_A_BF16 && (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE) &&
-        q.M % DM_ROWS == 0 && q.y_group_rows <= 0 && q.a_group_rows <= 0 && q.ldy % 8 == 0 && q.lda % 8 == 0 && q.sY % 8 == 0 && q.sA % 8 == 0 &&
-        (reinterpret_cast<uintptr_t>(q.dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.A) & 15) == 0 &&
-        (bias_room || (!q.dBias && q.a_kind == HMA_A_BF16))) {
-      const int affine = q.a_kind == HMA_A_BF16_AFFINE;
-      const int want_colsum = (q.dBias != nullptr) || affine;
-#define HMA_TND_LAUNCH(TR, CS)                                                                       \
-  {                                                                                                   \
-    if ((rc = set_smem_bytes<gemm_tn_dma_kernel<TR, CS>>(DM_SMEM_BYTES))) return rc;                  \
-    hipLaunchKernelGGL((gemm_tn_dma_kernel<TR, CS>), wgrid, dim3(512), DM_SMEM_BYTES, s, q, gn, gk);  \
-  }
+    if (tn_dma[0] != '0' && q.ws && tn_dma_eligible(q) && (bias_room || (!q.dBias && q.a_kind == HMA_A_BF16))) {
+      tn_pair_args args;
+      args.q[0] = tn_make_prob(q, q.ws, splits);
+      args.q[1] = args.q[0];
+      args.q[1].nb = 0;
 #ifdef HMA_PROF
 #define HMA_TND_ABL(A)                                                                                        \
   case A:                                                                                                     \
     if ((rc = set_smem_bytes<gemm_tn_dma_kernel<true, true, A>>(DM_SMEM_BYTES))) return rc;                   \
-    hipLaunchKernelGGL((gemm_tn_dma_kernel<true, true, A>), wgrid, dim3(512), DM_SMEM_BYTES, s, q, gn, gk);   \
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<true, true, A>), wgrid, dim3(512), DM_SMEM_BYTES, s, args);        \
     break;
       if (tn_ablate) {
+        args.q[0].colsum = 1;
         switch (tn_ablate) {
           HMA_TND_ABL(1) HMA_TND_ABL(2) HMA_TND_ABL(4) HMA_TND_ABL(8) HMA_TND_ABL(16) HMA_TND_ABL(6) HMA_TND_ABL(7) HMA_TND_ABL(15)
           HMA_TND_ABL(3) HMA_TND_ABL(9) HMA_TND_ABL(24)
           default: return HMA_EINVAL;
         }
+        HMA_CHECK_LAUNCH();
       } else
 #endif
-      if (tn_dma[0] == 'u') {
-        if (want_colsum) HMA_TND_LAUNCH(false, true) else HMA_TND_LAUNCH(false, false)
-      } else {
-        if (want_colsum) HMA_TND_LAUNCH(true, true) else HMA_TND_LAUNCH(true, false)
-      }
-      HMA_CHECK_LAUNCH();
-      hipLaunchKernelGGL(tn_reduce_native_kernel, dim3((unsigned)(WT * WT / 256), rgrid.y), dim3(256), 0, s, q, gn, gk, affine);
-      HMA_CHECK_LAUNCH();
-      return 0;
+      if ((rc = tn_dma[0] == 'u' ? tn_dma_launch<false>(s, args) : tn_dma_launch<true>(s, args))) return rc;
+      return tn_dma_reduce(s, q, args.q[0]);
     }
 #define HMA_TNW_CASE(YK, AK)                                                                        \
   if (q.y_kind == YK && q.a_kind == AK) {                                                            \
@@ -2924,6 +2983,41 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   HMA_TN_CASE(HMA_A_F32, HMA_A_F32)
   HMA_TN_CASE(HMA_A_F32, HMA_A_BF16_AFFINE)
   return HMA_EINVAL;
+}
+
+extern "C" int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_gemm_tn_t* b) {
+  if (!a || !b) return HMA_EINVAL;
+  static const bool no_pair = getenv("HMA_GEMM_TN_NOPAIR") != nullptr;
+  static const char* dma_env = getenv("HMA_GEMM_TN_DMA");
+  const bool dma_on = !(dma_env && dma_env[0] == '0') && !getenv("HMA_GEMM_TN_V1") && !getenv("HMA_GEMM_TN_ABLATE");
+  const int64_t need = (int64_t)256 * (WT * WT + WT);
+  bool ok = !no_pair && dma_on && a->dY && a->A && a->dW && b->dY && b->A && b->dW && a->ws && a->ws == b->ws &&
+            a->ws_elems >= need && b->ws_elems >= need && tn_dma_eligible(*a) && tn_dma_eligible(*b) &&
+            !(a->a_kind == HMA_A_BF16_AFFINE && (!a->gamma || !a->beta)) && !(b->a_kind == HMA_A_BF16_AFFINE && (!b->gamma || !b->beta));
+  int s0 = 0, s1 = 0;
+  if (ok) {
+    // workgroups in proportion to the operand bytes of each problem
+    const double w0 = (double)a->M * (double)(a->N + a->K) * (a->batch > 0 ? a->batch : 1);
+    const double w1 = (double)b->M * (double)(b->N + b->K) * (b->batch > 0 ? b->batch : 1);
+    int b0 = (int)(256.0 * w0 / (w0 + w1) + 0.5);
+    b0 = b0 < 1 ? 1 : (b0 > 255 ? 255 : b0);
+    s0 = tn_plan_splits(*a, b0);
+    s1 = tn_plan_splits(*b, 256 - b0);
+    ok = s0 > 0 && s1 > 0;
+  }
+  if (!ok) {
+    const int rc = hma_gemm_tn(stream, a);
+    return rc ? rc : hma_gemm_tn(stream, b);
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  tn_pair_args args;
+  args.q[0] = tn_make_prob(*a, a->ws, s0);
+  args.q[1] = tn_make_prob(*b, a->ws + (int64_t)args.q[0].nb * (WT * WT + WT), s1);
+  if (args.q[0].nb + args.q[1].nb > 256) return HMA_EINVAL;
+  int rc;
+  if ((rc = tn_dma_launch<true>(s, args))) return rc;
+  if ((rc = tn_dma_reduce(s, *a, args.q[0]))) return rc;
+  return tn_dma_reduce(s, *b, args.q[1]);
 }
 
 #ifdef HMA_PROF

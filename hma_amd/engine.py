@@ -57,6 +57,18 @@ class Plan:
         self.keep.append(g)
         self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
 
+    def gemm_tn_pair(self, kw0: dict, kw1: dict) -> None:
+        """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair)."""
+        gs = []
+        for kw in (kw0, kw1):
+            if Plan.tn_workspace is not None:
+                kw.setdefault("ws", Plan.tn_workspace.data_ptr())
+                kw.setdefault("ws_elems", Plan.tn_workspace.numel())
+            gs.append(make_gemm_tn(**kw))
+        self.keep.extend(gs)
+        self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
+                 flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs))
+
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
 
@@ -465,23 +477,25 @@ class STEngine:
             if self._drop(True, l, 1):
                 dmlp = ws["dxm"].data_ptr()
                 pl.add("hma_dropout_bf16", dx, dmlp, M, 256, float(cfg.mlp_drop), self.drop_seed.data_ptr(), 2 * l + 1)
-            pl.gemm_tn(dY=dmlp, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024, dW=gw("mlp.fc2.weight"),
-                       lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias))
             pl.gemm_nt(A=dmlp, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
                        U=u, ldu=1024, **self._drop(True, l, 0))  # dU overwrites u in place
-            pl.gemm_tn(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
-                       beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024, K=256, dW=gw("mlp.fc1.weight"), lddw=256,
-                       dBias=gb("mlp.fc1.bias", cfg.mlp_bias))
+            # the two MLP weight gradients in one launch (dmlp / hg and dU / xhat2 are all live here)
+            pl.gemm_tn_pair(dict(dY=dmlp, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024,
+                                 dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
+                            dict(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
+                                 gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024, K=256,
+                                 dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias)))
             pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
                    dxb)
             # ---- temporal attention
-            pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                       dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias))
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale)
-            pl.gemm_tn(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
-                       dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias))
+            # projection and qkv weight gradients in one launch (dxb is not updated before the dqkv dgrad below)
+            pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                                 dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
+                            dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
+                                 dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)))
             pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                        C2=dxb, ldc2=256)
             # ---- action modulation
@@ -494,13 +508,14 @@ class STEngine:
                            epi=EPI_BF16, Cp=t256, ldc=256)
                 pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
             # ---- spatial attention
-            pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                       dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias))
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale)
-            pl.gemm_tn(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, a_kind=A_BF16_AFFINE,
-                       gamma=self._lw(l, "norm1.weight", "p"), beta=self._lw(l, "norm1.bias", "p"), M=M, N=768, K=256,
-                       dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias))
+            # projection and qkv weight gradients in one launch (dxb is next updated by the LayerNorm backward below)
+            pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                                 dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
+                            dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, a_kind=A_BF16_AFFINE,
+                                 gamma=self._lw(l, "norm1.weight", "p"), beta=self._lw(l, "norm1.bias", "p"), M=M, N=768, K=256,
+                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias)))
             pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
                    dxb)

@@ -94,6 +94,11 @@ typedef struct {
   float* ws; int64_t ws_elems;
 } hma_gemm_tn_t;
 int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p);
+/* Two independent weight gradients in ONE launch (e.g. a block's fc2 and fc1 after `loss.backward()` reaches them,
+ * st_transformer.py:24-27): the M-splits of both share the 256 workgroups, which halves the partial-sum traffic of the
+ * two-stage reduction per problem.  Both must name the same workspace (>= 256 * 65792 floats); any pair that is not
+ * eligible for the LDS-DMA kernel is executed as two hma_gemm_tn calls.  Same results as two calls. */
+int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_gemm_tn_t* b);
 
 /* LayerNorm over d_model = 256 without the affine (applied by the consumer GEMM's prologue):
  * xhat = (x - mean) * rstd (bf16), rstd saved.  st_transformer.py:50,75,86,112 (eps 1e-5). */

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from hma_amd import _lib, ops  # noqa: E402
-from hma_amd._lib import (A_BF16, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID,
+from hma_amd._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID,
                           EPI_SILU2)  # noqa: E402
 from oracle import st_maskgit_ref as R  # noqa: E402
 
@@ -252,6 +252,38 @@ def test_gemm_tn_ring(M, N, K):
     dW.fill_(0.5)
     ops.linear_wgrad(dyd, xd, dW, None, gamma=gam.to(DEV), beta=bet.to(DEV), ws=ws)
     close(dW, 0.5 + refa, BF, "dW ring affine, no bias")
+
+
+@pytest.mark.parametrize("M", [4096, 32 * 130, 40])
+def test_gemm_tn_pair(M):
+    """hma_gemm_tn_pair: two weight gradients in one launch (MLP pair, fc1 with the deferred LayerNorm affine, and a
+    projection / qkv pair without a qkv bias) give what two hma_gemm_tn calls give; M = 40 is not eligible for the ring
+    kernel and must fall back to two calls."""
+    ws = torch.full((256 * (65536 + 256),), float("nan"), device=DEV)
+
+    def prob(N, K, seed, bias=True, affine=False):
+        dy = rb(torch.randn(M, N, generator=g(seed)) * 0.5)
+        x = rb(torch.randn(M, K, generator=g(seed + 1)))
+        gam = torch.randn(K, generator=g(seed + 2)) * 0.2 + 1 if affine else None
+        bet = torch.randn(K, generator=g(seed + 3)) * 0.2 if affine else None
+        xe = x.double() * gam.double() + bet.double() if affine else x.double()
+        t = dict(dy=dy.to(DEV).bfloat16(), x=x.to(DEV).bfloat16(), dW=torch.full((N, K), 0.5, device=DEV),
+                 db=torch.full((N,), 0.25, device=DEV) if bias else None, gam=None if gam is None else gam.to(DEV),
+                 bet=None if bet is None else bet.to(DEV), refW=0.5 + (dy.double().t() @ xe).float(),
+                 refb=0.25 + dy.double().sum(0).float())
+        t["g"] = ops.make_gemm_tn(dY=ops.ptr(t["dy"]), ldy=N, y_kind=A_BF16, A=ops.ptr(t["x"]), lda=K,
+                                  a_kind=A_BF16_AFFINE if affine else A_BF16, M=M, N=N, K=K, dW=ops.ptr(t["dW"]), lddw=K,
+                                  dBias=ops.ptr(t["db"]), gamma=ops.ptr(t["gam"]), beta=ops.ptr(t["bet"]), ws=ops.ptr(ws),
+                                  ws_elems=ws.numel())
+        return t
+
+    for pa, pb in ((prob(256, 1024, 60), prob(1024, 256, 64, affine=True)), (prob(256, 256, 70), prob(768, 256, 74, bias=False)),
+                   (prob(768, 256, 80, bias=False, affine=True), prob(256, 256, 84))):
+        _lib.call("hma_gemm_tn_pair", ops.stream_ptr(), C.byref(pa["g"]), C.byref(pb["g"]))
+        for t in (pa, pb):
+            close(t["dW"], t["refW"], BF, "paired dW")
+            if t["db"] is not None:
+                close(t["db"], t["refb"], 2e-5, "paired dbias")
 
 
 def test_gemm_tn_remap_and_batch():
