@@ -2194,12 +2194,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
 // split's partial): the 8 half-waves take every 8th split, 16 bytes per lane; 256 blocks per 256 x 256 output block.
 // affine != 0: dW += gamma[k] * P[n][k] + beta[k] * colsum(dY)[n] (the LayerNorm affine of A, which the DMA kernel cannot
 // apply on the way into LDS); colsum comes from the bias partials of the n-block's k0 == 0 group.
-__global__ __launch_bounds__(256) void tn_reduce_native_kernel(hma_gemm_tn_t p, int groups_n, int groups_k, int affine) {
+struct tn_reduce_args {
+  hma_gemm_tn_t p[2];  // ws / splits already set per problem
+  int gn[2], gk[2], affine[2];
+  int gy0;             // grid.y rows of problem 0 (problem 1's follow)
+};
+__global__ __launch_bounds__(256) void tn_reduce_native_kernel(tn_reduce_args ra) {
   __shared__ float red[8][32][8];
   __shared__ float csum[8][32];
+  const bool second = (int)blockIdx.y >= ra.gy0;
+  const hma_gemm_tn_t& p = second ? ra.p[1] : ra.p[0];
+  const int groups_n = second ? ra.gn[1] : ra.gn[0], groups_k = second ? ra.gk[1] : ra.gk[0];
+  const int affine = second ? ra.affine[1] : ra.affine[0];
+  const int by = (int)blockIdx.y - (second ? ra.gy0 : 0);
   const int groups = groups_n * groups_k;
-  const int g = blockIdx.y % groups;
-  const int64_t bz = blockIdx.y / groups;
+  const int g = by % groups;
+  const int64_t bz = by / groups;
   const int64_t n0 = (int64_t)(g / groups_k) * WT, k0 = (int64_t)(g % groups_k) * WT;
   const int tid = threadIdx.x, r = tid & 31, sl = tid >> 5;  // sl: split lane 0..7
   const int grp = blockIdx.x >> 1, hi = blockIdx.x & 1;      // 1 KB group of 64 pieces, and which half of it
@@ -2886,12 +2896,25 @@ static int tn_dma_launch(hipStream_t s, const tn_pair_args& a) {
   HMA_CHECK_LAUNCH();
   return 0;
 }
-static int tn_dma_reduce(hipStream_t s, hma_gemm_tn_t q, const tn_prob& t) {
-  q.splits = t.splits;
-  q.ws = t.ws;
-  const unsigned gy = (unsigned)(t.gn * t.gk * (q.batch > 0 ? q.batch : 1));
-  hipLaunchKernelGGL(tn_reduce_native_kernel, dim3((unsigned)(WT * WT / 256), gy), dim3(256), 0, s, q, t.gn, t.gk,
-                     (int)(q.a_kind == HMA_A_BF16_AFFINE));
+// one reduction launch for one problem (b == nullptr) or for both problems of a pair
+static int tn_dma_reduce(hipStream_t s, const hma_gemm_tn_t& a, const tn_prob& ta, const hma_gemm_tn_t* b = nullptr,
+                         const tn_prob* tb = nullptr) {
+  tn_reduce_args ra;
+  ra.p[0] = a;
+  ra.p[0].splits = ta.splits;
+  ra.p[0].ws = ta.ws;
+  ra.gn[0] = ta.gn; ra.gk[0] = ta.gk; ra.affine[0] = a.a_kind == HMA_A_BF16_AFFINE;
+  ra.gy0 = ta.gn * ta.gk * (a.batch > 0 ? a.batch : 1);
+  unsigned gy = (unsigned)ra.gy0;
+  ra.p[1] = ra.p[0]; ra.gn[1] = ra.gn[0]; ra.gk[1] = ra.gk[0]; ra.affine[1] = ra.affine[0];
+  if (b) {
+    ra.p[1] = *b;
+    ra.p[1].splits = tb->splits;
+    ra.p[1].ws = tb->ws;
+    ra.gn[1] = tb->gn; ra.gk[1] = tb->gk; ra.affine[1] = b->a_kind == HMA_A_BF16_AFFINE;
+    gy += (unsigned)(tb->gn * tb->gk * (b->batch > 0 ? b->batch : 1));
+  }
+  hipLaunchKernelGGL(tn_reduce_native_kernel, dim3((unsigned)(WT * WT / 256), gy), dim3(256), 0, s, ra);
   HMA_CHECK_LAUNCH();
   return 0;
 }
@@ -3016,8 +3039,7 @@ extern "C" int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_
   if (args.q[0].nb + args.q[1].nb > 256) return HMA_EINVAL;
   int rc;
   if ((rc = tn_dma_launch<true>(s, args))) return rc;
-  if ((rc = tn_dma_reduce(s, *a, args.q[0]))) return rc;
-  return tn_dma_reduce(s, *b, args.q[1]);
+  return tn_dma_reduce(s, *a, args.q[0], b, &args.q[1]);
 }
 
 #ifdef HMA_PROF
