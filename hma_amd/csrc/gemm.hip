@@ -1189,11 +1189,11 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   const int64_t bz = slab_id / slabs_n;
   const int64_t bn = (int64_t)(slab_id % slabs_n) * 256;
 
-  {  // park the weight slab: chunk ch of row n goes to position ch ^ (4 * ((n >> 4) & 1))  (bank spread, see below)
+  {  // park the weight slab: chunk ch of row n goes to position ch ^ (5 * (((n >> 3) ^ (n >> 4)) & 1))  (bank spread, see below)
     const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
     for (int c = tid; c < 256 * 32; c += 64 * NWAVES) {
       const int n = c >> 5, ch = c & 31;
-      *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) =
+      *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (5 * (((n >> 3) ^ (n >> 4)) & 1))) << 3)]) =
           *reinterpret_cast<const uint4*>(Wb + (int64_t)n * p.ldw + ch * 8);
     }
     if (AKIND == HMA_A_BF16_AFFINE) {
@@ -1255,12 +1255,14 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   };
 
   // lane constants of the weight-fragment address: MFMA row i = lane & 15 of tile (p, o) is
-  // n = 32 p + 8 (i >> 2) + (i & 3) + 4 o; logical chunk 4 j + g sits at 4 (j ^ ((i >> 3) & 1)) + g.
-  // Bank check (row stride 528 B = 33 x 16-B slots): a 16-lane group reads rows {0-3, 8-11, 16-19, 24-27} (+4 o);
-  // rows 16 apart would share a slot, the chunk swizzle moves them 4 slots on.
+  // n = 32 p + 8 (i >> 2) + (i & 3) + 4 o; logical chunk L = 4 j + g sits at L ^ 5 b, b = ((i >> 2) ^ (i >> 3)) & 1.
+  // Bank check (row stride 528 B = 33 x 16-B slots, slot = (row + chunk) mod 16): ds_read_b128 is served in the lane
+  // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, {32-35, 44-47, 52-59}, {36-43, 48-51, 60-63} (NOT 16 consecutive
+  // lanes); the first swizzle (4 j ^ 4 ((i >> 3) & 1), checked against consecutive groups) left one slot shared in every
+  // group -- SQ_LDS_BANK_CONFLICT = SQ_LDS_IDX_ACTIVE / 2 on every launch; this one is exhaustively conflict-free.
   const int i16 = lane & 15;
-  const uint16_t* wbase = Wsl + (8 * (i16 >> 2) + (i16 & 3)) * TW_LD + g * 8;
-  const int jsw = (i16 >> 3) & 1;
+  const int jsw = ((i16 >> 2) ^ (i16 >> 3)) & 1;
+  const uint16_t* wbase = Wsl + (8 * (i16 >> 2) + (i16 & 3)) * TW_LD + (g ^ jsw) * 8;
   const float* bias = p.bias ? p.bias + bz * p.sBias + bn : nullptr;
 
   bf16x8_t a[8], an[8];
