@@ -245,28 +245,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   }
 }
 
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+#define HMA_LDS(T) __attribute__((address_space(3))) T
+// Second-product A operand straight from a ROW-major tile (no transposed copy in LDS): 8 bf16 of column (lane & 31), rows
+// row0 + 4 hi + {0..3} and the same + 8 -- the order in which pack_acc_half lays the rows of a 32 x 32 accumulator into a
+// B operand (the kappa permutation of frag_cols).  ds_read_b64_tr_b16: a 16-lane group reads a [4 row][16 column] block,
+// lane i supplies the address of row i >> 2, columns 4 (i & 3) .. + 3 and receives column i of the 4 rows
+// (tools/probes/tr_read_dma.hip).  Rows must be 8-byte aligned (LDR = 40 elements: 80 B).
+__device__ __forceinline__ bf16x8_t frag_tr(const uint16_t* tile, int ld, int row0, int lane) {
+  const int i16 = lane & 15, g16 = lane >> 4;
+  const uint16_t* p = tile + (row0 + 4 * (g16 >> 1) + (i16 >> 2)) * ld + 16 * (g16 & 1) + 4 * (i16 & 3);
+  const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)p);
+  const v4s16_t hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(p + 8 * ld));
+  typedef short v8s16_t __attribute__((ext_vector_type(8)));
+  const v8s16_t v = __builtin_shufflevector(lo, hv, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // ------------------------------------------------------------------------------------- dQ
 template <int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                              const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, uint16_t* __restrict__ dqkv,
                                                              int64_t frames, float c_log2, float scale) {
-  constexpr int N = NT * 32, LDV = N + 4;
+  constexpr int N = NT * 32;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Ks = smem;                 // [N][LDR]
   uint16_t* Vs = Ks + N * LDR;         // [N][LDR]
-  uint16_t* Kt = Vs + N * LDR;         // [32][LDV]
+  // (no transposed K: the dQ product reads its K^T operand from Ks with transposing LDS reads -- 51 KB instead of 72 KB
+  // of LDS, three workgroups per CU instead of two)
   int64_t frame; int head;
   decode_block(blockIdx.x, frames, frame, head);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
   {
-    PairStage<N> ks;
-    RowStage<N> vs;
+    RowStage<N> ks, vs;
     ks.load(base + DM, QKV_LD, tid);
     vs.load(base + 2 * DM, QKV_LD, tid);
-    ks.store_rows(Ks, tid);
-    ks.store_cols(Kt, LDV, tid);
+    ks.store(Ks, tid);
     vs.store(Vs, tid);
   }
   __syncthreads();
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = fast_exp2(s[e] * c_log2 - L2) * (dp[e] - dl);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) acc = mfma32(frag_cols(Kt, LDV, kt * 32, s2, lane), pack_acc_half(s, s2), acc);
+      for (int s2 = 0; s2 < 2; ++s2) acc = mfma32(frag_tr(Ks, LDR, kt * 32 + 16 * s2, lane), pack_acc_half(s, s2), acc);
     }
     store_dt(dqkv + row0 * QKV_LD + head * HD, QKV_LD, acc, scale, lane);
   }
@@ -445,7 +461,7 @@ template <int NT>
 int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                void* dqkv, int64_t frames, float scale) {
   constexpr int N = NT * 32, LDV = N + 4;
-  constexpr int bytes_dq = (2 * N * LDR + 32 * LDV) * 2;
+  constexpr int bytes_dq = 2 * N * LDR * 2;
   constexpr int NRh = N / 2;
   constexpr int bytes_dkv = (2 * NRh * LDR + 2 * 32 * (NRh + 4)) * 2 + 2 * NRh * 4;
   int rc = set_lds<attn_bwd_dq_kernel<NT>>(bytes_dq);
