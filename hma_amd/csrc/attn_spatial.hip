@@ -170,7 +170,7 @@ __device__ __forceinline__ void store_dt(uint16_t* base, int64_t ld, const f32x1
 
 // ------------------------------------------------------------------------------------- forward
 template <int NT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int64_t frames, float c_log2) {
   constexpr int N = NT * 32, LDV = N + 4;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
