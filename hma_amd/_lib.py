@@ -46,6 +46,26 @@ class GemmTN(C.Structure):
         ("splits", c_i32), ("batch", c_i32),
         ("sY", c_i64), ("sA", c_i64), ("sdW", c_i64), ("sdBias", c_i64),
         ("ws", c_vp), ("ws_elems", c_i64),
+        ("w_master", c_vp), ("dgamma", c_vp), ("dbeta", c_vp),
+    ]
+
+
+class MlpFwd(C.Structure):
+    _fields_ = [
+        ("xhat", c_vp), ("x", c_vp),
+        ("w1p", c_vp), ("w2p", c_vp), ("b1", c_vp), ("b2", c_vp),
+        ("ln_xhat", c_vp), ("ln_rstd", c_vp), ("ln_eps", C.c_float), ("_pad", c_i32),
+        ("M", c_i64),
+    ]
+
+
+class MlpBwd(C.Structure):
+    _fields_ = [
+        ("xhat", c_vp), ("rstd", c_vp), ("dy", c_vp),
+        ("dx", c_vp), ("dx_bf16", c_vp),
+        ("w1p", c_vp), ("w2tp", c_vp), ("w1tp", c_vp), ("b1", c_vp),
+        ("hg", c_vp), ("du", c_vp),
+        ("M", c_i64),
     ]
 
 
@@ -92,6 +112,9 @@ _PROTOS = {
     "hma_dropout_bf16": [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_i32],
     "hma_transpose_cast_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64],
     "hma_fold_ln_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64],
+    "hma_mlp_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64],
+    "hma_mlp_fwd": [c_vp, C.POINTER(MlpFwd)],
+    "hma_mlp_bwd": [c_vp, C.POINTER(MlpBwd)],
     "hma_abi_version": [],
 }
 
@@ -120,7 +143,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = c_i32
-        if lib.hma_abi_version() != 0x484D4101:
+        if lib.hma_abi_version() != 0x484D4102:
             raise HmaKernelError("libhma_hip.so ABI mismatch: rebuild with `python -m hma_amd.build --force`")
         _lib = lib
     return _lib

@@ -263,167 +263,6 @@ struct PRegs {
   int k0;
 };
 
-template <int AKIND>
-__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(hma_gemm_nt_t p, int tiles_m, int tiles_n, int total_tiles) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int KT = (int)(p.K / PK);
-  const int kc = tid & 7;
-
-  // XCD-aware virtual id: the workgroups of one XCD (b % 8) take a contiguous run of tiles
-  const int G = gridDim.x;
-  const int b = blockIdx.x;
-  const int per = G >> 3;
-  const int vid = ((G & 7) == 0) ? (b & 7) * per + (b >> 3) : b;
-  const int my_tiles = vid < total_tiles ? (total_tiles - vid + G - 1) / G : 0;
-  const int total_it = my_tiles * KT;
-  if (total_it == 0) return;
-
-  struct Cursor { int tile; int kt; int64_t a_off[2]; int64_t w_off; int64_t bz; };
-  auto decode = [&](Cursor& c) {
-    const int per_b = tiles_m * tiles_n;
-    c.bz = c.tile / per_b;
-    const int r = c.tile % per_b;
-    const int mt = r / tiles_n, nt = r % tiles_n;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t gr = (int64_t)mt * PM + (tid >> 3) + i * 64;
-      c.a_off[i] = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
-    }
-    c.w_off = ((int64_t)nt * PN + (tid >> 3)) * p.ldw;
-  };
-  Cursor ld;
-  ld.tile = vid; ld.kt = 0;
-  decode(ld);
-
-  auto load = [&](PRegs<AKIND>& r) {
-    const int k0 = ld.kt * PK + kc * 8;
-    r.k0 = k0;
-    const char* Ab = reinterpret_cast<const char*>(p.A) + ld.bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
-    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + ld.bz * p.sW + ld.w_off + k0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.w[i] = *reinterpret_cast<const uint4*>(Wb + (int64_t)i * 64 * p.ldw);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      r.a_ok[i] = ld.a_off[i] >= 0;
-      if (r.a_ok[i]) {
-        if (AKIND == HMA_A_F32) {
-          const float* s = reinterpret_cast<const float*>(Ab) + ld.a_off[i] + k0;
-          r.a[i][0] = *reinterpret_cast<const uint4*>(s);
-          r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(s + 4);
-        } else {
-          r.a[i][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Ab) + ld.a_off[i] + k0);
-        }
-      } else {
-        r.a[i][0] = make_uint4(0, 0, 0, 0);
-        r.a[i][AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
-      }
-    }
-    if (++ld.kt == KT) {
-      ld.kt = 0;
-      ld.tile += G;
-      if (ld.tile < total_tiles) decode(ld);
-    }
-  };
-  auto store = [&](const PRegs<AKIND>& r, int buf) {
-    uint16_t* As = smem + buf * P_STAGE;
-    uint16_t* Ws = As + P_A;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&Ws[((tid >> 3) + i * 64) * LDT + kc * 8]) = r.w[i];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint4 v;
-      if (AKIND == HMA_A_F32) {
-        const float4 lo = __builtin_bit_cast(float4, r.a[i][0]);
-        const float4 hi = __builtin_bit_cast(float4, r.a[i][AKIND == HMA_A_F32 ? 1 : 0]);
-        v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
-        v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
-      } else if (AKIND == HMA_A_BF16_AFFINE) {
-        float f[8];
-        unpack8(r.a[i][0], f);
-        if (r.a_ok[i]) {
-          const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + r.k0), g1 = *reinterpret_cast<const float4*>(p.gamma + r.k0 + 4);
-          const float4 b0 = *reinterpret_cast<const float4*>(p.beta + r.k0), b1 = *reinterpret_cast<const float4*>(p.beta + r.k0 + 4);
-          f[0] = f[0] * g0.x + b0.x; f[1] = f[1] * g0.y + b0.y; f[2] = f[2] * g0.z + b0.z; f[3] = f[3] * g0.w + b0.w;
-          f[4] = f[4] * g1.x + b1.x; f[5] = f[5] * g1.y + b1.y; f[6] = f[6] * g1.z + b1.z; f[7] = f[7] * g1.w + b1.w;
-        }
-        v = pack8(f);
-      } else {
-        v = r.a[i][0];
-      }
-      *reinterpret_cast<uint4*>(&As[((tid >> 3) + i * 64) * LDT + kc * 8]) = v;
-    }
-  };
-
-  f32x16_t acc[2][2];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
-  };
-  zero_acc();
-
-  int cur_tile = vid, cur_kt = 0;
-  auto finish_tile = [&]() {
-    const int per_b = tiles_m * tiles_n;
-    const int64_t bz = cur_tile / per_b;
-    const int rr = cur_tile % per_b;
-    const int64_t bm = (int64_t)(rr / tiles_n) * PM, bn = (int64_t)(rr % tiles_n) * PN;
-    const int r = lane & 31, hi = lane >> 5;
-    const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int64_t m = bm + wm * 64 + mt * 32 + r;
-      if (m < p.M) {
-        const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int64_t n = bn + wn * 64 + nt * 32 + 8 * g + 4 * hi;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * g + e];
-            if (bias) {
-              const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-              v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-            }
-            epilogue_quad(p, p.epi, bz, crow, n, v);
-          }
-      }
-    }
-    zero_acc();
-  };
-
-  PRegs<AKIND> r0, r1;
-  load(r0);
-  if (total_it > 1) load(r1);
-  store(r0, 0);
-  __syncthreads();
-  const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
-  auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
-    // `mine` held step `it` (already in LDS) and is free: refill it with step it + 2
-    if (it + 2 < total_it && !(ablate & 2)) load(mine);
-    const uint16_t* As = smem + (it & 1) * P_STAGE;
-    if (!(ablate & 4)) mma_tile(As, As + P_A, acc, wm, wn, lane);
-    if (++cur_kt == KT) {
-      if (!(ablate & 1)) finish_tile();
-      cur_kt = 0;
-      cur_tile += G;
-    }
-    if (it + 1 < total_it) store(other, (it + 1) & 1);
-    __syncthreads();
-  };
-  for (int it = 0; it < total_it; it += 2) {
-    step(it, r0, r1);
-    if (it + 1 < total_it) step(it + 1, r1, r0);
-  }
-}
-
 // Two adjacent accumulator quads (columns nq + 8*g2 + 4*hi + {0..3} and the same for g2 + 1) of one row.
 // Measured (tools/probes/store_pattern.hip): 8-byte-per-lane stores at a row stride reach 3.2-3.6 TB/s,
 // 16-byte ones 5.8-7.0 TB/s.  For bf16 outputs the two half-waves therefore trade quads with
@@ -673,7 +512,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
   if (total_it > 1) load(r1);
   store(r0, 0);
   __syncthreads();
-  const int ablate = p._pad2;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+#ifdef HMA_PROF
+  const int ablate = p._pad2;  // debug build only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+#else
+  constexpr int ablate = 0;
+#endif
   PROF_DECL;
   auto step = [&](int it, PRegs<AKIND>& mine, PRegs<AKIND>& other) {
     PROF_MARK(0);
@@ -712,199 +555,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
   PROF_FLUSH();
 }
 
-
-// ---------------------------------------------------------------- NT, weight-stationary (K = 256)
-// Measured invariant of the variants above: whatever the schedule, a CU moves ~11-12 B/clk through its
-// vector-memory path, L2 hits included, so at K = 256 the 128 KB of W re-streamed per 128 x 256 tile
-// (twice the bytes of the A tile itself) sets the time.  Here a workgroup parks ONE 256 x 256 weight
-// slab in LDS (132 KB) for its whole life and streams only token rows: A tiles of 128 x 32 through a
-// 20 KB double buffer (loads two steps ahead), the deferred 16-byte epilogue of gemm_nt_p3_kernel.
-constexpr int SK = 256, SW_LD = SK + 8;
-constexpr int SBK = 32, SLD = SBK + 8;          // A K-step and padded stage row
-constexpr int S_W = 256 * SW_LD;                  // elements of the weight slab
-constexpr int S_A = PM * SLD;                     // one A stage: [128][32 + 8]
-constexpr int S_SMEM_BYTES = (S_W + 2 * S_A) * 2; // 155648 B
-
-template <int AKIND>
-struct SRegs {
-  uint4 a[AKIND == HMA_A_F32 ? 2 : 1];
-  bool ok;
-  int k0;
-};
-
-template <int AKIND, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(hma_gemm_nt_t p, int tiles_m, int groups, int per_group) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* Wsl = smem;           // [256 n][SW_LD]
-  uint16_t* Ast = smem + S_W;     // [2][128][SLD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int lr = lane & 31, lhi = lane >> 5;
-  constexpr int KT = SK / SBK;     // 8 steps of 32
-  const int kc = tid & 3, srow = tid >> 2;  // 128 rows x 4 chunks of 8 elements
-
-  // workgroup -> (group = (batch, n-tile), slot within the group); groups are interleaved over workgroup ids
-  const int b = blockIdx.x;
-  const int g = b % groups, slot = b / groups;
-  const int tiles_n = (int)(p.N / PN);
-  const int64_t bz = g / tiles_n;
-  const int nt_idx = g % tiles_n;
-  const int64_t bn = (int64_t)nt_idx * PN;
-  const int my_tiles = slot < tiles_m ? (tiles_m - slot + per_group - 1) / per_group : 0;
-  const int total_it = my_tiles * KT;
-  if (total_it == 0) return;
-
-  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
-  {  // park the weight slab
-    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
-    for (int c = tid; c < 256 * (SK / 8); c += 512) {
-      const int row = c >> 5, ch = c & 31;
-      *reinterpret_cast<uint4*>(&Wsl[row * SW_LD + ch * 8]) = *reinterpret_cast<const uint4*>(Wb + (int64_t)row * p.ldw + ch * 8);
-    }
-  }
-
-  int ld_tile = slot, ld_kt = 0;
-  int64_t ld_off = -1;
-  auto decode = [&]() {
-    const int64_t gr = (int64_t)ld_tile * PM + srow;
-    ld_off = gr < p.M ? remap_row(gr, p.a_group_rows, p.a_group_stride) * p.lda : -1;
-  };
-  decode();
-  auto load = [&](SRegs<AKIND>& r) {
-    const int k0 = ld_kt * SBK + kc * 8;
-    r.k0 = k0;
-    r.ok = ld_off >= 0;
-    if (r.ok) {
-      if (AKIND == HMA_A_F32) {
-        const float* sp = reinterpret_cast<const float*>(Ab) + ld_off + k0;
-        r.a[0] = *reinterpret_cast<const uint4*>(sp);
-        r.a[AKIND == HMA_A_F32 ? 1 : 0] = *reinterpret_cast<const uint4*>(sp + 4);
-      } else {
-        r.a[0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Ab) + ld_off + k0);
-      }
-    } else {
-      r.a[0] = make_uint4(0, 0, 0, 0);
-      r.a[AKIND == HMA_A_F32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
-    }
-    if (++ld_kt == KT) {
-      ld_kt = 0;
-      ld_tile += per_group;
-      if (ld_tile < tiles_m) decode();
-    }
-  };
-  auto store = [&](const SRegs<AKIND>& r, int buf) {
-    uint4 v;
-    if (AKIND == HMA_A_F32) {
-      const float4 lo = __builtin_bit_cast(float4, r.a[0]);
-      const float4 hi = __builtin_bit_cast(float4, r.a[AKIND == HMA_A_F32 ? 1 : 0]);
-      v.x = pack_bf16(lo.x, lo.y); v.y = pack_bf16(lo.z, lo.w);
-      v.z = pack_bf16(hi.x, hi.y); v.w = pack_bf16(hi.z, hi.w);
-    } else if (AKIND == HMA_A_BF16_AFFINE) {
-      float f[8];
-      unpack8(r.a[0], f);
-      if (r.ok) {
-        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + r.k0), g1 = *reinterpret_cast<const float4*>(p.gamma + r.k0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(p.beta + r.k0), b1 = *reinterpret_cast<const float4*>(p.beta + r.k0 + 4);
-        f[0] = f[0] * g0.x + b0.x; f[1] = f[1] * g0.y + b0.y; f[2] = f[2] * g0.z + b0.z; f[3] = f[3] * g0.w + b0.w;
-        f[4] = f[4] * g1.x + b1.x; f[5] = f[5] * g1.y + b1.y; f[6] = f[6] * g1.z + b1.z; f[7] = f[7] * g1.w + b1.w;
-      }
-      v = pack8(f);
-    } else {
-      v = r.a[0];
-    }
-    *reinterpret_cast<uint4*>(&Ast[buf * S_A + srow * SLD + kc * 8]) = v;
-  };
-
-  f32x16_t acc[2][2], pacc[2][2];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
-  };
-  zero_acc();
-  int cur_tile = slot, cur_kt = 0, ptile = -1;
-  auto emit_part = [&](auto mt_tag, auto nt_tag) __attribute__((always_inline)) {
-    constexpr int mt = decltype(mt_tag)::value, nt = decltype(nt_tag)::value;
-    const int64_t m = (int64_t)ptile * PM + wm * 64 + mt * 32 + lr;
-    if (m < p.M) {
-      const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride);
-      const int64_t nq = bn + wn * 64 + nt * 32;
-      const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
-#pragma unroll
-      for (int g2 = 0; g2 < 4; g2 += 2) {
-        float v0[4], v1[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v0[e] = pacc[nt][mt][4 * g2 + e];
-          v1[e] = pacc[nt][mt][4 * g2 + 4 + e];
-        }
-        if (bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 4 * lhi);
-          const float4 b1 = *reinterpret_cast<const float4*>(bias + nq + 8 * g2 + 8 + 4 * lhi);
-          v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
-          v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
-        }
-        epilogue_oct<EPI>(p, bz, crow, nq, g2, lhi, v0, v1);
-      }
-    }
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  auto emit_step = [&](int part) __attribute__((always_inline)) {
-    if (ptile < 0) return;
-    switch (part) {
-      case 0: emit_part(I0{}, I0{}); break;
-      case 2: emit_part(I0{}, I1{}); break;
-      case 4: emit_part(I1{}, I0{}); break;
-      case 6: emit_part(I1{}, I1{}); ptile = -1; break;
-      default: break;
-    }
-  };
-
-  SRegs<AKIND> r0, r1;
-  load(r0);
-  if (total_it > 1) load(r1);
-  store(r0, 0);
-  __syncthreads();
-  auto step = [&](int it, SRegs<AKIND>& mine, SRegs<AKIND>& other) {
-    if (it + 2 < total_it) load(mine);
-    const uint16_t* As = Ast + (it & 1) * S_A;
-#pragma unroll
-    for (int kk = 0; kk < SBK / 16; ++kk) {
-      bf16x8_t wf[2], tf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        wf[i] = *reinterpret_cast<const bf16x8_t*>(&Wsl[(wn * 64 + i * 32 + lr) * SW_LD + cur_kt * SBK + kk * 16 + lhi * 8]);
-        tf[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 64 + i * 32 + lr) * SLD + kk * 16 + lhi * 8]);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = mfma32(wf[nt], tf[mt], acc[nt][mt]);
-    }
-    emit_step(cur_kt);
-    if (++cur_kt == KT) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) pacc[a][c] = acc[a][c];
-      ptile = cur_tile;
-      zero_acc();
-      cur_kt = 0;
-      cur_tile += per_group;
-    }
-    if (it + 1 < total_it) store(other, (it + 1) & 1);
-    __syncthreads();
-  };
-  for (int it = 0; it < total_it; it += 2) {
-    step(it, r0, r1);
-    if (it + 1 < total_it) step(it + 1, r1, r0);
-  }
-  for (int part = 0; part < 8; part += 2) emit_step(part);
-}
 
 // --------------------------------------------------------------------- NT, persistent, 2 per CU
 // Measured on MI355X (tools/ablate.sh): with one 8-wave workgroup per CU the epilogue of a tile (its
@@ -1058,7 +708,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p2_kernel(hma_gemm_nt_t p, int
     zero_acc();
   };
   const int r = lane & 31, hi = lane >> 5;
-  const int ablate = p._pad2 & 7;  // debug only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+#ifdef HMA_PROF
+  const int ablate = p._pad2 & 7;  // debug build only (HMA_GEMM_ABLATE): 1 = skip epilogue, 2 = skip loads, 4 = skip MFMA
+#else
+  constexpr int ablate = 0;
+#endif
   PRegs<AKIND> r0, r1;
   load(r0);
   if (total_it > 1) load(r1);
@@ -1412,161 +1066,6 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   }
 }
 
-// ------------------------------------------------- NT, streaming waves, K = 128 * KH (K = 512 .. 1024)
-// Same wave-owns-its-rows structure for the K = 768 / 1024 GEMMs (fc2, dfc1, dqkv, readout dgrad), whose weight
-// slab (256 x K) does not fit LDS: it is streamed through two 256 x 128 LDS buffers.  Per step (one 128-wide K
-// piece of one tile round) every thread fetches its share of the NEXT piece into registers, the waves multiply
-// the current piece (64 MFMAs each, accumulators kept across the pieces of a tile), the registers are written to
-// the other buffer, one barrier.  A rows of the next step are in flight in registers too; epilogue per wave.
-// (A first version that re-parked whole 256-wide chunks between two barriers with nothing overlapping was
-// 1.3-1.5x SLOWER than the lock-step kernel; see profiles/.)
-constexpr int TH_LD = 128 + 8;                          // padded half-slab row (elements): 17 x 16-B slots
-constexpr int TH_BUF = 256 * TH_LD;                     // one buffer (elements)
-constexpr int TH_SMEM_BYTES = 2 * TH_BUF * 2;           // 139264 B
-
-template <int AKIND, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_swk_kernel(hma_gemm_nt_t p, int nslabs, int per_slab) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tok = lane & 15, g = lane >> 4;
-  const int KH = (int)(p.K >> 7);  // 128-wide pieces
-
-  const int b = blockIdx.x;
-  const int slab_id = b % nslabs, slot = b / nslabs;
-  const int slabs_n = (int)(p.N / 256);
-  const int64_t bz = slab_id / slabs_n;
-  const int64_t bn = (int64_t)(slab_id % slabs_n) * 256;
-  const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
-
-  const int64_t tiles = (p.M + 15) / 16;
-  const int64_t nw = (int64_t)per_slab * 8;
-  const int64_t gw0 = (int64_t)slot * 8, gw = gw0 + wave;
-  const int trips = gw0 < tiles ? (int)((tiles - gw0 + nw - 1) / nw) : 0;  // of wave 0: every wave runs this many (barriers)
-  const int total = trips * KH;
-  if (total == 0) return;
-
-  const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
-  auto load_a = [&](int64_t tile, int piece, bf16x8_t (&a)[4]) __attribute__((always_inline)) {
-    int64_t m = tile * 16 + tok;
-    m = m < p.M ? m : p.M - 1;
-    const int64_t off = remap_row(m, p.a_group_rows, p.a_group_stride) * p.lda + piece * 128;
-    if (AKIND == HMA_A_F32) {
-      const float* row = reinterpret_cast<const float*>(Ab) + off;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 lo = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(row + (4 * j + g) * 8 + 4);
-        const uint4 v = make_uint4(pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w));
-        a[j] = __builtin_bit_cast(bf16x8_t, v);
-      }
-    } else {
-      const uint16_t* row = reinterpret_cast<const uint16_t*>(Ab) + off;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(row + (4 * j + g) * 8));
-    }
-  };
-  // this thread's 8 chunks of a weight piece: chunk c = tid + 512 i -> row c >> 4, 16-B chunk c & 15 (swizzled as in sw).
-  // (Written inline below: passed through a lambda the 8-register array stayed in scratch memory.)
-  const uint16_t* wsrc = Wb + (int64_t)(tid >> 4) * p.ldw + (tid & 15) * 8;  // chunk i: + 32 i rows
-#define HMA_SWK_LOAD_W(piece_)                                                                         \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                        \
-    wq[i] = *reinterpret_cast<const u32x4_t*>(wsrc + (int64_t)(32 * i) * p.ldw + (piece_) * 128);
-#define HMA_SWK_STORE_W(buf_)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                      \
-    const int n = (tid >> 4) + 32 * i, ch = tid & 15;                                                  \
-    *reinterpret_cast<u32x4_t*>(&(buf_)[n * TH_LD + ((ch ^ (((n >> 4) & 1) << 2)) << 3)]) = wq[i];      \
-  }
-  const int i16 = lane & 15;
-  const int wofs = (8 * (i16 >> 2) + (i16 & 3)) * TH_LD + g * 8;
-  const int jsw = (i16 >> 3) & 1;
-  const float* bias = p.bias ? p.bias + bz * p.sBias + bn : nullptr;
-
-  bf16x8_t a[4], an[4];
-  u32x4_t wq[8];
-  HMA_SWK_LOAD_W(0)
-  load_a(gw < tiles ? gw : tiles - 1, 0, an);
-  HMA_SWK_STORE_W(smem)
-  __syncthreads();
-
-  int step = 0;
-  for (int trip = 0; trip < trips; ++trip) {
-    const int64_t tile = gw + (int64_t)trip * nw;
-    const bool active = tile < tiles;
-    const int64_t tile_c = active ? tile : tiles - 1;  // idle waves re-load a valid row and discard
-    const int64_t m = tile_c * 16 + tok;
-    const int64_t crow = remap_row(m < p.M ? m : p.M - 1, p.c_group_rows, p.c_group_stride);
-    float4 rx[EPI == HMA_EPI_RESID ? 16 : 1];
-    f32x4v_t acc[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-    for (int piece = 0; piece < KH; ++piece, ++step) {
-      const uint16_t* cur = smem + (step & 1) * TH_BUF;
-      const bool more = step + 1 < total;
-      int npiece = piece + 1, ntrip = trip;
-      if (npiece == KH) { npiece = 0; ++ntrip; }
-      const int wpiece = more ? npiece : piece;  // unconditional: the last prefetch is unused
-      HMA_SWK_LOAD_W(wpiece)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = an[j];
-      {
-        int64_t ntile = gw + (int64_t)ntrip * nw;
-        if (!more || ntile >= tiles) ntile = tile_c;
-        load_a(ntile, more ? npiece : piece, an);
-      }
-      if (EPI == HMA_EPI_RESID && piece == 0) {  // residual rows: fetched a whole tile ahead of their use
-        const float* C = reinterpret_cast<const float*>(p.C) + bz * p.sC + crow * p.ldc + bn + 8 * g;
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {
-          rx[2 * pr] = *reinterpret_cast<const float4*>(C + 32 * pr);
-          rx[2 * pr + 1] = *reinterpret_cast<const float4*>(C + 32 * pr + 4);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint16_t* wj = cur + wofs + ((j ^ jsw) << 5);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wj + (32 * (t >> 1) + 4 * (t & 1)) * TH_LD);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a[j], acc[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {
-        uint16_t* nbuf = smem + ((step + 1) & 1) * TH_BUF;
-        HMA_SWK_STORE_W(nbuf)
-      }
-      __syncthreads();
-    }
-    if (active && m < p.M) {
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        const int64_t nl = 32 * pr + 8 * g;
-        float v[8] = {acc[2 * pr][0], acc[2 * pr][1], acc[2 * pr][2], acc[2 * pr][3],
-                      acc[2 * pr + 1][0], acc[2 * pr + 1][1], acc[2 * pr + 1][2], acc[2 * pr + 1][3]};
-        if (bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(bias + nl), b1 = *reinterpret_cast<const float4*>(bias + nl + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (EPI == HMA_EPI_RESID) {
-          float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + bn + nl;
-          float4 x0 = rx[2 * pr], x1 = rx[2 * pr + 1];
-          x0.x += v[0]; x0.y += v[1]; x0.z += v[2]; x0.w += v[3];
-          x1.x += v[4]; x1.y += v[5]; x1.z += v[6]; x1.w += v[7];
-          *reinterpret_cast<float4*>(C) = x0;
-          *reinterpret_cast<float4*>(C + 4) = x1;
-          if (p.C2) {
-            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.C2) + bz * p.sC2 + crow * p.ldc2 + bn + nl) = pack8(xs);
-          }
-        } else {
-          epilogue_run8<EPI>(p, bz, crow, bn + nl, v);
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ TN
 // Stage a 64(m) x 128(col) slab of a row-major matrix TRANSPOSED into LDS as [128 col][64 m].
 // Thread task: rows 4*mi..4*mi+3, columns w*32 + ci*8 .. +8 (mi = lane & 15, ci = lane >> 4):
@@ -1828,7 +1327,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_wide_kernel(hma_gemm_tn_t p, i
   const int iters = (int)((m_end - m_begin + 63) / 64);
   const int r = lane & 31, hi = lane >> 5;
   PROF_DECL;
-  const int ablate = p._pad0;  // debug only (HMA_GEMM_TN_ABLATE): 1 = skip MFMA, 2 = skip LDS stores, 4 = skip loads, 8 = skip epilogue
+#ifdef HMA_PROF
+  const int ablate = p._pad0;  // debug build only (HMA_GEMM_TN_ABLATE): 1 = skip MFMA, 2 = skip LDS stores, 4 = skip loads, 8 = skip epilogue
+#else
+  constexpr int ablate = 0;
+#endif
   auto mma = [&](int cur) __attribute__((always_inline)) {
     const uint16_t* Ys = Yt + cur * W_TILE;
     const uint16_t* As = At + cur * W_TILE;
@@ -1974,22 +1477,9 @@ constexpr int DM_STAGES = DM_STAGES_N;  // 4 x 32 KB (5 slots, the whole LDS, me
 constexpr int DM_SMEM_BYTES = DM_STAGES * DM_STAGE_BYTES;
 
 typedef short v4s16_t __attribute__((ext_vector_type(4)));
-#define HMA_LDS(T) __attribute__((address_space(3))) T
 
 __device__ __forceinline__ int dm_off(int row, int col) {  // byte offset of element (row, col) in a swizzled tile
   return row * 512 + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + ((col & 7) << 1);
-}
-
-// One LDS-DMA piece: 64 lanes x 16 bytes from each lane's `src` to LDS bytes [dst, dst + 1024) in lane order.  Issued
-// from inline asm so that hipcc does not count it: with the builtin the compiler drains vmcnt(0) before the next LDS
-// read and nothing stays in flight.  The waits are the counted `s_waitcnt vmcnt(N)` in the loop below.
-__device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(dst)
-      : "memory");
 }
 
 // ABL (debug build only): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no partial stores, 16 no barrier
@@ -2257,6 +1747,29 @@ __global__ __launch_bounds__(256) void tn_reduce_native_kernel(tn_reduce_args ra
       float cs = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) cs += csum[q][r];
+      if (p.dgamma) {
+        // gradients of the folded LayerNorm affine from the un-scaled product t = (dY^T xhat)[n][k]:
+        // dgamma[k] += sum_n W[n][k] t[n][k], dbeta[k] += sum_n W[n][k] colsum(dY)[n]; the 32 lanes of a half-wave hold
+        // 32 different rows n of the same 4 columns
+        const float4 wm = *reinterpret_cast<const float4*>(p.w_master + bz * p.sdW + (n0 + nl) * p.lddw + k0 + kk);
+        float dg[4] = {wm.x * t.x, wm.y * t.y, wm.z * t.z, wm.w * t.w};
+        float db[4] = {wm.x * cs, wm.y * cs, wm.z * cs, wm.w * cs};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            dg[e] += __shfl_xor(dg[e], o, 64);
+            db[e] += __shfl_xor(db[e], o, 64);
+          }
+        }
+        if (r == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            atomicAdd(p.dgamma + k0 + kk + e, dg[e]);
+            atomicAdd(p.dbeta + k0 + kk + e, db[e]);
+          }
+        }
+      }
       t.x = gm.x * t.x + bt.x * cs; t.y = gm.y * t.y + bt.y * cs; t.z = gm.z * t.z + bt.z * cs; t.w = gm.w * t.w + bt.w * cs;
     }
     o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
@@ -2622,24 +2135,26 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2) && !p->C2) return HMA_EINVAL;
   if ((p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU) && !p->U) return HMA_EINVAL;
-  if (p->drop_p != 0.f) {  // dropout: streaming GELU2 / DGELU, persistent RESID
-    static const bool no_sw_d = getenv("HMA_GEMM_NT_NOSW") != nullptr;
+  if (p->drop_p != 0.f) {  // dropout: streaming GELU2 / DGELU (K = 256), ring RESID (K > 256)
     if (!(p->drop_p > 0.f && p->drop_p < 1.f) || !p->drop_seed || (p->batch > 1)) return HMA_EINVAL;
-    const bool act = (p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_DGELU) && p->K == 256 && !no_sw_d;
-    const bool res = p->epi == HMA_EPI_RESID && p->K > 256 && p->K % 64 == 0 && p->N % 256 == 0 && !p->ln_xhat &&
-                     getenv("HMA_GEMM_NT_V1") == nullptr && getenv("HMA_GEMM_NT_P1") == nullptr && getenv("HMA_GEMM_NT_SWK") == nullptr;
+    const bool act = (p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_DGELU) && p->K == 256;
+    const bool res = p->epi == HMA_EPI_RESID && p->K > 256 && p->K % 64 == 0 && p->N % 256 == 0 && !p->ln_xhat;
     if (!act && !res) return HMA_EINVAL;
     if (p->epi == HMA_EPI_DGELU && p->ldc != p->ldu) return HMA_EINVAL;  // the mask is indexed like the forward's C2
   }
   if (p->ln_xhat) {  // fused LayerNorm: only on the streaming residual path
-    static const bool no_sw_ln = getenv("HMA_GEMM_NT_NOSW") != nullptr;
-    if (no_sw_ln || p->epi != HMA_EPI_RESID || p->N != 256 || p->K != 256 || p->batch > 1 || !p->ln_rstd) return HMA_EINVAL;
+    if (p->epi != HMA_EPI_RESID || p->N != 256 || p->K != 256 || p->batch > 1 || !p->ln_rstd) return HMA_EINVAL;
     if (p->ln_ss && (!p->ln_xm || p->ln_rows_per_frame <= 0)) return HMA_EINVAL;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
-  static const bool use_v1 = getenv("HMA_GEMM_NT_V1") != nullptr;
-  if (!use_v1 && p->N % PN == 0) {
+  hma_gemm_nt_t pa = *p;
+  pa._pad2 = 0;
+#ifdef HMA_PROF
+  static const int ablate = getenv("HMA_GEMM_ABLATE") ? atoi(getenv("HMA_GEMM_ABLATE")) : 0;  // debug build only
+  pa._pad2 = ablate;
+#endif
+  if (p->N % PN == 0) {
     const int tiles_m = (int)((p->M + PM - 1) / PM), tiles_n = (int)(p->N / PN);
     const int total = tiles_m * tiles_n * (p->batch > 0 ? p->batch : 1);
     static int n_cu = 0;
@@ -2649,21 +2164,11 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HMA_EINVAL;
       n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    static const int ablate = getenv("HMA_GEMM_ABLATE") ? atoi(getenv("HMA_GEMM_ABLATE")) : 0;
-    static const bool use_p1 = getenv("HMA_GEMM_NT_P1") != nullptr;
-    hma_gemm_nt_t pa = *p;
-    pa._pad2 = ablate;
-    static const bool use_p2 = getenv("HMA_GEMM_NT_P2") != nullptr;
-    static const bool no_ws = getenv("HMA_GEMM_NT_NOWS") != nullptr;
-    // K = 256 (every forward GEMM but fc2, and the dgrads of proj / fc2): streaming waves.  Measured in situ
-    // (rocprofv3, bench.py): qkv 148 -> 105 us, temporal qkv 131 -> 105, fc1 308 -> 262, dfc2 287 -> 216,
-    // residual projections 102 -> 90 us against the lock-step kernels below (HMA_GEMM_NT_NOSW=1 restores them).
-    static const bool no_sw = getenv("HMA_GEMM_NT_NOSW") != nullptr;
-    if (!no_sw && !use_p1 && !use_p2 && p->K == 256 && p->epi != HMA_EPI_ATOMIC_F32) {
-      // streaming waves: blocks dealt round-robin over the (batch, n-slab) pairs
+    // K = 256 (qkv, proj, modulate linear, fc1 and the dgrads of proj / fc2): streaming waves
+    if (p->K == 256 && p->epi != HMA_EPI_ATOMIC_F32) {
       const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
       const int64_t tiles16 = (p->M + 15) / 16;
-      if (p->ln_xhat) {  // validated above: A bf16 or any kind, RESID, N = K = 256
+      if (p->ln_xhat) {  // validated above: RESID, N = K = 256
         int per_slab = n_cu;
         if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
 #define HMA_NTW_LN_CASE(AK)                                                                           \
@@ -2681,7 +2186,7 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       }
 #define HMA_NTW_CASE(AK, EP)                                                                          \
   if (p->a_kind == AK && p->epi == EP) {                                                              \
-    constexpr int NWV = 8; /* 12 waves (168 VGPRs) spill and measured 1.05-2.7x slower */                           \
+    constexpr int NWV = 8; /* 12 waves (168 VGPRs) spill and measured 1.05-2.7x slower */             \
     int per_slab = n_cu / nslabs;                                                                     \
     if (per_slab < 1) per_slab = 1;                                                                   \
     if ((int64_t)per_slab * NWV > tiles16) per_slab = (int)((tiles16 + NWV - 1) / NWV);               \
@@ -2698,10 +2203,10 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       HMA_NTW_ALL(HMA_A_BF16)
       HMA_NTW_ALL(HMA_A_F32)
       HMA_NTW_ALL(HMA_A_BF16_AFFINE)
+      return HMA_EINVAL;
     }
-    // deep-K, N = 256, plain bf16 operands: the LDS-DMA ring kernel (HMA_GEMM_NT_RING=0 disables)
-    static const bool nt_ring = !(getenv("HMA_GEMM_NT_RING") && getenv("HMA_GEMM_NT_RING")[0] == '0');
-    if (nt_ring && !use_p1 && !use_p2 && p->K > 256 && (p->K & 31) == 0 && p->N == 256 && p->a_kind == HMA_A_BF16 &&
+    // deep-K, N = 256, plain bf16 operands (fc2, dfc1, dqkv): the LDS-DMA ring kernel
+    if (p->K > 256 && (p->K & 31) == 0 && p->N == 256 && p->a_kind == HMA_A_BF16 &&
         (p->batch <= 1) && p->a_group_rows <= 0 && (p->epi == HMA_EPI_BF16 || p->epi == HMA_EPI_RESID) &&
         (p->lda & 7) == 0 && (p->ldw & 7) == 0 && (reinterpret_cast<uintptr_t>(p->A) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(p->W) & 15) == 0 && p->M >= 256) {
@@ -2721,65 +2226,25 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       HMA_NTR_ABLS(HMA_EPI_BF16) HMA_NTR_ABLS(HMA_EPI_RESID)
 #endif
       // stage depth: 64 (two slots) measured 5 % faster for the bf16 epilogue, 0-3 % slower for the residual one (which is
-      // at the register cap with its batched epilogue); HMA_GEMM_NT_RING=32 / 64 forces one for both
-      static const char* ring_env = getenv("HMA_GEMM_NT_RING");
-      const bool ring64 = ring_env && ring_env[0] == '6' ? true : ring_env && ring_env[0] == '3' ? false : p->epi == HMA_EPI_BF16;
-#define HMA_NTR_CASE(EP)                                                                              \
-  if (p->epi == EP) {                                                                                 \
-    if (ring64 && (p->K & 63) == 0) {                                                                 \
-      if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP, 0, 64, 2>>(NR_SMEM_BYTES))) return rc;         \
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EP, 0, 64, 2>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk); \
-    } else {                                                                                          \
-      if ((rc = set_smem_bytes<gemm_nt_ring_kernel<EP>>(NR_SMEM_BYTES))) return rc;                   \
-      hipLaunchKernelGGL((gemm_nt_ring_kernel<EP>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk); \
-    }                                                                                                 \
-    HMA_CHECK_LAUNCH();                                                                               \
-    return 0;                                                                                         \
-  }
-      HMA_NTR_CASE(HMA_EPI_BF16) HMA_NTR_CASE(HMA_EPI_RESID)
+      // at the register cap with its batched epilogue)
+      if (p->epi == HMA_EPI_BF16 && (p->K & 63) == 0) {
+        if ((rc = set_smem_bytes<gemm_nt_ring_kernel<HMA_EPI_BF16, 0, 64, 2>>(NR_SMEM_BYTES))) return rc;
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<HMA_EPI_BF16, 0, 64, 2>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk);
+      } else if (p->epi == HMA_EPI_BF16) {
+        if ((rc = set_smem_bytes<gemm_nt_ring_kernel<HMA_EPI_BF16>>(NR_SMEM_BYTES))) return rc;
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<HMA_EPI_BF16>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk);
+      } else {
+        if ((rc = set_smem_bytes<gemm_nt_ring_kernel<HMA_EPI_RESID>>(NR_SMEM_BYTES))) return rc;
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<HMA_EPI_RESID>), dim3(g), dim3(512), NR_SMEM_BYTES, s, pa, chunk);
+      }
+      HMA_CHECK_LAUNCH();
+      return 0;
     }
-    // K > 256 streaming variant (weights double-buffered through LDS in 128-wide pieces): measured EQUAL to the
-    // lock-step kernel in situ (fc2 / dqkv-resid 177 vs 182 us, dfc1 / dqkv 109 vs 110 us; 113.5 ms/step both ways) --
-    // both re-stream the 256 x K weight slab once per 128 token rows.  Opt-in (HMA_GEMM_NT_SWK=1).
-    static const bool no_swk = getenv("HMA_GEMM_NT_SWK") == nullptr;
-    if (!no_sw && !no_swk && !use_p1 && !use_p2 && p->K > 256 && p->K <= 1024 && (p->K & 127) == 0 && p->a_kind != HMA_A_BF16_AFFINE &&
-        (p->epi == HMA_EPI_BF16 || p->epi == HMA_EPI_F32 || p->epi == HMA_EPI_RESID)) {
-      const int nslabs = (int)(p->N / 256) * (p->batch > 0 ? p->batch : 1);
-      const int64_t tiles16 = (p->M + 15) / 16;
-      int per_slab = n_cu / nslabs;
-      if (per_slab < 1) per_slab = 1;
-      if ((int64_t)per_slab * 8 > tiles16) per_slab = (int)((tiles16 + 7) / 8);
-#define HMA_NTK_CASE(AK, EP)                                                                          \
-  if (p->a_kind == AK && p->epi == EP) {                                                              \
-    if ((rc = set_smem_bytes<gemm_nt_swk_kernel<AK, EP>>(TH_SMEM_BYTES))) return rc;                  \
-    hipLaunchKernelGGL((gemm_nt_swk_kernel<AK, EP>), dim3((unsigned)(nslabs * per_slab)), dim3(512), TH_SMEM_BYTES, s, pa, \
-                       nslabs, per_slab);                                                             \
-    HMA_CHECK_LAUNCH();                                                                               \
-    return 0;                                                                                         \
-  }
-      HMA_NTK_CASE(HMA_A_BF16, HMA_EPI_BF16) HMA_NTK_CASE(HMA_A_BF16, HMA_EPI_F32) HMA_NTK_CASE(HMA_A_BF16, HMA_EPI_RESID)
-      HMA_NTK_CASE(HMA_A_F32, HMA_EPI_BF16) HMA_NTK_CASE(HMA_A_F32, HMA_EPI_F32) HMA_NTK_CASE(HMA_A_F32, HMA_EPI_RESID)
-    }
-    // (measured per shape, profiles/gemm_shapes_r1.txt: it only wins for the N = K = 256 residual projections)
-    if (!use_p1 && !use_p2 && !no_ws && p->K == SK && p->N == PN && p->a_kind == HMA_A_BF16 && p->epi == HMA_EPI_RESID && !p->C2) {
-      // weight-stationary: one (batch, n-tile) group per workgroup, the groups dealt round-robin over the grid
-      const int groups = tiles_n * (p->batch > 0 ? p->batch : 1);
-      int per_group = n_cu / groups;
-      if (per_group < 1) per_group = 1;
-      if (per_group > tiles_m) per_group = tiles_m;
-      const dim3 sgrid((unsigned)(groups * per_group));
-#define HMA_NTS_CASE(AK, EP)                                                                          \
-  if (p->a_kind == AK && p->epi == EP) {                                                              \
-    if ((rc = set_smem_bytes<gemm_nt_ws_kernel<AK, EP>>(S_SMEM_BYTES))) return rc;                    \
-    hipLaunchKernelGGL((gemm_nt_ws_kernel<AK, EP>), sgrid, dim3(512), S_SMEM_BYTES, s, pa, tiles_m, groups, per_group); \
-    HMA_CHECK_LAUNCH();                                                                               \
-    return 0;                                                                                         \
-  }
-      HMA_NTS_CASE(HMA_A_BF16, HMA_EPI_RESID)
-    }
+    if (p->drop_p != 0.f && p->epi != HMA_EPI_RESID) return HMA_EINVAL;  // (activation dropout: streaming kernel only)
+    // everything else with N % 256 == 0: lock-step persistent tiles; plain epilogues on the 8-wave kernel,
+    // activation epilogues on the two-per-CU 4-wave kernel
     const bool valu_epi = p->epi == HMA_EPI_GELU2 || p->epi == HMA_EPI_SILU2 || p->epi == HMA_EPI_DGELU || p->epi == HMA_EPI_DSILU;
-    const bool wide_bf16 = p->epi == HMA_EPI_BF16 && p->K == 256 && p->N >= 768 && p->a_kind == HMA_A_BF16;
-    if (!use_p1 && !use_p2 && !valu_epi && !wide_bf16 && p->K % PK == 0) {
+    if (!valu_epi && p->K % PK == 0) {
       const dim3 p3grid((unsigned)(total < n_cu ? total : n_cu));
 #define HMA_NT3_CASE(AK, EP)                                                                          \
   if (p->a_kind == AK && p->epi == EP) {                                                              \
@@ -2796,7 +2261,7 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
       HMA_NT3_ALL(HMA_A_BF16_AFFINE)
       return HMA_EINVAL;
     }
-    if (!use_p1 && p->K % QK == 0) {
+    if (p->K % QK == 0) {
       const dim3 qgrid((unsigned)(total < 2 * n_cu ? total : 2 * n_cu));
 #define HMA_NTQ_CASE(AK, EP)                                                                          \
   if (p->a_kind == AK && p->epi == EP) {                                                              \
@@ -2806,42 +2271,30 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
     return 0;                                                                                         \
   }
 #define HMA_NTQ_ALL(AK)                                                                               \
-  HMA_NTQ_CASE(AK, HMA_EPI_BF16) HMA_NTQ_CASE(AK, HMA_EPI_F32) HMA_NTQ_CASE(AK, HMA_EPI_RESID)        \
   HMA_NTQ_CASE(AK, HMA_EPI_GELU2) HMA_NTQ_CASE(AK, HMA_EPI_SILU2) HMA_NTQ_CASE(AK, HMA_EPI_DGELU)     \
-  HMA_NTQ_CASE(AK, HMA_EPI_DSILU) HMA_NTQ_CASE(AK, HMA_EPI_ATOMIC_F32)
+  HMA_NTQ_CASE(AK, HMA_EPI_DSILU)
       HMA_NTQ_ALL(HMA_A_BF16)
       HMA_NTQ_ALL(HMA_A_F32)
       HMA_NTQ_ALL(HMA_A_BF16_AFFINE)
       return HMA_EINVAL;
     }
-    const dim3 pgrid((unsigned)(total < n_cu ? total : n_cu));
-#define HMA_NTP_CASE(AK)                                                                              \
-  case AK:                                                                                            \
-    if ((rc = set_smem_bytes<gemm_nt_persist_kernel<AK>>(P_SMEM_BYTES))) return rc;                   \
-    hipLaunchKernelGGL(gemm_nt_persist_kernel<AK>, pgrid, dim3(512), P_SMEM_BYTES, s, pa, tiles_m, tiles_n, total); \
-    break;
-    switch (p->a_kind) {
-      HMA_NTP_CASE(HMA_A_BF16)
-      HMA_NTP_CASE(HMA_A_F32)
-      HMA_NTP_CASE(HMA_A_BF16_AFFINE)
-      default: return HMA_EINVAL;
-    }
-    HMA_CHECK_LAUNCH();
-    return 0;
+    return HMA_EINVAL;
   }
+  if (p->drop_p != 0.f || p->ln_xhat) return HMA_EINVAL;
+  // N % 256 != 0 (N = 128: the diffusion head's padded output layer): one 128 x 128 tile per workgroup
   const dim3 grid((unsigned)((p->M + BM - 1) / BM), (unsigned)(p->N / BN), (unsigned)(p->batch > 0 ? p->batch : 1));
   switch (p->a_kind) {
     case HMA_A_BF16:
       if ((rc = set_smem<gemm_nt_kernel<HMA_A_BF16>>())) return rc;
-      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_BF16>, grid, dim3(256), SMEM_BYTES, s, *p);
+      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_BF16>, grid, dim3(256), SMEM_BYTES, s, pa);
       break;
     case HMA_A_F32:
       if ((rc = set_smem<gemm_nt_kernel<HMA_A_F32>>())) return rc;
-      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_F32>, grid, dim3(256), SMEM_BYTES, s, *p);
+      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_F32>, grid, dim3(256), SMEM_BYTES, s, pa);
       break;
     case HMA_A_BF16_AFFINE:
       if ((rc = set_smem<gemm_nt_kernel<HMA_A_BF16_AFFINE>>())) return rc;
-      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_BF16_AFFINE>, grid, dim3(256), SMEM_BYTES, s, *p);
+      hipLaunchKernelGGL(gemm_nt_kernel<HMA_A_BF16_AFFINE>, grid, dim3(256), SMEM_BYTES, s, pa);
       break;
     default:
       return HMA_EINVAL;
@@ -2927,14 +2380,17 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   if (p->N % 128 != 0 || p->K % 128 != 0) return HMA_EINVAL;
   if (p->y_kind == HMA_A_BF16_AFFINE) return HMA_EINVAL;
   if (p->a_kind == HMA_A_BF16_AFFINE && (!p->gamma || !p->beta)) return HMA_EINVAL;
+  if (p->dgamma && (p->a_kind != HMA_A_BF16_AFFINE || !p->dbeta || !p->w_master)) return HMA_EINVAL;
   hma_gemm_tn_t q = *p;
-  static const int tn_ablate = getenv("HMA_GEMM_TN_ABLATE") ? atoi(getenv("HMA_GEMM_TN_ABLATE")) : 0;
+  q._pad0 = 0;
+#ifdef HMA_PROF
+  static const int tn_ablate = getenv("HMA_GEMM_TN_ABLATE") ? atoi(getenv("HMA_GEMM_TN_ABLATE")) : 0;  // debug build only
   q._pad0 = tn_ablate;
+#endif
   const int64_t slabs = (q.M + 63) / 64;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc;
-  static const bool tn_v1 = getenv("HMA_GEMM_TN_V1") != nullptr;
-  if (!tn_v1 && q.N % WT == 0 && q.K % WT == 0) {
+  if (q.N % WT == 0 && q.K % WT == 0) {
     const int gn = (int)(q.N / WT), gk = (int)(q.K / WT);
     const int nb = q.batch > 0 ? q.batch : 1;
     int splits = 256 / (gn * gk * nb);  // one resident workgroup per CU
@@ -2950,12 +2406,9 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     const int64_t per = (slabs + splits - 1) / splits;
     if (q.ws && (q.ws_elems < (int64_t)nblocks * WT * WT || per * (splits - 1) >= slabs || splits == 1)) q.ws = nullptr;
     const dim3 rgrid((unsigned)(WT * WT / 512), (unsigned)(gn * gk * nb));
-    // bf16 x bf16 with a workspace: the LDS-DMA ring kernel (HMA_GEMM_TN_DMA=0 falls back to the register-staged kernel,
-    // =u16 selects the 2-byte reference gather instead of the transposing LDS read)
-    static const char* tn_dma_env = getenv("HMA_GEMM_TN_DMA");
-    static const char* tn_dma = tn_dma_env ? tn_dma_env : "tr";
+    // bf16 x bf16 with a workspace: the LDS-DMA ring kernel
     const bool bias_room = q.ws && q.ws_elems >= (int64_t)nblocks * (WT * WT + WT);
-    if (tn_dma[0] != '0' && q.ws && tn_dma_eligible(q) && (bias_room || (!q.dBias && q.a_kind == HMA_A_BF16))) {
+    if (q.ws && tn_dma_eligible(q) && (bias_room || (!q.dBias && q.a_kind == HMA_A_BF16))) {
       tn_pair_args args;
       args.q[0] = tn_make_prob(q, q.ws, splits);
       args.q[1] = args.q[0];
@@ -2976,9 +2429,10 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
         HMA_CHECK_LAUNCH();
       } else
 #endif
-      if ((rc = tn_dma[0] == 'u' ? tn_dma_launch<false>(s, args) : tn_dma_launch<true>(s, args))) return rc;
+      if ((rc = tn_dma_launch<true>(s, args))) return rc;
       return tn_dma_reduce(s, q, args.q[0]);
     }
+    if (q.dgamma) return HMA_EINVAL;  // the folded-affine gradients exist on the LDS-DMA path only
 #define HMA_TNW_CASE(YK, AK)                                                                        \
   if (q.y_kind == YK && q.a_kind == AK) {                                                            \
     if ((rc = set_smem_bytes<gemm_tn_wide_kernel<YK, AK>>(W_SMEM_BYTES))) return rc;                 \
@@ -2998,6 +2452,7 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     HMA_TNW_CASE(HMA_A_F32, HMA_A_BF16_AFFINE)
     return HMA_EINVAL;
   }
+  if (q.dgamma) return HMA_EINVAL;
   if (q.splits <= 0) q.splits = 1;
   if (q.splits > slabs) q.splits = (int32_t)slabs;
   const dim3 grid((unsigned)q.splits, (unsigned)((q.N / 128) * (q.K / 128)), (unsigned)(q.batch > 0 ? q.batch : 1));
@@ -3012,13 +2467,14 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
 
 extern "C" int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_gemm_tn_t* b) {
   if (!a || !b) return HMA_EINVAL;
-  static const bool no_pair = getenv("HMA_GEMM_TN_NOPAIR") != nullptr;
-  static const char* dma_env = getenv("HMA_GEMM_TN_DMA");
-  const bool dma_on = !(dma_env && dma_env[0] == '0') && !getenv("HMA_GEMM_TN_V1") && !getenv("HMA_GEMM_TN_ABLATE");
   const int64_t need = (int64_t)256 * (WT * WT + WT);
-  bool ok = !no_pair && dma_on && a->dY && a->A && a->dW && b->dY && b->A && b->dW && a->ws && a->ws == b->ws &&
+  bool ok = a->dY && a->A && a->dW && b->dY && b->A && b->dW && a->ws && a->ws == b->ws &&
             a->ws_elems >= need && b->ws_elems >= need && tn_dma_eligible(*a) && tn_dma_eligible(*b) &&
-            !(a->a_kind == HMA_A_BF16_AFFINE && (!a->gamma || !a->beta)) && !(b->a_kind == HMA_A_BF16_AFFINE && (!b->gamma || !b->beta));
+            !(a->a_kind == HMA_A_BF16_AFFINE && (!a->gamma || !a->beta)) && !(b->a_kind == HMA_A_BF16_AFFINE && (!b->gamma || !b->beta)) &&
+            !(a->dgamma && (!a->dbeta || !a->w_master)) && !(b->dgamma && (!b->dbeta || !b->w_master));
+#ifdef HMA_PROF
+  if (getenv("HMA_GEMM_TN_NOPAIR") || getenv("HMA_GEMM_TN_ABLATE")) ok = false;  // debug build only
+#endif
   int s0 = 0, s1 = 0;
   if (ok) {
     // workgroups in proportion to the operand bytes of each problem

@@ -109,4 +109,19 @@ __device__ __forceinline__ f32x16_t mfma32(const bf16x8_t& a, const bf16x8_t& b,
 // row of element r (0..15) of a 32x32 MFMA accumulator held by a lane with hi = lane >> 5
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+
+#define HMA_LDS(T) __attribute__((address_space(3))) T
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from each lane's `src` to LDS bytes [dst, dst + 1024) in lane order.  Issued
+// from inline asm so that hipcc does not count it: with the builtin the compiler drains vmcnt(0) before the next LDS
+// read and nothing stays in flight.  The waits are counted `s_waitcnt vmcnt(N)` written by hand at the use sites.
+__device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(dst)
+      : "memory");
+}
+
 }  // namespace hma

@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
-from .ops import make_gemm_nt, make_gemm_tn
+from .ops import make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -68,6 +68,16 @@ class Plan:
         self.keep.extend(gs)
         self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
                  flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs))
+
+    def mlp_fwd(self, M: int, **kw) -> None:
+        g = make_mlp_fwd(M=M, **kw)
+        self.keep.append(g)
+        self.add("hma_mlp_fwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2)
+
+    def mlp_bwd(self, M: int, **kw) -> None:
+        g = make_mlp_bwd(M=M, **kw)
+        self.keep.append(g)
+        self.add("hma_mlp_bwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2)  # algorithmic dgrad FLOPs (the recompute is not counted)
 
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
@@ -150,6 +160,10 @@ class STEngine:
         # (hma_fold_ln_bf16): the forward GEMM then reads the saved xhat as a plain bf16 operand
         self.WF = {"qkv_s": mk(L, 3 * d, d), "fc1": mk(L, hid, d)}
         self.BF = {"qkv_s": torch.zeros(L, 3 * d, dtype=F32, device=self.device), "fc1": torch.zeros(L, hid, dtype=F32, device=self.device)}
+        # fused MLP block (csrc/mlp.hip): the four MFMA-fragment-ordered weight streams per layer, 512 KB each
+        self.fused_mlp = float(getattr(cfg, "mlp_drop", 0.0) or 0.0) == 0.0 and hid == 1024
+        if self.fused_mlp:
+            self.MP = {k: mk(L, 512 * 512) for k in ("w1p", "w2p", "w2tp", "w1tp")}
         self.modulate = "modulate" in cfg.action_network
         if self.modulate:
             for dom in self.domains:
@@ -229,6 +243,13 @@ class STEngine:
                 _lib.call("hma_fold_ln_bf16", stream, self._p(pre + lin + ".weight"), self._p(pre + norm + ".weight"),
                           self._p(pre + norm + ".bias"), self._p(pre + lin + ".bias") if has_bias else None,
                           self.WF[key][L - 1].data_ptr(), self.BF[key][L - 1].data_ptr(), rows, d, L, ls, -rows * d, -rows)
+            if self.fused_mlp:
+                pre = f"decoder.layers.{L - 1}."
+                w1, w2, g2 = self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight"), self._p(pre + "norm2.weight")
+                n = 512 * 512
+                for key, src, rs, cs, rsc, csc, kind in (("w1p", w1, d, 1, None, g2, 0), ("w2p", w2, hid, 1, None, None, 1),
+                                                          ("w2tp", w2, 1, hid, None, None, 0), ("w1tp", w1, 1, d, g2, None, 1)):
+                    _lib.call("hma_mlp_pack", stream, src, rs, cs, rsc, csc, self.MP[key][L - 1].data_ptr(), kind, L, ls, -n)
             self._wt_ok = True
         if domain is not None and self.modulate and domain not in self._dom_fresh:
             pre = f"decoder.layers.0.action_projectors.{domain}"
@@ -272,8 +293,9 @@ class STEngine:
         buf("lse_s", (Ls, M, 8), F32)
         buf("rstd1", (Ls, M), F32)
         buf("rstd2", (Ls, M), F32)
-        buf("u", (Ls, M, 1024), BF16)
-        buf("hg", (Ls, M, 1024), BF16)
+        if not self.fused_mlp:  # the fused MLP block never materialises the hidden activation
+            buf("u", (Ls, M, 1024), BF16)
+            buf("hg", (Ls, M, 1024), BF16)
         if A > 0:
             buf("xhm", (Ls, M, 256), BF16)
             buf("xm", (Ls, M, 256), BF16)
@@ -293,6 +315,10 @@ class STEngine:
             buf("dlogits", (Mi, 1024), BF16)
             buf("dx", (M, 256), F32)
             buf("dxb", (M, 256), BF16)  # bf16 copy of dx: operand of the dgrad / wgrad GEMMs that read it
+            if self.fused_mlp:
+                buf("dxb2", (M, 256), BF16)   # hma_mlp_bwd writes the new copy while the fc2 weight gradient still reads the old one
+                buf("hg1", (M, 1024), BF16)   # gelu(u) and dL/du of the layer in flight (operands of its two weight gradients)
+                buf("du1", (M, 1024), BF16)
             if float(getattr(self.cfg, "mlp_drop", 0.0) or 0.0) > 0.0:
                 buf("dxm", (M, 256), BF16)  # dx behind the Dropout that follows fc2
             buf("t256", (M, 256), BF16)
@@ -315,7 +341,8 @@ class STEngine:
         return name in self.layout.entries
 
     def _emit_layer(self, pl: Plan, l: int, x: int, b: Dict[str, int], M: int, Fr: int, B: int, T: int, SA: int,
-                    use_mod: bool, domain: Optional[str], kv: Optional[dict] = None, train: bool = False) -> None:
+                    use_mod: bool, domain: Optional[str], kv: Optional[dict] = None, train: bool = False,
+                    have_ln1: bool = False, ln_next: Optional[Tuple[int, int]] = None) -> None:
         """One STBlock forward (st_transformer.py:79-114) on M rows = Fr frames of SA tokens.  `kv` redirects the
         temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
         "t_query": -1 | t, "T_cache": frames}."""
@@ -323,7 +350,8 @@ class STEngine:
         qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
         pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
         # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
-        pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
+        if not have_ln1:  # (otherwise the previous block's fused MLP already wrote this block's LN1 output)
+            pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
         pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
                    epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
         pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale)
@@ -349,6 +377,11 @@ class STEngine:
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
         # MLP (its LayerNorm: fused above)                   st_transformer.py:112
+        if self.fused_mlp:
+            pl.mlp_fwd(M, xhat=b["xh2"], x=x, w1p=self.MP["w1p"][l].data_ptr(), w2p=self.MP["w2p"][l].data_ptr(),
+                       b1=self.BF["fc1"][l].data_ptr(), b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
+                       ln_xhat=ln_next[0] if ln_next else None, ln_rstd=ln_next[1] if ln_next else None, ln_eps=1e-5)
+            return
         pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16, W=self.WF["fc1"][l].data_ptr(), ldw=256, M=M, N=1024, K=256,
                    epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024, bias=self.BF["fc1"][l].data_ptr(),
                    **self._drop(train, l, 0))  # norm2 folded into W / bias
@@ -415,12 +448,17 @@ class STEngine:
         x = ws["x"].data_ptr()
         for l in range(l0, l1):
             s = sl(l)
-            bufs = {k: dp(ws[k], s, ws[k][0].numel()) for k in ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t",
-                                                                 "xh2", "rstd2", "u", "hg")}
+            names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t", "xh2", "rstd2") + (() if self.fused_mlp else ("u", "hg"))
+            bufs = {k: dp(ws[k], s, ws[k][0].numel()) for k in names}
             if A > 0 and self.modulate:
                 bufs.update({k: dp(ws[k], s, ws[k][0].numel()) for k in ("xhm", "xm", "rstdm")})
                 bufs["ss"] = dp(ws["ss"], l, Fr * 512)
-            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train)
+            ln_next = None
+            if self.fused_mlp and l + 1 < l1:  # the MLP kernel also emits the next block's LN1 output
+                s1 = sl(l + 1)
+                ln_next = (dp(ws["xh1"], s1, ws["xh1"][0].numel()), dp(ws["rstd1"], s1, ws["rstd1"][0].numel()))
+            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train,
+                             have_ln1=self.fused_mlp and l > l0, ln_next=ln_next)
         # readout on the image tokens only                      st_mask_git.py:681-683
         if readout:
           pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,
@@ -468,26 +506,44 @@ class STEngine:
             x2b = dp(ws["x2b"], l, M * 256)
             qkv_t, o_t = dp(ws["qkv_t"], l, M * 768), dp(ws["o_t"], l, M * 256)
             xh2, rstd2 = dp(ws["xh2"], l, M * 256), dp(ws["rstd2"], l, M)
-            u, hg = dp(ws["u"], l, M * 1024), dp(ws["hg"], l, M * 1024)
             gw = lambda suffix: self._lw(l, suffix, "g")
             gb = lambda suffix, on=True: self._lw(l, suffix, "g") if on else None
             wt = lambda k: dp(self.WT[k], l, self.WT[k][0].numel())
-            # ---- MLP (with mlp_drop: the gradient first passes the Dropout behind fc2, then the one behind the GELU)
-            dmlp = dxb
-            if self._drop(True, l, 1):
-                dmlp = ws["dxm"].data_ptr()
-                pl.add("hma_dropout_bf16", dx, dmlp, M, 256, float(cfg.mlp_drop), self.drop_seed.data_ptr(), 2 * l + 1)
-            pl.gemm_nt(A=dmlp, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
-                       U=u, ldu=1024, **self._drop(True, l, 0))  # dU overwrites u in place
-            # the two MLP weight gradients in one launch (dmlp / hg and dU / xhat2 are all live here)
-            pl.gemm_tn_pair(dict(dY=dmlp, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024,
-                                 dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
-                            dict(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
-                                 gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024, K=256,
-                                 dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias)))
-            pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
-                   dxb)
+            if self.fused_mlp:
+                # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
+                # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
+                # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
+                dxb_new = ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr()
+                hg, du = ws["hg1"].data_ptr(), ws["du1"].data_ptr()
+                pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
+                           w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
+                           b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du)
+                pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024,
+                                     dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
+                                dict(dY=du, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
+                                     gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
+                                     K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias),
+                                     w_master=self._lw(l, "mlp.fc1.weight", "p"), dgamma=gw("norm2.weight"),
+                                     dbeta=gw("norm2.bias")))
+                dxb = dxb_new
+            else:
+                u, hg = dp(ws["u"], l, M * 1024), dp(ws["hg"], l, M * 1024)
+                # ---- MLP (with mlp_drop: the gradient first passes the Dropout behind fc2, then the one behind the GELU)
+                dmlp = dxb
+                if self._drop(True, l, 1):
+                    dmlp = ws["dxm"].data_ptr()
+                    pl.add("hma_dropout_bf16", dx, dmlp, M, 256, float(cfg.mlp_drop), self.drop_seed.data_ptr(), 2 * l + 1)
+                pl.gemm_nt(A=dmlp, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
+                           U=u, ldu=1024, **self._drop(True, l, 0))  # dU overwrites u in place
+                # the two MLP weight gradients in one launch (dmlp / hg and dU / xhat2 are all live here)
+                pl.gemm_tn_pair(dict(dY=dmlp, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024,
+                                     dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
+                                dict(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
+                                     gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
+                                     K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias)))
+                pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
+                pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
+                       dxb)
             # ---- temporal attention
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale)
@@ -690,8 +746,9 @@ class STEngine:
         buf("lse_s", (M1, 8), F32)
         for nm in ("rstd1", "rstd2", "rstdm"):
             buf(nm, (M1,), F32)
-        buf("u", (M1, 1024), BF16)
-        buf("hg", (M1, 1024), BF16)
+        if not self.fused_mlp:
+            buf("u", (M1, 1024), BF16)
+            buf("hg", (M1, 1024), BF16)
         buf("logits", (B * S, 1024), F32)
         buf("cache", (L, B * T_total * SA, 768), BF16)
         if A > 0:
@@ -738,7 +795,8 @@ class STEngine:
                self._p("pos_embed_TSC") + 4 * t * pfr * 256, d["a_emb"].data_ptr() if A > 0 else None, d["x"].data_ptr(), B, 1, S, A,
                pfr, cfg.factored_vocab_size, cfg.image_vocab_size)
         x = d["x"].data_ptr()
-        names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "o_t", "xh2", "rstd2", "u", "hg", "xhm", "xm", "rstdm")
+        names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "o_t", "xh2", "rstd2", "xhm", "xm", "rstdm") + (
+            () if self.fused_mlp else ("u", "hg"))
         for l in range(L):
             bufs = {k: d[k].data_ptr() for k in names}
             bufs["qkv_t"] = None
@@ -746,7 +804,8 @@ class STEngine:
                 bufs["ss"] = d["ss"].data_ptr() + l * B * 512 * 4
             kv = {"cache": d["cache"][l].data_ptr(), "row_off": t * SA, "c_group": (SA, T_total * SA), "t_query": t,
                   "T_cache": T_total}
-            self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv)
+            self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv, have_ln1=self.fused_mlp and l > 0,
+                             ln_next=(d["xh1"].data_ptr(), d["rstd1"].data_ptr()) if self.fused_mlp and l + 1 < L else None)
         if readout:
             pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=B * S, N=1024,
                        K=256, epi=EPI_F32, Cp=d["logits"].data_ptr(), ldc=1024, bias=self._p("out_x_proj.bias"))

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, GemmNT, GemmTN)
+                   EPI_RESID, EPI_SILU2, GemmNT, GemmTN, MlpBwd, MlpFwd)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -62,7 +62,8 @@ def make_gemm_nt(*, A: int, lda: int, a_kind: int, W: int, ldw: int, M: int, N: 
 def make_gemm_tn(*, dY: int, ldy: int, y_kind: int, A: int, lda: int, a_kind: int, M: int, N: int, K: int, dW: int,
                  lddw: int, dBias: Optional[int] = None, gamma: Optional[int] = None, beta: Optional[int] = None,
                  y_group=(0, 0), a_group=(0, 0), splits: int = 0, batch: int = 1, sY: int = 0, sA: int = 0, sdW: int = 0,
-                 sdBias: int = 0, ws: Optional[int] = None, ws_elems: int = 0) -> GemmTN:
+                 sdBias: int = 0, ws: Optional[int] = None, ws_elems: int = 0, w_master: Optional[int] = None,
+                 dgamma: Optional[int] = None, dbeta: Optional[int] = None) -> GemmTN:
     g = GemmTN()
     g.dY, g.ldy, g.y_kind = dY, ldy, y_kind
     g.y_group_rows, g.y_group_stride = y_group
@@ -77,6 +78,23 @@ def make_gemm_tn(*, dY: int, ldy: int, y_kind: int, A: int, lda: int, a_kind: in
     g.splits, g.batch = splits, batch
     g.sY, g.sA, g.sdW, g.sdBias = sY, sA, sdW, sdBias
     g.ws, g.ws_elems = ws, ws_elems
+    g.w_master, g.dgamma, g.dbeta = w_master, dgamma, dbeta
+    return g
+
+
+def make_mlp_fwd(*, M: int, xhat: int, x: int, w1p: int, w2p: int, b1: int, b2: Optional[int] = None,
+                 ln_xhat: Optional[int] = None, ln_rstd: Optional[int] = None, ln_eps: float = 1e-5) -> MlpFwd:
+    g = MlpFwd()
+    g.xhat, g.x, g.w1p, g.w2p, g.b1, g.b2 = xhat, x, w1p, w2p, b1, b2
+    g.ln_xhat, g.ln_rstd, g.ln_eps, g.M = ln_xhat, ln_rstd, ln_eps, M
+    return g
+
+
+def make_mlp_bwd(*, M: int, xhat: int, rstd: int, dy: int, dx: int, dx_bf16: int, w1p: int, w2tp: int, w1tp: int, b1: int,
+                 hg: int, du: int) -> MlpBwd:
+    g = MlpBwd()
+    g.xhat, g.rstd, g.dy, g.dx, g.dx_bf16 = xhat, rstd, dy, dx, dx_bf16
+    g.w1p, g.w2tp, g.w1tp, g.b1, g.hg, g.du, g.M = w1p, w2tp, w1tp, b1, hg, du, M
     return g
 
 

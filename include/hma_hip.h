@@ -92,6 +92,12 @@ typedef struct {
   /* optional scratch for a two-stage (atomic-free) reduction of the M-splits: >= 256 * 65536 floats
    * covers every shape of this model; NULL or too small -> fp32 atomics */
   float* ws; int64_t ws_elems;
+  /* optional, a_kind == HMA_A_BF16_AFFINE on the workspace (LDS-DMA) path only: the gradients of the LayerNorm affine that
+   * was folded into this Linear's forward weights (hma_fold_ln_bf16), taken from the un-scaled product P = dY^T xhat
+   * the reduction holds anyway: dgamma[k] += sum_n w_master[n][k] P[n][k], dbeta[k] += sum_n w_master[n][k] colsum(dY)[n]
+   * (w_master = the Linear's fp32 weight, leading dimension lddw).  Replaces the dgamma / dbeta outputs of hma_ln_bwd
+   * when the LayerNorm backward itself is fused into another kernel (hma_mlp_bwd). */
+  const float* w_master; float* dgamma; float* dbeta;
 } hma_gemm_tn_t;
 int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p);
 /* Two independent weight gradients in ONE launch (e.g. a block's fc2 and fc1 after `loss.backward()` reaches them,
@@ -290,9 +296,45 @@ int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t r
  * sit `in_stride` floats after those of batch b - 1 (the per-layer blocks of the flat parameter buffer). */
 int hma_fold_ln_bf16(void* stream, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* bf,
                      int32_t rows, int32_t cols, int32_t batch, int64_t in_stride, int64_t wf_stride, int64_t bf_stride);
-/* out[r] = sum_{j<reps} in[(r / inner) * reps * inner + j * inner + r % inner] helper is not exported */
 
-/* library identity, for the loader: returns 0x484d4101 */
+/* ---- Fused MLP block (st_transformer.py:24-27 Mlp.forward as called from STBlock.forward :112; mlp_drop == 0) ----------
+ * hma_mlp_pack: a weight matrix rearranged into the MFMA-fragment order the fused kernels stream (512 fragments of 1 KB):
+ *   kind 0: logical A[1024][256], kind 1: logical A[256][1024]; A[r][c] = src[r * row_stride + c * col_stride] *
+ *   (row_scale ? row_scale[r] : 1) * (col_scale ? col_scale[c] : 1), rounded to bf16.  `batch` matrices, `src_batch_stride`
+ *   floats apart (row_scale / col_scale move by the same stride), outputs `dst_batch_stride` bf16 elements apart.
+ *   fc1 forward / recompute:  kind 0 of fc1.weight [1024][256] with col_scale = norm2.weight   (w1p)
+ *   fc2 forward:              kind 1 of fc2.weight [256][1024]                                 (w2p)
+ *   d gelu input:             kind 0 of fc2.weight^T (row_stride 1, col_stride 1024)           (w2tp)
+ *   d xhat:                   kind 1 of fc1.weight^T (row_stride 1, col_stride 256) with row_scale = norm2.weight (w1tp) */
+int hma_mlp_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
+                 const float* col_scale, void* dst, int32_t kind, int32_t batch, int64_t src_batch_stride,
+                 int64_t dst_batch_stride);
+/* x += fc2(gelu(fc1(norm2(x)))) with xhat = LN(x) (no affine; bf16, saved by the kernel that last wrote x), b1 = fc1.bias
+ * + fc1.weight @ norm2.bias (hma_fold_ln_bf16's bf), b2 = fc2.bias or NULL.  The hidden activation stays on chip.
+ * ln_xhat != NULL: also ln_xhat = LN(new x, ln_eps, no affine) (bf16) and ln_rstd -- the next block's norm1
+ * (st_transformer.py:86), what hma_ln_fwd would produce. */
+typedef struct {
+  const void* xhat; float* x;
+  const void* w1p; const void* w2p; const float* b1; const float* b2;
+  void* ln_xhat; float* ln_rstd; float ln_eps; int32_t _pad;
+  int64_t M;
+} hma_mlp_fwd_t;
+int hma_mlp_fwd(void* stream, const hma_mlp_fwd_t* p);
+/* Backward of the block above from dy = bf16 gradient wrt its output (the bf16 copy of the residual gradient dx):
+ * u is recomputed from xhat; hg = gelu(u) and du = (dy fc2.weight) * gelu'(u) are written (bf16 [M, 1024]) for the two
+ * weight gradients (hma_gemm_tn_pair: fc2 from dy / hg, fc1 from du / xhat with the affine + dgamma / dbeta);
+ * dx += LayerNorm-backward(du fc1.weight * gamma) (rstd = the saved 1 / sigma of norm2) and dx_bf16 = bf16(new dx),
+ * which must not alias dy (the fc2 weight gradient still reads dy). */
+typedef struct {
+  const void* xhat; const float* rstd; const void* dy;
+  float* dx; void* dx_bf16;
+  const void* w1p; const void* w2tp; const void* w1tp; const float* b1;
+  void* hg; void* du;
+  int64_t M;
+} hma_mlp_bwd_t;
+int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p);
+
+/* library identity, for the loader: returns 0x484d4102 */
 int hma_abi_version(void);
 
 #ifdef __cplusplus

@@ -626,3 +626,138 @@ def test_gemm_dropout_masks_are_consistent_between_forward_and_backward():
     _lib.call("hma_dropout_bf16", ops.stream_ptr(), gsrc.to(DEV).data_ptr(), gdst.data_ptr(), M, 256, p, seed.data_ptr(), 8)
     assert torch.equal(gdst.float().cpu() != 0, k2 & (rb(gsrc / (1 - p)) != 0))
     close(gdst, gsrc * k2.float() / (1 - p), BF, "masked gradient")
+
+
+# ------------------------------------------------------------------------------------------ fused MLP block
+def _mlp_weights(seed):
+    w1 = torch.randn(1024, 256, generator=g(seed)) * 0.06
+    b1 = torch.randn(1024, generator=g(seed + 1)) * 0.3
+    w2 = torch.randn(256, 1024, generator=g(seed + 2)) * 0.04
+    b2 = torch.randn(256, generator=g(seed + 3)) * 0.2
+    gam = torch.randn(256, generator=g(seed + 4)) * 0.2 + 1.0
+    bet = torch.randn(256, generator=g(seed + 5)) * 0.2
+    return w1, b1, w2, b2, gam, bet
+
+
+def _mlp_pack(src, rs, cs, rscale, cscale, kind):
+    dst = torch.empty(512 * 512, dtype=torch.bfloat16, device=DEV)
+    _lib.call("hma_mlp_pack", ops.stream_ptr(), ops.ptr(src), rs, cs, ops.ptr(rscale), ops.ptr(cscale), ops.ptr(dst), kind, 1, 0, 0)
+    return dst
+
+
+def _mlp_packed(w1, w2, gam):
+    w1d, w2d, gd = w1.to(DEV), w2.to(DEV), gam.to(DEV)
+    return dict(w1p=_mlp_pack(w1d, 256, 1, None, gd, 0), w2p=_mlp_pack(w2d, 1024, 1, None, None, 1),
+                w2tp=_mlp_pack(w2d, 1, 1024, None, None, 0), w1tp=_mlp_pack(w1d, 1, 256, gd, None, 1), keep=(w1d, w2d, gd))
+
+
+def test_mlp_pack_layout():
+    # fragment f, lane (rho, hi), element i  <->  logical (row, col) as documented in include/hma_hip.h / csrc/mlp.hip
+    w = torch.arange(1024 * 256, dtype=torch.float32).reshape(1024, 256) % 251.0  # exactly representable in bf16
+    rowmap = lambda r: (r & 3) + 4 * (r >> 3) + 16 * ((r >> 2) & 1)
+    p0 = _mlp_pack(w.to(DEV), 256, 1, None, None, 0).float().cpu().reshape(512, 64, 8)
+    for f, lane, i in [(0, 0, 0), (17, 5, 3), (300, 37, 7), (511, 63, 7), (123, 32, 0)]:
+        mb, j, rho, hi = f >> 4, f & 15, lane & 31, lane >> 5
+        assert p0[f, lane, i] == w[32 * mb + rowmap(rho), 32 * (j >> 1) + 16 * hi + 8 * (j & 1) + i]
+    wt = torch.arange(256 * 1024, dtype=torch.float32).reshape(256, 1024) % 241.0
+    p1 = _mlp_pack(wt.to(DEV), 1024, 1, None, None, 1).float().cpu().reshape(512, 64, 8)
+    for f, lane, i in [(0, 0, 0), (17, 5, 3), (300, 37, 7), (511, 63, 7)]:
+        s, mb, j, rho, hi = f >> 4, (f >> 1) & 7, f & 1, lane & 31, lane >> 5
+        assert p1[f, lane, i] == wt[32 * mb + rowmap(rho), 32 * s + 16 * hi + 8 * j + i]
+
+
+@pytest.mark.parametrize("M,with_ln", [(128, True), (1000, True), (5 * 128 + 37, False), (40960, True)])
+def test_mlp_fwd_fused(M, with_ln):
+    w1, b1, w2, b2, gam, bet = _mlp_weights(100)
+    x = torch.randn(M, 256, generator=g(7)) * 1.5 + 0.3
+    xh = rb(F.layer_norm(x, (256,), eps=1e-5))
+    pk = _mlp_packed(w1, w2, gam)
+    b1f = (b1 + w1 @ bet).to(DEV)
+    xd = x.to(DEV).clone()
+    ln_x = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV) if with_ln else None
+    ln_r = torch.empty(M, dtype=torch.float32, device=DEV) if with_ln else None
+    xhd = xh.to(DEV).bfloat16()
+    a = ops.make_mlp_fwd(M=M, xhat=ops.ptr(xhd), x=ops.ptr(xd), w1p=ops.ptr(pk["w1p"]), w2p=ops.ptr(pk["w2p"]), b1=ops.ptr(b1f),
+                         b2=ops.ptr(b2.to(DEV)), ln_xhat=ops.ptr(ln_x), ln_rstd=ops.ptr(ln_r), ln_eps=1e-5)
+    b2d = b2.to(DEV)
+    a.b2 = ops.ptr(b2d)
+    _lib.call("hma_mlp_fwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    # reference on the bf16-rounded operands the kernel multiplies
+    u = xh @ rb(w1 * gam).t() + (b1 + w1 @ bet)
+    hgr = rb(F.gelu(u))
+    ref = x + hgr @ rb(w2).t() + b2
+    close(xd, ref, 3e-3, "mlp fwd x")  # bf16 rounding of the hidden activation flips with the GELU's 1e-7 differences
+    err = (xd.cpu() - ref).pow(2).mean().sqrt() / (ref - x).pow(2).mean().sqrt()
+    assert err < 4e-3, err
+    if with_ln:
+        lr = F.layer_norm(ref, (256,), eps=1e-5)
+        close(ln_x, lr, 2 * BF, "fused next LN")
+        var = ref.var(dim=1, unbiased=False)
+        close(ln_r, torch.rsqrt(var + 1e-5), 2e-3, "rstd")
+
+
+@pytest.mark.parametrize("M", [128, 1000, 40960])
+def test_mlp_bwd_fused(M):
+    w1, b1, w2, b2, gam, bet = _mlp_weights(200)
+    x = torch.randn(M, 256, generator=g(17)) * 1.5 + 0.3
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + 1e-5)
+    xh = rb((x - mean) * rstd)
+    dy = rb(torch.randn(M, 256, generator=g(18)) * 0.02)
+    dx0 = torch.randn(M, 256, generator=g(19)) * 0.02
+    pk = _mlp_packed(w1, w2, gam)
+    b1f = (b1 + w1 @ bet).to(DEV)
+    xhd, dyd, rsd = xh.to(DEV).bfloat16(), dy.to(DEV).bfloat16(), rstd.reshape(-1).to(DEV)
+    dxd = dx0.to(DEV).clone()
+    dxb = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
+    hg = torch.empty(M, 1024, dtype=torch.bfloat16, device=DEV)
+    du = torch.empty(M, 1024, dtype=torch.bfloat16, device=DEV)
+    a = ops.make_mlp_bwd(M=M, xhat=ops.ptr(xhd), rstd=ops.ptr(rsd), dy=ops.ptr(dyd), dx=ops.ptr(dxd), dx_bf16=ops.ptr(dxb),
+                         w1p=ops.ptr(pk["w1p"]), w2tp=ops.ptr(pk["w2tp"]), w1tp=ops.ptr(pk["w1tp"]), b1=ops.ptr(b1f),
+                         hg=ops.ptr(hg), du=ops.ptr(du))
+    _lib.call("hma_mlp_bwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    # reference (fp32 math on the rounded operands)
+    w1f = rb(w1 * gam)
+    u = xh @ w1f.t() + (b1 + w1 @ bet)
+    cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+    hgr = u * cdf
+    dhg = dy @ rb(w2)
+    dur = dhg * (cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi))
+    close(hg, hgr, 2 * BF, "hg")
+    close(du, dur, 2 * BF, "du")
+    gk = rb(dur) @ w1f  # dxhat with gamma folded (the kernel multiplies the bf16-rounded du it hands to the wgrad)
+    s1 = gk.mean(1, keepdim=True)
+    s2 = (gk * xh).mean(1, keepdim=True)
+    ref = dx0 + rstd * (gk - s1 - xh * s2)
+    close(dxd, ref, 2e-3, "dx")
+    close(dxb, ref, 2 * BF, "dx bf16")
+    assert (dxd.cpu() - ref).pow(2).mean().sqrt() / (ref - dx0).pow(2).mean().sqrt() < 3e-3
+
+
+def test_gemm_tn_folded_affine_grads():
+    # dgamma / dbeta of a LayerNorm folded into the Linear, from the weight-gradient reduction (hma_gemm_tn_t.w_master)
+    M, N, K = 4096, 1024, 256
+    dy = rb(torch.randn(M, N, generator=g(31)) * 0.05)
+    xh = rb(torch.randn(M, K, generator=g(32)))
+    w = torch.randn(N, K, generator=g(33)) * 0.1
+    gam = torch.randn(K, generator=g(34)) * 0.2 + 1.0
+    bet = torch.randn(K, generator=g(35)) * 0.2
+    dW = torch.zeros(N, K, device=DEV)
+    dB = torch.zeros(N, device=DEV)
+    dG = torch.zeros(K, device=DEV)
+    dBt = torch.zeros(K, device=DEV)
+    ws = torch.empty(256 * (65536 + 256), device=DEV)
+    wd, gd, bd = w.to(DEV), gam.to(DEV), bet.to(DEV)
+    dyd, xhd = dy.to(DEV).bfloat16(), xh.to(DEV).bfloat16()
+    t = ops.make_gemm_tn(dY=ops.ptr(dyd), ldy=N, y_kind=A_BF16, A=ops.ptr(xhd), lda=K, a_kind=A_BF16_AFFINE, M=M, N=N, K=K,
+                         dW=ops.ptr(dW), lddw=K, dBias=ops.ptr(dB), gamma=ops.ptr(gd), beta=ops.ptr(bd), ws=ops.ptr(ws),
+                         ws_elems=ws.numel(), w_master=ops.ptr(wd), dgamma=ops.ptr(dG), dbeta=ops.ptr(dBt))
+    _lib.call("hma_gemm_tn", ops.stream_ptr(), C.byref(t))
+    torch.cuda.synchronize()
+    P = dy.t() @ xh
+    cs = dy.sum(0)
+    close(dW, P * gam + cs[:, None] * bet[None, :], 1e-2, "dW")  # bf16 partials
+    close(dG, (w * P).sum(0), 1e-2, "dgamma")
+    close(dBt, (w * cs[:, None]).sum(0), 1e-2, "dbeta")
