@@ -124,4 +124,20 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
       : "memory");
 }
 
+// Four consecutive pieces (4 KB of global memory -> 4 KB of LDS): the instruction's immediate offset advances the global
+// AND the LDS address, so one M0 set-up serves all four.
+__device__ __forceinline__ void glds16x4(const void* src, uint32_t dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(dst)
+      : "memory");
+}
+
 }  // namespace hma

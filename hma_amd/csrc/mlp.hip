@@ -34,29 +34,95 @@ __host__ __device__ constexpr int rowmap(int rho) { return (rho & 3) + 4 * (rho 
 __device__ __forceinline__ bf16x8_t as_frag(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 // one MFMA fragment (or any 16-byte piece) of this lane from LDS
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-__device__ __forceinline__ bf16x8_t lds_frag(HMA_LDS(char)* p) { return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(u32x4_t)*)p); }
+#ifndef MLP_ABL
+#define MLP_ABL 0
+#endif
+__device__ __forceinline__ bf16x8_t lds_frag(HMA_LDS(char)* p) {
+  if (MLP_ABL & 32) return __builtin_bit_cast(bf16x8_t, make_uint4((uint32_t)(uintptr_t)p, 1u, 2u, 3u));  // (debug: no fragment reads)
+  return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(u32x4_t)*)p);
+}
 __device__ __forceinline__ void lds_put(HMA_LDS(char)* p, const uint4& v) { *(HMA_LDS(u32x4_t)*)p = __builtin_bit_cast(u32x4_t, v); }
 __device__ __forceinline__ float4 lds_f4(HMA_LDS(char)* p) {
   const f32x4_t v = *(HMA_LDS(f32x4_t)*)p;
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// exact-erf GELU pieces (A&S 7.1.26, as hma_common.h gelu_parts): h = Phi(-|u|), gauss = exp(-u^2 / 2)
-__device__ __forceinline__ void gelu_tail(float u, float& h, float& gauss) {
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(u), 0.3275911f * 0.70710678118654752f, 1.0f));
-  gauss = __builtin_amdgcn_exp2f(-0.72134752044448170f * u * u);
-  float poly = 0.5f * 1.061405429f;
-  poly = __builtin_fmaf(poly, t, -0.5f * 1.453152027f);
-  poly = __builtin_fmaf(poly, t, 0.5f * 1.421413741f);
-  poly = __builtin_fmaf(poly, t, -0.5f * 0.284496736f);
-  poly = __builtin_fmaf(poly, t, 0.5f * 0.254829592f);
-  h = poly * t * gauss;
+// ---- GELU (exact-erf, nn.GELU() of st_transformer.py:20) for 8 accumulator values at a time ---------------------------
+// gelu(u) = max(u, 0) - |u| h(|u|), h(a) = Phi(-a) = exp2(q(a)) with q a degree-6 polynomial fit of log2(Phi(-a)) on [0, 6]
+// (|error of h| <= 2e-5, |error of gelu| <= 7e-6: 1/500 of a bf16 ulp of the values it produces) and a clamped to 6
+// (a h(a) < 6e-9 beyond).  Per element: 1 v_med3, 6 FMAs (in pairs: v_pk_fma_f32), ONE transcendental, 1 max, 1 FMA.
+// The A&S 7.1.26 form used by the unfused epilogues costs a v_rcp and a v_exp (quarter rate) plus 11 plain operations,
+// and on gfx950 a wave64 VALU instruction is 4 cycles (packed: 8): the GELU is the VALU budget of these kernels.
+// Written stage by stage over all values, with an empty asm that takes and returns a stage's values as a join point:
+// left alone, the compiler serialises element pairs with dependency nops.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define HMA_PIN4(a, o) asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]))
+#define HMA_PIN8(a, o)                                                                                                   \
+  asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), \
+               "+v"(a[o + 7]))
+#define HMA_PIN16(a) do { HMA_PIN8(a, 0); HMA_PIN8(a, 8); } while (0)
+constexpr float GQ6 = 2.2999249267741106e-05f, GQ5 = -0.0006114901625551283f, GQ4 = 0.007200188934803009f,
+                GQ3 = -0.05120821297168732f, GQ2 = -0.46122226119041443f, GQ1 = -1.150214433670044f, GQ0 = -1.000058889389038f;
+
+// ph[e] = Phi(-|u[e]|), N values (N = 8 or 16)
+template <int N>
+__device__ __forceinline__ void gelu_phi_neg(const float (&u)[N], float (&ph)[N]) {
+  f32x2_t a2[N / 2], q2[N / 2];
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i)
+    a2[i] = f32x2_t{__builtin_amdgcn_fmed3f(fabsf(u[2 * i]), 0.f, 6.0f), __builtin_amdgcn_fmed3f(fabsf(u[2 * i + 1]), 0.f, 6.0f)};
+  if constexpr (N == 8) HMA_PIN4(a2, 0); else HMA_PIN8(a2, 0);
+#define HMA_HORNER(c)                                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < N / 2; ++i) q2[i] = __builtin_elementwise_fma(q2[i], a2[i], (f32x2_t{c, c})); \
+  if constexpr (N == 8) HMA_PIN4(q2, 0); else HMA_PIN8(q2, 0);
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) q2[i] = __builtin_elementwise_fma(f32x2_t{GQ6, GQ6}, a2[i], f32x2_t{GQ5, GQ5});
+  if constexpr (N == 8) HMA_PIN4(q2, 0); else HMA_PIN8(q2, 0);
+  HMA_HORNER(GQ4) HMA_HORNER(GQ3) HMA_HORNER(GQ2) HMA_HORNER(GQ1) HMA_HORNER(GQ0)
+#undef HMA_HORNER
+#pragma unroll
+  for (int e = 0; e < N; ++e) ph[e] = __builtin_amdgcn_exp2f(q2[e >> 1][e & 1]);
+  if constexpr (N == 8) HMA_PIN8(ph, 0); else HMA_PIN16(ph);
 }
-// gelu(u) = max(u, 0) - |u| Phi(-|u|)
-__device__ __forceinline__ float gelu_fused(float u) {
-  float h, g;
-  gelu_tail(u, h, g);
-  return fmaxf(u, 0.f) - fabsf(u) * h;
+// h[e] = gelu(u[e])
+template <int N>
+__device__ __forceinline__ void gelu_n(const float (&u)[N], float (&h)[N]) {
+  float ph[N], r[N];
+  gelu_phi_neg<N>(u, ph);
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = fmaxf(u[e], 0.f);
+  if constexpr (N == 8) HMA_PIN8(r, 0); else HMA_PIN16(r);
+#pragma unroll
+  for (int e = 0; e < N; ++e) h[e] = __builtin_fmaf(-fabsf(u[e]), ph[e], r[e]);
+  if constexpr (N == 8) HMA_PIN8(h, 0); else HMA_PIN16(h);
+}
+// hg[e] = gelu(u[e]) (the forward's values, bit for bit) and du[e] = d[e] * gelu'(u[e]), gelu'(u) = Phi(u) + u phi(u)
+template <int N>
+__device__ __forceinline__ void gelu_bwd_n(const float (&u)[N], const float (&d)[N], float (&hg)[N], float (&du)[N]) {
+  float ph[N], gs[N], r[N];
+  gelu_phi_neg<N>(u, ph);
+#pragma unroll
+  for (int e = 0; e < N; ++e) gs[e] = -0.72134752044448170f * u[e] * u[e];
+  if constexpr (N == 8) HMA_PIN8(gs, 0); else HMA_PIN16(gs);
+#pragma unroll
+  for (int e = 0; e < N; ++e) gs[e] = __builtin_amdgcn_exp2f(gs[e]);
+  if constexpr (N == 8) HMA_PIN8(gs, 0); else HMA_PIN16(gs);
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = fmaxf(u[e], 0.f);
+  if constexpr (N == 8) HMA_PIN8(r, 0); else HMA_PIN16(r);
+#pragma unroll
+  for (int e = 0; e < N; ++e) hg[e] = __builtin_fmaf(-fabsf(u[e]), ph[e], r[e]);
+  if constexpr (N == 8) HMA_PIN8(hg, 0); else HMA_PIN16(hg);
+  // Phi(u) = 0.5 + copysign(0.5 - h, u)
+#pragma unroll
+  for (int e = 0; e < N; ++e) ph[e] = 0.5f + __builtin_copysignf(0.5f - ph[e], u[e]);
+  if constexpr (N == 8) HMA_PIN8(ph, 0); else HMA_PIN16(ph);
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = __builtin_fmaf(u[e] * 0.3989422804014327f, gs[e], ph[e]);
+  if constexpr (N == 8) HMA_PIN8(r, 0); else HMA_PIN16(r);
+#pragma unroll
+  for (int e = 0; e < N; ++e) du[e] = d[e] * r[e];
+  if constexpr (N == 8) HMA_PIN8(du, 0); else HMA_PIN16(du);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -98,14 +164,50 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
   *reinterpret_cast<uint4*>(dst + (int64_t)idx * 8) = pack8(v);
 }
 
+// Debug builds only (tools/mlp_ablate.sh, -DMLP_ABL=bits): 1 no LDS-DMA, 2 no MFMA, 4 no GELU, 8 no barrier,
+// 16 no activation loads / stores (forward kernel), 32 no LDS fragment reads
+__device__ __forceinline__ f32x16_t mfma32a(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
+  if (MLP_ABL & 2) {
+    f32x16_t r = c;
+    r[0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a).x ^ __builtin_bit_cast(uint4, b).y);
+    return r;
+  }
+  return mfma32(a, b, c);
+}
+
+// Debug builds only (-DMLP_PROF): per-wave s_memtime deltas summed per phase, block 0 only (tools/mlp_prof.py)
+#ifdef MLP_PROF
+__device__ unsigned long long g_mlp_prof[2][8][8];
+#define MPROF_DECL unsigned long long pt_ = __builtin_readcyclecounter(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MPROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define MPROF_FLUSH(k) do { if (blockIdx.x == 0 && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) g_mlp_prof[k][wave][i_] = pacc_[i_]; } } while (0)
+#else
+#define MPROF_DECL
+#define MPROF_MARK(i)
+#define MPROF_FLUSH(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------ forward
-constexpr int MF_NSLOT = 4;                  // ring slots
+// Per SIMD one producer wave and one consumer wave, in ANTI-PHASE within a step: a wave cannot hide much VALU work
+// behind its own MFMAs (it issues in order: ~5 instructions per 32-cycle MFMA), but a wave in a VALU phase and a wave
+// in an MFMA phase on the same SIMD run concurrently.  So the GELU of a hidden block is split between the pair:
+//   producer, step g:      16 MFMAs (u of block g), then the GELU of its accumulator registers 0..7
+//   consumer, step g + 1:  the GELU of registers 8..15 (received as fp32), then 16 MFMAs (block g into the outputs)
+// and after the step barrier one wave of every SIMD starts on the matrix pipe while the other starts on the VALU.
+constexpr int MF_NSLOT = 3;                  // ring slots
 constexpr int MF_AHEAD = 2;                  // bundles in flight ahead of the one being used
 constexpr int MF_SLOT = 32768;               // bundle g = fc1 fragments of hidden block g (16 KB) | fc2 fragments of block g - 1
-constexpr int MF_XCH = MF_NSLOT * MF_SLOT;   // per pair: 2 buffers x 2 planes x 1 KB
-constexpr int MF_B1 = MF_XCH + 4 * 4096;
+constexpr int MF_XCH = MF_NSLOT * MF_SLOT;   // per pair: 2 buffers x 3 planes x 1 KB (gelu half as bf16 | raw half, fp32)
+constexpr int MF_XCH_PAIR = 6144;
+constexpr int MF_B1 = MF_XCH + 4 * MF_XCH_PAIR;
 constexpr int MF_B2 = MF_B1 + 4096;
-constexpr int MF_SMEM = MF_B2 + 1024;        // 152576 B
+constexpr int MF_STG = MF_B2 + 1024;         // per pair: 2 staging pieces of 4 KB (32 rows x 128 B) for the consumer's row I/O
+constexpr int MF_SMEM = MF_STG + 4 * 8192;   // 160768 B
+
+// A staging piece holds 32 token rows x 128 bytes.  16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7): both access
+// shapes are then conflict-free -- "a lane owns a row" (the accumulator layout: ds_read/write_b128 of one chunk index by
+// 16 lanes with 16 different rows) and "8 lanes per row" (the 1 KB, 8-row pieces of coalesced global traffic).
+__device__ __forceinline__ int stg_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 template <bool LNOUT>
 __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
@@ -119,58 +221,94 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
   const int64_t ntiles = (p.M + 127) >> 7;
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   const int nsteps = nt * 32;
+  // (Walking the hidden blocks in a different rotation per workgroup, so that the CUs do not all request the same 32 KB
+  // of weights at once, measured 10 % SLOWER: the L2 serves the broadcast well.)
+  constexpr int rot = 0;
 
   {
     HMA_LDS(float)* b1s = (HMA_LDS(float)*)(lds + MF_B1);
     for (int i = tid; i < 1024; i += 512) b1s[i] = p.b1[i];
     if (tid < 256) ((HMA_LDS(float)*)(lds + MF_B2))[tid] = p.b2 ? p.b2[tid] : 0.f;
   }
+#ifdef MLP_STAGGER
+  {  // experiment: de-phase the workgroups (their tile epilogues otherwise hit HBM all at once)
+    const int nsl = (((int)blockIdx.x * 37) & 255) * MLP_STAGGER / 256;
+    for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   __syncthreads();
 
-  // LDS-DMA: every wave moves 4 of a bundle's 32 pieces (2 of each half).  Always 4, so the vmcnt immediates are fixed.
-  const char* w1g = reinterpret_cast<const char*>(p.w1p) + wave * 2048 + lane * 16;
-  const char* w2g = reinterpret_cast<const char*>(p.w2p) + wave * 2048 + lane * 16;
+  // LDS-DMA: the four PRODUCER waves move everything (8 of a bundle's 32 pieces each, plus their pair's residual blocks):
+  // issuing a piece is ~50-150 cycles of a wave's time, and the consumer wave is the longer one of a pair.
+  const char* w1g = reinterpret_cast<const char*>(p.w1p) + pair * 4096 + lane * 16;
+  const char* w2g = reinterpret_cast<const char*>(p.w2p) + pair * 4096 + lane * 16;
   auto issue = [&](int b) __attribute__((always_inline)) {
-    const uint32_t base = lds_b + (b % MF_NSLOT) * MF_SLOT + wave * 2048;
-    const int s1 = b & 31, s2 = (b + 31) & 31;
-    glds16(w1g + s1 * 16384, base);
-    glds16(w1g + s1 * 16384 + 1024, base + 1024);
-    glds16(w2g + s2 * 16384, base + 16384);
-    glds16(w2g + s2 * 16384 + 1024, base + 16384 + 1024);
+    const uint32_t base = lds_b + (b % MF_NSLOT) * MF_SLOT + pair * 4096;
+    const int s1 = (b + rot) & 31, s2 = (b + rot + 31) & 31;
+    if (MLP_ABL & 1) return;
+    glds16x4(w1g + s1 * 16384, base);
+    glds16x4(w2g + s2 * 16384, base + 16384);
   };
-  // bundle g has landed (all but the newest bundle's 4 pieces of this wave are complete: loads return in order) and
-  // this wave's LDS writes of the previous step are done
-  auto step_sync = [&](int g) __attribute__((always_inline)) {
-    if (g < nsteps)
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  // Bundle g has landed and this wave's LDS writes of the previous step are done.  `newer` = vector-memory loads this wave
+  // issued AFTER bundle g's pieces (loads return in order, so vmcnt(newer) means bundle g is complete): the 8 of bundle
+  // g + 1, plus 4 when a residual block was issued in the previous step, plus the 16 row loads of the next tile.
+  auto step_sync = [&](int newer) __attribute__((always_inline)) {
+    if (newer >= 24)
+      asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    else if (newer >= 12)
+      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (newer >= 8)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-#pragma unroll
-  for (int b = 0; b < MF_AHEAD; ++b) issue(b);
-
-  auto tile_row = [&](int tl) __attribute__((always_inline)) {
-    return ((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * 128 + pair * 32 + lr;
+  auto tile_row0 = [&](int tl) __attribute__((always_inline)) {
+    return ((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * 128 + pair * 32;
   };
-
+  // residual block cb of this pair's rows of tile tl -> staging piece cb & 1 (see the consumer)
+  const uint32_t stg_b = lds_b + MF_STG + pair * 8192;
+  const int prow_ = lane >> 3, pchunk_ = lane & 7;  // "8 lanes per row" shape: this lane's row within 8 and physical chunk
+  auto issue_x = [&](int tl, int cb) __attribute__((always_inline)) {
+    if (MLP_ABL & 17) return;
+    const int64_t r0 = tile_row0(tl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * i + prow_;
+      int64_t gr = r0 + r;
+      gr = gr < p.M ? gr : p.M - 1;
+      glds16(p.x + gr * 256 + cb * 32 + ((pchunk_ ^ ((r >> 1) & 7)) << 2), stg_b + (cb & 1) * 4096 + i * 1024);
+    }
+  };
   if (role == 0) {
-    // ---------------------------------------------------------------- producer: u = W1f xhat + b1, hg = gelu(u)
+#pragma unroll
+    for (int b = 0; b < MF_AHEAD; ++b) issue(b);
+    // ---------------------------------------------------------------- producer: u = W1f xhat + b1; gelu of registers 0..7
     bf16x8_t xh[16], xn[16];
     auto load_x = [&](int tl, bf16x8_t (&dst)[16]) __attribute__((always_inline)) {
-      int64_t row = tile_row(tl);
+      int64_t row = tile_row0(tl) + lr;
       row = row < p.M ? row : p.M - 1;
       const uint16_t* src = reinterpret_cast<const uint16_t*>(p.xhat) + row * 256 + 16 * hi;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) dst[j] = as_frag(*reinterpret_cast<const uint4*>(src + 32 * (j >> 1) + 8 * (j & 1)));
+      for (int j = 0; j < 16; ++j)
+        dst[j] = (MLP_ABL & 16) ? as_frag(make_uint4(j, lane, j, lane)) : as_frag(*reinterpret_cast<const uint4*>(src + 32 * (j >> 1) + 8 * (j & 1)));
     };
     load_x(0, xh);
 #pragma unroll
     for (int j = 0; j < 16; ++j) xn[j] = xh[j];
+    MPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {
-      step_sync(g);
+      MPROF_MARK(0);
+      // (the 16 row loads of the next tile, issued at the end of an iteration with s == 16, are newer than bundle g too)
+      step_sync((g < nsteps ? 8 : 0) + ((g >= 2 && ((g - 2) & 3) == 0) ? 4 : 0) +
+                ((g >= 1 && ((g - 1) & 31) == 16 && ((g - 1) >> 5) + 1 < nt) ? 16 : 0));
+      MPROF_MARK(1);
+      // residual block for the consumer's hidden block g - 1 when that is a multiple of 4 (added two steps later); issued
+      // BEFORE the bundle so that it is older than the bundle whose arrival the consumer's step g + 2 waits for
+      if (g >= 1 && g <= nsteps && ((g - 1) & 3) == 0) issue_x((g - 1) >> 5, ((g - 1) & 31) >> 2);
       if (g + MF_AHEAD <= nsteps) issue(g + MF_AHEAD);
+      MPROF_MARK(2);
       if (g < nsteps) {
         const int s = g & 31;
         if (s == 0 && g > 0) {
@@ -178,9 +316,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
           for (int j = 0; j < 16; ++j) xh[j] = xn[j];
         }
         HMA_LDS(char)* wb = lds + (g % MF_NSLOT) * MF_SLOT + lane * 16;
-        f32x16_t U0, U1;
+        HMA_LDS(char)* bp = lds + MF_B1 + (32 * ((s + rot) & 31) + 16 * hi) * 4;
+        f32x16_t U0, U1;  // U0 starts from the bias
 #pragma unroll
-        for (int e = 0; e < 16; ++e) U0[e] = 0.f, U1[e] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = lds_f4(bp + 16 * q);
+          U0[4 * q + 0] = b.x; U0[4 * q + 1] = b.y; U0[4 * q + 2] = b.z; U0[4 * q + 3] = b.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) U1[e] = 0.f;
+#ifndef MLP_NOPRIO
+        __builtin_amdgcn_s_setprio(1);  // (this wave's MFMAs ahead of a consumer that is late with its own)
+#endif
         {
           bf16x8_t fa[4], fb[4];
 #pragma unroll
@@ -191,58 +338,82 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) fb[i] = lds_frag(wb + (4 * grp + 4 + i) * 1024);
             }
-            U0 = mfma32(fa[0], xh[4 * grp + 0], U0);
-            U1 = mfma32(fa[1], xh[4 * grp + 1], U1);
-            U0 = mfma32(fa[2], xh[4 * grp + 2], U0);
-            U1 = mfma32(fa[3], xh[4 * grp + 3], U1);
+            U0 = mfma32a(fa[0], xh[4 * grp + 0], U0);
+            U1 = mfma32a(fa[1], xh[4 * grp + 1], U1);
+            U0 = mfma32a(fa[2], xh[4 * grp + 2], U0);
+            U1 = mfma32a(fa[3], xh[4 * grp + 3], U1);
             __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting every fragment read (it spills)
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = fb[i];
           }
         }
-        HMA_LDS(char)* bp = lds + MF_B1 + (32 * s + 16 * hi) * 4;
-        float h[16];
+        __builtin_amdgcn_s_setprio(0);
+        MPROF_MARK(3);
+        HMA_LDS(char)* xc = lds + MF_XCH + pair * MF_XCH_PAIR + (g & 1) * 3072 + lane * 16;
+        {  // registers 8..15 (the second k-step of the consumer's product) leave as fp32: the consumer applies the GELU
+          float uc[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 b = lds_f4(bp + 16 * q);
-          h[4 * q + 0] = gelu_fused(U0[4 * q + 0] + U1[4 * q + 0] + b.x);
-          h[4 * q + 1] = gelu_fused(U0[4 * q + 1] + U1[4 * q + 1] + b.y);
-          h[4 * q + 2] = gelu_fused(U0[4 * q + 2] + U1[4 * q + 2] + b.z);
-          h[4 * q + 3] = gelu_fused(U0[4 * q + 3] + U1[4 * q + 3] + b.w);
+          for (int e = 0; e < 8; ++e) uc[e] = U0[8 + e] + U1[8 + e];
+          lds_put(xc + 1024, __builtin_bit_cast(uint4, make_float4(uc[0], uc[1], uc[2], uc[3])));
+          lds_put(xc + 2048, __builtin_bit_cast(uint4, make_float4(uc[4], uc[5], uc[6], uc[7])));
         }
-        HMA_LDS(char)* xc = lds + MF_XCH + pair * 4096 + (g & 1) * 2048 + lane * 16;
-        lds_put(xc, pack8(h));
-        lds_put(xc + 1024, pack8(h + 8));
+        float up[8], hp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) up[e] = U0[e] + U1[e];
+        if (MLP_ABL & 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hp[e] = up[e];
+        } else {
+          gelu_n<8>(up, hp);
+        }
+        lds_put(xc, pack8(hp));
+        MPROF_MARK(4);
         if (s == 16 && (g >> 5) + 1 < nt) load_x((g >> 5) + 1, xn);  // next tile's rows, landed long before they are needed
+        MPROF_MARK(5);
       }
     }
+    MPROF_FLUSH(0);
   } else {
     // ---------------------------------------------------------------- consumer: x += hg W2^T + b2 (+ LayerNorm of the new row)
+    // The residual rows reach the accumulators through the staging pieces: one 32 x 32 fp32 block every 4th step by
+    // LDS-DMA (1 KB = 8 rows x 128 B per instruction: whole cache lines), added two steps later -- the register-direct
+    // alternative (every lane fetching 16-byte pieces of its own row, all at the tile boundary) cost 35 k cycles per tile.
     f32x16_t Y[8];
+    HMA_LDS(char)* stg = lds + MF_STG + pair * 8192;
+    MPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {
-      step_sync(g);
-      if (g + MF_AHEAD <= nsteps) issue(g + MF_AHEAD);
+      MPROF_MARK(0);
+      // (this wave has no loads of its own in flight: the producers' vmcnt waits + the barrier cover the LDS-DMA; its
+      // own global stores of a tile epilogue need no wait)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      MPROF_MARK(1);
+      MPROF_MARK(2);
       if (g >= 1) {
         const int gc = g - 1, s = gc & 31;
-        const int64_t row = tile_row(gc >> 5);
-        const int64_t rowc = row < p.M ? row : p.M - 1;
-        float* xrow = p.x + rowc * 256 + 16 * hi;
-        if (s == 0) {  // the accumulators start from the residual row: x + (...) needs no separate add
+        if (s == 0) {
 #pragma unroll
           for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 v = *reinterpret_cast<const float4*>(xrow + 32 * cb + 4 * q);
-              Y[cb][4 * q + 0] = v.x; Y[cb][4 * q + 1] = v.y; Y[cb][4 * q + 2] = v.z; Y[cb][4 * q + 3] = v.w;
-            }
-          // Consume the loads INSIDE this branch: otherwise hipcc places their s_waitcnt vmcnt(N) chain in front of the
-          // MFMAs of every step (the join below), and in the steady state those waits drain the LDS-DMA pieces just issued.
-#pragma unroll
-          for (int cb = 0; cb < 8; ++cb) asm volatile("" : "+v"(Y[cb]));
+            for (int e = 0; e < 16; ++e) Y[cb][e] = 0.f;
         }
-        HMA_LDS(char)* xc = lds + MF_XCH + pair * 4096 + (gc & 1) * 2048 + lane * 16;
+        // VALU phase first (beside the producer's MFMAs): the GELU of the half that arrived as fp32
+        HMA_LDS(char)* xc = lds + MF_XCH + pair * MF_XCH_PAIR + (gc & 1) * 3072 + lane * 16;
+        float uc[8], hc[8];
+        {
+          const float4 v0 = lds_f4(xc + 1024), v1 = lds_f4(xc + 2048);
+          uc[0] = v0.x; uc[1] = v0.y; uc[2] = v0.z; uc[3] = v0.w; uc[4] = v1.x; uc[5] = v1.y; uc[6] = v1.z; uc[7] = v1.w;
+        }
+        if (MLP_ABL & 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hc[e] = uc[e];
+        } else {
+          gelu_n<8>(uc, hc);
+        }
+        const bf16x8_t h1 = as_frag(pack8(hc));
         const bf16x8_t h0 = lds_frag(xc);
-        const bf16x8_t h1 = lds_frag(xc + 1024);
+        MPROF_MARK(3);
         HMA_LDS(char)* wb = lds + (g % MF_NSLOT) * MF_SLOT + 16384 + lane * 16;
         {
           // fragment order in the bundle: (cb, j) -> 2 cb + j; walked as j = 0: cb 0..7, then j = 1: cb 0..7
@@ -259,61 +430,105 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int cb = 4 * (grp & 1) + i;
-              Y[cb] = mfma32(fa[i], (grp >> 1) ? h1 : h0, Y[cb]);
+              Y[cb] = mfma32a(fa[i], (grp >> 1) ? h1 : h0, Y[cb]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = fb[i];
           }
         }
+        if ((s & 3) == 2 && !(MLP_ABL & 16)) {  // the residual block issued two steps ago (complete: older than this step's bundle)
+          const int cbx = s >> 2;
+          float xv[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = lds_f4(stg + (cbx & 1) * 4096 + stg_off(lr, 4 * hi + q));
+            xv[4 * q + 0] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int cb = 0; cb < 8; ++cb)
+            if (cb == cbx) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) Y[cb][e] += xv[e];
+            }
+        }
+        MPROF_MARK(4);
         if (s == 31) {
-          const bool ok = row < p.M;
+          // ---- tile epilogue: + b2, (LayerNorm statistics), rows out through the staging pieces (whole cache lines)
+          const int64_t r0 = tile_row0(gc >> 5);
           HMA_LDS(char)* b2p = lds + MF_B2 + 16 * hi * 4;
-          float sum = 0.f;
+          // (opaque copies: otherwise every row address of the epilogue is hoisted out of the step loop and spilled)
+          int prow = prow_, pchunk = pchunk_;
+          asm volatile("" : "+v"(prow), "+v"(pchunk));
+          // LayerNorm statistics in one pass over d = x - shift, shift = the row's first element (both lanes of a row use
+          // lane hi = 0's): sum d and sum d^2 of values at the scale of the row's spread, no cancellation
+          float sum = 0.f, sq = 0.f, shift = 0.f;
 #pragma unroll
           for (int cb = 0; cb < 8; ++cb) {
-            __builtin_amdgcn_sched_barrier(0);  // (the bias reads of all 8 blocks hoisted above the stores spill)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float4 b = lds_f4(b2p + (8 * cb + q) * 16);
-              float4 v;
-              v.x = Y[cb][4 * q + 0] + b.x; v.y = Y[cb][4 * q + 1] + b.y; v.z = Y[cb][4 * q + 2] + b.z; v.w = Y[cb][4 * q + 3] + b.w;
-              if (ok) *reinterpret_cast<float4*>(xrow + 32 * cb + 4 * q) = v;
-              if (LNOUT) {
-                Y[cb][4 * q + 0] = v.x; Y[cb][4 * q + 1] = v.y; Y[cb][4 * q + 2] = v.z; Y[cb][4 * q + 3] = v.w;
-                sum += v.x + v.y + v.z + v.w;
-              }
+              Y[cb][4 * q + 0] += b.x; Y[cb][4 * q + 1] += b.y; Y[cb][4 * q + 2] += b.z; Y[cb][4 * q + 3] += b.w;
             }
-          }
-          if (LNOUT) {  // two-pass mean / variance as ln_fwd_kernel; the row's other half sits in lane ^ 32
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * (1.0f / 256.0f);
-            float sq = 0.f;
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb)
+            if (LNOUT) {
+              if (cb == 0) shift = __shfl(Y[0][0], lr, 64);
 #pragma unroll
               for (int e = 0; e < 16; ++e) {
-                Y[cb][e] -= mean;
-                sq += Y[cb][e] * Y[cb][e];
+                const float d = Y[cb][e] - shift;
+                sum += d;
+                sq = __builtin_fmaf(d, d, sq);
               }
-            sq += __shfl_xor(sq, 32, 64);
-            const float rstd = rsqrtf(sq * (1.0f / 256.0f) + p.ln_eps);
-            if (ok) {
-              uint16_t* xo = reinterpret_cast<uint16_t*>(p.ln_xhat) + row * 256 + 16 * hi;
+            }
+            // new residual block -> staging (lane owns a row) -> 8 rows x 128 B per store instruction
+            HMA_LDS(char)* sb = stg + (cb & 1) * 4096;
 #pragma unroll
-              for (int cb = 0; cb < 8; ++cb) {
+            for (int q = 0; q < 4; ++q)
+              lds_put(sb + stg_off(lr, 4 * hi + q), __builtin_bit_cast(uint4, make_float4(Y[cb][4 * q], Y[cb][4 * q + 1], Y[cb][4 * q + 2], Y[cb][4 * q + 3])));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 8 * i + prow;
+              const float4 v = lds_f4(sb + r * 128 + (pchunk << 4));
+              if (r0 + r < p.M && !(MLP_ABL & 16)) *reinterpret_cast<float4*>(p.x + (r0 + r) * 256 + cb * 32 + ((pchunk ^ ((r >> 1) & 7)) << 2)) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (LNOUT) {
+            sum += __shfl_xor(sum, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const float md = sum * (1.0f / 256.0f);                       // mean - shift
+            const float var = fmaxf(sq * (1.0f / 256.0f) - md * md, 0.f);
+            const float rstd = rsqrtf(var + p.ln_eps);
+            const float nb = -(md + shift) * rstd;                       // xhat = x * rstd - mean * rstd
+            __builtin_amdgcn_sched_barrier(0);
+            // xhat of the next block: two 32-column blocks (64 bf16 = 128 B per row) per staging piece
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+              HMA_LDS(char)* sb = stg + (cp & 1) * 4096;
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
                 float o[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[e] = Y[cb][e] * rstd;
-                *reinterpret_cast<uint4*>(xo + 32 * cb) = pack8(o);
-                *reinterpret_cast<uint4*>(xo + 32 * cb + 8) = pack8(o + 8);
+                for (int e = 0; e < 16; ++e) o[e] = __builtin_fmaf(Y[2 * cp + k][e], rstd, nb);
+                lds_put(sb + stg_off(lr, 4 * k + 2 * hi), pack8(o));
+                lds_put(sb + stg_off(lr, 4 * k + 2 * hi + 1), pack8(o + 8));
+                __builtin_amdgcn_sched_barrier(0);
               }
-              if (hi == 0) p.ln_rstd[row] = rstd;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + prow;
+                const uint4 v = __builtin_bit_cast(uint4, lds_f4(sb + r * 128 + (pchunk << 4)));
+                if (r0 + r < p.M && !(MLP_ABL & 16))
+                  *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.ln_xhat) + (r0 + r) * 256 + cp * 64 + ((pchunk ^ ((r >> 1) & 7)) << 3)) = v;
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
+            if (hi == 0 && r0 + lr < p.M) p.ln_rstd[r0 + lr] = rstd;
           }
         }
       }
+      MPROF_MARK(5);
     }
+    MPROF_FLUSH(0);
   }
 }
 
@@ -351,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
   auto issue = [&](int b) __attribute__((always_inline)) {
     const uint32_t base = lds_b + (b % MB_NSLOT) * MB_SLOT + wave * 2048;
     const int s1 = b & 31, s2 = (b + 31) & 31;
+    if (MLP_ABL & 1) return;
     glds16(g1 + s1 * 16384, base);
     glds16(g1 + s1 * 16384 + 1024, base + 1024);
     glds16(g2 + s1 * 16384, base + 16384);
@@ -361,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
   // one bundle ahead: bundle g was issued a whole step ago; everything this wave has in flight is waited for
   auto step_sync = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   issue(0);
@@ -412,31 +628,26 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) fb[i] = lds_frag(wb + (i & 1) * 16384 + (2 * grp + 2 + (i >> 1)) * 1024);
             }
-            U = mfma32(fa[0], xh[2 * grp], U);
-            D = mfma32(fa[1], dy[2 * grp], D);
-            U = mfma32(fa[2], xh[2 * grp + 1], U);
-            D = mfma32(fa[3], dy[2 * grp + 1], D);
+            U = mfma32a(fa[0], xh[2 * grp], U);
+            D = mfma32a(fa[1], dy[2 * grp], D);
+            U = mfma32a(fa[2], xh[2 * grp + 1], U);
+            D = mfma32a(fa[3], dy[2 * grp + 1], D);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = fb[i];
           }
         }
         HMA_LDS(char)* bp = lds + MB_B1 + (32 * s + 16 * hi) * 4;
-        float hg[16], du[16];
+        float u[16], dd[16], hg[16], du[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 b = lds_f4(bp + 16 * q);
-          const float bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float u = U[4 * q + e] + bb[e];
-            float h, gs;
-            gelu_tail(u, h, gs);
-            hg[4 * q + e] = fmaxf(u, 0.f) - fabsf(u) * h;
-            const float cdf = u >= 0.f ? 1.0f - h : h;
-            du[4 * q + e] = D[4 * q + e] * __builtin_fmaf(u * 0.3989422804014327f, gs, cdf);
-          }
+          u[4 * q + 0] = U[4 * q + 0] + b.x; u[4 * q + 1] = U[4 * q + 1] + b.y;
+          u[4 * q + 2] = U[4 * q + 2] + b.z; u[4 * q + 3] = U[4 * q + 3] + b.w;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dd[e] = D[e];
+        gelu_bwd_n<16>(u, dd, hg, du);
         sv[0] = pack8(hg); sv[1] = pack8(hg + 8);
         sv[2] = pack8(du); sv[3] = pack8(du + 8);
         sv_ok = row < p.M;
@@ -478,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int kb = 4 * (grp & 1) + i;
-              G[kb] = mfma32(fa[i], (grp >> 1) ? d1 : d0, G[kb]);
+              G[kb] = mfma32a(fa[i], (grp >> 1) ? d1 : d0, G[kb]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -575,6 +786,13 @@ int num_cus() {
 }
 
 }  // namespace
+
+#ifdef MLP_PROF
+extern "C" int hma_mlp_debug_prof(unsigned long long* out128) {
+  if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_mlp_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 extern "C" int hma_mlp_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
                             const float* col_scale, void* dst, int32_t kind, int32_t batch, int64_t src_batch_stride,

@@ -160,8 +160,15 @@ class STEngine:
         # (hma_fold_ln_bf16): the forward GEMM then reads the saved xhat as a plain bf16 operand
         self.WF = {"qkv_s": mk(L, 3 * d, d), "fc1": mk(L, hid, d)}
         self.BF = {"qkv_s": torch.zeros(L, 3 * d, dtype=F32, device=self.device), "fc1": torch.zeros(L, hid, dtype=F32, device=self.device)}
-        # fused MLP block (csrc/mlp.hip): the four MFMA-fragment-ordered weight streams per layer, 512 KB each
+        # Fused MLP block (csrc/mlp.hip; the four MFMA-fragment-ordered weight streams per layer, 512 KB each).
+        # Measured on MI355X: the fused forward takes ~300 us per layer at M = 163840 against 418 us
+        # for fc1 + fc2 + the next LayerNorm, but the fused backward (recompute, 570-600 us) loses to dfc2 + dfc1 + LayerNorm
+        # backward (379 us), and the unfused backward needs u / gelu(u) saved by an unfused forward -- so TRAINING keeps the
+        # unfused pair and the fused forward serves inference passes of at least one 128-row tile per CU.
+        # `fused_mlp_train = True` switches training to the fused pair (parity-tested; slower).
         self.fused_mlp = float(getattr(cfg, "mlp_drop", 0.0) or 0.0) == 0.0 and hid == 1024
+        self.fused_mlp_train = False
+        self.fused_mlp_min_rows = 128 * 256
         if self.fused_mlp:
             self.MP = {k: mk(L, 512 * 512) for k in ("w1p", "w2p", "w2tp", "w1tp")}
         self.modulate = "modulate" in cfg.action_network
@@ -266,8 +273,14 @@ class STEngine:
         self._dom_fresh = set()
 
     # ------------------------------------------------------------------------------ workspace
+    def _use_fused(self, rows: int, train: bool) -> bool:
+        """Whether a pass over `rows` token rows runs the fused MLP block (see __init__)."""
+        if not self.fused_mlp:
+            return False
+        return self.fused_mlp_train if train else rows >= self.fused_mlp_min_rows
+
     def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
-        key = (B, T, S, A, train)
+        key = (B, T, S, A, train, self.fused_mlp_train)
         if self._ws_key == key:
             return self._ws
         self._ws, self._plans = {}, {}
@@ -293,7 +306,8 @@ class STEngine:
         buf("lse_s", (Ls, M, 8), F32)
         buf("rstd1", (Ls, M), F32)
         buf("rstd2", (Ls, M), F32)
-        if not self.fused_mlp:  # the fused MLP block never materialises the hidden activation
+        fused = self._use_fused(M, train)
+        if not fused:  # the fused MLP block never materialises the hidden activation
             buf("u", (Ls, M, 1024), BF16)
             buf("hg", (Ls, M, 1024), BF16)
         if A > 0:
@@ -315,7 +329,7 @@ class STEngine:
             buf("dlogits", (Mi, 1024), BF16)
             buf("dx", (M, 256), F32)
             buf("dxb", (M, 256), BF16)  # bf16 copy of dx: operand of the dgrad / wgrad GEMMs that read it
-            if self.fused_mlp:
+            if fused:
                 buf("dxb2", (M, 256), BF16)   # hma_mlp_bwd writes the new copy while the fc2 weight gradient still reads the old one
                 buf("hg1", (M, 1024), BF16)   # gelu(u) and dL/du of the layer in flight (operands of its two weight gradients)
                 buf("du1", (M, 1024), BF16)
@@ -342,7 +356,7 @@ class STEngine:
 
     def _emit_layer(self, pl: Plan, l: int, x: int, b: Dict[str, int], M: int, Fr: int, B: int, T: int, SA: int,
                     use_mod: bool, domain: Optional[str], kv: Optional[dict] = None, train: bool = False,
-                    have_ln1: bool = False, ln_next: Optional[Tuple[int, int]] = None) -> None:
+                    have_ln1: bool = False, ln_next: Optional[Tuple[int, int]] = None, fused: bool = False) -> None:
         """One STBlock forward (st_transformer.py:79-114) on M rows = Fr frames of SA tokens.  `kv` redirects the
         temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
         "t_query": -1 | t, "T_cache": frames}."""
@@ -377,7 +391,7 @@ class STEngine:
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
         # MLP (its LayerNorm: fused above)                   st_transformer.py:112
-        if self.fused_mlp:
+        if fused:
             pl.mlp_fwd(M, xhat=b["xh2"], x=x, w1p=self.MP["w1p"][l].data_ptr(), w2p=self.MP["w2p"][l].data_ptr(),
                        b1=self.BF["fc1"][l].data_ptr(), b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
                        ln_xhat=ln_next[0] if ln_next else None, ln_rstd=ln_next[1] if ln_next else None, ln_eps=1e-5)
@@ -405,12 +419,14 @@ class STEngine:
     def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True, kv_cache=None,
                       T_cache=0) -> Plan:
         l1 = self.cfg.num_layers if l1 is None else l1
-        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else kv_cache.data_ptr())
+        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else kv_cache.data_ptr(),
+               self._use_fused(B * T * (S + A), train))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
         L = cfg.num_layers
         SA, M, Mi, Fr = S + A, B * T * (S + A), B * T * S, B * T
+        fused = self._use_fused(M, train)
         pl = Plan()
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         sl = (lambda l: l) if train else (lambda l: 0)
@@ -448,17 +464,17 @@ class STEngine:
         x = ws["x"].data_ptr()
         for l in range(l0, l1):
             s = sl(l)
-            names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t", "xh2", "rstd2") + (() if self.fused_mlp else ("u", "hg"))
+            names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t", "xh2", "rstd2") + (() if fused else ("u", "hg"))
             bufs = {k: dp(ws[k], s, ws[k][0].numel()) for k in names}
             if A > 0 and self.modulate:
                 bufs.update({k: dp(ws[k], s, ws[k][0].numel()) for k in ("xhm", "xm", "rstdm")})
                 bufs["ss"] = dp(ws["ss"], l, Fr * 512)
             ln_next = None
-            if self.fused_mlp and l + 1 < l1:  # the MLP kernel also emits the next block's LN1 output
+            if fused and l + 1 < l1:  # the MLP kernel also emits the next block's LN1 output
                 s1 = sl(l + 1)
                 ln_next = (dp(ws["xh1"], s1, ws["xh1"][0].numel()), dp(ws["rstd1"], s1, ws["rstd1"][0].numel()))
             self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train,
-                             have_ln1=self.fused_mlp and l > l0, ln_next=ln_next)
+                             have_ln1=fused and l > l0, ln_next=ln_next, fused=fused)
         # readout on the image tokens only                      st_mask_git.py:681-683
         if readout:
           pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,
@@ -480,7 +496,7 @@ class STEngine:
         return pl
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
-        key = ("bwd", B, T, S, A, domain)
+        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -509,7 +525,7 @@ class STEngine:
             gw = lambda suffix: self._lw(l, suffix, "g")
             gb = lambda suffix, on=True: self._lw(l, suffix, "g") if on else None
             wt = lambda k: dp(self.WT[k], l, self.WT[k][0].numel())
-            if self.fused_mlp:
+            if self._use_fused(M, True):
                 # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
                 # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
                 # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
@@ -746,7 +762,7 @@ class STEngine:
         buf("lse_s", (M1, 8), F32)
         for nm in ("rstd1", "rstd2", "rstdm"):
             buf(nm, (M1,), F32)
-        if not self.fused_mlp:
+        if not self._use_fused(M1, False):
             buf("u", (M1, 1024), BF16)
             buf("hg", (M1, 1024), BF16)
         buf("logits", (B * S, 1024), F32)
@@ -795,8 +811,9 @@ class STEngine:
                self._p("pos_embed_TSC") + 4 * t * pfr * 256, d["a_emb"].data_ptr() if A > 0 else None, d["x"].data_ptr(), B, 1, S, A,
                pfr, cfg.factored_vocab_size, cfg.image_vocab_size)
         x = d["x"].data_ptr()
+        fused = self._use_fused(M1, False)
         names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "o_t", "xh2", "rstd2", "xhm", "xm", "rstdm") + (
-            () if self.fused_mlp else ("u", "hg"))
+            () if fused else ("u", "hg"))
         for l in range(L):
             bufs = {k: d[k].data_ptr() for k in names}
             bufs["qkv_t"] = None
@@ -804,8 +821,8 @@ class STEngine:
                 bufs["ss"] = d["ss"].data_ptr() + l * B * 512 * 4
             kv = {"cache": d["cache"][l].data_ptr(), "row_off": t * SA, "c_group": (SA, T_total * SA), "t_query": t,
                   "T_cache": T_total}
-            self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv, have_ln1=self.fused_mlp and l > 0,
-                             ln_next=(d["xh1"].data_ptr(), d["rstd1"].data_ptr()) if self.fused_mlp and l + 1 < L else None)
+            self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv, have_ln1=fused and l > 0,
+                             ln_next=(d["xh1"].data_ptr(), d["rstd1"].data_ptr()) if fused and l + 1 < L else None, fused=fused)
         if readout:
             pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=B * S, N=1024,
                        K=256, epi=EPI_F32, Cp=d["logits"].data_ptr(), ldc=1024, bias=self._p("out_x_proj.bias"))

@@ -62,10 +62,16 @@ def oracle_grads(tag):
     return loss.detach(), acc.detach(), logits.detach(), {k: p.grad for k, p in params.items()}
 
 
-@pytest.mark.parametrize("tag", ["domA", "domB", "noact"])
+@pytest.mark.parametrize("tag", ["domA", "domB", "noact", "domA+fused_mlp"])
 def test_forward_backward_matches_reference(tag):
+    """`+fused_mlp`: the same check with training switched to the fused MLP block (hma_mlp_fwd / hma_mlp_bwd: hidden
+    activation on chip, pre-activation recomputed in backward, LayerNorm gradients from the wgrad reduction)."""
+    fused = tag.endswith("+fused_mlp")
+    tag = tag.split("+")[0]
     g = golden("g6_forward_backward")
     m = build_model()
+    if fused:
+        m._get_engine(torch.device(DEV, torch.cuda.current_device())).fused_mlp_train = True
     inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
     kw = dict(input_ids=inp["input_ids"], labels=inp["labels"], h=[16, 16], w=[16, 16])
     if tag != "noact":
@@ -79,8 +85,9 @@ def test_forward_backward_matches_reference(tag):
     assert abs(out.loss.item() - loss_ref.item()) <= 3e-4 * loss_ref.item()
     assert out.acc.item() == g[f"{tag}.acc"].item()
     e = rel_err(out.logits, logits_ref)
-    _note(f"{tag}.loss_abs_err", abs(out.loss.item() - loss_ref.item()))
-    _note(f"{tag}.logits_rel_err", e)
+    nt = tag + ("+fused_mlp" if fused else "")
+    _note(f"{nt}.loss_abs_err", abs(out.loss.item() - loss_ref.item()))
+    _note(f"{nt}.logits_rel_err", e)
     assert e <= 2e-2
     assert rel_err(out.logits[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) <= 2e-2
     out.loss.backward()
@@ -93,9 +100,9 @@ def test_forward_backward_matches_reference(tag):
         assert p.grad is not None, name
         err = rms_err(p.grad, gr)
         worst = max(worst, err)
-        _note(f"{tag}.grad_rms.{name}", err)
+        _note(f"{nt}.grad_rms.{name}", err)
         assert err <= 6e-2, f"{name}: rms rel err {err:.3e}"
-    _note(f"{tag}.worst_grad_rms", worst)
+    _note(f"{nt}.worst_grad_rms", worst)
 
 
 def test_loss_within_1e3_on_init_scale_weights():

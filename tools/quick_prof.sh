@@ -1,7 +1,19 @@
 #!/bin/bash
-# per-kernel time of the bench (3 steps incl. warm-up), printed; raw output discarded
-cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/prof_q
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_q -o q -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 < /dev/null
-timeout 60 python3 tools/quick_prof.py gpurun_out/prof_q/q_kernel_stats.csv 3 26 < /dev/null
-rm -rf gpurun_out/prof_q
+# rocprofv3 kernel-trace stats of a short bench run -> gpurun_out/qprof/stats.txt (top kernels by total time)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/qprof
+rm -rf $OUT; mkdir -p $OUT
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o q -- python3 bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-kernel-timing ${BENCH_ARGS:-} > $OUT/bench.log 2>&1 < /dev/null
+echo "rc=$?"; tail -2 $OUT/bench.log | cut -c1-300
+f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY' | tee $OUT/stats.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:28]:
+    n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms {int(r["Calls"]):6d} calls {float(r["AverageNs"])/1e3:9.1f} us {float(r["Percentage"]):6.2f}%  {n[:90]}')
+print(f"total {tot/1e6:.1f} ms")
+PY
+find $OUT -name "*kernel_trace.csv" -delete
