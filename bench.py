@@ -238,8 +238,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--mode", choices=["train", "decode", "mar"], default="train")
-    ap.add_argument("--fused-mlp-train", action="store_true",
-                    help="measurement only: train with the fused MLP block (hma_mlp_fwd / hma_mlp_bwd) instead of the default unfused pair")
+    ap.add_argument("--unfused-mlp", action="store_true",
+                    help="measurement only: train with the unfused MLP GEMMs (fc1 / fc2 / dfc2 / dfc1 + LayerNorm kernels) instead of "
+                         "the fused block (hma_mlp_fwd / hma_mlp_bwd)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,7 +287,8 @@ def main():
     for di in sorted(set(mine)):
         batches[di] = synthetic_batch(B, T, 100 + di, d_actions[di], dev)
     eng = trainer.engine
-    eng.fused_mlp_train = bool(args.fused_mlp_train)
+    if args.unfused_mlp:
+        eng.fused_mlp_train = False
 
     def one(k):
         di = mine[k]

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
 }
 
 // Debug builds only (tools/mlp_ablate.sh, -DMLP_ABL=bits): 1 no LDS-DMA, 2 no MFMA, 4 no GELU, 8 no barrier,
-// 16 no activation loads / stores (forward kernel), 32 no LDS fragment reads
+// 16 no activation loads / stores (forward kernel), 32 no LDS fragment reads, 64 no backward epilogue, 128 no hg / du stores
 __device__ __forceinline__ f32x16_t mfma32a(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
   if (MLP_ABL & 2) {
     f32x16_t r = c;
@@ -534,13 +534,22 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
 
 // ------------------------------------------------------------------------------------------------ backward
 // Producer: u = W1f xhat + b1 (recomputed), dhg = W2^T dy, hg = gelu(u), du = dhg * gelu'(u); hg and du go to HBM for the
-// two weight-gradient GEMMs (hma_gemm_tn_pair), du also to the consumer.  Consumer: dxhat = W1f^T du, then the LayerNorm
-// backward (gamma already folded into W1f) added to the residual gradient.
+// two weight-gradient GEMMs (hma_gemm_tn_pair), du also to the consumer.  Consumer: g = dxhat = W1f^T du (gamma already
+// folded into W1f), then the LayerNorm backward added to the residual gradient:
+//     dx_new = dx_old + rstd (g - mean_k g - xhat mean_k (g xhat)).
+// The row statistic mean_k (g xhat) never needs xhat: sum_k g[k] xhat[k] = sum_h du[h] (W1f xhat)[h], i.e. the producer's
+// du times its own pre-bias accumulator, summed over the hidden units as they go by.  dx_old reaches the accumulators
+// during the main loop (one 32 x 32 fp32 block every 4th step by LDS-DMA, scaled by 1 / rstd when added), so the tile
+// epilogue only subtracts the xhat term (4 staged pieces), scales, and writes whole cache lines through the staging
+// pieces.  All LDS-DMA is issued by the CONSUMER waves (the producers' queues hold the hg / du stores, which drain slowly
+// and out of order with loads: a producer never waits on vmcnt inside the loop).
 constexpr int MB_NSLOT = 2;
 constexpr int MB_SLOT = 49152;               // bundle g = fc1 frags | fc2^T frags of hidden block g | fc1^T frags of block g - 1
-constexpr int MB_XCH = MB_NSLOT * MB_SLOT;
+constexpr int MB_XCH = MB_NSLOT * MB_SLOT;   // per pair: 2 buffers x 2 planes x 1 KB (du, bf16)
 constexpr int MB_B1 = MB_XCH + 4 * 4096;
-constexpr int MB_SMEM = MB_B1 + 4096;        // 118784 B
+constexpr int MB_ST2 = MB_B1 + 4096;         // per pair: 32 floats (sum_h du (W1f xhat) per token row) | 32 floats (rstd)
+constexpr int MB_STG = MB_ST2 + 1024;        // per pair: 2 staging pieces of 4 KB
+constexpr int MB_SMEM = MB_STG + 4 * 8192;   // 152576 B
 
 __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -560,42 +569,23 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
   }
   __syncthreads();
 
-  const char* g1 = reinterpret_cast<const char*>(p.w1p) + wave * 2048 + lane * 16;
-  const char* g2 = reinterpret_cast<const char*>(p.w2tp) + wave * 2048 + lane * 16;
-  const char* g3 = reinterpret_cast<const char*>(p.w1tp) + wave * 2048 + lane * 16;
-  auto issue = [&](int b) __attribute__((always_inline)) {
-    const uint32_t base = lds_b + (b % MB_NSLOT) * MB_SLOT + wave * 2048;
-    const int s1 = b & 31, s2 = (b + 31) & 31;
-    if (MLP_ABL & 1) return;
-    glds16(g1 + s1 * 16384, base);
-    glds16(g1 + s1 * 16384 + 1024, base + 1024);
-    glds16(g2 + s1 * 16384, base + 16384);
-    glds16(g2 + s1 * 16384 + 1024, base + 16384 + 1024);
-    glds16(g3 + s2 * 16384, base + 32768);
-    glds16(g3 + s2 * 16384 + 1024, base + 32768 + 1024);
-  };
-  // one bundle ahead: bundle g was issued a whole step ago; everything this wave has in flight is waited for
-  auto step_sync = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  issue(0);
-
-  auto tile_row = [&](int tl) __attribute__((always_inline)) {
-    return ((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * 128 + pair * 32 + lr;
+  auto tile_row0 = [&](int tl) __attribute__((always_inline)) {
+    return ((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * 128 + pair * 32;
   };
 
   if (role == 0) {
+    // ---------------------------------------------------------------- producer
     bf16x8_t xh[16], dy[16];
     uint4 sv[4];             // packed hg | du of the previous step, stored at the start of the next one
     uint16_t* sp_hg = nullptr;
     uint16_t* sp_du = nullptr;
     bool sv_ok = false;
+    float s2acc = 0.f;
     for (int g = 0; g <= nsteps; ++g) {
-      step_sync();
-      if (g + 1 <= nsteps) issue(g + 1);
-      if (g > 0 && sv_ok) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (g > 0 && sv_ok && !(MLP_ABL & 128)) {
         *reinterpret_cast<uint4*>(sp_hg) = sv[0];
         *reinterpret_cast<uint4*>(sp_hg + 8) = sv[1];
         *reinterpret_cast<uint4*>(sp_du) = sv[2];
@@ -603,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
       }
       if (g < nsteps) {
         const int s = g & 31;
-        const int64_t row = tile_row(g >> 5);
+        const int64_t row = tile_row0(g >> 5) + lr;
         const int64_t rowc = row < p.M ? row : p.M - 1;
         if (s == 0) {
           const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.xhat) + rowc * 256 + 16 * hi;
@@ -613,6 +603,12 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             xh[j] = as_frag(*reinterpret_cast<const uint4*>(xs + 32 * (j >> 1) + 8 * (j & 1)));
             dy[j] = as_frag(*reinterpret_cast<const uint4*>(ds + 32 * (j >> 1) + 8 * (j & 1)));
           }
+          float rs = p.rstd[rowc];
+          // (consumed inside this branch: see the forward kernel's note on hipcc's waitcnt placement)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(xh[j]), "+v"(dy[j]));
+          asm volatile("" : "+v"(rs));
+          if (hi == 0) ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lr] = rs;  // the consumer reads it one step later
         }
         HMA_LDS(char)* wb = lds + (g % MB_NSLOT) * MB_SLOT + lane * 16;
         f32x16_t U, D;
@@ -638,39 +634,120 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           }
         }
         HMA_LDS(char)* bp = lds + MB_B1 + (32 * s + 16 * hi) * 4;
-        float u[16], dd[16], hg[16], du[16];
+        // (two halves of 8: the staged GELU holds ~8 values per element in flight)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 b = lds_f4(bp + 16 * q);
-          u[4 * q + 0] = U[4 * q + 0] + b.x; u[4 * q + 1] = U[4 * q + 1] + b.y;
-          u[4 * q + 2] = U[4 * q + 2] + b.z; u[4 * q + 3] = U[4 * q + 3] + b.w;
+        for (int half = 0; half < 2; ++half) {
+          float u[8], dd[8], hg[8], du[8];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float4 b = lds_f4(bp + 32 * half + 16 * q);
+            u[4 * q + 0] = U[8 * half + 4 * q + 0] + b.x; u[4 * q + 1] = U[8 * half + 4 * q + 1] + b.y;
+            u[4 * q + 2] = U[8 * half + 4 * q + 2] + b.z; u[4 * q + 3] = U[8 * half + 4 * q + 3] + b.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dd[e] = D[8 * half + e];
+          if (MLP_ABL & 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hg[e] = u[e], du[e] = dd[e];
+          } else {
+            gelu_bwd_n<8>(u, dd, hg, du);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s2acc = __builtin_fmaf(du[e], U[8 * half + e], s2acc);  // du (W1f xhat): the pre-bias accumulator
+          sv[half] = pack8(hg);
+          sv[2 + half] = pack8(du);
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dd[e] = D[e];
-        gelu_bwd_n<16>(u, dd, hg, du);
-        sv[0] = pack8(hg); sv[1] = pack8(hg + 8);
-        sv[2] = pack8(du); sv[3] = pack8(du + 8);
         sv_ok = row < p.M;
         sp_hg = reinterpret_cast<uint16_t*>(p.hg) + rowc * 1024 + 32 * s + 16 * hi;
         sp_du = reinterpret_cast<uint16_t*>(p.du) + rowc * 1024 + 32 * s + 16 * hi;
         HMA_LDS(char)* xc = lds + MB_XCH + pair * 4096 + (g & 1) * 2048 + lane * 16;
         lds_put(xc, sv[2]);
         lds_put(xc + 1024, sv[3]);
+        if (s == 31) {  // the tile's sum_h du (W1f xhat) per token row -> the consumer (read after the next barrier)
+          const float t2 = s2acc + __shfl_xor(s2acc, 32, 64);
+          if (hi == 0) ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256))[lr] = t2;
+          s2acc = 0.f;
+        }
       }
     }
   } else {
+    // ---------------------------------------------------------------- consumer
     f32x16_t G[8];
+    HMA_LDS(char)* stg = lds + MB_STG + pair * 8192;
+    const uint32_t stg_b = lds_b + MB_STG + pair * 8192;
+    const int prow_ = lane >> 3, pchunk_ = lane & 7;
+    const char* g1 = reinterpret_cast<const char*>(p.w1p) + pair * 4096 + lane * 16;
+    const char* g2 = reinterpret_cast<const char*>(p.w2tp) + pair * 4096 + lane * 16;
+    const char* g3 = reinterpret_cast<const char*>(p.w1tp) + pair * 4096 + lane * 16;
+    auto issue = [&](int b) __attribute__((always_inline)) {
+      const uint32_t base = lds_b + (b % MB_NSLOT) * MB_SLOT + pair * 4096;
+      const int s1 = b & 31, s2 = (b + 31) & 31;
+      if (MLP_ABL & 1) return;
+      glds16x4(g1 + s1 * 16384, base);
+      glds16x4(g2 + s1 * 16384, base + 16384);
+      glds16x4(g3 + s2 * 16384, base + 32768);
+    };
+    // one 32-row x 128-byte block of a row-major matrix (fp32 dx: 32 columns; bf16 xhat: 64 columns) -> staging piece `buf`
+    auto issue_rows = [&](const char* base, int64_t row_bytes, int tl, int buf) __attribute__((always_inline)) {
+      if (MLP_ABL & 65) return;
+      const int64_t r0 = tile_row0(tl);
+      int pr = prow_, pc = pchunk_;
+      asm volatile("" : "+v"(pr), "+v"(pc));  // (opaque: the address arithmetic of every call site is otherwise hoisted and spilled)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + pr;
+        int64_t gr = r0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        glds16(base + gr * row_bytes + ((pc ^ ((r >> 1) & 7)) << 4), stg_b + buf * 4096 + i * 1024);
+      }
+    };
+    auto wait_vm = [&](int newer) __attribute__((always_inline)) {  // all but the `newer` youngest loads of this wave are complete
+      if (newer >= 63)
+        return;
+      else if (newer >= 12)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (newer >= 9)
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (newer >= 8)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (newer >= 5)
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (newer >= 4)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) G[kb][e] = 0.f;
+    issue(0);
+    int pend = 0;            // loads issued after the newest bundle (they are younger than it: vmcnt(pend) = bundle complete)
+    float invr = 1.f, rstd = 1.f, sumold = 0.f;
     for (int g = 0; g <= nsteps; ++g) {
-      step_sync();
+      wait_vm(pend);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       if (g + 1 <= nsteps) issue(g + 1);
+      pend = 0;
       if (g >= 1) {
-        const int gc = g - 1, s = gc & 31;
-        const int64_t row = tile_row(gc >> 5);
-        const int64_t rowc = row < p.M ? row : p.M - 1;
+        const int gc = g - 1, s = gc & 31, tl = gc >> 5;
+        // staged row blocks, issued AFTER the bundle (so that the bundle wait of the next step does not wait for HBM):
+        // dx block cb at s = 4 cb (added at s = 4 cb + 2), xhat pieces 0 / 1 at s = 28 / 30 (used by the epilogue)
+        if ((s & 3) == 0) {
+          issue_rows(reinterpret_cast<const char*>(p.dx) + (s >> 2) * 128, 1024, tl, (s >> 2) & 1);
+          pend += 4;
+        }
+        if (s == 28) {
+          issue_rows(reinterpret_cast<const char*>(p.xhat), 512, tl, 0);
+          pend += 4;
+        }
+        if (s == 0) {
+          rstd = ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lr];  // published by the producer at its s == 0
+          invr = 1.0f / rstd;
+          sumold = 0.f;
+        }
         HMA_LDS(char)* xc = lds + MB_XCH + pair * 4096 + (gc & 1) * 2048 + lane * 16;
         const bf16x8_t d0 = lds_frag(xc);
         const bf16x8_t d1 = lds_frag(xc + 1024);
@@ -696,60 +773,105 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             for (int i = 0; i < 4; ++i) fa[i] = fb[i];
           }
         }
-        if (s == 31) {
-          // dx += rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxhat (gamma folded into the weights).  xhat is read
-          // twice (row statistics, then the update) in register-sized batches: holding the row across the main loop, or
-          // letting the scheduler hoist all 48 loads, spills the 128 accumulators.
-          const bool ok = row < p.M;
-          const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.xhat) + rowc * 256 + 16 * hi;
-          const float rstd = p.rstd[rowc];
-          float s1 = 0.f, s2 = 0.f;
+        if ((s & 3) == 2 && !(MLP_ABL & 64)) {  // dx block issued two steps ago (older than the bundle waited for above)
+          const int cbx = s >> 2;
+          float xv[16];
 #pragma unroll
-          for (int bt = 0; bt < 2; ++bt) {
-            uint4 xe[8];
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = lds_f4(stg + (cbx & 1) * 4096 + stg_off(lr, 4 * hi + q));
+            xv[4 * q + 0] = v.x * invr; xv[4 * q + 1] = v.y * invr; xv[4 * q + 2] = v.z * invr; xv[4 * q + 3] = v.w * invr;
+          }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xe[i] = *reinterpret_cast<const uint4*>(xs + 32 * (4 * bt + (i >> 1)) + 8 * (i & 1));
+          for (int e = 0; e < 16; ++e) sumold += xv[e];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int kb = 4 * bt + (i >> 1);
-              float xf[8];
-              unpack8(xe[i], xf);
+          for (int kb = 0; kb < 8; ++kb)
+            if (kb == cbx) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                s1 += G[kb][8 * (i & 1) + e];
-                s2 += G[kb][8 * (i & 1) + e] * xf[e];
-              }
+              for (int e = 0; e < 16; ++e) G[kb][e] += xv[e];
+            }
+        }
+        if (s == 30) {  // (after the last dx block left staging piece 1)
+          issue_rows(reinterpret_cast<const char*>(p.xhat) + 128, 512, tl, 1);
+          pend += 4;
+        }
+        if (s == 31 && (MLP_ABL & 64)) {
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) G[kb][e] = 0.f;
+        } else if (s == 31) {
+          // ---- tile epilogue.  G = g + dx_old / rstd.  Row statistics, the xhat term (4 staged pieces, before any store),
+          // then dx_new = rstd (G - mean g - xhat s2) out through the staging pieces.
+          const int64_t r0 = tile_row0(tl);
+          int prow = prow_, pchunk = pchunk_;
+          asm volatile("" : "+v"(prow), "+v"(pchunk));
+          float sg = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sg += G[kb][e];
+          sg -= sumold;
+          sg += __shfl_xor(sg, 32, 64);
+          const float s1 = sg * (1.0f / 256.0f);
+          const float s2 = ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256))[lr] * (1.0f / 256.0f);
+          // xhat pieces: piece cp holds columns 64 cp .. 64 cp + 63 (blocks kb = 2 cp, 2 cp + 1); 0 and 1 are in flight since
+          // s = 28 / 30, 2 and 3 are issued as the buffers free up.  This wave's queue: [piece 1]? [bundle g + 1 (12)] ...
+          wait_vm(12);  // pieces 0 and 1 (older than this step's bundle)
+#pragma unroll
+          for (int cp = 0; cp < 4; ++cp) {
+            if (cp == 2) wait_vm(4);   // piece 2 (piece 3 is younger)
+            if (cp == 3) wait_vm(0);
+            HMA_LDS(char)* sb = stg + (cp & 1) * 4096;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              float xf[16];
+              unpack8(__builtin_bit_cast(uint4, lds_f4(sb + stg_off(lr, 4 * k + 2 * hi))), xf);
+              unpack8(__builtin_bit_cast(uint4, lds_f4(sb + stg_off(lr, 4 * k + 2 * hi + 1))), xf + 8);
+#pragma unroll
+              for (int e = 0; e < 16; ++e) G[2 * cp + k][e] = __builtin_fmaf(-s2, xf[e], G[2 * cp + k][e]);
+            }
+            if (cp < 2) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's reads of the piece are done before it is refilled)
+              issue_rows(reinterpret_cast<const char*>(p.xhat) + (cp + 2) * 128, 512, tl, cp & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          s1 += __shfl_xor(s1, 32, 64);
-          s2 += __shfl_xor(s2, 32, 64);
-          s1 *= (1.0f / 256.0f);
-          s2 *= (1.0f / 256.0f);
-          float* dxr = p.dx + rowc * 256 + 16 * hi;
-          uint16_t* dbr = reinterpret_cast<uint16_t*>(p.dx_bf16) + rowc * 256 + 16 * hi;
+          const float nb = -s1 * rstd;
 #pragma unroll
-          for (int bt = 0; bt < 4; ++bt) {  // two 32-column blocks per batch: 4 + 8 loads in flight
-            uint4 xe[4];
-            float4 od[8];
+          for (int cp = 0; cp < 4; ++cp) {  // blocks kb = 2 cp, 2 cp + 1: two fp32 pieces (dx), then their bf16 copy as one piece
+            uint4 qb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xe[i] = *reinterpret_cast<const uint4*>(xs + 32 * (2 * bt + (i >> 1)) + 8 * (i & 1));
+            for (int k = 0; k < 2; ++k) {
+              const int kb = 2 * cp + k;
+              float o[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) od[i] = *reinterpret_cast<const float4*>(dxr + 32 * (2 * bt + (i >> 2)) + 4 * (i & 3));
+              for (int e = 0; e < 16; ++e) o[e] = __builtin_fmaf(G[kb][e], rstd, nb);
+              HMA_LDS(char)* sb = stg + k * 4096;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                lds_put(sb + stg_off(lr, 4 * hi + q), __builtin_bit_cast(uint4, make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3])));
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + prow;
+                const float4 v = lds_f4(sb + r * 128 + (pchunk << 4));
+                if (r0 + r < p.M) *reinterpret_cast<float4*>(p.dx + (r0 + r) * 256 + kb * 32 + ((pchunk ^ ((r >> 1) & 7)) << 2)) = v;
+              }
+              qb[2 * k] = pack8(o);
+              qb[2 * k + 1] = pack8(o + 8);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            HMA_LDS(char)* sb = stg;  // (piece 0: its fp32 rows were read back above, LDS operations of a wave execute in order)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              lds_put(sb + stg_off(lr, 4 * k + 2 * hi), qb[2 * k]);
+              lds_put(sb + stg_off(lr, 4 * k + 2 * hi + 1), qb[2 * k + 1]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int kb = 2 * bt + (i >> 1), hf = i & 1;
-              float xf[8], o[8];
-              unpack8(xe[i], xf);
-              const float old[8] = {od[2 * i].x, od[2 * i].y, od[2 * i].z, od[2 * i].w,
-                                    od[2 * i + 1].x, od[2 * i + 1].y, od[2 * i + 1].z, od[2 * i + 1].w};
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] = old[e] + rstd * (G[kb][8 * hf + e] - s1 - xf[e] * s2);
-              if (ok) {
-                *reinterpret_cast<float4*>(dxr + 32 * kb + 8 * hf) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4*>(dxr + 32 * kb + 8 * hf + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                *reinterpret_cast<uint4*>(dbr + 32 * kb + 8 * hf) = pack8(o);
-              }
+              const int r = 8 * i + prow;
+              const uint4 v = __builtin_bit_cast(uint4, lds_f4(sb + r * 128 + (pchunk << 4)));
+              if (r0 + r < p.M)
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.dx_bf16) + (r0 + r) * 256 + cp * 64 + ((pchunk ^ ((r >> 1) & 7)) << 3)) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -757,6 +879,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) G[kb][e] = 0.f;
+          pend = 63;  // every load of this wave is complete (vmcnt(0) above); the stores need no wait
         }
       }
     }

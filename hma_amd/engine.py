@@ -160,14 +160,13 @@ class STEngine:
         # (hma_fold_ln_bf16): the forward GEMM then reads the saved xhat as a plain bf16 operand
         self.WF = {"qkv_s": mk(L, 3 * d, d), "fc1": mk(L, hid, d)}
         self.BF = {"qkv_s": torch.zeros(L, 3 * d, dtype=F32, device=self.device), "fc1": torch.zeros(L, hid, dtype=F32, device=self.device)}
-        # Fused MLP block (csrc/mlp.hip; the four MFMA-fragment-ordered weight streams per layer, 512 KB each).
-        # Measured on MI355X: the fused forward takes ~300 us per layer at M = 163840 against 418 us
-        # for fc1 + fc2 + the next LayerNorm, but the fused backward (recompute, 570-600 us) loses to dfc2 + dfc1 + LayerNorm
-        # backward (379 us), and the unfused backward needs u / gelu(u) saved by an unfused forward -- so TRAINING keeps the
-        # unfused pair and the fused forward serves inference passes of at least one 128-row tile per CU.
-        # `fused_mlp_train = True` switches training to the fused pair (parity-tested; slower).
+        # Fused MLP block (csrc/mlp.hip; the four MFMA-fragment-ordered weight streams per layer, 512 KB each): training and
+        # large inference passes.  Measured in situ on MI355X: forward 256 us per layer at M = 163840
+        # against 418 us for fc1 + fc2 + the next LayerNorm; backward 535-570 us against 379 us for dfc2 + dfc1 + LayerNorm
+        # backward; the step as a whole comes out 1-2 % ahead with 1.4 GB less HBM traffic per layer.  Passes with fewer
+        # rows than one 128-row tile per CU (the decode frame pass) keep the two GEMM launches.
         self.fused_mlp = float(getattr(cfg, "mlp_drop", 0.0) or 0.0) == 0.0 and hid == 1024
-        self.fused_mlp_train = False
+        self.fused_mlp_train = self.fused_mlp
         self.fused_mlp_min_rows = 128 * 256
         if self.fused_mlp:
             self.MP = {k: mk(L, 512 * 512) for k in ("w1p", "w2p", "w2tp", "w1tp")}
@@ -277,10 +276,10 @@ class STEngine:
         """Whether a pass over `rows` token rows runs the fused MLP block (see __init__)."""
         if not self.fused_mlp:
             return False
-        return self.fused_mlp_train if train else rows >= self.fused_mlp_min_rows
+        return rows >= self.fused_mlp_min_rows and (self.fused_mlp_train or not train)
 
     def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
-        key = (B, T, S, A, train, self.fused_mlp_train)
+        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train))
         if self._ws_key == key:
             return self._ws
         self._ws, self._plans = {}, {}

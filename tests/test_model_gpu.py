@@ -62,16 +62,20 @@ def oracle_grads(tag):
     return loss.detach(), acc.detach(), logits.detach(), {k: p.grad for k, p in params.items()}
 
 
-@pytest.mark.parametrize("tag", ["domA", "domB", "noact", "domA+fused_mlp"])
+@pytest.mark.parametrize("tag", ["domA", "domB", "noact", "domA+fused_mlp", "domA+unfused_mlp"])
 def test_forward_backward_matches_reference(tag):
-    """`+fused_mlp`: the same check with training switched to the fused MLP block (hma_mlp_fwd / hma_mlp_bwd: hidden
-    activation on chip, pre-activation recomputed in backward, LayerNorm gradients from the wgrad reduction)."""
+    """`+fused_mlp` / `+unfused_mlp`: the same check with the MLP block forced onto the fused kernels (hma_mlp_fwd /
+    hma_mlp_bwd: hidden activation on chip, pre-activation recomputed in backward, LayerNorm gradients from the wgrad
+    reduction -- the default from one 128-row tile per CU upwards) or onto the GEMM pair (smaller passes)."""
     fused = tag.endswith("+fused_mlp")
+    unfused = tag.endswith("+unfused_mlp")
     tag = tag.split("+")[0]
     g = golden("g6_forward_backward")
     m = build_model()
-    if fused:
-        m._get_engine(torch.device(DEV, torch.cuda.current_device())).fused_mlp_train = True
+    if fused or unfused:
+        eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+        eng.fused_mlp_train = fused
+        eng.fused_mlp_min_rows = 0 if fused else 1 << 60
     inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
     kw = dict(input_ids=inp["input_ids"], labels=inp["labels"], h=[16, 16], w=[16, 16])
     if tag != "noact":
@@ -85,7 +89,7 @@ def test_forward_backward_matches_reference(tag):
     assert abs(out.loss.item() - loss_ref.item()) <= 3e-4 * loss_ref.item()
     assert out.acc.item() == g[f"{tag}.acc"].item()
     e = rel_err(out.logits, logits_ref)
-    nt = tag + ("+fused_mlp" if fused else "")
+    nt = tag + ("+fused_mlp" if fused else "+unfused_mlp" if unfused else "")
     _note(f"{nt}.loss_abs_err", abs(out.loss.item() - loss_ref.item()))
     _note(f"{nt}.logits_rel_err", e)
     assert e <= 2e-2
