@@ -1,0 +1,226 @@
+"""Full-depth parity on the GPU box: the BASELINE configurations' depth and frame count (L = 32, T = 16, 16 x 16 tokens,
++64 action tokens per frame), HIP engine against the pinned CPU oracle run on the box's host cores.
+
+The fixture tests (tests/test_model_gpu.py) use L = 2, T = 3; bf16 error grows with depth, so the north-star bounds are
+asserted here at the depth they are quoted for:
+  * loss within 1e-3 of the oracle, logits within 2 % of their range, parameter gradients of the first / middle / last
+    layer (and the embeddings / readout) within 3 % rms -- B = 1 per action domain, init-scale weights (N(0, 0.02), what
+    a training run starts from; reference init: hma/model/st_transformer.py:160-170, st_mask_git.py:78-113);
+  * B = 32 (configs[1]'s batch) property pass: finite outputs, and the batch loss equal to the masked-token-weighted
+    mean of the per-chunk losses (the loss is a masked mean, st_mask_git.py:620-627) within 1e-3;
+  * decode at configs[4] size (B = 64, 8 MaskGIT iterations per frame): the K/V-cached frame loop (`generate`) and the
+    full-window recomputation (`maskgit_generate`, what the reference does, st_mask_git.py:382,392) produce identical
+    token ids at L = 32.
+Reference lines: st_mask_git.py:688-735 (forward), :338-467 (maskgit_generate).
+"""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hma_amd.config import GenieConfig  # noqa: E402
+from hma_amd.model import STMaskGIT  # noqa: E402
+from oracle import st_maskgit_ref as R  # noqa: E402
+from oracle.param_spec import state_dict_spec  # noqa: E402
+from tests.helpers import rel_err, rms_err  # noqa: E402
+
+DEV = "cuda"
+FULL = dict(num_layers=32, num_heads=8, d_model=256, T=16, S=256, image_vocab_size=262144, use_mup=True,
+            action_network="concat+modulate", num_factored_vocabs=2, qkv_bias=False, proj_bias=True, attn_drop=0.0,
+            qk_norm=False, mlp_ratio=4.0, mlp_drop=0.0, mlp_bias=True)
+DOMAINS, D_ACTIONS = ["domA", "domB"], [7, 14]
+STATS = [[[0.05 * i for i in range(7)], [0.6 + 0.1 * i for i in range(7)]],
+         [[-0.1 * i for i in range(7)], [1.0 + 0.05 * i for i in range(7)]]]
+REPORT = {}
+
+
+def _note(key, val):
+    REPORT[key] = val
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_report_fulldepth.json", "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _ref_cfg():
+    return R.RefConfig(**{k: v for k, v in FULL.items() if k in R.RefConfig.__dataclass_fields__})
+
+
+def _state_dict():
+    """The reference's initialisation scheme with a fixed seed (what a training run starts from): decoder Linears and the
+    ModulateLayer xavier-uniform with gain 0.1 (st_transformer.py:160-170, st_mask_git.py:78-87), BasicMLP and the readout
+    gain 0.01 (:104-113, 778-782), nn.Embedding N(0, 1).  Where the reference starts from exact zeros / ones (biases,
+    LayerNorm affine, positional and mask embeddings) small random values are used instead so that an indexing error in
+    those tensors cannot hide."""
+    spec = state_dict_spec(_ref_cfg(), DOMAINS, D_ACTIONS, [7, 7])
+    g = torch.Generator().manual_seed(3)
+    sd = {}
+    for name in sorted(spec):
+        shape = spec[name]
+        if name.endswith(".mean") or name.endswith(".std"):
+            continue
+        if "factored_embeds" in name:
+            t = torch.randn(shape, generator=g)
+        elif name.endswith(".weight") and len(shape) == 2:
+            gain = 0.01 if (name.startswith("action_mlp") or name.startswith("out_x_proj") or name.startswith("action_out")) else 0.1
+            a = gain * math.sqrt(6.0 / (shape[0] + shape[1]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * a
+        elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("model.1.weight"):
+            t = 1.0 + 0.02 * torch.randn(shape, generator=g)
+        elif name in ("pos_embed_TSC", "token_embed.mask_token_embed", "action_mask_tokens"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        else:  # biases
+            t = 0.005 * torch.randn(shape, generator=g)
+        sd[name] = t.float()
+    for dom, st in zip(DOMAINS, STATS):
+        sd[f"action_preprocessor.{dom}.mean"] = torch.tensor(st[0], dtype=torch.float32)
+        sd[f"action_preprocessor.{dom}.std"] = torch.tensor(st[1], dtype=torch.float32)
+    return sd
+
+
+def _model(train=True, readout_gain=1.0):
+    cfg = GenieConfig(**FULL)
+    m = STMaskGIT(cfg)
+    m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, cfg.action_network)
+    sd = _state_dict()
+    sd["out_x_proj.weight"] = sd["out_x_proj.weight"] * readout_gain
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    m.train(train)
+    return m
+
+
+def _inputs(B, seed, d_a):
+    T = FULL["T"]
+    g = torch.Generator().manual_seed(seed)
+    labels = torch.randint(0, 8192, (B, T, 256), generator=g)
+    labels[:, :, :4] = torch.randint(0, 262144, (B, T, 4), generator=g)
+    u = torch.rand(B, T - 1, 1, generator=g)
+    m = torch.rand(B, T - 1, 256, generator=g) < torch.cos(u * math.pi / 2)
+    ids = labels.clone()
+    ids[:, 1:][m] = FULL["image_vocab_size"]
+    return ids.reshape(B, -1), labels.reshape(B, -1), torch.randn(B, T, d_a, generator=g)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dom", ["domA", "domB"])
+def test_full_depth_forward_backward_vs_oracle(dom):
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 128)))
+    d_a = D_ACTIONS[DOMAINS.index(dom)]
+    ids, labels, act = _inputs(1, 21 + d_a, d_a)
+    # ---- oracle (fp32, CPU)
+    cfg = _ref_cfg()
+    sd = _state_dict()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(leaf)
+    loss_ref, acc_ref, logits_ref = R.forward(full, cfg, ids, labels, act, [dom])
+    loss_ref.backward()
+    # ---- HIP (domB: with the MLP block forced onto the fused kernels, which a B = 1 pass is otherwise too small for)
+    m = _model()
+    if dom == "domB":
+        m._get_engine(torch.device(DEV, torch.cuda.current_device())).fused_mlp_min_rows = 0
+    out = m(input_ids=ids.to(DEV), labels=labels.to(DEV), action_ids=act.to(DEV), domain=[dom])
+    dl = abs(out.loss.item() - loss_ref.item())
+    el = rel_err(out.logits, logits_ref.detach())
+    _note(f"{dom}.loss_abs_err", dl)
+    _note(f"{dom}.loss_ref", loss_ref.item())
+    _note(f"{dom}.logits_rel_err", el)
+    assert dl <= 1e-3, (out.loss.item(), loss_ref.item())
+    assert el <= 2e-2, el
+    assert abs(out.acc.item() - acc_ref.item()) <= 2e-3  # (one near-tie argmax in 3840 masked tokens = 2.6e-4)
+    out.loss.backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    picks = ["token_embed.factored_embeds.0.weight", "pos_embed_TSC", "out_x_proj.weight", "out_x_proj.bias",
+             f"action_mlp.{dom}.model.3.weight"]
+    for l in (0, 15, 31):
+        p = f"decoder.layers.{l}."
+        picks += [p + "norm1.weight", p + "spatial_attn.qkv.weight", p + "spatial_attn.proj.weight", p + "temporal_attn.qkv.weight",
+                  p + "temporal_attn.proj.bias", p + "norm2.weight", p + "norm2.bias", p + "mlp.fc1.weight", p + "mlp.fc1.bias",
+                  p + "mlp.fc2.weight", p + f"action_projectors.{dom}.linear_out.weight",
+                  p + f"action_projectors.{dom}.adaLN_modulation.2.weight"]
+    for name in picks:
+        g_ref = leaf[name].grad
+        g_hip = named[name].grad
+        assert g_hip is not None and g_ref is not None, name
+        e = rms_err(g_hip, g_ref)
+        worst = max(worst, e)
+        _note(f"{dom}.grad_rms.{name}", e)
+        assert e <= 3e-2, f"{name}: rms rel err {e:.3e}"
+    _note(f"{dom}.worst_grad_rms", worst)
+
+
+@pytest.mark.timeout(600)
+def test_full_size_batch_properties():
+    """configs[1] batch (B = 32): finite, and the masked-mean loss decomposes over batch chunks."""
+    m = _model(train=False)
+    ids, labels, act = _inputs(32, 5, 7)
+    dev = lambda t: t.to(DEV)
+    with torch.no_grad():
+        out = m(input_ids=dev(ids), labels=dev(labels), action_ids=dev(act), domain=["domA"] * 32)
+        assert torch.isfinite(out.loss) and torch.isfinite(out.logits).all()
+        num, den = 0.0, 0.0
+        for c in range(0, 32, 8):
+            sl = slice(c, c + 8)
+            oc = m(input_ids=dev(ids[sl]), labels=dev(labels[sl]), action_ids=dev(act[sl]), domain=["domA"] * 8)
+            n = float((ids[sl].reshape(8, 16, 256)[:, 1:] == FULL["image_vocab_size"]).sum())
+            num += oc.loss.item() * n
+            den += n
+    err = abs(out.loss.item() - num / den)
+    _note("b32.loss_vs_chunked", err)
+    assert err <= 1e-3, (out.loss.item(), num / den)
+
+
+@pytest.mark.timeout(900)
+def test_decode_cached_vs_full_window_at_full_depth():
+    """configs[4] size: B = 64, 8 MaskGIT iterations; exact frame-causal K/V cache vs the reference's full-window passes.
+
+    The two paths are the same mathematics through different kernels (temporal attention over the cache vs over the
+    window, 20 480-row vs 327 680-row launches): different fp32 summation orders, and every bf16 rounding of an
+    intermediate can fall on the other side for a value that differs in its last fp32 bit.  So the logits agree to bf16
+    noise, not bitwise, and the rule asserted is the one SURVEY.md section 7 states for bf16 decode: a token id may differ
+    only where the top-2 margin of its factor is below the logits tolerance.  (At initialisation the readout, gain 0.01,
+    makes every logit a near-tie; it is scaled to a trained model's logit range first.)"""
+    m = _model(train=False, readout_gain=300.0)
+    cfg = m.config
+    B, T0, new = 64, 4, 2
+    g = torch.Generator().manual_seed(9)
+    prompt = torch.randint(0, 8192, (B, T0 * 256), generator=g).to(DEV)
+    act = torch.randn(B, FULL["T"], 7, generator=g).to(DEV)
+    with torch.no_grad():
+        # ---- one frame pass, both ways, on the same tokens: frame T0 fully masked behind the prompt
+        win = torch.full((B, FULL["T"], 16, 16), FULL["image_vocab_size"], dtype=torch.long, device=DEV)
+        win[:, :T0] = prompt.reshape(B, T0, 16, 16)
+        logits_full, _ = m.compute_logits(win, action_ids=act, domain=["domA"] * B)                 # (B, 1024, T, 16, 16)
+        lf = logits_full[:, :, T0].permute(0, 2, 3, 1).reshape(B * 256, 2, 512).float()
+        eng = m._engine
+        eng.decode_prefill(prompt.reshape(B, T0, 256).contiguous(), act.float(), "domA", FULL["T"])
+        lc = eng.decode_frame(win[:, T0].reshape(B, 256).contiguous(), act[:, T0].float(), "domA", T0, FULL["T"])
+        lc = lc.reshape(B * 256, 2, 512).float().clone()
+        scale = lf.abs().max().item()
+        diff = (lf - lc).abs().max().item()
+        _note("decode.frame_logits_max_abs_diff", diff)
+        _note("decode.frame_logits_scale", scale)
+        assert diff <= 5e-3 * scale, (diff, scale)
+        top2 = lf.topk(2, dim=-1).values
+        margin = top2[..., 0] - top2[..., 1]                         # per token and factor
+        flips = lf.argmax(-1) != lc.argmax(-1)
+        _note("decode.frame_argmax_flips", int(flips.sum().item()))
+        assert not (flips & (margin > 2.0 * diff)).any(), "an id differs where the reference margin exceeds the logits tolerance"
+        # ---- the 8-iteration rollout (flips compound: a changed token changes the sample's later iterations)
+        kw = dict(max_new_tokens=new * 256, maskgit_steps=8, temperature=0.0, action_ids=act, domain=["domA"] * B, h=[16] * B,
+                  w=[16] * B, unmask_mode="greedy")
+        full = m.generate(prompt, None, use_cache=False, **kw)
+        cached = m.generate(prompt, None, use_cache=True, **kw)
+    assert full.shape == cached.shape == (B, (T0 + new) * 256)
+    assert (cached != FULL["image_vocab_size"]).all()
+    same = (full[:, T0 * 256:] == cached[:, T0 * 256:]).float().mean().item()
+    _note("decode.cached_vs_window_agreement_8it", same)
+    assert same >= 0.98, same
