@@ -209,6 +209,19 @@ constexpr int MF_SMEM = MF_STG + 4 * 8192;   // 160768 B
 // 16 lanes with 16 different rows) and "8 lanes per row" (the 1 KB, 8-row pieces of coalesced global traffic).
 __device__ __forceinline__ int stg_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
+// two consecutive LDS-DMA pieces (2 KB) behind one M0 set-up
+__device__ __forceinline__ void glds16x2(const void* src, uint32_t dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(dst)
+      : "memory");
+}
+
 template <bool LNOUT>
 __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -307,7 +320,17 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
       // residual block for the consumer's hidden block g - 1 when that is a multiple of 4 (added two steps later); issued
       // BEFORE the bundle so that it is older than the bundle whose arrival the consumer's step g + 2 waits for
       if (g >= 1 && g <= nsteps && ((g - 1) & 3) == 0) issue_x((g - 1) >> 5, ((g - 1) & 31) >> 2);
+#ifdef MLP_DMA_INTERLEAVE
+      // (the bundle's 8 pieces are issued between the MFMA groups below: a piece costs 60-150 cycles of issue time, which
+      // an in-order wave otherwise spends before its first MFMA)
+      const bool do_issue = g + MF_AHEAD <= nsteps && !(MLP_ABL & 1);
+      const int bi = g + MF_AHEAD;
+      const uint32_t ibase = lds_b + (bi % MF_NSLOT) * MF_SLOT + pair * 4096;
+      const char* isrc1 = w1g + ((bi + rot) & 31) * 16384;
+      const char* isrc2 = w2g + ((bi + rot + 31) & 31) * 16384;
+#else
       if (g + MF_AHEAD <= nsteps) issue(g + MF_AHEAD);
+#endif
       MPROF_MARK(2);
       if (g < nsteps) {
         const int s = g & 31;
@@ -340,6 +363,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fwd_kernel(hma_mlp_fwd_t p) {
             }
             U0 = mfma32a(fa[0], xh[4 * grp + 0], U0);
             U1 = mfma32a(fa[1], xh[4 * grp + 1], U1);
+#ifdef MLP_DMA_INTERLEAVE
+            if (do_issue) {
+              if (grp < 2) glds16x2(isrc1 + grp * 2048, ibase + grp * 2048);
+              else glds16x2(isrc2 + (grp - 2) * 2048, ibase + 16384 + (grp - 2) * 2048);
+            }
+#endif
             U0 = mfma32a(fa[2], xh[4 * grp + 2], U0);
             U1 = mfma32a(fa[3], xh[4 * grp + 3], U1);
             __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting every fragment read (it spills)
@@ -567,6 +596,12 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
     HMA_LDS(float)* b1s = (HMA_LDS(float)*)(lds + MB_B1);
     for (int i = tid; i < 1024; i += 512) b1s[i] = p.b1[i];
   }
+#ifdef MLP_STAGGER
+  {
+    const int nsl = (((int)blockIdx.x * 37) & 255) * MLP_STAGGER / 256;
+    for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   __syncthreads();
 
   auto tile_row0 = [&](int tl) __attribute__((always_inline)) {
