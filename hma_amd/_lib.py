@@ -89,9 +89,13 @@ _PROTOS = {
     "hma_count_masked": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64],
     "hma_ce_fwd_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_i32, c_i64, c_f32],
     "hma_maskgit_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32],
+    "hma_maskgit_step_sampled": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32,
+                                 c_i32],
     "hma_attn_temporal_cached": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32],
     "hma_sqnorm": [c_vp, c_vp, c_i64, c_vp],
     "hma_adamw": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_f32, c_vp],
+    "hma_adamw_counted": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_i32, c_vp, c_f32,
+                          c_vp],
     "hma_cast_bf16": [c_vp, c_vp, c_vp, c_i64],
     "hma_diff_prepare": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
     "hma_silu_cast": [c_vp, c_vp, c_vp, c_i64],

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 __global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ logits, int64_t* __restrict__ prompt,
                                                       uint8_t* __restrict__ unmasked, const float* __restrict__ conf_override,
                                                       float* __restrict__ conf_out, int T, int S, int out_t, int n_mask, int last,
-                                                      int64_t mask_id, int logits_T, int logits_t) {
+                                                      int64_t mask_id, int logits_T, int logits_t,
+                                                      const float* __restrict__ sample_noise) {
   extern __shared__ float sm[];              // conf[S] | sample[S] (as int)
   float* conf = sm;
   int* samp = reinterpret_cast<int*>(sm + S);
@@ -146,8 +147,33 @@ __global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ 
       float x[8];
       load8(lg + (int64_t)s * C + f * V + lane * 8, x);
       const FactorStats st = factor_stats(x, lane, -1);
-      sample = sample * V + st.arg;
-      c *= 1.0f / st.sumexp;  // softmax prob of the arg-max = exp(0) / sum exp(x - max)
+      if (!sample_noise) {  // greedy (temperature <= 1e-8, :409-410)
+        sample = sample * V + st.arg;
+        c *= 1.0f / st.sumexp;  // softmax prob of the arg-max = exp(0) / sum exp(x - max)
+      } else {
+        // Categorical(probs).sample() (:411-416; the temperature cancels in the normalisation): torch.multinomial draws ONE
+        // sample as argmax_k p_k / q_k with q ~ Exp(1) -- q is the injected draw, so a run is replayable bit for bit.
+        float q[8];
+        load8(sample_noise + ((b * (int64_t)S + s) * 2 + f) * V + lane * 8, q);
+        const float inv = 1.0f / st.sumexp;
+        float best = -1.f, pbest = 0.f;
+        int a = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pj = __expf(x[j] - st.m) * inv;
+          const float r = pj / q[j];
+          if (r > best) { best = r; a = j; pbest = pj; }
+        }
+        a += lane * 8;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ob = __shfl_xor(best, o, 64), op = __shfl_xor(pbest, o, 64);
+          const int oa = __shfl_xor(a, o, 64);
+          if (ob > best || (ob == best && oa < a)) { best = ob; a = oa; pbest = op; }
+        }
+        sample = sample * V + a;
+        c *= pbest;  // torch.gather(probs, 1, sample) (:420)
+      }
     }
     if (lane == 0) {
       conf[s] = c;
@@ -215,10 +241,9 @@ extern "C" int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* 
   return 0;
 }
 
-extern "C" int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
-                                const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
-                                int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id, int32_t logits_T,
-                                int32_t logits_t) {
+static int maskgit_launch(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked, const float* conf_override,
+                          float* conf_out, int64_t B, int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last,
+                          int64_t mask_id, int32_t logits_T, int32_t logits_t, const float* sample_noise) {
   if (!logits || !prompt || !unmasked) return HMA_EINVAL;
   if (S > 256 || out_t < 0 || out_t >= T) return HMA_EINVAL;  // one pass of 256 threads covers the frame
   if (logits_T <= 0) { logits_T = T; logits_t = out_t; }
@@ -227,7 +252,24 @@ extern "C" int hma_maskgit_step(void* stream, const float* logits, int64_t* prom
   const size_t smem = (size_t)S * 8;
   hipLaunchKernelGGL(maskgit_kernel, dim3((unsigned)B), dim3(256), smem, (hipStream_t)stream, logits, prompt, unmasked,
                      conf_override, conf_out, (int)T, (int)S, (int)out_t, (int)n_mask, (int)last, mask_id, (int)logits_T,
-                     (int)logits_t);
+                     (int)logits_t, sample_noise);
   HMA_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                                const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
+                                int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id, int32_t logits_T,
+                                int32_t logits_t) {
+  return maskgit_launch(stream, logits, prompt, unmasked, conf_override, conf_out, B, T, S, out_t, n_mask, last, mask_id, logits_T,
+                        logits_t, nullptr);
+}
+
+extern "C" int hma_maskgit_step_sampled(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                                        const float* conf_override, float* conf_out, const float* sample_noise, int64_t B,
+                                        int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id,
+                                        int32_t logits_T, int32_t logits_t) {
+  if (!sample_noise) return HMA_EINVAL;
+  return maskgit_launch(stream, logits, prompt, unmasked, conf_override, conf_out, B, T, S, out_t, n_mask, last, mask_id, logits_T,
+                        logits_t, sample_noise);
 }

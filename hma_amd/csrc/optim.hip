@@ -33,12 +33,27 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, uint16_t* __restrict__ pb, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, float inv_bc1,
                                                     float inv_sqrt_bc2, const float* __restrict__ sqnorm, float max_norm,
-                                                    const uint8_t* __restrict__ flags) {
+                                                    const uint8_t* __restrict__ flags, int32_t* __restrict__ step_pair, int parity) {
   float coef = 1.f;
-  if (sqnorm && max_norm > 0.f) {
-    const float c = max_norm / (sqrtf(*sqnorm) + 1e-6f);
-    coef = c < 1.f ? c : 1.f;
+  bool finite = true;
+  if (sqnorm) {
+    const float sq = *sqnorm;
+    finite = sq == sq && sq < INFINITY;  // a NaN / Inf anywhere in the (already all-reduced) gradients lands here on every rank
+    if (max_norm > 0.f) {
+      const float c = max_norm / (sqrtf(sq) + 1e-6f);
+      coef = c < 1.f ? c : 1.f;
+    }
   }
+  if (step_pair) {
+    // Device-side update count of this range: read slot `parity`, publish to the other slot (no launch reads the slot
+    // another block of the same launch writes).  A skipped step does not count, so Adam's bias correction stays that
+    // of the updates actually applied.
+    const int step = step_pair[parity] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) step_pair[parity ^ 1] = finite ? step : step - 1;
+    inv_bc1 = 1.0f / (1.0f - powf(b1, (float)step));
+    inv_sqrt_bc2 = 1.0f / sqrtf(1.0f - powf(b2, (float)step));
+  }
+  if (!finite) return;  // non-finite loss / gradients: leave weights and moments untouched (train_multi.py:572-583)
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     float wdi = wd;
@@ -114,17 +129,33 @@ extern "C" int hma_sqnorm(void* stream, const float* g, int64_t n, float* out) {
   return 0;
 }
 
+static int adamw_launch(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int32_t step, const float* sqnorm,
+                        float max_norm, const uint8_t* flags, int32_t* step_pair, int32_t parity) {
+  if (!p || !g || !m || !v || (step < 1 && !step_pair) || (step_pair && (parity < 0 || parity > 1))) return HMA_EINVAL;
+  if (n <= 0) return 0;
+  const double st = step_pair ? 1.0 : (double)step;
+  const double bc1 = 1.0 - std::pow((double)beta1, st);
+  const double bc2 = 1.0 - std::pow((double)beta2, st);
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (uint16_t*)p_bf16, n, lr,
+                     beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / std::sqrt(bc2)), sqnorm, max_norm, flags,
+                     step_pair, (int)parity);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int hma_adamw(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int32_t step, const float* sqnorm,
                          float max_norm, const uint8_t* flags) {
-  if (!p || !g || !m || !v || step < 1) return HMA_EINVAL;
-  if (n <= 0) return 0;
-  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (uint16_t*)p_bf16, n, lr,
-                     beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / std::sqrt(bc2)), sqnorm, max_norm, flags);
-  HMA_CHECK_LAUNCH();
-  return 0;
+  return adamw_launch(stream, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, sqnorm, max_norm, flags, nullptr, 0);
+}
+
+extern "C" int hma_adamw_counted(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int32_t* step_pair, int32_t parity,
+                                 const float* sqnorm, float max_norm, const uint8_t* flags) {
+  if (!step_pair) return HMA_EINVAL;
+  return adamw_launch(stream, p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, 0, sqnorm, max_norm, flags, step_pair,
+                      parity);
 }
 
 extern "C" int hma_cast_bf16(void* stream, const float* src, void* dst, int64_t n) {

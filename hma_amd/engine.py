@@ -146,10 +146,13 @@ class STEngine:
         self.V: Optional[torch.Tensor] = None
         self.flags = self.layout.decay_flags().to(self.device)
         self.sqnorm = torch.zeros(1, dtype=F32, device=self.device)
-        self.opt_step = 0
+        # Update counts per flat range (0 = dense, 1 + i = action domain i) live ON THE DEVICE (hma_adamw_counted): a step whose
+        # all-reduced gradient norm is not finite is skipped identically on every rank and does not count, without a host sync.
+        # Slot [r, calls & 1] is current after `calls` launches on range r.
+        self.steps_dev = torch.zeros(1 + len(self.domains), 2, dtype=torch.int32, device=self.device)
+        self._step_calls = [0] * (1 + len(self.domains))
         self.drop_seed = torch.zeros(1, dtype=torch.int32, device=self.device)  # bumped per training forward (dropout masks)
         self._drop_counter = 0
-        self.dom_steps: Dict[str, int] = {}  # per-domain Adam step counts (a head is only stepped when its domain had a gradient)
         L, d = cfg.num_layers, cfg.d_model
         hid = int(d * cfg.mlp_ratio)
         mk = lambda *s: torch.zeros(*s, dtype=BF16, device=self.device)
@@ -203,6 +206,29 @@ class STEngine:
         if idx not in Plan._tn_workspaces:
             Plan._tn_workspaces[idx] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))  # 64 MB + bias partials
         Plan.tn_workspace = Plan._tn_workspaces[idx]
+
+    # ------------------------------------------------------------------------------ Adam update counts (device-resident)
+    def _steps_now(self) -> List[int]:
+        vals = self.steps_dev.cpu()
+        return [int(vals[i, self._step_calls[i] & 1]) for i in range(len(self._step_calls))]
+
+    @property
+    def opt_step(self) -> int:
+        """Updates applied to the dense range (reads the device counter: synchronises)."""
+        return self._steps_now()[0]
+
+    @property
+    def dom_steps(self) -> Dict[str, int]:
+        """Updates applied to each action domain's block (a head is only stepped when its domain had a gradient on some rank)."""
+        cur = self._steps_now()
+        return {d: cur[1 + i] for i, d in enumerate(self.domains) if cur[1 + i] > 0}
+
+    def set_steps(self, opt_step: int, dom_steps: Dict[str, int]) -> None:
+        vals = self.steps_dev.cpu()
+        vals[0, self._step_calls[0] & 1] = int(opt_step)
+        for i, d in enumerate(self.domains):
+            vals[1 + i, self._step_calls[1 + i] & 1] = int(dom_steps.get(d, 0))
+        self.steps_dev.copy_(vals)
 
     # ------------------------------------------------------------------------------ pointers
     def _p(self, name: str) -> int:
@@ -726,15 +752,23 @@ class STEngine:
 
     def maskgit_step(self, prompt_BTS: torch.Tensor, unmasked: torch.Tensor, out_t: int, n_mask: int, last: bool,
                      conf_override: Optional[torch.Tensor] = None, conf_out: Optional[torch.Tensor] = None,
-                     logits_T: int = 0, logits_t: int = 0, logits: Optional[torch.Tensor] = None) -> None:
-        """One sampling step on the logits of the last forward (st_mask_git.py:397-453); updates in place."""
+                     logits_T: int = 0, logits_t: int = 0, logits: Optional[torch.Tensor] = None,
+                     sample_noise: Optional[torch.Tensor] = None) -> None:
+        """One sampling step on the logits of the last forward (st_mask_git.py:397-453); updates in place.  `sample_noise`
+        (f32 [B, S, 2, 512], Exp(1) draws) selects the categorical branch (:411-416)."""
         B, T, S = prompt_BTS.shape
         assert prompt_BTS.is_contiguous() and prompt_BTS.dtype == torch.int64 and unmasked.dtype == torch.uint8
         stream = torch.cuda.current_stream().cuda_stream
         lg = self._ws["logits"] if logits is None else logits
-        _lib.call("hma_maskgit_step", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(),
-                  None if conf_override is None else conf_override.data_ptr(), None if conf_out is None else conf_out.data_ptr(),
-                  B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
+        co = None if conf_override is None else conf_override.data_ptr()
+        cout = None if conf_out is None else conf_out.data_ptr()
+        if sample_noise is None:
+            _lib.call("hma_maskgit_step", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co, cout,
+                      B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
+        else:
+            assert sample_noise.is_contiguous() and sample_noise.dtype == F32 and sample_noise.numel() == B * S * 1024
+            _lib.call("hma_maskgit_step_sampled", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co, cout,
+                      sample_noise.data_ptr(), B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
 
     # ------------------------------------------------------------------------------ incremental decode
     # Frame t of the trunk depends on frames <= t only (spatial attention, modulation, MLP, positions and the
@@ -931,26 +965,23 @@ class STEngine:
         ranges = self.layout.trainable_ranges(active_domains)
         # Adam's bias correction uses the number of updates EACH parameter has received (torch.optim.AdamW keeps
         # `state["step"]` per parameter and skips parameters whose grad is None): the dense range is stepped every
-        # time, a domain's block only when that domain was active on some rank.
-        self.opt_step += 1
-        steps = [self.opt_step]
-        for dom in self.layout.domains:
-            if dom in active_domains:
-                self.dom_steps[dom] = self.dom_steps.get(dom, 0) + 1
-                steps.append(self.dom_steps[dom])
-        assert len(steps) == len(ranges)
-        sq = None
-        if max_norm is not None and max_norm > 0:
-            self.sqnorm.zero_()
-            for a, b in ranges:
-                _lib.call("hma_sqnorm", stream, self.G.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr())
-            for g in extra_grads:  # gradients held outside the flat buffer (STMAR's head) count towards the global norm
-                _lib.call("hma_sqnorm", stream, g.data_ptr(), g.numel(), self.sqnorm.data_ptr())
-            sq = self.sqnorm.data_ptr()
-        for (a, b), step in zip(ranges, steps):
-            _lib.call("hma_adamw", stream, self.P.data_ptr() + 4 * a, self.G.data_ptr() + 4 * a, self.M.data_ptr() + 4 * a,
+        # time, a domain's block only when that domain was active on some rank.  The counts live on the device.
+        idxs = [0] + [1 + i for i, dom in enumerate(self.layout.domains) if dom in active_domains]
+        assert len(idxs) == len(ranges)
+        # The square norm is always taken: besides the clip coefficient it carries the non-finite check (a NaN / Inf loss on
+        # any rank makes the all-reduced gradients, hence this norm, non-finite on every rank -> every rank skips the update).
+        self.sqnorm.zero_()
+        for a, b in ranges:
+            _lib.call("hma_sqnorm", stream, self.G.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr())
+        for g in extra_grads:  # gradients held outside the flat buffer (STMAR's own range) count towards the global norm
+            _lib.call("hma_sqnorm", stream, g.data_ptr(), g.numel(), self.sqnorm.data_ptr())
+        sq = self.sqnorm.data_ptr()
+        for (a, b), ri in zip(ranges, idxs):
+            _lib.call("hma_adamw_counted", stream, self.P.data_ptr() + 4 * a, self.G.data_ptr() + 4 * a, self.M.data_ptr() + 4 * a,
                       self.V.data_ptr() + 4 * a, self.Wb.data_ptr() + 2 * a, b - a, lr, betas[0], betas[1], eps, weight_decay,
-                      step, sq, float(max_norm or 0.0), self.flags.data_ptr() + a // ALIGN)
+                      self.steps_dev.data_ptr() + 8 * ri, self._step_calls[ri] & 1, sq, float(max_norm or 0.0),
+                      self.flags.data_ptr() + a // ALIGN)
+            self._step_calls[ri] += 1
         # bf16 copies were emitted by the update itself; only the transposed copies are stale
         self._wt_ok = False
         self._dom_fresh = set()

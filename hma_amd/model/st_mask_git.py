@@ -350,15 +350,17 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         assert out_t, "maskgit_generate requires out_t > 0"
         assert torch.all(prompt_THW[:, out_t:] == self.mask_token_id), \
             f"when generating z{out_t}, frames {out_t} and later must be masked"
-        if temperature > 1e-8:
-            raise NotImplementedError("categorical sampling (temperature > 0) is not built; the reference's temperature "
-                                      "only toggles argmax vs sampling (st_mask_git.py:409-416)")
         if unmask_mode not in ("greedy", "random"):
             raise NotImplementedError(f"Expected `unmask_mode` to be one of ['greedy', 'random'], got {unmask_mode}")
         bs, t, h, w = prompt_THW.shape
         S = h * w
         cfg = self.config
         rand_draws = kwargs.pop("rand_draws", None)  # replay hook for tests: one (B, H, W) draw per step
+        # Categorical branch (temperature > 1e-8, :411-416; the temperature cancels inside Categorical's normalisation, so it
+        # only toggles argmax vs sampling).  torch.multinomial draws its single sample as argmax_k p_k / q_k, q ~ Exp(1):
+        # `sample_draws` replays those q, one (B, H*W, num_factored_vocabs, vocab) tensor per step; otherwise they are drawn here.
+        sample_draws = kwargs.pop("sample_draws", None)
+        sampled = temperature > 1e-8
         work = prompt_THW.reshape(bs, t, S).contiguous()
         unmasked = torch.zeros(bs, S, dtype=torch.uint8, device=prompt_THW.device)
         first = None
@@ -374,7 +376,12 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
                     override = rand_draws[step].reshape(bs, S).contiguous().float()
                 else:
                     override = torch.rand(bs, h, w, device=prompt_THW.device).reshape(bs, S).contiguous()  # torch.rand_like, :435
-            eng.maskgit_step(work, unmasked, out_t, n, last, override)
+            noise = None
+            if sampled:
+                noise = (sample_draws[step].to(prompt_THW.device, torch.float32).reshape(bs, S, 2, 512).contiguous()
+                         if sample_draws is not None else
+                         torch.empty(bs, S, 2, 512, device=prompt_THW.device, dtype=torch.float32).exponential_())
+            eng.maskgit_step(work, unmasked, out_t, n, last, override, sample_noise=noise)
         prompt_THW.copy_(work.view(bs, t, h, w))
         samples_HW = work[:, out_t].view(bs, h, w).clone()
         V, NV = cfg.factored_vocab_size, cfg.num_factored_vocabs
@@ -386,10 +393,12 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         """`generate` with a per-layer temporal K/V cache: exactly the reference's arithmetic per frame (frame t's
         logits depend on frames <= t only), but each MaskGIT iteration moves the 320 rows of ONE frame through the
         trunk instead of the whole window; one extra pass per finished frame stores its final K/V."""
-        if temperature > 1e-8:
-            raise NotImplementedError("categorical sampling (temperature > 0) is not built")
         unmask_mode = kwargs.pop("unmask_mode", "random")
         rand_draws = kwargs.pop("rand_draws", None)
+        sample_draws = kwargs.pop("sample_draws", None)  # (see maskgit_generate) one tensor per MaskGIT step of the rollout
+        sampled = temperature > 1e-8
+        sdraw = 0
+        step_hook = kwargs.pop("step_hook", None)  # tests: called before each sampling step with (t, step, window ids, frame logits)
         skip_norm = bool(kwargs.get("skip_normalization", False))
         S = h * w
         B = input_ids.size(0)
@@ -409,6 +418,10 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
             a_t = None if acts is None else acts[:, t]
             for step in range(maskgit_steps):
                 logits = eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total)
+                if step_hook is not None:
+                    win = out.clone()
+                    win[:, t] = frame[:, 0]
+                    step_hook(t, step, win, logits)
                 last = step == maskgit_steps - 1
                 n = 0 if last else math.ceil(cosine_schedule((step + 1) / maskgit_steps) * S)
                 override = None
@@ -418,7 +431,14 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
                         draw += 1
                     else:
                         override = torch.rand(B, h, w, device=dev).reshape(B, S).contiguous()
-                eng.maskgit_step(frame, unmasked, 0, n, last, override, logits_T=1, logits_t=0, logits=logits)
+                noise = None
+                if sampled:
+                    if sample_draws is not None:
+                        noise = sample_draws[sdraw].to(dev, torch.float32).reshape(B, S, 2, 512).contiguous()
+                        sdraw += 1
+                    else:
+                        noise = torch.empty(B, S, 2, 512, device=dev, dtype=torch.float32).exponential_()
+                eng.maskgit_step(frame, unmasked, 0, n, last, override, logits_T=1, logits_t=0, logits=logits, sample_noise=noise)
             out[:, t] = frame[:, 0]
             if t + 1 < T_total:  # store the finished frame's K/V (its tokens changed after the last pass)
                 eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total, readout=False)

@@ -279,8 +279,7 @@ class Trainer:
                         eng.M[e.offset:e.offset + e.numel].copy_(f.get_tensor(f"m.{name}"))
                         eng.V[e.offset:e.offset + e.numel].copy_(f.get_tensor(f"v.{name}"))
         self.completed = int(meta["completed"])
-        eng.opt_step = int(meta["opt_step"])
-        eng.dom_steps = {k: int(v) for k, v in json.loads(meta["dom_steps"]).items()}
+        eng.set_steps(int(meta["opt_step"]), {k: int(v) for k, v in json.loads(meta["dom_steps"]).items()})
 
     def loss_and_acc(self, ws) -> Tuple[torch.Tensor, torch.Tensor]:
         st = ws["stats"]

@@ -190,18 +190,36 @@ int hma_maskgit_step(void* stream, const float* logits, int64_t* prompt, uint8_t
                      const float* conf_override, float* conf_out, int64_t B, int32_t T, int32_t S,
                      int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id, int32_t logits_T,
                      int32_t logits_t);
+/* The same step with categorical sampling (temperature > 1e-8, st_mask_git.py:411-416:
+ * Categorical(probs = softmax / temperature).sample(); the temperature cancels in Categorical's normalisation).
+ * sample_noise f32 [B, S, 2, 512] holds the Exp(1) draws q of torch.multinomial's single-sample path
+ * (sample = argmax_k p_k / q_k) for factor v at [.., v, :]; injecting them makes a run replayable.  The confidence of a
+ * token is the product of the sampled entries' probabilities (:420). */
+int hma_maskgit_step_sampled(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                             const float* conf_override, float* conf_out, const float* sample_noise,
+                             int64_t B, int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last,
+                             int64_t mask_id, int32_t logits_T, int32_t logits_t);
 
 /* sum of squares of g[0:n) accumulated into *out (fp32 atomic; zero it first) -- clip_grad_norm_,
  * train_multi.py:594 */
 int hma_sqnorm(void* stream, const float* g, int64_t n, float* out);
 /* AdamW on a flat range with the clip coefficient min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) read
  * on device (sqnorm NULL or max_norm <= 0: no clip); also emits the bf16 copy of the new weights.
+ * A non-finite *sqnorm skips the update (weights, moments untouched).
  * torch.optim.AdamW semantics (decoupled decay, bias correction), train_multi.py:900-922.
  * flags (may be NULL) holds one byte per 64 elements of the range (which must start on a multiple
  * of 64): 0 = frozen, 1 = update without weight decay ("bias" parameters, :907-918), 2 = decay. */
 int hma_adamw(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
               float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
               const float* sqnorm, float max_norm, const uint8_t* flags);
+/* The same update with the range's update count kept ON THE DEVICE: step_pair[parity] holds the number of updates the
+ * range has received, the launch uses step = that + 1 and writes the new count to step_pair[parity ^ 1] (the caller
+ * alternates `parity` per call on a range).  When *sqnorm is not finite -- a NaN / Inf loss on ANY rank reaches every
+ * rank's norm through the gradient all-reduce -- nothing is written and the count does not advance: the
+ * all-rank-consistent form of the reference's non-finite-loss skip (train_multi.py:572-583), with no host sync. */
+int hma_adamw_counted(void* stream, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int32_t* step_pair,
+                      int32_t parity, const float* sqnorm, float max_norm, const uint8_t* flags);
 /* dst(bf16) = src(f32) for n elements */
 int hma_cast_bf16(void* stream, const float* src, void* dst, int64_t n);
 

@@ -248,16 +248,19 @@ def forward(sd: SD, cfg: RefConfig, input_ids: torch.Tensor, labels: torch.Tenso
 @torch.no_grad()
 def maskgit_generate(sd: SD, cfg: RefConfig, prompt_THW: torch.Tensor, out_t: int, maskgit_steps: int = 1,
                      temperature: float = 0.0, unmask_mode: str = "random", action_ids=None, domain=None,
-                     rand_draws: Optional[List[torch.Tensor]] = None):
-    """STMaskGIT.maskgit_generate, hma/model/st_mask_git.py:338-467 (temperature <= 1e-8 path).
+                     rand_draws: Optional[List[torch.Tensor]] = None, sample_draws: Optional[List[torch.Tensor]] = None,
+                     trace: Optional[list] = None):
+    """STMaskGIT.maskgit_generate, hma/model/st_mask_git.py:338-467.
 
     `rand_draws[step]` (B, H, W) replaces `torch.rand_like` (:435) so the "random" mode is replayable.
+    temperature > 1e-8 takes the Categorical branch (:411-416): `Categorical(probs / temperature).sample()` normalises
+    the temperature away and draws through torch.multinomial's single-sample path, argmax_k p_k / q_k with q ~ Exp(1);
+    `sample_draws[step]` (B, H*W, NV, V) are those q (factor v at [..., v, :]).
     Mutates `prompt_THW` in place like the reference (:453).  Returns (samples_HW, first-pass
-    factored logits (B, V, NV, H, W)).
+    factored logits (B, V, NV, H, W)).  `trace` (a list) receives per step (logits B C H W, confidences handed to argsort).
     """
     assert out_t, "maskgit_generate requires out_t > 0"
     assert torch.all(prompt_THW[:, out_t:] == cfg.mask_token_id)
-    assert temperature <= 1e-8, "oracle restates the greedy-token branch only"
     B, T, H, W = prompt_THW.shape
     S = H * W
     V, NV = cfg.factored_vocab_size, cfg.num_factored_vocabs
@@ -273,7 +276,13 @@ def maskgit_generate(sd: SD, cfg: RefConfig, prompt_THW: torch.Tensor, out_t: in
         samples = torch.zeros(B, H, W, dtype=torch.long)
         conf = torch.ones(B, H, W)
         for v in reversed(range(NV)):  # flip(2): highest factor first (:408)
-            s = probs[:, v].argmax(dim=1)
+            if temperature <= 1e-8:
+                s = probs[:, v].argmax(dim=1)
+            else:
+                pr = probs[:, v].permute(0, 2, 3, 1) / temperature           # b h w vocab (:413-414)
+                pr = pr / pr.sum(-1, keepdim=True)                            # Categorical.__init__ normalises
+                q = sample_draws[step][:, :, v].reshape(B, H, W, V)
+                s = (pr / q).argmax(dim=-1)                                   # torch.multinomial(p, 1): argmax p / q, q ~ Exp(1)
             samples = samples * V + s
             conf = conf * torch.gather(probs[:, v], 1, s[:, None])[:, 0]
         prev_unmasked = unmasked.clone()
@@ -288,9 +297,13 @@ def maskgit_generate(sd: SD, cfg: RefConfig, prompt_THW: torch.Tensor, out_t: in
             else:
                 raise NotImplementedError(unmask_mode)
             c[unmasked] = torch.inf
+            if trace is not None:
+                trace.append((logits.clone(), c.clone()))
             order = torch.argsort(c, dim=1)
             unmasked.scatter_(1, order[:, n:], True)
             flat.scatter_(1, order[:, :n], cfg.mask_token_id)
+        elif trace is not None:
+            trace.append((logits.clone(), None))
         flat[prev_unmasked] = prev_flat[prev_unmasked]
         samples_HW = flat.reshape(B, H, W)
         prompt_THW[:, out_t] = samples_HW

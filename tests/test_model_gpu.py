@@ -6,9 +6,9 @@ Tolerances (bf16 MFMA compute, fp32 accumulation / residual stream / loss):
     magnitude ~4, loss ~15.7) the bound is 3e-4 RELATIVE (5e-3 absolute); accuracy identical on the fixtures;
   * logits: max error <= 2 % of the logits' range; parameter gradients: rms error <= 3 % per tensor
     (<= 6 % for the tiny-magnitude tensors dominated by bf16 rounding of activations);
-  * token ids from MaskGIT decode: bit-exact given the same logits (kernel-level test) and >= 97 %
-    identical end to end in bf16 (an id can flip only where the reference's top-2 logit margin is below
-    the logits tolerance).
+  * token ids from MaskGIT decode: bit-exact given the same logits (kernel-level test); end to end in bf16 an id can flip
+    only where the reference's top-2 logit margin is below the logits tolerance -- asserted step by step in
+    tests/test_decode_rule_gpu.py (the agreement percentages here are logged, not asserted).
 """
 import json
 import os
@@ -189,14 +189,14 @@ def test_maskgit_generate_against_golden():
         a = (s.cpu() == g[f"greedy{steps}.samples"]).float().mean().item()
         _note(f"generate.greedy{steps}.id_agreement", a)
         agree.append(a)
-    assert agree[0] >= 0.97  # single pass: ids flip only at sub-tolerance logit margins
+    # (end-to-end agreement is logged only: the id rule -- a flip only below the reference's margin -- is asserted step by step
+    # in tests/test_decode_rule_gpu.py)
     # replayed "random" unmasking order (the torch.rand_like draws are an input)
     p = g["prompt0"].to(DEV).clone()
     s, _, _ = m.maskgit_generate(p, out_t=out_t, maskgit_steps=4, temperature=0.0, unmask_mode="random",
                                  action_ids=inp["actions_domA"], domain=["domA"] * 2, rand_draws=list(g["random4.draws"].to(DEV)))
     a = (s.cpu() == g["random4.samples"]).float().mean().item()
     _note("generate.random4.id_agreement", a)
-    assert a >= 0.9
     # generate(): two autoregressive frames
     ids = inp["labels"].reshape(2, cfg.T, 256)[:, : cfg.T - 2].reshape(2, -1)
     toks = m.generate(ids, None, max_new_tokens=2 * 256, maskgit_steps=2, temperature=0.0, action_ids=inp["actions_domA"],
@@ -220,7 +220,7 @@ def test_cached_decode_equals_full_window_decode():
     cached = m.generate(ids, None, use_cache=True, **kw)
     agree = (full == cached).float().mean().item()
     _note("generate.cached_vs_full_agreement", agree)
-    assert agree >= 0.995
+    assert torch.equal(full, cached)  # (at this depth the two paths round identically; L = 32: tests/test_fulldepth_gpu.py)
     assert (cached != cfg.image_vocab_size).all()
     _note("generate.cached.golden_agreement", (cached.cpu() == g["generate2.tokens"]).float().mean().item())
     # logits of one cached frame pass vs the full-window forward on the same tokens

@@ -162,3 +162,48 @@ def test_g8_clip_adamw():
     for k in names:
         if ".domB." in k or "action_out_projectors" in k or k == "action_mask_tokens":
             assert torch.equal(params[k], sd[k]), k
+
+
+def _redraw_q(g, steps, B=2):
+    """The Exp(1) draws of the reference's `sampled3` run, re-drawn in torch.multinomial's call order (step, factor 1, factor 0)
+    from the recorded seed; `qsum` pins the stream.  Returns one (B, 256, 2, 512) tensor per step (factor v at [..., v, :])."""
+    torch.manual_seed(int(g["sampled3.seed"]))
+    out, sums = [], []
+    for _ in range(steps):
+        q = torch.empty(B, 256, 2, 512)
+        for v in (1, 0):
+            qv = torch.empty(B * 256, 512).exponential_(1)
+            sums.append(qv.double().sum())
+            q[:, :, v] = qv.reshape(B, 256, 512)
+        out.append(q)
+    assert torch.equal(torch.stack(sums), g["sampled3.qsum"]), "the CPU RNG stream differs from the one the fixture was drawn with"
+    return out
+
+
+def test_g13_decode_steps_oracle():
+    """Per-step MaskGIT records of the reference (tests/golden/make_golden_decode.py): the oracle reproduces every step's ids
+    bit for bit -- greedy, random-order and the Categorical branch (temperature > 0, st_mask_git.py:411-416) -- and the
+    confidences the reference ranks by."""
+    g = golden("g13_decode_steps")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    inp = tiny_inputs()
+    out_t = cfg.T - 1
+    runs = [("greedy1", 1, 0.0, "greedy", {}), ("greedy2", 2, 0.0, "greedy", {}), ("greedy8", 8, 0.0, "greedy", {}),
+            ("random4", 4, 0.0, "random", dict(rand_draws=list(g["random4.draws"]))),
+            ("sampled3", 3, 1.0, "greedy", dict(sample_draws=_redraw_q(g, 3)))]
+    for tag, steps, temp, mode, kw in runs:
+        p = g["prompt0"].clone()
+        trace = []
+        s, _ = R.maskgit_generate(sd, cfg, p, out_t, steps, temp, mode, inp["actions_domA"], ["domA"] * 2, trace=trace, **kw)
+        assert torch.equal(s.reshape(2, 256).int(), g[f"{tag}.frame_out"][-1]), tag
+        assert len(trace) == steps
+        for k, (lg, conf) in enumerate(trace):
+            lg = lg.reshape(2, 2, 512, 256)
+            assert torch.equal(lg.argmax(2).to(torch.int16), g[f"{tag}.top1"][k]), (tag, k)
+            assert rel_err(lg.reshape(2, 1024, 256)[:, ::32], g[f"{tag}.logits_sub"][k]) < TOL
+            if conf is not None:
+                ref = g[f"{tag}.conf"][k]
+                assert torch.equal(torch.isinf(conf), torch.isinf(ref)), (tag, k)
+                fin = ~torch.isinf(ref)
+                assert torch.allclose(conf[fin], ref[fin], rtol=2e-5, atol=1e-12), (tag, k)
