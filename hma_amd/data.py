@@ -28,7 +28,28 @@ from .config import GenieConfig
 
 # frames per second of the source datasets (datasets/encode_openx_dataset.py DATA_FREQ_TABLE); the stride of a
 # dataset is hz // natural_hz.  Unknown names use 1 like the reference's `.get(name, 1)`.
-DATA_FREQ_TABLE: Dict[str, int] = {}
+_X = "_converted_externally_to_rlds"
+_HZ_TO_NAMES = {
+    1: ["robo_net", "uiuc_d3field", "ego4d"],
+    2: ["ucsd_kitchen_dataset" + _X, "language_table", "kuka"],
+    3: ["ucsd_pick_and_place_dataset" + _X, "nyu_door_opening_surprising_effectiveness", "nyu_franka_play_dataset" + _X,
+        "fractal20220817_data"],
+    5: ["berkeley_mvp" + _X, "stanford_robocook" + _X, "cmu_play_fusion", "bridge", "robo_set",
+        "dlr_edan_shared_control" + _X, "berkeley_autolab_ur5"],
+    6: ["robomimic", "metaworld", "robomimic_new", "robomimic_multitask_new", "robomimic_new_perturb",
+        "robomimic_multitask_new_perturb"],
+    10: ["stanford_hydra_dataset" + _X, "imperialcollege_sawyer_wrist_cam", "bc_z", "dlr_sara_pour" + _X,
+         "furniture_bench_dataset" + _X, "usc_cloth_sim" + _X, "roboturk", "kaist_nonprehensile" + _X,
+         "utokyo_xarm_pick_and_place" + _X, "berkeley_cable_routing", "columbia_cairlab_pusht_real", "berkeley_gnm_sac_son"],
+    12: ["asu_table_top" + _X],
+    15: ["droid", "mimic_play"],
+    20: ["austin_sailor_dataset" + _X, "austin_buds_dataset" + _X, "austin_sirius_dataset" + _X,
+         "iamlab_cmu_pickup_insert" + _X, "utaustin_mutex", "stanford_kuka_multimodal_dataset" + _X,
+         "maniskill_dataset" + _X],
+    30: ["berkeley_rpt" + _X, "toto", "conq_hose_manipulation", "aloha_mobile", "1x_humanoid", "epic_kitchen_originalres",
+         "epic_kitchen", "exoego4d", "frodobot"],
+}
+DATA_FREQ_TABLE: Dict[str, int] = {name: hz for hz, names in _HZ_TO_NAMES.items() for name in names}
 
 
 def normalize_actions(actions: np.ndarray):

@@ -444,7 +444,8 @@ class STEngine:
     def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True, kv_cache=None,
                       T_cache=0) -> Plan:
         l1 = self.cfg.num_layers if l1 is None else l1
-        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else kv_cache.data_ptr(),
+        # (T_cache is part of the key: a re-allocated cache of another length can land on the old one's address)
+        key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else (kv_cache.data_ptr(), T_cache),
                self._use_fused(B * T * (S + A), train))
         if key in self._plans:
             return self._plans[key]
@@ -921,6 +922,12 @@ class STEngine:
         else:
             for a, b in self.layout.trainable_ranges(active_domains):
                 self.G[a:b].zero_()
+
+    def zero_grad_domains(self, domains: Sequence[str]) -> None:
+        """Zero only the blocks of `domains` (a domain that first appears in a later micro-batch of an accumulation window)."""
+        for dom in domains:
+            a, b = self.layout.regions[f"dom:{dom}"]
+            self.G[a:b].zero_()
 
     def backward(self, grad_scale: float = 1.0, on_segment: Optional[Callable[[str], None]] = None,
                  segment_layers: int = 0) -> None:

@@ -1,14 +1,20 @@
 """Training-step driver for the MI355X engine: the hot slice of hma/train_multi.py:556-599.
 
 One process per GPU.  Per optimizer step:
-  1. ranks exchange their batch's action domain (a tiny all-gather) -> the union of active domains;
-  2. forward + fused CE, hand-written backward into the flat gradient buffer;
+  1. the set of action domains that receive a gradient on SOME rank in SOME micro-batch of the step is fixed: passed in by
+     the driver (every process builds the same sampler, train_multi.py:928-932, so it is local knowledge -- no collective,
+     no host sync), or, for callers that cannot know it, found by a tiny all-gather per micro-batch;
+  2. forward + fused CE, hand-written backward into the flat gradient buffer (micro-batches of ANY domain accumulate);
   3. gradients are all-reduced (RCCL, `nccl` backend) in contiguous buckets of the flat buffer that
      become final as backward walks layers L-1..0 -- launched on a side HIP stream behind an event so
      they overlap the remaining backward; only the dense trunk and the domains that are active on
-     SOME rank are reduced (the reference's DDP reduces all 362 M parameters, ~90 % zeros);
+     SOME rank are reduced (the reference's DDP reduces all 362 M parameters, ~90 % zeros); the step's
+     loss bookkeeping [sum loss * batch, batch count, non-finite count] rides along (train_multi.py:599);
   4. global-norm clip + AdamW over exactly those ranges.  Parameters unused on every rank are left
      untouched (no moment update, no weight decay) -- DDP's globally-unused rule.
+     A non-finite loss on ANY rank makes the reduced gradient norm non-finite on EVERY rank; the update
+     kernel then leaves weights, moments and update counts alone (the all-rank-consistent form of
+     train_multi.py:572-583), decided on the device.
 The per-micro-step barrier of the reference (train_multi.py:568) is dropped on purpose.
 """
 from __future__ import annotations
@@ -43,15 +49,24 @@ class GradReducer:
         self._dom_index = {d: i for i, d in enumerate(layout.domains)}
 
     def active_domains(self, local_domain: Optional[str]) -> List[str]:
-        """Union over ranks of this step's domains, in layout order (same list on every rank)."""
+        """Union over ranks of this micro-batch's domains, in layout order (same list on every rank).  FALLBACK for callers
+        that do not pass `step_domains` to `Trainer.micro_step`: a blocking all-gather + host read per call."""
         if self.world == 1:
             return [local_domain] if local_domain is not None else []
         idx = -1 if local_domain is None else self._dom_index[local_domain]
         mine = torch.tensor([idx], dtype=torch.int64, device=self.G.device)
         allv = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(allv, mine, group=self.group)
-        seen = sorted({int(v.item()) for v in allv if int(v.item()) >= 0})
+        seen = sorted({int(v) for v in torch.cat(allv).tolist() if int(v) >= 0})
         return [self.layout.domains[i] for i in seen]
+
+    def order(self, domains) -> List[str]:
+        """`domains` de-duplicated, in layout order."""
+        want = {d for d in domains if d is not None}
+        unknown = want - set(self._dom_index)
+        if unknown:
+            raise KeyError(f"unknown action domains {sorted(unknown)}")
+        return [d for d in self.layout.domains if d in want]
 
     def _launch(self, a: int, b: int) -> None:
         if self.world == 1 or b <= a:
@@ -75,14 +90,29 @@ class GradReducer:
             self._launch(*self.dense_buckets[self._next])
             self._next += 1
 
-    def finish(self, active: Sequence[str]) -> None:
-        """Reduce what is left (unlaunched dense buckets, embeddings, active domain blocks) and wait."""
+    def _launch_tensor(self, t: torch.Tensor) -> None:
+        if self.world == 1 or t.numel() == 0:
+            return
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self, active: Sequence[str], extra: Sequence[torch.Tensor] = ()) -> None:
+        """Reduce what is left (unlaunched dense buckets, embeddings, active domain blocks, `extra` flat tensors such as the
+        loss bookkeeping or STMAR's own gradient range) and wait."""
         while self._next < len(self.dense_buckets):
             self._launch(*self.dense_buckets[self._next])
             self._next += 1
         self._launch(*self.tail)
         for dom in active:
             self._launch(*self.layout.regions[f"dom:{dom}"])
+        for t in extra:
+            self._launch_tensor(t)
         for w in self._pending:
             w.wait()
         if self.side is not None and self.world > 1:
@@ -94,7 +124,7 @@ def lr_at(step: int, base_lr: float, warmup_steps: int) -> float:
     """`constant_with_warmup` (train_multi.py:194-199, 979-986); `step` counts completed optimizer steps."""
     if warmup_steps <= 0:
         return base_lr
-    return base_lr * min(1.0, float(step + 1) / float(warmup_steps))
+    return base_lr * min(1.0, float(step) / float(warmup_steps))  # LambdaLR: lr of update k + 1 = base * k / warmup
 
 
 class Trainer:
@@ -114,22 +144,57 @@ class Trainer:
         self.completed = 0
         self._micro = 0
         self._active: List[str] = []
+        self._known = False  # the step's domain set was given up front (no collective needed)
+        # [sum over finite micro-batches of loss * batch, their batch count, non-finite micro-batches, unused]; all-reduced with
+        # the gradients of each optimizer step (train_multi.py:560-577, 599) and snapshotted into `last_loss_info`
+        self.loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.last_loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
         # hipGraph replay of (zero-grad, forward, loss, backward) per (shape, domain): ~1500 launches per step
         # become one graph launch.  Single-GPU fast path only; the N > 1 path interleaves all-reduces eagerly.
         self.use_graphs = True
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._seen: Dict[tuple, int] = {}
 
-    def micro_step(self, input_ids, labels, action_ids=None, domain=None) -> Dict[str, torch.Tensor]:
-        """forward + backward of one micro-batch; gradients accumulate in the flat buffer."""
+    def _announce(self, dom: Optional[str], step_domains) -> None:
+        """Fix (first micro-batch) or extend (later ones) the set of domains whose blocks are zeroed, reduced and stepped."""
+        eng, red = self.engine, self.reducer
+        first = self._micro == 0
+        if first:
+            self._known = step_domains is not None
+            self._active = red.order(step_domains) if self._known else red.active_domains(dom)
+            eng.zero_grad(self._active)
+            self.loss_info.zero_()
+            return
+        if self._known:
+            if dom is not None and dom not in self._active:
+                raise RuntimeError(f"domain {dom!r} is not in the step_domains announced for this optimizer step")
+            return
+        # not announced up front: a later micro-batch may bring a new domain (mixed-domain accumulation, train_multi.py:563-579);
+        # its block still holds an earlier step's gradient -> zero it on first appearance
+        now = red.active_domains(dom)
+        fresh = [d for d in now if d not in self._active]
+        if fresh:
+            eng.zero_grad_domains(fresh)
+            self._active = red.order(list(self._active) + fresh)
+
+    def _book(self, ws, B: int) -> None:
+        """loss bookkeeping of one micro-batch, on the device (train_multi.py:572-577: non-finite losses are not summed)."""
+        st = ws["stats"]
+        loss = st[0] / st[2]
+        ok = torch.isfinite(loss)
+        okf = ok.to(torch.float32)
+        self.loss_info += torch.stack([torch.where(ok, loss, torch.zeros_like(loss)) * B, okf * B, 1.0 - okf, okf * 0.0])
+
+    def micro_step(self, input_ids, labels, action_ids=None, domain=None, step_domains=None) -> Dict[str, torch.Tensor]:
+        """forward + backward of one micro-batch; gradients accumulate in the flat buffer.
+
+        `step_domains`: every domain that any rank sees in any micro-batch of THIS optimizer step (only read on the first
+        micro-batch).  The driver knows it without communication -- all processes iterate the same sampler
+        (train_multi.py:928-932) -- and passing it removes the per-step all-gather and its host sync."""
         eng, red = self.engine, self.reducer
         dom = None if action_ids is None else (domain if isinstance(domain, str) else domain[0])
-        first, last = self._micro == 0, self._micro == self.accum - 1
-        if first:
-            self._active = red.active_domains(dom)
-            eng.zero_grad(self._active)
-        elif dom is not None and dom not in self._active:
-            raise RuntimeError("all micro-batches of one optimizer step must use the domains announced by its first micro-batch")
+        last = self._micro == self.accum - 1
+        self._announce(dom, step_domains)
         B = input_ids.shape[0]
         T = self.model.config.T
         eng.grad_scale.value = 1.0 / (self.accum * red.world)
@@ -139,10 +204,11 @@ class Trainer:
             self._micro += 1
             return ws
         ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True)
+        self._book(ws, B)
         if last and red.world > 1:
             red.begin()
             eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
-            red.finish(self._active)
+            red.finish(self._active, extra=[self.loss_info])
         else:
             eng.backward(eng.grad_scale.value)
         self._micro += 1
@@ -180,10 +246,11 @@ class Trainer:
             n = self._seen.get(key, 0) + 1
             self._seen[key] = n
             ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True)
+            self._book(ws, B)
             if red.world > 1:
                 red.begin()
                 eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
-                red.finish(self._active)
+                red.finish(self._active, extra=[self.loss_info])
             else:
                 eng.backward(eng.grad_scale.value)
             if n >= 2:  # buffers, plans and lazily-initialised kernel attributes exist now: capture for next time
@@ -220,12 +287,14 @@ class Trainer:
         eng._last = (B, T, S, A, dom if A > 0 else None)
         if red.world > 1:
             red.begin()
-        for g, label in graphs:
+        for i, (g, label) in enumerate(graphs):
             g.replay()
+            if i == 0:
+                self._book(ws, B)  # (the first graph holds forward + loss: `stats` is final behind it)
             if label is not None:
                 red.on_segment(label)
         if red.world > 1:
-            red.finish(self._active)
+            red.finish(self._active, extra=[self.loss_info])
         return ws
 
     def optimizer_step(self) -> None:
@@ -233,10 +302,20 @@ class Trainer:
         self.engine.optimizer_step(lr, self._active, self.betas, self.eps, self.wd, self.max_grad_norm)
         self.completed += 1
         self._micro = 0
+        self.last_loss_info.copy_(self.loss_info)
 
-    def step(self, input_ids, labels, action_ids=None, domain=None) -> Dict[str, torch.Tensor]:
+    def reduced_loss(self) -> torch.Tensor:
+        """Mean training loss of the last optimizer step over all ranks and micro-batches with a finite loss
+        (`accelerator.reduce(loss_info)`, train_multi.py:599-601); a device scalar, read it only when logging."""
+        return self.last_loss_info[0] / self.last_loss_info[1]
+
+    def skipped_last_step(self) -> bool:
+        """Whether the last optimizer step was skipped on every rank because some rank's loss was not finite (host read)."""
+        return bool(self.last_loss_info[2].item() > 0) or not bool(torch.isfinite(self.engine.sqnorm).item())
+
+    def step(self, input_ids, labels, action_ids=None, domain=None, step_domains=None) -> Dict[str, torch.Tensor]:
         """One full optimizer step on one micro-batch (grad_accum must be 1)."""
-        ws = self.micro_step(input_ids, labels, action_ids, domain)
+        ws = self.micro_step(input_ids, labels, action_ids, domain, step_domains=step_domains)
         self.optimizer_step()
         return ws
 

@@ -92,47 +92,61 @@ def main(argv=None):
         model = STMaskGIT(config)
         model.init_action_projectors(domains, [d.n_action for d in datasets], [d.action_stat for d in datasets], config.action_network)
     model = model.to("cuda")
-    trainer = Trainer(model, lr=args.learning_rate, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
+    accum = args.gradient_accumulation_steps
+    # the reference scales the base rate with the effective batch (train_multi.py:902-904)
+    lr = args.learning_rate * min(max(1, args.per_device_train_batch_size * accum * world / 64), 8)
+    trainer = Trainer(model, lr=lr, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
                       weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, warmup_steps=args.num_warmup_steps,
-                      grad_accum=args.gradient_accumulation_steps)
+                      grad_accum=accum)
     start_step = 0
     if args.resume_from_checkpoint and os.path.exists(os.path.join(args.resume_from_checkpoint, Trainer.STATE_FILE)):
         trainer.load_state(args.resume_from_checkpoint)  # Adam moments + step counts (train_multi.py:484-533)
         start_step = trainer.completed
 
     concat = ConcatDataset(datasets)
-    sampler = MultiTaskBatchSampler([len(d) for d in datasets], args.per_device_train_batch_size, args.sampling_temperature,
+    sizes = [len(d) for d in datasets]
+    sampler = MultiTaskBatchSampler(sizes, args.per_device_train_batch_size, args.sampling_temperature,
                                     seed=args.seed)  # defaults num_replicas=1, rank=0: every process draws the same sequence
+    bounds = np.cumsum(sizes)
+    domain_of = lambda indices: domains[int(np.searchsorted(bounds, indices[0], side="right"))]  # one domain per batch
     collate = get_maskgit_collator(config)
-    steps_per_epoch = max(len(sampler) // (world * args.gradient_accumulation_steps), 1)
+    group = world * accum                                   # batches consumed by one optimizer step, all ranks together
+    steps_per_epoch = max(len(sampler) // group, 1)         # (every rank gets the same number of batches per epoch)
     max_steps = args.max_train_steps or args.num_train_epochs * steps_per_epoch
     out_dir = Path(args.output_dir)
     step, t0, tokens = start_step, time.time(), 0
-    for epoch in range(10 ** 9):
+    # resume: skip what the finished steps consumed (train_multi.py:519-528, 547-549) instead of replaying epoch 0
+    first_epoch, skip_steps = divmod(start_step, steps_per_epoch)
+    for epoch in range(first_epoch, 10 ** 9):
+        if step >= max_steps:
+            break
         sampler.set_epoch(epoch)
-        micro = 0
-        for k, indices in enumerate(sampler):
-            if k % world != rank:  # BatchSamplerShard: rank r takes every world-th batch
-                continue
-            batch = collate([concat[i] for i in indices])
-            ws = trainer.micro_step(batch["input_ids"], batch["labels"], batch.get("action_ids"), batch["domain"])
-            tokens += batch["input_ids"].numel()
-            micro += 1
-            if micro % args.gradient_accumulation_steps:
-                continue
+        batches = list(sampler)
+        for k in range(skip_steps if epoch == first_epoch else 0, steps_per_epoch):
+            window = batches[k * group:(k + 1) * group]
+            if len(window) < group:
+                break
+            # Every process iterates the SAME sampler, so the domains all ranks will touch in this optimizer step are known
+            # here without communication; rank r takes every world-th batch (BatchSamplerShard, train_multi.py:939, 990).
+            step_domains = [domain_of(ix) for ix in window]
+            for j in range(accum):
+                indices = window[j * world + rank]
+                batch = collate([concat[i] for i in indices])
+                ws = trainer.micro_step(batch["input_ids"], batch["labels"], batch.get("action_ids"), batch["domain"],
+                                        step_domains=step_domains)
+                tokens += batch["input_ids"].numel()
             trainer.optimizer_step()
             step += 1
             if rank == 0 and (step % args.log_every == 0 or step == max_steps):
-                loss, acc = trainer.loss_and_acc(ws)
+                _, acc = trainer.loss_and_acc(ws)
                 dt = time.time() - t0
-                print(json.dumps({"step": step, "loss": float(loss), "acc": float(acc), "domain": batch["domain"][0],
+                print(json.dumps({"step": step, "loss": float(trainer.reduced_loss()), "acc": float(acc),
+                                  "domain": batch["domain"][0], "skipped": trainer.skipped_last_step(),
                                   "tokens_per_s_per_gpu": tokens / dt}), flush=True)
             if rank == 0 and args.checkpointing_steps and step % args.checkpointing_steps == 0:
                 trainer.save_state(out_dir / f"step_{step}")
             if step >= max_steps:
                 break
-        if step >= max_steps:
-            break
     if rank == 0:
         trainer.save_state(out_dir / f"step_{step}")
     if world > 1:

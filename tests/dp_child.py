@@ -1,0 +1,92 @@
+"""One rank of the 2-process data-parallel equivalence test (tests/test_dp_gpu.py): a fresh interpreter per rank, both on GPU 0,
+gloo between them (the GPU box has ONE device; the same GradReducer code runs over RCCL on a multi-GPU node).
+
+    RANK=r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_child.py OUT.safetensors [nan_step]
+
+Runs STEPS optimizer steps of `Trainer.step` with rank-specific domains and batches (rank 0: domA, rank 1: domB; domC idle
+everywhere) and rank 0 writes the resulting weights, Adam update counts and the reduced per-step losses."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+STEPS = 4
+L = 4
+DOMAINS, D_ACTIONS = ["domA", "domB", "domC"], [7, 14, 7]
+CFG = dict(num_layers=L, num_heads=8, d_model=256, T=3, S=256, image_vocab_size=262144, use_mup=True,
+           action_network="concat+modulate", num_factored_vocabs=2, qkv_bias=False, proj_bias=True, attn_drop=0.0, qk_norm=False,
+           mlp_ratio=4.0, mlp_drop=0.0, mlp_bias=True)
+STATS = [[[0.0] * 7, [1.0] * 7]] * 3
+
+
+def build_model():
+    from hma_amd.config import GenieConfig
+    from hma_amd.model import STMaskGIT
+
+    torch.manual_seed(1234)
+    m = STMaskGIT(GenieConfig(**CFG))
+    m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, CFG["action_network"])
+    with torch.no_grad():
+        for p in m.parameters():  # (no exact zeros: an indexing error in a zero tensor would hide)
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.02)
+    return m.to("cuda").train()
+
+
+def batch(which: int, step: int):
+    """micro-batch `which` (0: domA, 1: domB) of optimizer step `step`."""
+    import math
+    g = torch.Generator().manual_seed(100 + 10 * step + which)
+    B, T = 2, CFG["T"]
+    labels = torch.randint(0, 8192, (B, T, 256), generator=g)
+    m = torch.rand(B, T - 1, 256, generator=g) < math.cos(0.3 * math.pi / 2)
+    ids = labels.clone()
+    ids[:, 1:][m] = CFG["image_vocab_size"]
+    act = torch.randn(B, T, D_ACTIONS[which], generator=g)
+    return ids.reshape(B, -1).cuda(), labels.reshape(B, -1).cuda(), act.cuda(), [DOMAINS[which]] * B
+
+
+def digest(model, trainer, losses):
+    out = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()
+           if n.startswith(("decoder.layers.0.", f"decoder.layers.{L - 1}.", "out_x_proj", "token_embed", "action_mlp"))}
+    eng = trainer.engine
+    out["_opt_step"] = torch.tensor(eng.opt_step)
+    out["_dom_steps"] = torch.tensor([eng.dom_steps.get(d, 0) for d in DOMAINS])
+    out["_losses"] = torch.stack(losses).cpu()
+    return out
+
+
+def main():
+    import torch.distributed as dist
+    from safetensors.torch import save_file
+    from hma_amd.train import Trainer
+
+    out_path = sys.argv[1]
+    nan_step = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+    rank = int(os.environ["RANK"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    model = build_model()
+    tr = Trainer(model, lr=1e-3, warmup_steps=0, layers_per_bucket=2)
+    assert tr.reducer.world == 2
+    losses = []
+    for step in range(STEPS):
+        ids, labels, act, dom = batch(rank, step)
+        if step == nan_step and rank == 1:
+            act = act.clone()
+            act[0, 0, 0] = float("nan")  # a non-finite loss on ONE rank: every rank must skip this update
+        tr.step(ids, labels, act, dom, step_domains=["domA", "domB"])
+        losses.append(tr.reduced_loss().detach().clone())
+    torch.cuda.synchronize()
+    assert len(tr._graphs) == 1 and len(next(iter(tr._graphs.values()))) == L // 2 + 1  # per-bucket graph segments were used
+    if rank == 0:
+        save_file(digest(model, tr, losses), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

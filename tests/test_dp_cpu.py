@@ -68,8 +68,10 @@ def test_buckets_tile_the_dense_region_in_backward_order(lpb):
 
 
 def test_lr_schedule_constant_with_warmup():
-    assert lr_at(0, 1e-4, 500) == pytest.approx(1e-4 / 500)
-    assert lr_at(499, 1e-4, 500) == pytest.approx(1e-4)
+    # LambdaLR(constant_with_warmup): the k-th update (0-based) runs at base * k / warmup (train_multi.py:194-199, 979-986)
+    assert lr_at(0, 1e-4, 500) == 0.0
+    assert lr_at(1, 1e-4, 500) == pytest.approx(1e-4 / 500)
+    assert lr_at(500, 1e-4, 500) == pytest.approx(1e-4)
     assert lr_at(10_000, 1e-4, 500) == 1e-4
     assert lr_at(3, 2e-4, 0) == 2e-4
 
@@ -85,6 +87,9 @@ def _worker(rank, world, port, lpb, out):
         local = ["domC", "domA"][rank]  # ranks hold different domains; domB is idle everywhere
         active = red.active_domains(local)
         assert active == ["domA", "domC"], active
+        # the collective-free form: the driver knows every rank's domain (all processes iterate one shared sampler)
+        assert red.order(["domC", "domA", "domC", None]) == active
+        loss_info = torch.tensor([2.5 * (rank + 1), 2.0, float(rank), 0.0])  # [sum loss * B, count, non-finite, -]
         # what a rank's backward leaves in G: dense range + its own domain block, zeros elsewhere
         dense = lay.trainable_ranges([])[0]
         G[dense[0]:dense[1]] = torch.arange(dense[1] - dense[0], dtype=torch.float32) * (rank + 1) * 1e-3
@@ -96,7 +101,8 @@ def _worker(rank, world, port, lpb, out):
             if (L - l) % lpb == 0 or l == 0:
                 red.on_segment(f"layer{l}")
         red.on_segment("end")
-        red.finish(active)
+        red.finish(active, extra=[loss_info])
+        assert loss_info.tolist() == [7.5, 4.0, 1.0, 0.0]  # rides along with the gradients (train_multi.py:599)
         exp = torch.zeros(lay.total)
         exp[dense[0]:dense[1]] = torch.arange(dense[1] - dense[0], dtype=torch.float32) * 3e-3  # ranks 1x + 2x
         a, b = lay.regions["dom:domC"]
