@@ -312,7 +312,10 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
     # ------------------------------------------------------------------------------------------ backward
     def _accum(self, p: nn.Parameter, g: torch.Tensor):
         g = g.reshape(p.shape)
-        p.grad = g if p.grad is None else p.grad + g
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)  # in place: with the own flat range (`_own_flat`) the gradient is a view into ONE buffer
 
     def _backward(self, grad_out: torch.Tensor):
         sv = self._saved
@@ -368,32 +371,91 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                     prm.grad = eng.view(name, eng.G)
         self._saved = None
 
+    def _save_pretrained(self, save_directory) -> None:
+        """model.safetensors with the reference's tensor names (the parameters are views into flat buffers: cloned out first)."""
+        import os
+
+        from safetensors.torch import save_file
+
+        state = {k: v.detach().to("cpu").contiguous().clone() for k, v in self.state_dict().items()}
+        save_file(state, os.path.join(str(save_directory), "model.safetensors"))
+
     # ------------------------------------------------------------------------------------------ optimizer
-    def optimizer_step(self, lr: float, domain: str, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
+    _OWN_ALIGN = 64
+
+    def _own_named(self):
+        """Parameters this class owns outside the engine's flat layout (input / output stages, the DiffLoss head), in a fixed
+        order.  `action_diff_losses.*` and `action_mask_tokens` never receive a gradient (jointly_predict_actions is off): like
+        the reference's grad-None parameters they are never stepped."""
+        return [(n, p) for n, p in self.named_parameters()
+                if not n.startswith(("decoder.", "action_mlp.", "action_diff_losses.")) and n != "action_mask_tokens"]
+
+    def _own_flat(self, dev=None):
+        """A SECOND flat range next to the engine's: the own parameters become views into one fp32 buffer with mirrored gradient
+        and Adam-moment buffers, so they are all-reduced with ONE collective and stepped by ONE fused clip + AdamW launch
+        (hma_adamw_counted) instead of tensor by tensor.  Decay flags per 64 elements follow train_multi.py:907-918: only
+        names containing "bias" are un-decayed."""
+        named = self._own_named()
+        dev = torch.device(dev) if dev is not None else named[0][1].device
+        own = self.__dict__.get("_own")
+        if own is not None and own["P"].device == dev and all(p.data_ptr() == v.data_ptr() for (_, p), v in zip(named, own["pviews"])):
+            return own
+        A = self._OWN_ALIGN
+        offs, total = [], 0
+        for _, p in named:
+            offs.append(total)
+            total += (p.numel() + A - 1) // A * A
+        P = torch.zeros(total, dtype=F32, device=dev)
+        flags = torch.zeros(total // A, dtype=torch.uint8)
+        pviews, gviews = [], []
+        G = torch.zeros_like(P)
+        with torch.no_grad():
+            for (n, p), o in zip(named, offs):
+                v = P[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                pviews.append(v)
+                gviews.append(G[o:o + p.numel()].view(p.shape))
+                flags[o // A:(o + p.numel() + A - 1) // A] = 1 if "bias" in n else 2
+        own = dict(P=P, G=G, M=torch.zeros_like(P), V=torch.zeros_like(P), flags=flags.to(dev), pviews=pviews, gviews=gviews,
+                   names=[n for n, _ in named], steps=torch.zeros(2, dtype=torch.int32, device=dev), calls=0)
+        self.__dict__["_own"] = own
+        return own
+
+    def _own_gather_grads(self, own) -> None:
+        """Make the flat gradient buffer hold every own gradient (a caller may have produced fresh .grad tensors)."""
+        for (n, p), gv in zip(self._own_named(), own["gviews"]):
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+            p.grad = gv
+
+    def optimizer_step(self, lr: float, domain, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
                        max_norm: Optional[float] = 1.0) -> None:
         """Global-norm clip + AdamW over everything that received a gradient (train_multi.py:593-598): the trunk and the active
-        domain's block through the engine's flat ranges, the parameters this class owns (input / output stages, DiffLoss head)
-        tensor by tensor with the same `hma_adamw` kernel and the same clip coefficient.  Biases and 1-D tensors are not decayed."""
+        domains' blocks through the engine's flat ranges, the parameters this class owns through their own flat range, with one
+        clip coefficient over both.  `domain`: a name or the list of domains active on some rank this step.  Weight decay
+        grouping as the reference (train_multi.py:907-918): only names containing "bias" are exempt."""
         eng = self._core._engine
-        own = [(n, p) for n, p in self.named_parameters() if p.grad is not None and not n.startswith(("decoder.", "action_mlp.")) and
-               n != "action_mask_tokens"]
-        grads = [p.grad.contiguous() for _, p in own]
-        eng.optimizer_step(lr, [domain], betas, eps, weight_decay, max_norm, extra_grads=grads)
+        own = self._own_flat(eng.device)
+        self._own_gather_grads(own)
+        domains = [domain] if isinstance(domain, str) else list(domain)
+        eng.optimizer_step(lr, domains, betas, eps, weight_decay, max_norm, extra_grads=[own["G"]])
         stream = torch.cuda.current_stream().cuda_stream
-        st = self.__dict__.setdefault("_opt_state", {})
-        sq = eng.sqnorm.data_ptr() if max_norm else None
-        for (n, p), g in zip(own, grads):
-            if n not in st:
-                st[n] = [torch.zeros_like(p.data), torch.zeros_like(p.data), 0]
-            st[n][2] += 1
-            wd = weight_decay if (p.dim() >= 2 and not n.endswith(".bias")) else 0.0
-            _lib.call("hma_adamw", stream, ptr(p.data), ptr(g), ptr(st[n][0]), ptr(st[n][1]), None, p.numel(), lr, betas[0], betas[1], eps, wd,
-                      st[n][2], sq, float(max_norm or 0.0), None)
-            p._version  # (in-place through the kernel: the engine-side caches hold no copy of these tensors)
+        _lib.call("hma_adamw_counted", stream, ptr(own["P"]), ptr(own["G"]), ptr(own["M"]), ptr(own["V"]), None, own["P"].numel(), lr,
+                  betas[0], betas[1], eps, weight_decay, ptr(own["steps"]), own["calls"] & 1, eng.sqnorm.data_ptr(),
+                  float(max_norm or 0.0), ptr(own["flags"]))
+        own["calls"] += 1
 
     def zero_grad(self, set_to_none: bool = True):
+        own = self.__dict__.get("_own")
         for prm in self.parameters():
             prm.grad = None
+        if own is not None:  # own gradients accumulate in place in the flat buffer
+            own["G"].zero_()
+            for (_, p), gv in zip(self._own_named(), own["gviews"]):
+                p.grad = gv
         if self._core._engine is not None:
             self._core._engine.zero_grad()
         self._grads_live = False

@@ -365,6 +365,70 @@ class Trainer:
         return st[0] / st[2], st[1] / st[2]
 
 
+class MarTrainer:
+    """Data-parallel train step for STMAR (BASELINE configs[3] is an 8-GPU config; the reference wraps the whole model in DDP,
+    train_multi.py:779, 990).  Same semantics as `Trainer`: gradients pre-scaled by 1 / (accum * world) and SUM-reduced -- the
+    engine's dense range and active domain blocks in buckets, the model's own flat range (input / output stages + diffusion
+    head, `STMAR._own_flat`) as one more collective, the loss bookkeeping behind them -- then ONE global-norm clip and fused
+    AdamW over both flat ranges, skipped on every rank when any rank's loss was not finite."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.05,
+                 max_grad_norm: Optional[float] = 1.0, warmup_steps: int = 0, layers_per_bucket: int = 8, grad_accum: int = 1,
+                 device=None):
+        self.model = model
+        dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.engine = model._engine(dev)
+        self.own = model._own_flat(dev)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_grad_norm, self.warmup, self.accum = max_grad_norm, warmup_steps, grad_accum
+        self.reducer = GradReducer(self.engine.layout, self.engine.G, layers_per_bucket)
+        self.completed, self._micro = 0, 0
+        self._active: List[str] = []
+        self.loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.last_loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def micro_step(self, step_domains=None, **batch):
+        """forward + backward of one micro-batch (`batch` = STMAR.forward's keyword arguments)."""
+        red = self.reducer
+        domain = batch["domain"]
+        dom = domain if isinstance(domain, str) else domain[0]
+        if self._micro == 0:
+            self._active = red.order(step_domains) if step_domains is not None else red.active_domains(dom)
+            self.model.zero_grad()
+            self.loss_info.zero_()
+        elif dom not in self._active:
+            fresh = [d for d in (red.active_domains(dom) if step_domains is None else [dom]) if d not in self._active]
+            self._active = red.order(list(self._active) + fresh)  # (model.zero_grad() zeroed every block: nothing stale to clear)
+        out = self.model(**batch)
+        loss = out.loss.detach()
+        ok = torch.isfinite(loss)
+        okf = ok.to(torch.float32)
+        B = batch["input_ids"].shape[0]
+        self.loss_info += torch.stack([torch.where(ok, loss, torch.zeros_like(loss)) * B, okf * B, 1.0 - okf, okf * 0.0])
+        (out.loss * (1.0 / (self.accum * red.world))).backward()
+        self._micro += 1
+        if self._micro == self.accum and red.world > 1:
+            self.model._own_gather_grads(self.own)
+            red.begin()
+            red.finish(self._active, extra=[self.own["G"], self.loss_info])
+        return out
+
+    def optimizer_step(self) -> None:
+        lr = lr_at(self.completed, self.lr, self.warmup)
+        self.model.optimizer_step(lr, self._active, self.betas, self.eps, self.wd, self.max_grad_norm)
+        self.completed += 1
+        self._micro = 0
+        self.last_loss_info.copy_(self.loss_info)
+
+    def step(self, step_domains=None, **batch):
+        out = self.micro_step(step_domains=step_domains, **batch)
+        self.optimizer_step()
+        return out
+
+    def reduced_loss(self) -> torch.Tensor:
+        return self.last_loss_info[0] / self.last_loss_info[1]
+
+
 class FusedAdamW:
     """torch.optim-shaped facade over the engine's fused clip + AdamW for the autograd (drop-in) path:
     `loss.backward(); opt.step(); opt.zero_grad()`."""

@@ -133,3 +133,51 @@ def test_mlp_dropout_trains_and_eval_is_deterministic():
         m.optimizer_step(2e-3, "domA")
         losses.append(out.loss.item())
     assert min(losses[-2:]) < 0.9 * losses[0], losses
+
+
+def test_two_adamw_steps_match_reference():
+    """G14 (tests/golden/make_golden_stmar_adamw.py): two clip + AdamW steps of the reference, optimizer grouped as
+    train_multi.py:907-918 -- only names containing "bias" are un-decayed; domB, the action-diffusion heads and
+    action_mask_tokens get no gradient and are never touched."""
+    from hma_amd.train import MarTrainer
+    g = load_file(os.path.join(HERE, "golden", "g14_stmar_adamw.safetensors"))
+    untouched = set(open(os.path.join(HERE, "golden", "g14_stmar_untouched.txt")).read().split())
+    m = build()
+    state = seeded_state(m.state_dict())
+    m.load_state_dict(state)
+    m = m.to(DEV).train()
+    tr = MarTrainer(m, lr=1e-3, warmup_steps=0)
+    # decay grouping of the own flat range, name by name
+    own = tr.own
+    off = 0
+    for name, pv in zip(own["names"], own["pviews"]):
+        f = int(own["flags"][off // 64])
+        assert f == (1 if "bias" in name else 2), name
+        off += (pv.numel() + 63) // 64 * 64
+    for n in ("decoder_norm.weight", "z_proj_ln.weight", "mask_token", "pos_embed_TSC", "diffloss.net.res_blocks.0.in_ln.weight"):
+        assert n in own["names"]
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    kw = dict(input_ids=inp["latents"], labels=inp["latents"], action_ids=inp["actions_domA"], domain=["domA"] * 2,
+              masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=inp["t"], diffusion_noise=inp["noise"])
+    for it in range(2):
+        out = tr.step(**kw)
+        ref = g[f"step{it}.loss"].item()
+        assert abs(out.loss.item() - ref) <= (2e-3 if it == 0 else 2e-2) * abs(ref), (it, out.loss.item(), ref)  # step 1 sees the update
+        norm = tr.engine.grad_norm().item()
+        assert abs(norm - g[f"step{it}.grad_norm"].item()) <= 2e-2 * g[f"step{it}.grad_norm"].item(), (it, norm)
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for name, p in params.items():
+        flat = p.detach().float().cpu().reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 64).long()
+        init = state[name].reshape(-1)[idx]
+        if name in untouched:
+            assert torch.equal(flat[idx], init), f"{name} must not be touched (no gradient: no decay, no moments)"
+            continue
+        ref = g[f"param_samp.{name}"]
+        moved = (ref - init).double().pow(2).mean().sqrt().item()
+        err = (flat[idx] - ref).double().pow(2).mean().sqrt().item()
+        assert moved > 0, name
+        worst = max(worst, err / moved)
+        # Adam turns a gradient into +-lr steps: an element whose gradient is bf16 rounding noise can land one step away
+        assert err <= 0.35 * moved, (name, err, moved)
