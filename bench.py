@@ -9,8 +9,15 @@ Workload (BASELINE.json configs[1]): `magvit_n32_h8_d256_a
 use_mup = True, 40 action domains (the "362M" model), per-GPU batch 32 of synthetic VQ tokens
 (ids ~ U{0..8191} inside the 2 x 512 factorised vocabulary, frames 1..15 masked at the collator's
 cos(u pi/2) rate), fp32 master weights, bf16 MFMA compute.  Inputs are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the NT GEMM): algorithmic
-FLOPs / HIP-event time over the timed steps; `cpu_baseline` times the CPU oracle on the host cores.
+region.  Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family: algorithmic
+FLOPs / HIP-event time over the timed steps; `cpu_baseline` times the CPU oracle on the host cores following
+BASELINE.md section 3 (fp32, all host cores, >= 2 warm-up + median of >= 5 steps at B = 1; B = 4 beside it).
+
+At --gpus 1 the same line carries two more measured sub-objects (each with value / unit / ms_per_step / roofline /
+cpu_baseline), so that the driver's one command sees every BASELINE config that fits one GPU:
+  "decode": configs[4]  MaskGIT iterative decode, B = 64, 4 prompt + 12 generated frames, 8 iterations -> frames/s
+  "mar":    configs[3]  STMAR (continuous latents + diffusion head) train step at its per-GPU batch 16 -> patch-tokens/s
+`--mode decode` / `--mode mar` run one of them alone (and print it as the line).
 """
 from __future__ import annotations
 
@@ -29,6 +36,9 @@ sys.path.insert(0, ROOT)
 FREQ = [20, 10, 20, 20, 5, 30, 2, 20, 20, 10, 2, 2, 10, 1, 10, 5, 5, 5, 10, 3, 10, 20, 10, 10, 12, 10, 10, 15, 1, 5, 30,
         3, 3, 15, 20, 10, 30, 5, 10, 5]
 FLOP_PER_TOKEN_FWD_BWD = 3.104e8
+# every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
+FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_attn_spatial_fwd",
+            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
 
 
@@ -71,10 +81,12 @@ def domain_sequence(n_domains, n_draws, seed=0):
 
 
 def pmc_traffic_per_launch(kernel_substr="gemm_nt"):
-    """HBM bytes per launch of the NT GEMM kernels from the committed rocprofv3 PMC passes (profiles/pmc_hbm_r1.json:
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_hbm_r2.json, else _r1:
     separate FETCH_SIZE / WRITE_SIZE runs of this bench on an 8-layer model; counters are in KB and, on gfx950,
     FETCH_SIZE reports half of a wide coalesced read -- MI355X_MICROARCH.md section HBM -- so it is doubled)."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_r1.json")
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_r2.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "pmc_hbm_r1.json")
     try:
         d = json.load(open(path))
         tot, launches = 0.0, 0
@@ -90,9 +102,32 @@ def pmc_traffic_per_launch(kernel_substr="gemm_nt"):
         return None
 
 
-def cpu_baseline(model, domain, d_a, T, budget_s=25.0):
-    """The CPU oracle (a port of the reference path, oracle/st_maskgit_ref.py) on the host cores: B = 1
-    fwd + bwd + clip + AdamW, timed for a bounded number of steps."""
+def _cpu_train_steps(sd, rc, names, domain, d_a, T, B, warm, timed):
+    """`warm` untimed + `timed` timed optimizer steps of the CPU oracle at batch B; returns the step times."""
+    from oracle import st_maskgit_ref as R
+
+    params = {k: sd[k].clone() for k in names}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(v) for k, v in params.items()}
+    ids, labels, act = synthetic_batch(B, T, 1234, d_a, "cpu")
+    times = []
+    for step in range(warm + timed):
+        t0 = time.perf_counter()
+        leaf = {k: p.clone().requires_grad_(True) for k, p in params.items()}
+        full = dict(sd)
+        full.update(leaf)
+        loss, _, _ = R.forward(full, rc, ids, labels, act, [domain])
+        loss.backward()
+        R.clip_and_adamw(params, {k: leaf[k].grad for k in names}, m, v, step + 1, 1e-4)
+        if step >= warm:
+            times.append(time.perf_counter() - t0)
+    return times
+
+
+def cpu_baseline(model, domain, d_a, T, quick=False):
+    """The CPU oracle (a port of the reference path, oracle/st_maskgit_ref.py) on the host cores, BASELINE.md section 3:
+    fp32, every host core, one optimizer step = fwd + bwd + clip + AdamW; B = 1: 2 warm-up + median of 5; B = 4 beside it
+    (1 warm-up + median of 2: a step is ~4x as long).  `quick`: one warm-up + one timed step at B = 1 only."""
     from oracle import st_maskgit_ref as R
 
     cfg = model.config
@@ -100,86 +135,118 @@ def cpu_baseline(model, domain, d_a, T, budget_s=25.0):
     keep = lambda k: (".action_projectors." not in k and not k.startswith("action_")) or f".{domain}." in k
     sd = {k: v.detach().to("cpu", copy=True) for k, v in model.state_dict().items() if keep(k)}
     names = [k for k in sd if not (k.endswith(".mean") or k.endswith(".std"))]
-    params = {k: sd[k] for k in names}
-    m = {k: torch.zeros_like(v) for k, v in params.items()}
-    v = {k: torch.zeros_like(v) for k, v in params.items()}
-    ids, labels, act = synthetic_batch(1, T, 1234, d_a, "cpu")
     cores = torch.get_num_threads()
-    times = []
-    t_begin = time.perf_counter()
-    step = 0
-    while True:
-        t0 = time.perf_counter()
-        leaf = {k: p.clone().requires_grad_(True) for k, p in params.items()}
-        full = dict(sd)
-        full.update(leaf)
-        loss, _, _ = R.forward(full, rc, ids, labels, act, [domain])
-        loss.backward()
-        step += 1
-        R.clip_and_adamw(params, {k: leaf[k].grad for k in names}, m, v, step, 1e-4)
-        times.append(time.perf_counter() - t0)
-        if len(times) >= 4 or time.perf_counter() - t_begin > budget_s:
-            break
-    warm = times[1:] if len(times) > 1 else times
-    med = sorted(warm)[len(warm) // 2]
-    return {"value": T * 256 / med, "unit": "video-tokens/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (plain PyTorch fp32), B=1 T={T} L={cfg.num_layers}, fwd+bwd+clip+AdamW, "
-                      f"median of {len(warm)} warm steps ({med:.2f} s/step)"}
+    med = lambda ts: sorted(ts)[len(ts) // 2]
+    w1, n1 = (1, 1) if quick else (2, 5)
+    t1 = _cpu_train_steps(sd, rc, names, domain, d_a, T, 1, w1, n1)
+    out = {"value": T * 256 / med(t1), "unit": "video-tokens/s", "cores": cores, "kind": "port",
+           "sample": f"CPU oracle (plain PyTorch fp32, {cores} threads), B=1 T={T} L={cfg.num_layers}, fwd+bwd+clip+AdamW, "
+                     f"{w1} warm-up + median of {n1} steps ({med(t1):.2f} s/step)"}
+    if not quick:
+        t4 = _cpu_train_steps(sd, rc, names, domain, d_a, T, 4, 1, 2)
+        out["b4"] = {"value": 4 * T * 256 / med(t4), "unit": "video-tokens/s",
+                     "sample": f"same, B=4, 1 warm-up + median of 2 steps ({med(t4):.2f} s/step)"}
+    return out
 
 
-def mar_bench(args, dev):
+MAR_FLOP_PER_TOKEN = 3.0 * (1.04e8 + 4.94e7)  # trunk 104 MFLOP + diffusion head 49.4 MFLOP per patch token fwd, x3
+
+
+def mar_bench(args, dev, steps=None, warmup=None):
     """BASELINE.json configs[3] on ONE GPU (its 8-GPU form shards samples exactly like the headline config): STMAR (continuous
     VAE latents 32x32x4 -> 256 patch tokens + 64 action tokens per frame, T = 16, diffusion head width 1024 / depth 4), batch 16,
-    forward + backward + clip + AdamW.  Not the headline metric: a measured line for the C4 row."""
-    import time
+    forward + backward + clip + AdamW through `MarTrainer` (the data-parallel step driver; world 1 here)."""
     from hma_amd.config import DiffusionGenieConfig
     from hma_amd.model.st_mar import STMAR
+    from hma_amd.train import MarTrainer
 
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     B, T = (args.batch if args.batch != 32 else 16), args.frames
-    cfg = DiffusionGenieConfig(num_layers=args.layers, num_heads=8, d_model=256, T=T, S=1024, use_mup=True, action_network="concat+modulate",
-                               num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.0, mlp_bias=False,
-                               patch_size=2, vae_embed_dim=4, diffloss_w=1024, diffloss_d=4, num_sampling_steps="100", attn_drop=0.0)
-    m = STMAR(cfg)
-    m.init_action_projectors(["dom0", "dom1"], [14, 7], [[[0.0] * 7, [1.0] * 7]] * 2, cfg.action_network)
+    cfgd = dict(num_layers=args.layers, num_heads=8, d_model=256, T=T, S=1024, use_mup=True, action_network="concat+modulate",
+                num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.0, mlp_bias=False,
+                patch_size=2, vae_embed_dim=4, diffloss_w=1024, diffloss_d=4, num_sampling_steps="100", attn_drop=0.0)
+    m = STMAR(DiffusionGenieConfig(**cfgd))
+    m.init_action_projectors(["dom0", "dom1"], [14, 7], [[[0.0] * 7, [1.0] * 7]] * 2, cfgd["action_network"])
     with torch.no_grad():
         for p_ in m.parameters():
             if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
                 p_.normal_(0, 0.02)
     m = m.to(dev).train()
+    tr = MarTrainer(m, lr=1e-4, warmup_steps=0, device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
     lat = torch.randn(B, T * 1024, 4, device=dev, generator=g) * 0.7
     masked = torch.rand(B, T, 32, 32, device=dev, generator=g) < 0.6
     act = torch.randn(B, T, 14, device=dev, generator=g)
+    kw = dict(input_ids=lat, labels=lat, action_ids=act, domain=["dom0"] * B, masked_tokens_indicator=masked, h=[32] * B, w=[32] * B)
 
-    def step():
-        m.zero_grad()
-        out = m(input_ids=lat, labels=lat, action_ids=act, domain=["dom0"] * B, masked_tokens_indicator=masked, h=[32] * B, w=[32] * B)
-        out.loss.backward()
-        m.optimizer_step(1e-4, "dom0")
-        return out.loss
-
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(1, warmup)):
+        out = tr.step(step_domains=["dom0"], **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        out = tr.step(step_domains=["dom0"], **kw)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({
-        "metric": "patch-tokens/sec (STMAR train step: fwd+bwd+clip+AdamW) HMA-MAR T=16 32x32x4 latents", "value": B * T * 256 / dt,
-        "unit": "patch-tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True,
+    dt = (time.perf_counter() - t0) / steps
+    tokens = B * T * 256
+    res = {
+        "metric": "patch-tokens/sec (STMAR train step: fwd+bwd+clip+AdamW) HMA-MAR T=16 32x32x4 latents", "value": tokens / dt,
+        "unit": "patch-tokens/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"HMA-MAR d256/h8/L{args.layers}, diffusion head 1024x4, synthetic latents T={T} 32x32x4 (+64 action "
                                f"tokens/frame), batch {B}/GPU, eager launches (no hipGraph)", "global_batch": B, "parallelism": "dp1"},
-        "final_loss": float(loss)}), flush=True)
+        "roofline": {"bound": "mfma", "kernel": "whole step (algorithmic FLOPs: trunk 3 x 1.04e8 + diffusion head 3 x 4.94e7 per patch token)",
+                     "achieved": tokens / dt * MAR_FLOP_PER_TOKEN / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": tokens / dt * MAR_FLOP_PER_TOKEN / MFMA_PEAK, "traffic": None},
+        "final_loss": float(out.loss)}
+    if not args.no_cpu_baseline:
+        from oracle import st_maskgit_ref as R
+        from oracle import st_mar_ref as MR
+        rc = R.RefConfig(num_layers=args.layers, num_heads=8, d_model=256, T=T, use_mup=True, qkv_bias=True, mlp_bias=False)
+        keep = lambda k: (".action_projectors." not in k and not k.startswith("action_")) or ".dom0." in k
+        sd = {k: v.detach().to("cpu", copy=True) for k, v in m.state_dict().items() if keep(k)}
+        names = [k for k in sd if not (k.endswith(".mean") or k.endswith(".std")) and not k.startswith("action_diff_losses")]
+        n = T * 256
+        gc = torch.Generator().manual_seed(1)
+        lat1, mk1, act1 = lat[:1].cpu(), masked[:1].cpu(), act[:1].cpu()
+        tt, nz = torch.randint(0, 1000, (n,), generator=gc), torch.randn(n, 16, generator=gc)
+        times = []
+        for it in range(3):
+            t1 = time.perf_counter()
+            leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+            full = dict(sd)
+            full.update(leaf)
+            loss, _ = MR.forward(full, rc, lat1, lat1, act1, ["dom0"], mk1, tt, nz, 2, 32, 32, 4)
+            loss.backward()
+            with torch.no_grad():  # clip + a plain AdamW-shaped pass over every tensor (the update itself is < 1 % of the step)
+                tot = torch.sqrt(sum((leaf[k].grad.double() ** 2).sum() for k in names if leaf[k].grad is not None))
+                for k in names:
+                    if leaf[k].grad is not None:
+                        sd[k].add_(leaf[k].grad * min(1.0, 1.0 / (float(tot) + 1e-6)), alpha=-1e-4)
+            if it >= 1:
+                times.append(time.perf_counter() - t1)
+        med = sorted(times)[len(times) // 2]
+        res["cpu_baseline"] = {"value": n / med, "unit": "patch-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"CPU oracle (oracle/st_mar_ref.py, fp32), B=1 T={T} L={args.layers}, fwd+bwd+clip+update, "
+                                         f"1 warm-up + median of 2 steps ({med:.2f} s/step)"}
+    del tr, m
+    torch.cuda.empty_cache()
+    return res
 
 
-def decode_bench(args, dev):
+def decode_bench(args, dev, steps=None, warmup=None, batch=None):
     """BASELINE.json configs[4]: MaskGIT iterative decode, T = 16, 4 prompt + 12 generated frames, 8 iterations,
-    batch 64 -> generated frames/s (replicas only: no exchange step).  `--steps` rollouts are timed."""
+    batch 64 -> generated frames/s (replicas only: no exchange step).  `steps` rollouts are timed."""
     from hma_amd.model import STMaskGIT  # noqa: F401
 
+    class _A:  # (the rollout count of this leg is its own: a rollout is ~1 s)
+        pass
+    a2 = _A()
+    a2.__dict__.update(vars(args))
+    a2.steps = args.steps if steps is None else steps
+    a2.warmup = args.warmup if warmup is None else warmup
+    a2.batch = args.batch if batch is None else batch
+    args = a2
     B, T, P, iters = args.batch, args.frames, 4, 8
     model, domains, d_actions = build_model(args.domains, T, args.layers)
     model = model.to(dev).eval()
@@ -199,6 +266,7 @@ def decode_bench(args, dev):
     assert int((out == 262144).sum()) == 0
     frames = B * (T - P)
     flops_min = 2.97e12 * B * (args.layers / 32.0)  # minimal algorithmic count with frame-causal reuse, SURVEY.md 8d
+    flops_ref = 4.07e13 * B * (args.layers / 32.0)  # what the reference computes: a full-window forward per iteration
     res = {
         "metric": "generated frames/sec (MaskGIT iterative decode, autoregressive rollout) HMA-base T=16 16x16",
         "value": frames / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -207,8 +275,9 @@ def decode_bench(args, dev):
         "config": {"workload": f"HMA-base-disc L{args.layers}, prompt {P} + {T - P} generated frames, {iters} MaskGIT iterations, "
                                f"batch {B}, per-layer temporal K/V cache (one 320-row frame per pass)", "global_batch": B,
                    "parallelism": "dp1"},
-        "roofline": {"bound": "mfma", "kernel": "whole rollout (minimal algorithmic FLOPs)", "achieved": flops_min / dt / 1e12,
-                     "peak": 2500.0, "unit": "TFLOP/s", "frac": flops_min / dt / 2.5e15, "traffic": None},
+        "roofline": {"bound": "mfma", "kernel": "whole rollout (minimal algorithmic FLOPs, frame-causal reuse)",
+                     "achieved": flops_min / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops_min / dt / 2.5e15,
+                     "traffic": None, "reference_equivalent_tflops": flops_ref / dt / 1e12},
     }
     if not args.no_cpu_baseline:
         from oracle import st_maskgit_ref as R
@@ -219,11 +288,14 @@ def decode_bench(args, dev):
         p1 = torch.full((1, T, 16, 16), 262144, dtype=torch.long)
         p1[:, :P] = prompt[:1].cpu().reshape(1, P, 16, 16)
         t1 = time.perf_counter()
-        R.maskgit_generate(sd, rc, p1, P, 2, 0.0, "greedy", acts[:1].cpu(), [dom])
+        R.maskgit_generate(sd, rc, p1, P, iters, 0.0, "greedy", acts[:1].cpu(), [dom])
         el = time.perf_counter() - t1
-        res["cpu_baseline"] = {"value": 1.0 / (el * iters / 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"CPU oracle, B=1, one frame, 2 of {iters} MaskGIT iterations timed ({el:.1f} s) and scaled"}
-    print(json.dumps(res), flush=True)
+        res["cpu_baseline"] = {"value": 1.0 / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"CPU oracle (full-window recompute like the reference), B=1, one frame, {iters} MaskGIT "
+                                         f"iterations ({el:.1f} s)"}
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -237,7 +309,9 @@ def main():
     ap.add_argument("--domains", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--mode", choices=["train", "decode", "mar"], default="train")
+    ap.add_argument("--mode", choices=["all", "train", "decode", "mar"], default="all",
+                    help="all (default): the train line, plus the decode and mar sub-objects when --gpus 1")
+    ap.add_argument("--quick-cpu", action="store_true", help="one warm-up + one timed CPU-oracle step instead of the BASELINE.md protocol")
     ap.add_argument("--unfused-mlp", action="store_true",
                     help="measurement only: train with the unfused MLP GEMMs (fc1 / fc2 / dfc2 / dfc1 + LayerNorm kernels) instead of "
                          "the fused block (hma_mlp_fwd / hma_mlp_bwd)")
@@ -266,11 +340,11 @@ def main():
 
     if args.mode == "decode":
         if rank == 0:
-            decode_bench(args, dev)
+            print(json.dumps(decode_bench(args, dev, batch=64 if args.batch == 32 else args.batch)), flush=True)
         return
     if args.mode == "mar":
         if rank == 0:
-            mar_bench(args, dev)
+            print(json.dumps(mar_bench(args, dev)), flush=True)
         return
 
     from hma_amd.engine import LaunchTimer
@@ -293,7 +367,8 @@ def main():
     def one(k):
         di = mine[k]
         ids, labels, act = batches[di]
-        return trainer.step(ids, labels, act, [domains[di]] * B)
+        # every rank knows the whole draw sequence (one shared sampler): the step's domain set needs no collective
+        return trainer.step(ids, labels, act, [domains[di]] * B, step_domains=[domains[j] for j in seq[k * world:(k + 1) * world]])
 
     # untimed preparation: every (shape, domain) pair of the schedule is run until its launch plan is captured
     # as a hipGraph (N = 1 path), so the timed steps replay graphs only -- the analogue of a compiler warm-up
@@ -305,7 +380,7 @@ def main():
             ids, labels, act = batches[mine[k]]
             if world == 1 and not first:
                 continue
-            trainer.step(ids, labels, act, [domains[mine[k]]] * B)
+            trainer.step(ids, labels, act, [domains[mine[k]]] * B, step_domains=[domains[j] for j in seq[k * world:(k + 1) * world]])
             prepare_steps += 1
     for k in range(args.warmup):
         ws = one(k)
@@ -325,7 +400,7 @@ def main():
     if not args.no_kernel_timing:
         # per-launch HIP events need eager launches: an instrumented pass of the same steps right after the timed
         # region (the timed region itself replays hipGraphs on the N = 1 path)
-        eng.timer = LaunchTimer(["hma_gemm_nt"])
+        eng.timer = LaunchTimer(FAMILIES)
         for k in range(args.warmup, min(total, args.warmup + 3)):
             one(k)
         torch.cuda.synchronize()
@@ -356,26 +431,42 @@ def main():
             "final_loss": loss,
         }
         if timer is not None:
-            s = timer.summary().get("hma_gemm_nt")
-            if s:
-                ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
-                traffic = pmc_traffic_per_launch()
-                avg_s = 1e-3 * s["ms"] / s["launches"]
-                out["roofline"] = {"bound": "mfma", "kernel": "hma_gemm_nt (gemm_nt_sw_kernel at K = 256, gemm_nt_ring_kernel at K = 768 / 1024)",
-                                   "achieved": ach, "peak": 2500.0,
-                                   "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": traffic,
-                                   # the same launches against the HBM roofline (they are output-dominated streams at K = 256)
+            summ = timer.summary()
+            step_ms = 1e3 * dt / args.steps
+            fams = {}
+            for name, sm in summ.items():
+                if sm["ms"] <= 0:
+                    continue
+                ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
+                fams[name] = {"achieved": ach, "frac": ach / 2500.0, "launches": sm["launches"], "avg_launch_us": 1e3 * sm["ms"] / sm["launches"],
+                              "flops_per_launch": sm["flops"] / sm["launches"], "share_of_step_time": (sm["ms"] / inst_steps) / step_ms}
+            # `roofline` = the family with the largest share of the step
+            dom_name = max(fams, key=lambda k: fams[k]["share_of_step_time"]) if fams else None
+            if dom_name:
+                d0 = fams[dom_name]
+                traffic = pmc_traffic_per_launch({"hma_gemm_nt": "gemm_nt", "hma_mlp_bwd": "mlp_bwd", "hma_mlp_fwd": "mlp_fwd",
+                                                  "hma_gemm_tn_pair": "gemm_tn"}.get(dom_name, dom_name))
+                avg_s = 1e-6 * d0["avg_launch_us"]
+                out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s",
+                                   "frac": d0["frac"], "traffic": traffic,
                                    "hbm": None if not traffic else {"achieved": traffic / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                                                                     "frac": traffic / avg_s / 8e12},
-                                   "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/pmc_hbm_r1.json",
-                                   "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
-                                   "flops_per_launch": s["flops"] / s["launches"],
-                                   "share_of_step_time": (s["ms"] / inst_steps) / (1e3 * dt / args.steps),
-                                   "measured": f"HIP events around every hma_gemm_nt launch of {inst_steps} eager steps run "
-                                               "right after the timed region"}
+                                   "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes (profiles/pmc_hbm_*.json)",
+                                   "launches": d0["launches"], "avg_launch_us": d0["avg_launch_us"], "flops_per_launch": d0["flops_per_launch"],
+                                   "share_of_step_time": d0["share_of_step_time"],
+                                   "measured": f"HIP events around every launch of the MFMA kernel families in {inst_steps} eager steps run "
+                                               "right after the timed region (algorithmic FLOPs: recomputation is not counted)",
+                                   "families": fams}
             out["config"]["prepare_steps"] = prepare_steps
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, domains[mine[0]], d_actions[mine[0]], T)
+            out["cpu_baseline"] = cpu_baseline(model, domains[mine[0]], d_actions[mine[0]], T, quick=args.quick_cpu)
+        if world == 1 and args.mode == "all" and args.layers == 32:
+            # the other single-GPU BASELINE configs, measured by the same command (sub-objects of the one line)
+            del trainer, eng, batches
+            model = None
+            torch.cuda.empty_cache()
+            out["decode"] = decode_bench(args, dev, steps=2, warmup=1, batch=64)
+            out["mar"] = mar_bench(args, dev, steps=5, warmup=2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

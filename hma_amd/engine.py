@@ -393,7 +393,7 @@ class STEngine:
             pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
         pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
                    epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
-        pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale)
+        pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale, flops=4.0 * Fr * SA * SA * 256)
         # (the LayerNorm / modulate prologue of the NEXT sub-block is fused into this projection's epilogue)
         fuse = dict(ln_xhat=b["xhm"], ln_rstd=b["rstdm"], ln_eps=1e-6, ln_ss=b["ss"], ln_xm=b["xm"], ln_rows_per_frame=SA) if use_mod else {}
         pl.gemm_nt(A=b["o_s"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
@@ -407,7 +407,7 @@ class STEngine:
         if kv is None:
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
                        K=256, epi=EPI_BF16, Cp=b["qkv_t"], ldc=768, bias=qb("temporal_attn"))
-            pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale)
+            pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256)
         else:
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
                        K=256, epi=EPI_BF16, Cp=kv["cache"] + kv["row_off"] * 768 * 2, ldc=768, c_group=kv["c_group"],
@@ -588,7 +588,7 @@ class STEngine:
                        dxb)
             # ---- temporal attention
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale)
+            pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256)
             # projection and qkv weight gradients in one launch (dxb is not updated before the dqkv dgrad below)
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
@@ -607,7 +607,8 @@ class STEngine:
                 pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
             # ---- spatial attention
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale)
+            pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale,
+                   flops=10.0 * Fr * SA * SA * 256)  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
             # projection and qkv weight gradients in one launch (dxb is next updated by the LayerNorm backward below)
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
