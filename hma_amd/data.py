@@ -222,3 +222,119 @@ def get_maskgit_collator(config: GenieConfig, device: Optional[str] = "cuda") ->
 
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------ continuous features (MAR)
+SVD_SCALE = 0.18215  # latents are stored unscaled and multiplied on load (hma/data.py:16, 416)
+
+
+def write_feature_dataset(data_dir, latents: np.ndarray, segment_ids: np.ndarray, actions: Optional[np.ndarray] = None,
+                          name: str = "synthetic", hz: int = 1, **extra_metadata) -> Path:
+    """Writes `video.bin` (float16 [n, c, h, w] VAE latents), `segment_ids.bin`, `actions/actions.bin`, `metadata.json` in the
+    layout `RawFeatureDataset` (hma/data.py:298-376) reads."""
+    data_dir = Path(data_dir)
+    data_dir.mkdir(parents=True, exist_ok=True)
+    latents = np.ascontiguousarray(latents)
+    assert latents.ndim == 4 and len(segment_ids) == len(latents)
+    latents.tofile(data_dir / "video.bin")
+    np.asarray(segment_ids, dtype=np.int32).tofile(data_dir / "segment_ids.bin")
+    meta = {"token_dtype": str(latents.dtype), "h": int(latents.shape[2]), "w": int(latents.shape[3]), "latent_channels": int(latents.shape[1]),
+            "hz": hz, "num_images": int(len(latents)), "name": name, "quantized": False}
+    if actions is not None:
+        assert len(actions) == len(latents)
+        (data_dir / "actions").mkdir(exist_ok=True)
+        np.asarray(actions, dtype=np.float32).tofile(data_dir / "actions" / "actions.bin")
+        meta["action_dim"] = int(np.asarray(actions).shape[-1])
+    meta.update(extra_metadata)
+    with open(data_dir / "metadata.json", "w") as f:
+        json.dump(meta, f)
+    return data_dir
+
+
+class RawFeatureDataset(TorchDataset):
+    """Sliding windows over a memory-mapped file of continuous VAE latents [n, c, h, w] (hma/data.py:298-435): an item is the
+    window's frames as (T*h*w, c) float32 rows scaled by SVD_SCALE, with the stride's actions concatenated per frame."""
+
+    def __init__(self, data_dir, window_size, stride=1, filter_interrupts=True, filter_overlaps=False, use_actions=False,
+                 max_traj_num=1000000, compute_stride_from_freq_table=True, natural_hz=2, datio_noise_ratio=0.0,
+                 use_raw_image_as_latent=False, domain=None):
+        data_dir = Path(data_dir)
+        with open(data_dir / "metadata.json") as f:
+            self.metadata = json.load(f)
+        n, h, w = self.metadata["num_images"], self.metadata["h"], self.metadata["w"]
+        c = self.metadata.get("latent_channels", 4)
+        self.data = np.memmap(data_dir / "video.bin", mode="r", shape=(n, c, h, w),
+                              dtype=np.dtype(self.metadata.get("token_dtype", "float16")))
+        self.window_size, self.datio_noise_ratio = window_size, datio_noise_ratio
+        self.name = (domain if domain is not None else self.metadata["name"]).replace("_noquant", "")
+        self.stride = max(DATA_FREQ_TABLE.get(self.name, 1) // natural_hz, 1) if compute_stride_from_freq_table else stride
+        self.n_action = self.metadata.get("action_dim", 1) * self.stride
+        if use_actions:
+            parts = [np.memmap(p, dtype=np.float32, mode="r").reshape(n, -1) for p in sorted((data_dir / "actions").iterdir())]
+            self.actions, self.action_stat = normalize_actions(np.concatenate(parts, axis=-1))
+        seg_path = data_dir / "segment_ids.bin"
+        if os.path.isfile(seg_path):
+            self.segment_ids = np.memmap(seg_path, dtype=np.int32, mode="r", shape=(n,))
+        else:
+            self.segment_ids = None
+            if filter_interrupts:
+                raise NotImplementedError("Cannot filter interrupted sequences without segment ids.")
+        self.video_len = (window_size - 1) * self.stride
+        starts = np.arange(max(n - self.video_len - self.stride, 0))
+        if filter_interrupts and len(starts):
+            seg = np.asarray(self.segment_ids)
+            starts = starts[seg[starts] == seg[starts + self.video_len]]
+        self.valid_start_inds = starts[:max_traj_num].tolist()  # (this class caps the number of WINDOWS, :374-375)
+        if filter_overlaps:
+            kept: List[int] = []
+            for s in self.valid_start_inds:
+                clash = {s - i * self.stride for i in range(1, window_size)}
+                if not any(e in clash for e in kept[-window_size * self.stride:]):
+                    kept.append(s)
+            self.valid_start_inds = kept
+
+    def __len__(self):
+        return len(self.valid_start_inds)
+
+    def __getitem__(self, idx):
+        s = self.valid_start_inds[idx]
+        x = torch.from_numpy(np.array(self.data[s: s + self.video_len + 1: self.stride])).float() * SVD_SCALE   # (T, c, h, w)
+        x = x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])                                                          # (t h w) c
+        item = {"input_ids": x, "labels": x, "attention_mask": torch.ones_like(x), "h": self.metadata["h"], "w": self.metadata["w"],
+                "c": self.metadata["latent_channels"]}
+        if hasattr(self, "actions"):
+            a = self.actions[s: s + self.video_len + self.stride].reshape(self.window_size, -1)
+            item["action_ids"] = torch.from_numpy(a.astype(np.float32))
+        item["domain"] = self.name
+        return item
+
+
+def get_maskgit_collator_feature(config, device: Optional[str] = "cuda") -> Callable:
+    """collate_fn(features) -> {"input_ids", "labels" (B, T*h*w, c) float32, "masked_tokens_indicator" (B, T, h, w),
+    "action_ids", "domain", "h", "w"} on `device` (hma/data.py:103-157).  The latents themselves are not changed here (STMAR
+    substitutes its mask latent, st_mar.py:245); only the indicator is drawn.  Draw order -- it defines the result for a given
+    RNG state: python random() [non-MLM?], randint(num_prompt_frames, T-1), then until something is masked
+    rand(B, T-fmf, 1, 1) and rand(B, T-fmf, h, w)."""
+
+    def collate_fn(features) -> dict:
+        h, w = features[0]["h"], features[0]["w"]
+        x = torch.stack([ex["input_ids"] for ex in features])
+        B, T = len(features), config.T
+        ind = torch.zeros((B, T, h, w), dtype=torch.long)
+        if config.dataloader_apply_mask:
+            fmf = random.randint(config.num_prompt_frames, T - 1) if random.random() < config.non_mlm_ratio else 1
+            mask = torch.zeros(1, dtype=torch.bool)
+            while not bool(mask.any()):  # "we could get unlucky and mask no tokens"
+                rate = torch.rand(B, T - fmf, 1, 1) * (1 - config.dataloader_mask_ratio_min) + config.dataloader_mask_ratio_min
+                mask = torch.rand((B, T - fmf, h, w), dtype=torch.float) < cosine_schedule(rate)
+            ind = torch.cat([torch.zeros((B, fmf, h, w), dtype=mask.dtype), mask], dim=1)
+        to = (lambda t: t.to(device, non_blocking=True)) if device is not None else (lambda t: t)
+        batch = {"input_ids": to(x), "labels": to(x.clone()), "masked_tokens_indicator": to(ind)}
+        if "action_ids" in features[0]:
+            batch["action_ids"] = to(torch.stack([ex["action_ids"] for ex in features]))
+        batch["domain"] = [ex["domain"] for ex in features]
+        batch["h"] = [ex["h"] for ex in features]
+        batch["w"] = [ex["w"] for ex in features]
+        return batch
+
+    return collate_fn

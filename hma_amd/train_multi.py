@@ -24,11 +24,11 @@ import torch
 import torch.distributed as dist
 from torch.utils.data import ConcatDataset
 
-from .config import GenieConfig
-from .data import RawTokenDataset, get_maskgit_collator
+from .config import DiffusionGenieConfig, GenieConfig
+from .data import RawFeatureDataset, RawTokenDataset, get_maskgit_collator, get_maskgit_collator_feature
 from .data_sampler import MultiTaskBatchSampler
 from .model.st_mask_git import STMaskGIT
-from .train import Trainer
+from .train import MarTrainer, Trainer
 
 
 def parse_args(argv=None):
@@ -55,6 +55,8 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--sampling_temperature", type=float, default=3.0, help="Dataset-mix temperature (train_multi.py:931).")
     p.add_argument("--log_every", type=int, default=10)
+    p.add_argument("--model_type", type=str, default="discrete", choices=["discrete", "continuous"],
+                   help="discrete: STMaskGIT on VQ tokens; continuous: STMAR on VAE latents with a diffusion head (train_multi.py:756-775)")
     for ignored in ("--no_compile", "--mu_transfer", "--pin_memory", "--overfit_first_batch"):
         p.add_argument(ignored, action="store_true", help="accepted for script compatibility; no effect")
     for ignored in ("--report_to", "--run_name", "--lr_scheduler_type", "--val_data_dir", "--domain", "--num_workers"):
@@ -62,11 +64,12 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
-def build_datasets(args) -> List[RawTokenDataset]:
+def build_datasets(args) -> list:
     kw = dict(window_size=args.window_size, filter_overlaps=args.filter_overlaps, use_actions=True)
     if args.stride is not None:
         kw.update(stride=args.stride, compute_stride_from_freq_table=False)
-    return [RawTokenDataset(d, **kw) for d in args.train_data_dir]
+    cls = RawTokenDataset if args.model_type == "discrete" else RawFeatureDataset
+    return [cls(d, **kw) for d in args.train_data_dir]
 
 
 def main(argv=None):
@@ -83,23 +86,30 @@ def main(argv=None):
 
     datasets = build_datasets(args)
     domains = [d.name for d in datasets]
-    config = GenieConfig.from_pretrained(args.genie_config)
+    continuous = args.model_type == "continuous"
+    config = (DiffusionGenieConfig if continuous else GenieConfig).from_pretrained(args.genie_config)
     config.T = args.window_size
     config.use_mup = True  # train_multi.py forces the muP attention scale (8 / head_dim)
-    if args.resume_from_checkpoint:
-        model = STMaskGIT.from_pretrained(args.resume_from_checkpoint)
+    if continuous:
+        from .model.st_mar import STMAR as model_cls
+        config.S = datasets[0].metadata["h"] * datasets[0].metadata["w"]
+        config.vae_embed_dim = datasets[0].metadata["latent_channels"]
     else:
-        model = STMaskGIT(config)
+        model_cls = STMaskGIT
+    if args.resume_from_checkpoint:
+        model = model_cls.from_pretrained(args.resume_from_checkpoint)
+    else:
+        model = model_cls(config)
         model.init_action_projectors(domains, [d.n_action for d in datasets], [d.action_stat for d in datasets], config.action_network)
     model = model.to("cuda")
     accum = args.gradient_accumulation_steps
     # the reference scales the base rate with the effective batch (train_multi.py:902-904)
     lr = args.learning_rate * min(max(1, args.per_device_train_batch_size * accum * world / 64), 8)
-    trainer = Trainer(model, lr=lr, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps,
-                      weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, warmup_steps=args.num_warmup_steps,
-                      grad_accum=accum)
+    trainer = (MarTrainer if continuous else Trainer)(
+        model, lr=lr, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps, weight_decay=args.weight_decay,
+        max_grad_norm=args.max_grad_norm, warmup_steps=args.num_warmup_steps, grad_accum=accum)
     start_step = 0
-    if args.resume_from_checkpoint and os.path.exists(os.path.join(args.resume_from_checkpoint, Trainer.STATE_FILE)):
+    if not continuous and args.resume_from_checkpoint and os.path.exists(os.path.join(args.resume_from_checkpoint, Trainer.STATE_FILE)):
         trainer.load_state(args.resume_from_checkpoint)  # Adam moments + step counts (train_multi.py:484-533)
         start_step = trainer.completed
 
@@ -109,11 +119,12 @@ def main(argv=None):
                                     seed=args.seed)  # defaults num_replicas=1, rank=0: every process draws the same sequence
     bounds = np.cumsum(sizes)
     domain_of = lambda indices: domains[int(np.searchsorted(bounds, indices[0], side="right"))]  # one domain per batch
-    collate = get_maskgit_collator(config)
+    collate = get_maskgit_collator_feature(config) if continuous else get_maskgit_collator(config)
     group = world * accum                                   # batches consumed by one optimizer step, all ranks together
     steps_per_epoch = max(len(sampler) // group, 1)         # (every rank gets the same number of batches per epoch)
     max_steps = args.max_train_steps or args.num_train_epochs * steps_per_epoch
     out_dir = Path(args.output_dir)
+    save = (lambda d: model.save_pretrained(d)) if continuous else trainer.save_state
     step, t0, tokens = start_step, time.time(), 0
     # resume: skip what the finished steps consumed (train_multi.py:519-528, 547-549) instead of replaying epoch 0
     first_epoch, skip_steps = divmod(start_step, steps_per_epoch)
@@ -132,23 +143,26 @@ def main(argv=None):
             for j in range(accum):
                 indices = window[j * world + rank]
                 batch = collate([concat[i] for i in indices])
-                ws = trainer.micro_step(batch["input_ids"], batch["labels"], batch.get("action_ids"), batch["domain"],
-                                        step_domains=step_domains)
-                tokens += batch["input_ids"].numel()
+                if continuous:
+                    ws = trainer.micro_step(step_domains=step_domains, **batch)
+                    tokens += batch["input_ids"].shape[0] * batch["input_ids"].shape[1]
+                else:
+                    ws = trainer.micro_step(batch["input_ids"], batch["labels"], batch.get("action_ids"), batch["domain"],
+                                            step_domains=step_domains)
+                    tokens += batch["input_ids"].numel()
             trainer.optimizer_step()
             step += 1
             if rank == 0 and (step % args.log_every == 0 or step == max_steps):
-                _, acc = trainer.loss_and_acc(ws)
+                acc = 0.0 if continuous else float(trainer.loss_and_acc(ws)[1])
                 dt = time.time() - t0
-                print(json.dumps({"step": step, "loss": float(trainer.reduced_loss()), "acc": float(acc),
-                                  "domain": batch["domain"][0], "skipped": trainer.skipped_last_step(),
-                                  "tokens_per_s_per_gpu": tokens / dt}), flush=True)
+                print(json.dumps({"step": step, "loss": float(trainer.reduced_loss()), "acc": acc, "domain": batch["domain"][0],
+                                  "skipped": bool(trainer.last_loss_info[2].item() > 0), "tokens_per_s_per_gpu": tokens / dt}), flush=True)
             if rank == 0 and args.checkpointing_steps and step % args.checkpointing_steps == 0:
-                trainer.save_state(out_dir / f"step_{step}")
+                save(out_dir / f"step_{step}")
             if step >= max_steps:
                 break
     if rank == 0:
-        trainer.save_state(out_dir / f"step_{step}")
+        save(out_dir / f"step_{step}")
     if world > 1:
         dist.barrier()
     return step

@@ -125,3 +125,67 @@ def test_batch_sampler_matches_reference(tag):
 def test_sampler_rank_validation():
     with pytest.raises(ValueError):
         MultiTaskBatchSampler([10, 10], 2, 1.0, num_replicas=2, rank=2)
+
+
+# ------------------------------------------------------------------------------------------------ continuous features (MAR)
+def test_feature_collator_and_dataset_match_reference(tmp_path):
+    """G15 (tests/golden/make_golden_feature.py): `get_maskgit_collator_feature` draws the reference's indicator for the same
+    RNG state (hma/data.py:103-157), and `RawFeatureDataset` yields the reference's windows / items from files written by
+    `write_feature_dataset` (hma/data.py:298-435)."""
+    import json
+    import random
+
+    import numpy as np
+    from safetensors.torch import load_file
+
+    from hma_amd import data as D
+    from hma_amd.config import DiffusionGenieConfig
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = load_file(os.path.join(here, "g15_feature.safetensors"))
+    meta = json.load(open(os.path.join(here, "g15_feature.json")))
+    base = dict(num_layers=2, num_heads=8, d_model=256, T=6, S=64)
+    for tag, extra in (("mlm", {}), ("nonmlm", {}), ("nomask", dict(dataloader_apply_mask=False))):
+        m = meta[tag]
+        cfg = DiffusionGenieConfig(**base, **extra)
+        feats = [{"input_ids": g[f"{tag}.features"][b], "h": m["h"], "w": m["w"], "domain": "d", "action_ids": torch.zeros(cfg.T, 3)}
+                 for b in range(m["B"])]
+        torch.manual_seed(m["seed"])
+        random.seed(m["seed"])
+        batch = D.get_maskgit_collator_feature(cfg, device=None)(feats)
+        assert torch.equal(batch["masked_tokens_indicator"].to(torch.uint8), g[f"{tag}.indicator"]), tag
+        assert torch.equal(batch["input_ids"], g[f"{tag}.features"]) and torch.equal(batch["labels"], batch["input_ids"])
+        assert batch["input_ids"].shape == (m["B"], cfg.T * m["h"] * m["w"], 4)
+    lat = g["ds.latents"].numpy().astype(np.float16)
+    old = dict(D.DATA_FREQ_TABLE)
+    D.DATA_FREQ_TABLE["dom_fast"] = 6  # (the fixture's table entry)
+    try:
+        for name in ("dom_slow", "dom_fast"):
+            D.write_feature_dataset(tmp_path / name, lat, g["ds.seg"].numpy(), g["ds.actions"].numpy(), name=name)
+            for tag, kw in (("plain", {}), ("overlaps", dict(filter_overlaps=True)), ("cap", dict(max_traj_num=7))):
+                ds = D.RawFeatureDataset(tmp_path / name, window_size=3, use_actions=True, **kw)
+                rec = meta["datasets"][f"{name}.{tag}"]
+                assert ds.stride == rec["stride"] and ds.n_action == rec["n_action"] and ds.valid_start_inds == rec["starts"], (name, tag)
+                item = ds[len(ds) // 2]
+                assert torch.equal(item["input_ids"], g[f"ds.{name}.{tag}.input_ids"]) and item["domain"] == rec["domain"]
+                assert torch.equal(item["action_ids"], g[f"ds.{name}.{tag}.action_ids"]) and item["c"] == rec["c"]
+    finally:
+        D.DATA_FREQ_TABLE.clear()
+        D.DATA_FREQ_TABLE.update(old)
+
+
+def test_named_openx_domain_uses_the_reference_frequency(tmp_path):
+    """ADVICE r1: the table ships populated -- a real OpenX name gets stride = hz // 2 and n_action = action_dim * stride
+    (datasets/encode_openx_dataset.py:51-109, hma/data.py:204-208) without any test-side patching."""
+    import numpy as np
+
+    from hma_amd import data as D
+
+    assert D.DATA_FREQ_TABLE["austin_sailor_dataset_converted_externally_to_rlds"] == 20 and len(D.DATA_FREQ_TABLE) == 54
+    n = 80
+    tokens = np.zeros((n, 4, 4), dtype=np.uint32)
+    D.write_token_dataset(tmp_path / "s", tokens, np.zeros(n, dtype=np.int32), np.zeros((n, 7), dtype=np.float32),
+                          name="austin_sailor_dataset_converted_externally_to_rlds")
+    ds = D.RawTokenDataset(tmp_path / "s", window_size=3, use_actions=True)
+    assert ds.stride == 10 and ds.n_action == 70
+    assert ds[0]["action_ids"].shape == (3, 70)
