@@ -127,6 +127,50 @@ def lr_at(step: int, base_lr: float, warmup_steps: int) -> float:
     return base_lr * min(1.0, float(step) / float(warmup_steps))  # LambdaLR: lr of update k + 1 = base * k / warmup
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Accelerate-layout optimizer / scheduler files (SURVEY (f) row 4; hma/train_multi.py:310-321 `accelerator.save_state`,
+# :484-533 `accelerator.load_state`, hma/generate.py:80-84 reads scheduler.bin).  `optimizer.bin` is
+# torch.save(optimizer.state_dict()) of the AdamW the reference builds (train_multi.py:907-922): two parameter groups --
+# [names without "bias" / "layer_norm.weight"], [the rest] -- each in named_parameters() order, state keyed by the running
+# index over both groups, only for parameters that have been stepped.  `scheduler.bin` is the LambdaLR state dict; Accelerate
+# steps the scheduler once per process per optimizer step, so its counters run at `world` times the optimizer-step count.
+NO_DECAY_SUBSTRINGS = ("bias", "layer_norm.weight")
+
+
+def reference_param_groups(names: Sequence[str]) -> Tuple[List[str], List[str]]:
+    """(decayed, un-decayed) parameter names in the order the reference hands them to AdamW (train_multi.py:907-918)."""
+    nd = lambda n: any(k in n for k in NO_DECAY_SUBSTRINGS)
+    return [n for n in names if not nd(n)], [n for n in names if nd(n)]
+
+
+def build_optimizer_state_dict(names: Sequence[str], moments, steps, lr: float, base_lr: float, betas, eps: float,
+                               weight_decay: float) -> dict:
+    """`optimizer.state_dict()` of the reference's AdamW.  `moments(name) -> (exp_avg, exp_avg_sq)` CPU tensors in the
+    parameter's shape; `steps(name) -> int` updates applied to that parameter (0: never stepped -> no state entry)."""
+    g0, g1 = reference_param_groups(names)
+    template = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=base_lr, betas=tuple(betas), eps=eps,
+                                 weight_decay=weight_decay).state_dict()["param_groups"][0]
+    groups, state, idx = [], {}, 0
+    for members, wd in ((g0, weight_decay), (g1, 0.0)):
+        ids = []
+        for n in members:
+            k = int(steps(n))
+            if k > 0:
+                m, v = moments(n)
+                state[idx] = {"step": torch.tensor(float(k)), "exp_avg": m, "exp_avg_sq": v}
+            ids.append(idx)
+            idx += 1
+        groups.append(dict(template, lr=lr, initial_lr=base_lr, weight_decay=wd, params=ids))
+    return {"state": state, "param_groups": groups}
+
+
+def build_scheduler_state_dict(completed: int, world: int, lr: float, base_lr: float) -> dict:
+    """LambdaLR.state_dict() after `completed` optimizer steps under Accelerate (`world` scheduler steps per optimizer step)."""
+    n = completed * world
+    return {"base_lrs": [base_lr, base_lr], "last_epoch": n, "_step_count": n + 1, "_get_lr_called_within_step": False,
+            "_last_lr": [lr, lr], "lr_lambdas": [None, None], "verbose": False}
+
+
 class Trainer:
     """Fused train step on one GPU of a data-parallel job (no autograd, no per-tensor optimizer)."""
 
@@ -322,11 +366,26 @@ class Trainer:
     # ------------------------------------------------------------------ resume (SURVEY (f) row 4)
     STATE_FILE = "trainer_state.safetensors"
 
+    def _range_steps(self) -> Dict[str, int]:
+        """updates applied per parameter name (its flat range's device counter)."""
+        eng = self.engine
+        dense, doms = eng.opt_step, eng.dom_steps
+        out = {}
+        for name, e in eng.layout.entries.items():
+            if e.region == "frozen":
+                out[name] = 0
+            elif e.region.startswith("dom:"):
+                out[name] = doms.get(e.region[4:], 0)
+            else:
+                out[name] = dense
+        return out
+
     def save_state(self, directory) -> None:
-        """Model (`config.json` + `model.safetensors`, as `save_pretrained`) plus the optimizer state needed to resume:
-        Adam moments per named parameter, the optimizer-step counts (global and per action domain) -- the role of
-        Accelerate's `optimizer.bin` / `scheduler.bin` (hma/train_multi.py:310-321; the lr schedule is a pure function
-        of the step count here).  Own format: torch's per-parameter AdamW state dict is not reproduced."""
+        """Everything needed to resume, in the layout `accelerator.save_state` leaves (hma/train_multi.py:310-321): the model
+        (`config.json` + `model.safetensors`), `optimizer.bin` (= torch AdamW's state dict for the reference's two parameter
+        groups: per-parameter step / exp_avg / exp_avg_sq for every parameter that has been stepped) and `scheduler.bin`
+        (LambdaLR counters) -- the reference's `accelerator.load_state` and `generate.py:80-84` read them as their own.
+        `trainer_state.safetensors` keeps the same moments in this trainer's flat order (kept for older checkpoints' readers)."""
         import json
         import os
         from safetensors.torch import save_file
@@ -340,13 +399,52 @@ class Trainer:
         meta = {"completed": str(self.completed), "opt_step": str(eng.opt_step), "dom_steps": json.dumps(eng.dom_steps)}
         tensors["_"] = torch.zeros(1)
         save_file(tensors, os.path.join(str(directory), self.STATE_FILE), metadata=meta)
+        names = [n for n, _ in self.model.named_parameters()]
+        steps = self._range_steps() if eng.M is not None else {n: 0 for n in names}
+        shape = lambda n: eng.layout.entries[n].shape
+        moments = lambda n: (tensors[f"m.{n}"].view(shape(n)), tensors[f"v.{n}"].view(shape(n)))
+        lr_now = lr_at(self.completed, self.lr, self.warmup)
+        torch.save(build_optimizer_state_dict(names, moments, lambda n: steps[n], lr_now, self.lr, self.betas, self.eps, self.wd),
+                   os.path.join(str(directory), "optimizer.bin"))
+        torch.save(build_scheduler_state_dict(self.completed, self.reducer.world, lr_now, self.lr),
+                   os.path.join(str(directory), "scheduler.bin"))
 
     def load_state(self, directory) -> None:
-        """Inverse of `save_state` for a Trainer built on a model loaded from the same directory."""
+        """Inverse of `save_state` for a Trainer built on a model loaded from the same directory.  Reads the Accelerate-layout
+        `optimizer.bin` / `scheduler.bin` when present (also a checkpoint the REFERENCE wrote), else `trainer_state.safetensors`."""
         import json
         import os
         from safetensors import safe_open
         eng = self.engine
+        opt_path = os.path.join(str(directory), "optimizer.bin")
+        if os.path.exists(opt_path):
+            sd = torch.load(opt_path, map_location="cpu", weights_only=False)
+            names = [n for n, _ in self.model.named_parameters()]
+            g0, g1 = reference_param_groups(names)
+            order = g0 + g1
+            if [len(g["params"]) for g in sd["param_groups"]] != [len(g0), len(g1)]:
+                raise RuntimeError("optimizer.bin does not have the reference's two parameter groups for this model")
+            if eng.M is None:
+                eng.M, eng.V = torch.zeros_like(eng.P), torch.zeros_like(eng.P)
+            dense, doms = 0, {}
+            for idx, st in sd["state"].items():
+                name = order[int(idx)]
+                e = eng.layout.entries[name]
+                eng.M[e.offset:e.offset + e.numel].copy_(st["exp_avg"].reshape(-1))
+                eng.V[e.offset:e.offset + e.numel].copy_(st["exp_avg_sq"].reshape(-1))
+                k = int(float(st["step"]))
+                if e.region.startswith("dom:"):
+                    doms[e.region[4:]] = max(doms.get(e.region[4:], 0), k)
+                elif e.region != "frozen":
+                    dense = max(dense, k)
+            eng.set_steps(dense, doms)
+            sch_path = os.path.join(str(directory), "scheduler.bin")
+            if os.path.exists(sch_path):
+                sch = torch.load(sch_path, map_location="cpu", weights_only=False)
+                self.completed = int(sch["last_epoch"]) // max(self.reducer.world, 1)
+            else:
+                self.completed = dense
+            return
         with safe_open(os.path.join(str(directory), self.STATE_FILE), framework="pt") as f:
             meta = f.metadata()
             names = set(f.keys())

@@ -127,3 +127,49 @@ def test_sparse_by_domain_allreduce_world2_gloo(lpb):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, lpb, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_accelerate_layout_optimizer_state_loads_into_the_reference_optimizer():
+    """SURVEY (f) row 4: `optimizer.bin` / `scheduler.bin` in the layout accelerator.save_state writes (train_multi.py:310-321).
+    The exported dict must be what torch's AdamW -- built the way the reference builds it (train_multi.py:907-922) -- produces
+    itself: same groups, same indices, state only for stepped parameters; and it must load into that optimizer."""
+    from hma_amd.model import STMaskGIT
+    from hma_amd.train import build_optimizer_state_dict, build_scheduler_state_dict, reference_param_groups
+
+    cfg = GenieConfig(**{**TINY["config"], "num_layers": 1})
+    m = STMaskGIT(cfg)  # (construction is plain nn.Module code: no GPU needed)
+    m.init_action_projectors(TINY["domains"], TINY["d_actions"], TINY["action_stats"], cfg.action_network)
+    named = list(m.named_parameters())
+    no_decay = ["bias", "layer_norm.weight"]
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.05},
+              {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = torch.optim.AdamW(groups, lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(1.0, s / 500))
+    g = torch.Generator().manual_seed(0)
+    stepped = {n for n, _ in named if ".domB." not in n and "action_out" not in n and n != "action_mask_tokens"}
+    for it in range(2):
+        for n, p in named:
+            p.grad = torch.randn(p.shape, generator=g) if n in stepped else None
+        opt.step()
+        sched.step()
+    ref = opt.state_dict()
+    names = [n for n, _ in named]
+    g0, g1 = reference_param_groups(names)
+    order = g0 + g1
+    by_name = {order[i]: st for i, st in ref["state"].items()}
+    ours = build_optimizer_state_dict(names, lambda n: (by_name[n]["exp_avg"], by_name[n]["exp_avg_sq"]),
+                                      lambda n: 2 if n in stepped else 0, sched.get_last_lr()[0], 1e-3, (0.9, 0.95), 1e-8, 0.05)
+    assert [gr["params"] for gr in ours["param_groups"]] == [gr["params"] for gr in ref["param_groups"]]
+    assert set(ours["state"]) == set(ref["state"])
+    for i in ref["state"]:
+        assert float(ours["state"][i]["step"]) == float(ref["state"][i]["step"]) == 2.0
+        assert torch.equal(ours["state"][i]["exp_avg"], ref["state"][i]["exp_avg"])
+    for a, b in zip(ours["param_groups"], ref["param_groups"]):
+        assert set(b) <= set(a), set(b) - set(a)
+        assert all(a[k] == b[k] for k in b if k != "params"), {k: (a[k], b[k]) for k in b if a[k] != b[k]}
+    opt2 = torch.optim.AdamW(groups, lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    opt2.load_state_dict(ours)  # what accelerator.load_state does with optimizer.bin
+    sch = build_scheduler_state_dict(2, 1, sched.get_last_lr()[0], 1e-3)
+    want = sched.state_dict()
+    assert {k: sch[k] for k in ("last_epoch", "_step_count", "base_lrs", "_last_lr")} == {k: want[k] for k in ("last_epoch", "_step_count", "base_lrs", "_last_lr")}
+    torch.optim.lr_scheduler.LambdaLR(opt2, lambda s: min(1.0, s / 500)).load_state_dict(sch)
