@@ -52,6 +52,30 @@ class ModulateLayer(nn.Module):
                 torch.nn.init.xavier_uniform_(m.weight, gain=0.1)
                 nn.init.constant_(m.bias, 0)
 
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+        """linear_out(LN(x) * (1 + scale) + shift), (shift, scale) = adaLN(c) (st_mask_git.py:66-76), inference only; in the
+        model the same arithmetic runs fused inside the trunk plans.  x ((b s), t, d), c (b, T, d)."""
+        from .. import ops
+        from .._lib import EPI_F32, EPI_SILU2
+        shp = x.shape
+        b, t, d = c.shape[0], shp[1], shp[2]
+        s_ = shp[0] // b
+        bf = lambda w: w.detach().to(torch.bfloat16).contiguous()
+        cc = c[:, :t].reshape(b * t, d).float().contiguous()
+        pre = torch.empty(b * t, d, dtype=torch.bfloat16, device=x.device)
+        act = torch.empty_like(pre)
+        ops.linear(cc, bf(self.adaLN_modulation[0].weight), self.adaLN_modulation[0].bias, epi=EPI_SILU2, out=pre, out2=act)
+        ss = ops.linear(act, bf(self.adaLN_modulation[2].weight), self.adaLN_modulation[2].bias, epi=EPI_F32)   # (b t, [shift | scale])
+        # rows in (b, t, s) order: one (shift, scale) per run of s rows
+        xr = x.reshape(b, s_, t, d).permute(0, 2, 1, 3).reshape(b * t * s_, d).float().contiguous()
+        xhat = torch.empty(xr.shape, dtype=torch.bfloat16, device=x.device)
+        xm = torch.empty_like(xhat)
+        rstd = torch.empty(xr.shape[0], dtype=torch.float32, device=x.device)
+        _lib.call("hma_modln_fwd", stream_ptr(), ptr(xr), ptr(ss), ptr(xhat), ptr(xm), ptr(rstd), b * t, s_, 1e-6)
+        y = ops.linear(xm, bf(self.linear_out.weight), self.linear_out.bias, epi=EPI_F32)
+        return y.reshape(b, t, s_, d).permute(0, 2, 1, 3).reshape(shp).to(x.dtype)
+
 
 class BasicMLP(nn.Module):
     """Action stem Linear-LN-ReLU-Linear (st_mask_git.py:90-113); runs inside hma_action_stem_fwd."""
@@ -64,6 +88,22 @@ class BasicMLP(nn.Module):
             if isinstance(m, nn.Linear):
                 torch.nn.init.xavier_uniform_(m.weight, gain=0.01)
                 nn.init.constant_(m.bias, 0)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Linear -> LayerNorm -> ReLU -> Linear (st_mask_git.py:101-102) on already normalised actions, through the action
+        stem kernel (fp32; identity statistics, skip_norm = 1).  Inference only."""
+        d_a, d = self.model[0].weight.shape[1], self.model[0].weight.shape[0]
+        rows = x.numel() // d_a
+        dev = x.device
+        a = x.reshape(rows, d_a).float().contiguous()
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        zero, one = torch.zeros(d_a, device=dev), torch.ones(d_a, device=dev)
+        an, xhat, rstd, h, out = e(rows, d_a), e(rows, d), e(rows), e(rows, d), e(rows, d)
+        _lib.call("hma_action_stem_fwd", stream_ptr(), ptr(a), ptr(zero), ptr(one), d_a, ptr(self.model[0].weight), ptr(self.model[0].bias),
+                  ptr(self.model[1].weight), ptr(self.model[1].bias), ptr(self.model[3].weight), ptr(self.model[3].bias), ptr(an),
+                  ptr(xhat), ptr(rstd), ptr(h), ptr(out), rows, d_a, 1)
+        return out.reshape(*x.shape[:-1], d).to(x.dtype)
 
 
 class ActionStat(nn.Module):
@@ -264,7 +304,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         h, w = self._hw(kwargs)
         B, T = x_THW.shape[:2]
         _, ws = self._run(x_THW, None, action_ids, domain, False, kwargs)
-        logits = ws["logits"].view(B, T, h, w, -1).permute(0, 4, 1, 2, 3)
+        logits = ws["logits"].view(B, T, h, w, -1).clone().permute(0, 4, 1, 2, 3)  # (own storage: valid after the next forward)
         return logits, None
 
     def forward(self, input_ids, labels, action_ids=None, domain="default", **kwargs):
@@ -278,7 +318,9 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         stats = ws["stats"]
         loss_value = stats[0] / stats[2]
         acc = stats[1] / stats[2]
-        logits = ws["logits"].view(B, T, H, W, -1).permute(0, 4, 1, 2, 3)
+        # (a copy: the engine's logits buffer is overwritten by the next forward, and reference callers -- evaluate.py -- keep
+        # `outputs.logits` across steps.  The fused Trainer path never comes through here.)
+        logits = ws["logits"].view(B, T, H, W, -1).clone().permute(0, 4, 1, 2, 3)
         if train:
             if action_ids is not None:
                 self.touched_domains.add(self._domain_key(domain))

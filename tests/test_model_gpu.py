@@ -172,6 +172,20 @@ def test_submodule_forwards_match_golden():
     assert torch.equal(emb(g2["ids"].to(DEV)).cpu(), g2["out"])  # gather + fp32 add: bit-exact
 
 
+def test_modulate_layer_and_basic_mlp_forward_match_golden():
+    """The module-level `forward`s of the two small blocks the reference also exposes (st_mask_git.py:66-76, 101-102), G4."""
+    g4 = golden("g4_blocks")
+    from hma_amd.model.st_mask_git import BasicMLP, ModulateLayer
+    mod = ModulateLayer(256, 256)
+    mod.load_state_dict({k[4:]: v for k, v in g4.items() if k.startswith("mod.") and k[4:] not in ("x", "c", "y")})
+    mod = mod.to(DEV)
+    assert rel_err(mod(g4["mod.x"].to(DEV), g4["mod.c"].to(DEV)), g4["mod.y"]) <= 1.5e-2
+    bm = BasicMLP(14, 256)
+    bm.load_state_dict({k[5:]: v for k, v in g4.items() if k.startswith("stem.model.")})
+    bm = bm.to(DEV)
+    assert rel_err(bm(g4["stem.norm"].to(DEV)), g4["stem.y"]) <= 1e-4   # fp32 VALU kernel
+
+
 def test_maskgit_generate_against_golden():
     g = golden("g7_generate")
     m = build_model(train=False)
