@@ -44,7 +44,8 @@ def test_train_then_generate(tmp_path):
     # [prompt (2) | generated (2) | ground truth (2)] frames per example
     assert out.shape[1:] == (6, 16, 16)
     meta = json.load(open(tmp_path / "gen" / "metadata.json"))
-    assert meta["num_images"] == 6 and meta["t"] == 4 and meta["trained_steps"] == 4 and meta["token_dtype"] == "uint32"
+    # trained_steps is scheduler.bin's `_step_count` like the reference reports it (generate.py:80-84): optimizer steps + 1
+    assert meta["num_images"] == 6 and meta["t"] == 4 and meta["trained_steps"] == 5 and meta["token_dtype"] == "uint32"
     raw = np.fromfile(tmp_path / "gen" / "video.bin", dtype=np.uint32).reshape(-1, 6, 16, 16)
     assert raw.shape[0] == out.shape[0]
     first = RawTokenDataset(tmp_path / "domA", window_size=4, compute_stride_from_freq_table=False)[0]["input_ids"].reshape(4, 16, 16)
