@@ -69,16 +69,6 @@ class MlpBwd(C.Structure):
     ]
 
 
-class TBlockFwd(C.Structure):
-    _fields_ = [
-        ("xb", c_vp), ("x", c_vp),
-        ("wqkvp", c_vp), ("wprojp", c_vp), ("bqkv", c_vp), ("bproj", c_vp),
-        ("qkv", c_vp), ("o", c_vp),
-        ("ln_xhat", c_vp), ("ln_rstd", c_vp), ("ln_eps", C.c_float), ("scale", C.c_float),
-        ("B", c_i64), ("T", c_i32), ("SA", c_i32),
-    ]
-
-
 _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
@@ -129,8 +119,6 @@ _PROTOS = {
     "hma_mlp_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64],
     "hma_mlp_fwd": [c_vp, C.POINTER(MlpFwd)],
     "hma_mlp_bwd": [c_vp, C.POINTER(MlpBwd)],
-    "hma_tblock_pack": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64],
-    "hma_tblock_fwd": [c_vp, C.POINTER(TBlockFwd)],
     "hma_abi_version": [],
 }
 

@@ -124,17 +124,6 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
       : "memory");
 }
 
-// The same with the global address as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit vector
-// address arithmetic at the call site.
-__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(sbase), "v"(voff), "s"(dst)
-      : "memory");
-}
-
 // Four consecutive pieces (4 KB of global memory -> 4 KB of LDS): the instruction's immediate offset advances the global
 // AND the LDS address, so one M0 set-up serves all four.
 __device__ __forceinline__ void glds16x4(const void* src, uint32_t dst) {

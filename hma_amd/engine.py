@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
-from .ops import make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd, make_tblock_fwd
+from .ops import make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -78,11 +78,6 @@ class Plan:
         g = make_mlp_bwd(M=M, **kw)
         self.keep.append(g)
         self.add("hma_mlp_bwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2)  # algorithmic dgrad FLOPs (the recompute is not counted)
-
-    def tblock_fwd(self, M: int, T: int, **kw) -> None:
-        g = make_tblock_fwd(T=T, **kw)
-        self.keep.append(g)
-        self.add("hma_tblock_fwd", C.byref(g), flops=2.0 * M * 256 * 768 + 4.0 * M * T * 256 + 2.0 * M * 256 * 256)
 
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
@@ -178,12 +173,6 @@ class STEngine:
         self.fused_mlp_min_rows = 128 * 256
         if self.fused_mlp:
             self.MP = {k: mk(L, 512 * 512) for k in ("w1p", "w2p", "w2tp", "w1tp")}
-        # Fused temporal-attention block (csrc/tblock.hip): qkv projection + causal attention over the 16 frames of a column +
-        # output projection + residual + the MLP's LayerNorm in one launch, for full windows (T = 16) with enough rows to give
-        # every CU a 128-row tile; anything else (short windows, the decode frame pass with its K/V cache) keeps the three launches.
-        self.fused_tblock = True
-        self.fused_tblock_min_rows = 128 * 256
-        self.TBP = {"wqkv": mk(L, 384 * 512), "wproj": mk(L, 128 * 512)}
         self.modulate = "modulate" in cfg.action_network
         if self.modulate:
             for dom in self.domains:
@@ -286,11 +275,6 @@ class STEngine:
                 _lib.call("hma_fold_ln_bf16", stream, self._p(pre + lin + ".weight"), self._p(pre + norm + ".weight"),
                           self._p(pre + norm + ".bias"), self._p(pre + lin + ".bias") if has_bias else None,
                           self.WF[key][L - 1].data_ptr(), self.BF[key][L - 1].data_ptr(), rows, d, L, ls, -rows * d, -rows)
-            pre = f"decoder.layers.{L - 1}."
-            _lib.call("hma_tblock_pack", stream, self._p(pre + "temporal_attn.qkv.weight"), self.TBP["wqkv"][L - 1].data_ptr(), 0, L, ls,
-                      -384 * 512)
-            _lib.call("hma_tblock_pack", stream, self._p(pre + "temporal_attn.proj.weight"), self.TBP["wproj"][L - 1].data_ptr(), 1, L, ls,
-                      -128 * 512)
             if self.fused_mlp:
                 pre = f"decoder.layers.{L - 1}."
                 w1, w2, g2 = self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight"), self._p(pre + "norm2.weight")
@@ -314,10 +298,6 @@ class STEngine:
         self._dom_fresh = set()
 
     # ------------------------------------------------------------------------------ workspace
-    def _use_tblock(self, rows: int, T: int, SA: int) -> bool:
-        """Whether a pass over `rows` token rows of T-frame windows runs the fused temporal block (see __init__)."""
-        return self.fused_tblock and T == 16 and SA % 8 == 0 and rows >= self.fused_tblock_min_rows
-
     def _use_fused(self, rows: int, train: bool) -> bool:
         """Whether a pass over `rows` token rows runs the fused MLP block (see __init__)."""
         if not self.fused_mlp:
@@ -325,7 +305,7 @@ class STEngine:
         return rows >= self.fused_mlp_min_rows and (self.fused_mlp_train or not train)
 
     def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
-        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train), self._use_tblock(B * T * (S + A), T, S + A))
+        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train))
         if self._ws_key == key:
             return self._ws
         self._ws, self._plans = {}, {}
@@ -424,12 +404,7 @@ class STEngine:
             pl.gemm_nt(A=b["xm"], lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
                        epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=b["x2b"], ldc2=256)
         # temporal (causal, un-normed input)                st_transformer.py:111
-        if kv is None and self._use_tblock(M, T, SA):
-            # qkv -> causal attention over the column's frames -> proj -> residual -> norm2, one launch (csrc/tblock.hip)
-            pl.tblock_fwd(M, T, xb=b["x2b"], x=x, wqkvp=self.TBP["wqkv"][l].data_ptr(), wprojp=self.TBP["wproj"][l].data_ptr(),
-                          bqkv=qb("temporal_attn"), bproj=pb("temporal_attn"), qkv=b["qkv_t"], o=b["o_t"], ln_xhat=b["xh2"],
-                          ln_rstd=b["rstd2"], ln_eps=1e-5, scale=self.scale, B=B, SA=SA)
-        elif kv is None:
+        if kv is None:
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
                        K=256, epi=EPI_BF16, Cp=b["qkv_t"], ldc=768, bias=qb("temporal_attn"))
             pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256)
@@ -438,9 +413,8 @@ class STEngine:
                        K=256, epi=EPI_BF16, Cp=kv["cache"] + kv["row_off"] * 768 * 2, ldc=768, c_group=kv["c_group"],
                        bias=qb("temporal_attn"))
             pl.add("hma_attn_temporal_cached", kv["cache"], b["o_t"], B, T, kv["t_query"], kv["T_cache"], SA, self.scale)
-        if not (kv is None and self._use_tblock(M, T, SA)):
-            pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
+        pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
         # MLP (its LayerNorm: fused above)                   st_transformer.py:112
         if fused:
             pl.mlp_fwd(M, xhat=b["xh2"], x=x, w1p=self.MP["w1p"][l].data_ptr(), w2p=self.MP["w2p"][l].data_ptr(),
@@ -472,7 +446,7 @@ class STEngine:
         l1 = self.cfg.num_layers if l1 is None else l1
         # (T_cache is part of the key: a re-allocated cache of another length can land on the old one's address)
         key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else (kv_cache.data_ptr(), T_cache),
-               self._use_fused(B * T * (S + A), train), self._use_tblock(B * T * (S + A), T, S + A))
+               self._use_fused(B * T * (S + A), train))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, GemmNT, GemmTN, MlpBwd, MlpFwd, TBlockFwd)
+                   EPI_RESID, EPI_SILU2, GemmNT, GemmTN, MlpBwd, MlpFwd)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -87,15 +87,6 @@ def make_mlp_fwd(*, M: int, xhat: int, x: int, w1p: int, w2p: int, b1: int, b2: 
     g = MlpFwd()
     g.xhat, g.x, g.w1p, g.w2p, g.b1, g.b2 = xhat, x, w1p, w2p, b1, b2
     g.ln_xhat, g.ln_rstd, g.ln_eps, g.M = ln_xhat, ln_rstd, ln_eps, M
-    return g
-
-
-def make_tblock_fwd(*, xb: int, x: int, wqkvp: int, wprojp: int, qkv: int, o: int, B: int, T: int, SA: int, scale: float,
-                    bqkv: Optional[int] = None, bproj: Optional[int] = None, ln_xhat: Optional[int] = None,
-                    ln_rstd: Optional[int] = None, ln_eps: float = 1e-5) -> TBlockFwd:
-    g = TBlockFwd()
-    g.xb, g.x, g.wqkvp, g.wprojp, g.bqkv, g.bproj, g.qkv, g.o = xb, x, wqkvp, wprojp, bqkv, bproj, qkv, o
-    g.ln_xhat, g.ln_rstd, g.ln_eps, g.scale, g.B, g.T, g.SA = ln_xhat, ln_rstd, ln_eps, scale, B, T, SA
     return g
 
 

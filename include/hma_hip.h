@@ -352,26 +352,6 @@ typedef struct {
 } hma_mlp_bwd_t;
 int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p);
 
-/* ---- Fused temporal-attention block, forward (csrc/tblock.hip): SelfAttention.forward with causal = True on the
- * "(B S) T C" view (hma/model/attention.py:37-61 as called at hma/model/st_transformer.py:111), the residual add and the
- * following norm2 (st_transformer.py:112) in ONE launch:
- *     qkv = xb Wqkv^T (+ bqkv)  ->  o = softmax(scale q k^T, causal over the T frames of a column) v  ->
- *     x += o Wproj^T + bproj     ->  ln_xhat = LayerNorm(x, ln_eps, no affine), ln_rstd          (ln_xhat may be NULL)
- * xb = bf16 copy of the residual rows (no LayerNorm precedes temporal attention), row = (b T + t)(S + A) + s; T must be
- * 16 and (S + A) a multiple of 8.  qkv (bf16 [M, 768], q unscaled) and o (bf16 [M, 256]) are written for
- * hma_attn_temporal_bwd and the weight gradients.  wqkvp / wprojp: hma_tblock_pack(kind 0 / 1) of the fp32 qkv.weight
- * [768, 256] / proj.weight [256, 256] (MFMA-fragment order; batch = layers with the given element strides). */
-int hma_tblock_pack(void* stream, const float* src, void* dst, int32_t kind, int32_t batch, int64_t src_batch_stride,
-                    int64_t dst_batch_stride);
-typedef struct {
-  const void* xb; float* x;
-  const void* wqkvp; const void* wprojp; const float* bqkv; const float* bproj;
-  void* qkv; void* o;
-  void* ln_xhat; float* ln_rstd; float ln_eps; float scale;
-  int64_t B; int32_t T; int32_t SA;
-} hma_tblock_fwd_t;
-int hma_tblock_fwd(void* stream, const hma_tblock_fwd_t* p);
-
 /* library identity, for the loader: returns 0x484d4102 */
 int hma_abi_version(void);
 

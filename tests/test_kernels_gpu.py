@@ -761,65 +761,3 @@ def test_gemm_tn_folded_affine_grads():
     close(dW, P * gam + cs[:, None] * bet[None, :], 1e-2, "dW")  # bf16 partials
     close(dG, (w * P).sum(0), 1e-2, "dgamma")
     close(dBt, (w * cs[:, None]).sum(0), 1e-2, "dbeta")
-
-
-# ------------------------------------------------------------------------------------------------ fused temporal block
-def _tblock_ref(x, wqkv, bqkv, wproj, bproj, B, T, SA, scale, eps):
-    """fp32 math of attention.py:37-61 (causal over the T frames of a (b, s) column) + residual + LayerNorm (no affine) on
-    bf16-rounded operands; the bf16 roundings the kernel makes at its hand-over points (qkv rows, probabilities, o) are
-    mirrored so that the comparison isolates accumulation order."""
-    xb = rb(x)
-    qkv = rb(xb @ rb(wqkv).t() + (bqkv if bqkv is not None else 0.0))                      # [M, 768], what is saved
-    q, k, v = qkv.view(B, T, SA, 3, 8, 32).permute(3, 0, 2, 4, 1, 5)                        # (B, SA, heads, T, 32)
-    att = (q @ k.transpose(-1, -2)) * scale
-    mask = torch.ones(T, T).tril().bool()
-    att = att.masked_fill(~mask, float("-inf")).softmax(-1)
-    o = rb(rb(att) @ v)                                                                     # (B, SA, heads, T, 32)
-    o = o.permute(0, 3, 1, 2, 4).reshape(B * T * SA, 256)
-    y = x + o @ rb(wproj).t() + (bproj if bproj is not None else 0.0)
-    mu = y.mean(-1, keepdim=True)
-    var = y.var(-1, unbiased=False, keepdim=True)
-    rstd = (var + eps).rsqrt()
-    return qkv, o, y, (y - mu) * rstd, rstd.squeeze(-1)
-
-
-@pytest.mark.parametrize("B,SA,bias", [(2, 320, True), (7, 320, False), (3, 256, True)])
-def test_tblock_fwd_fused(B, SA, bias):
-    """hma_tblock_fwd (csrc/tblock.hip) = qkv GEMM + hma_attn_temporal_fwd + proj GEMM with residual and LayerNorm epilogue;
-    B = 7 gives 280 tiles on 256 workgroups (a second, partial round of tiles)."""
-    T, scale = 16, 0.25
-    M = B * T * SA
-    gg = g(31 + B)
-    x = torch.randn(M, 256, generator=gg)
-    wqkv = torch.randn(768, 256, generator=gg) * 0.08
-    wproj = torch.randn(256, 256, generator=gg) * 0.08
-    bqkv = torch.randn(768, generator=gg) * 0.1 if bias else None
-    bproj = torch.randn(256, generator=gg) * 0.1 if bias else None
-    qkv_r, o_r, y_r, xh_r, rstd_r = _tblock_ref(x, wqkv, bqkv, wproj, bproj, B, T, SA, scale, 1e-5)
-    d = lambda t: None if t is None else t.to(DEV).contiguous()
-    st = torch.cuda.current_stream().cuda_stream
-    wq_p = torch.empty(384 * 512, dtype=torch.bfloat16, device=DEV)
-    wp_p = torch.empty(128 * 512, dtype=torch.bfloat16, device=DEV)
-    wqkv_d, wproj_d = d(wqkv), d(wproj)
-    _lib.call("hma_tblock_pack", st, ops.ptr(wqkv_d), ops.ptr(wq_p), 0, 1, 0, 0)
-    _lib.call("hma_tblock_pack", st, ops.ptr(wproj_d), ops.ptr(wp_p), 1, 1, 0, 0)
-    xd = d(x)
-    xb = xd.to(torch.bfloat16)
-    qkv = torch.empty(M, 768, dtype=torch.bfloat16, device=DEV)
-    o = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
-    xh = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
-    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
-    bq, bp = d(bqkv), d(bproj)
-    a = ops.make_tblock_fwd(xb=ops.ptr(xb), x=ops.ptr(xd), wqkvp=ops.ptr(wq_p), wprojp=ops.ptr(wp_p), bqkv=ops.ptr(bq), bproj=ops.ptr(bp),
-                            qkv=ops.ptr(qkv), o=ops.ptr(o), ln_xhat=ops.ptr(xh), ln_rstd=ops.ptr(rstd), ln_eps=1e-5, scale=scale, B=B,
-                            T=T, SA=SA)
-    _lib.call("hma_tblock_fwd", st, C.byref(a))
-    torch.cuda.synchronize()
-    close(qkv, qkv_r, BF, "qkv")
-    close(o, o_r, 2 * BF, "o")
-    close(xd, y_r, 1e-3, "x")
-    close(xh, xh_r, 2 * BF, "ln_xhat")
-    close(rstd, rstd_r, 1e-4, "ln_rstd")
-    # T != 16 or a ragged column count is refused, not mis-computed
-    a.T = 12
-    assert _lib.load().hma_tblock_fwd(st, C.byref(a)) != 0

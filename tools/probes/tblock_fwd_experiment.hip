@@ -76,12 +76,39 @@ __global__ __launch_bounds__(256) void tblock_pack_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Debug builds only (tools/tblock_variants.sh, -DTB_ABL=bits): 1 no q / k / v / o stores, 2 no ring LDS-DMA, 4 no residual staging, 32 no
+// epilogue stores, 64 producer stores to an L2-resident scratch, 8 projection fragments not loaded, 16 no q / k / v MFMA loop
+#ifndef TB_ABL
+#define TB_ABL 0
+#endif
+// Debug builds only (-DTB_PROF): per-wave cycle counts per phase, block 0 (tools/tblock_bench.py prints them)
+#ifdef TB_PROF
+__device__ unsigned long long g_tb_prof[8][8];
+#define TPROF_DECL unsigned long long pt_ = __builtin_readcyclecounter(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TPROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define TPROF_FLUSH() do { if (blockIdx.x == 0 && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) g_tb_prof[wave][i_] = pacc_[i_]; } } while (0)
+#else
+#define TPROF_DECL
+#define TPROF_MARK(i)
+#define TPROF_FLUSH()
+#endif
 constexpr int TB_SLOT = 49152;                  // one head's q | k | v fragments
-constexpr int TB_XCH = 2 * TB_SLOT;             // per pair: 2 buffers x 2 KB (o of the head as the projection's B operand)
-constexpr int TB_STG = TB_XCH + 4 * 4096;       // per pair: 2 staging pieces of 4 KB (32 rows x 128 B)
-constexpr int TB_BQKV = TB_STG + 4 * 8192;      // 768 floats
+constexpr int TB_OUT = 2 * TB_SLOT;             // per pair: hand-over tiles q | k | v | o of the head (4 x 2 KB)
+constexpr int TB_OUT_PAIR = 8192;
+constexpr int TB_STG = TB_OUT + 4 * TB_OUT_PAIR; // per pair: ONE staging piece of 4 KB (32 rows x 128 B)
+constexpr int TB_BQKV = TB_STG + 4 * 4096;      // 768 floats
 constexpr int TB_BPROJ = TB_BQKV + 3072;        // 256 floats
-constexpr int TB_SMEM = TB_BPROJ + 1024;        // 151552 B
+constexpr int TB_FLAG = TB_BPROJ + 1024;        // per pair: the step whose hand-over tiles the consumer has drained
+constexpr int TB_SMEM = TB_FLAG + 64;           // 151616 B
+
+// Row-major 2 KB tile of a pair (q, k, v or o of one head): row n (token of the pair) holds the head's 32 channels as four
+// 16-byte chunks, chunk c = 2 hi + e (channels 8 c .. 8 c + 7) at position c ^ ((n >> 1) & 3): writes in the accumulator
+// shape ("a lane owns a token") and row-major reads (4 lanes per row = 64 contiguous bytes of a global row) are both
+// conflict-free.  The producer leaves q, k, v, o of a head in these tiles and never touches global memory inside its loop: a
+// store instruction of the compute-critical wave stalls whenever HBM is busy (measured: +60 ... +108 us per launch).  The
+// consumer, which has the slack, reads the tiles row-major and stores whole 64-byte row pieces (16 rows per instruction) at
+// the START of its step, so that they drain while the producers compute; a flag tells the producer the tiles are free again.
+__device__ __forceinline__ int out_off(int n, int c) { return n * 64 + ((c ^ ((n >> 1) & 3)) << 4); }
 
 __device__ __forceinline__ int stg_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
@@ -106,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
     HMA_LDS(float)* bq = (HMA_LDS(float)*)(lds + TB_BQKV);
     for (int i = tid; i < 768; i += 512) bq[i] = p.bqkv ? p.bqkv[i] : 0.f;
     if (tid < 256) ((HMA_LDS(float)*)(lds + TB_BPROJ))[tid] = p.bproj ? p.bproj[tid] : 0.f;
+    if (tid < 16) ((HMA_LDS(int)*)(lds + TB_FLAG))[tid] = 0;
   }
   __syncthreads();
 
@@ -120,23 +148,55 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
 
   if (role == 0) {
     // ================================================================ producer: q, k, v, attention of one head per step
-    bf16x8_t xh[16];
+    // The 32 token rows of the pair as B operands (16 k-steps), loaded by ONE asm block that also waits for them.  As
+    // compiler-visible loads they put an `s_waitcnt vmcnt(0)` in front of the first MFMA of EVERY step (the pass cannot tell
+    // which iteration issued them), and that wait also covers the previous step's q / k / v / o stores: every byte stored was
+    // paid for at HBM speed with the matrix pipe idle (+60 us per launch).  Now the producer's loop has no vmcnt wait at all.
+    u32x4_t xr[16];
     auto load_x = [&](int64_t base) __attribute__((always_inline)) {
       const uint16_t* src = reinterpret_cast<const uint16_t*>(p.xb) + grow(base, lr) * 256 + 16 * hi;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) xh[j] = as_frag(*reinterpret_cast<const uint4*>(src + 32 * (j >> 1) + 8 * (j & 1)));
+      asm volatile(
+          "global_load_dwordx4 %0, %16, off\n\t"
+          "global_load_dwordx4 %1, %16, off offset:16\n\t"
+          "global_load_dwordx4 %2, %16, off offset:64\n\t"
+          "global_load_dwordx4 %3, %16, off offset:80\n\t"
+          "global_load_dwordx4 %4, %16, off offset:128\n\t"
+          "global_load_dwordx4 %5, %16, off offset:144\n\t"
+          "global_load_dwordx4 %6, %16, off offset:192\n\t"
+          "global_load_dwordx4 %7, %16, off offset:208\n\t"
+          "global_load_dwordx4 %8, %16, off offset:256\n\t"
+          "global_load_dwordx4 %9, %16, off offset:272\n\t"
+          "global_load_dwordx4 %10, %16, off offset:320\n\t"
+          "global_load_dwordx4 %11, %16, off offset:336\n\t"
+          "global_load_dwordx4 %12, %16, off offset:384\n\t"
+          "global_load_dwordx4 %13, %16, off offset:400\n\t"
+          "global_load_dwordx4 %14, %16, off offset:448\n\t"
+          "global_load_dwordx4 %15, %16, off offset:464\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(xr[0]), "=&v"(xr[1]), "=&v"(xr[2]), "=&v"(xr[3]), "=&v"(xr[4]), "=&v"(xr[5]), "=&v"(xr[6]), "=&v"(xr[7]),
+            "=&v"(xr[8]), "=&v"(xr[9]), "=&v"(xr[10]), "=&v"(xr[11]), "=&v"(xr[12]), "=&v"(xr[13]), "=&v"(xr[14]), "=&v"(xr[15])
+          : "v"(src)
+          : "memory");
     };
+#define xh(j) __builtin_bit_cast(bf16x8_t, xr[j])
     int64_t base = tbase(0);
     load_x(base);
-    const uint32_t loff = (uint32_t)((lr & 15) * SA + (lr >> 4));  // this lane's row relative to the tile's first
     const int c = lr >> 4, t = lr & 15;
     const float alpha = p.scale * 1.4426950408889634f;  // scores in the log2 domain
+    TPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {
+      TPROF_MARK(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      TPROF_MARK(1);
       if (g == nsteps) break;
       const int h = g & 7, tl = g >> 3;
+      if (h == 0 && tl > 0) {  // next tile's rows (once per tile; also drains the previous tile's stores)
+        base = tbase(tl);
+        load_x(base);
+      }
+      TPROF_MARK(2);
       HMA_LDS(char)* wb = lds + (g & 1) * TB_SLOT + lane * 16;
       HMA_LDS(char)* bp = lds + TB_BQKV + (32 * h + 16 * hi) * 4;
       f32x16_t Q, K, V, VT;
@@ -151,22 +211,24 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
       for (int e = 0; e < 16; ++e) VT[e] = 0.f;
       {
         // per k-step j: the q, k, v fragments of the head (fragment (w, j) at (16 w + j) KB of the slot)
-        bf16x8_t fa[3], fb[3];
+        bf16x8_t fa[3], fb[3], fc[3];  // k-steps j, j + 1, j + 2: an LDS read has two MFMA groups (256 cycles) to arrive
 #pragma unroll
         for (int w = 0; w < 3; ++w) fa[w] = lds_frag(wb + (16 * w) * 1024);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j < 15) {
+        for (int w = 0; w < 3; ++w) fb[w] = lds_frag(wb + (16 * w + 1) * 1024);
 #pragma unroll
-            for (int w = 0; w < 3; ++w) fb[w] = lds_frag(wb + (16 * w + j + 1) * 1024);
+        for (int j = 0; j < ((TB_ABL & 16) ? 1 : 16); ++j) {
+          if (j < 14) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) fc[w] = lds_frag(wb + (16 * w + j + 2) * 1024);
           }
-          Q = mfma32(fa[0], xh[j], Q);
-          K = mfma32(fa[1], xh[j], K);
-          V = mfma32(fa[2], xh[j], V);
-          VT = mfma32(xh[j], fa[2], VT);  // operands exchanged: rows = tokens, columns = the fragment's (permuted) channels
+          Q = mfma32(fa[0], xh(j), Q);
+          K = mfma32(fa[1], xh(j), K);
+          V = mfma32(fa[2], xh(j), V);
+          VT = mfma32(xh(j), fa[2], VT);  // operands exchanged: rows = tokens, columns = the fragment's (permuted) channels
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int w = 0; w < 3; ++w) fa[w] = fb[w];
+          for (int w = 0; w < 3; ++w) fa[w] = fb[w], fb[w] = fc[w];
         }
       }
       // V^T came out without the bias (its lanes are channels): lane rho holds channel rowmap(rho) of the head
@@ -175,19 +237,20 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) VT[e] += bv;
       }
-      {  // q | k | v rows of the head for the backward kernels: 32 B per lane and tensor
-        uint16_t* dst = reinterpret_cast<uint16_t*>(p.qkv) + base * 768 + (loff * 768u + 32 * h + 16 * hi);
-        *reinterpret_cast<uint4*>(dst) = pack8r(Q, 0);
-        *reinterpret_cast<uint4*>(dst + 8) = pack8r(Q, 8);
-        *reinterpret_cast<uint4*>(dst + 256) = pack8r(K, 0);
-        *reinterpret_cast<uint4*>(dst + 264) = pack8r(K, 8);
-        *reinterpret_cast<uint4*>(dst + 512) = pack8r(V, 0);
-        *reinterpret_cast<uint4*>(dst + 520) = pack8r(V, 8);
+      TPROF_MARK(3);
+      HMA_LDS(char)* oa = lds + TB_OUT + pair * TB_OUT_PAIR;
+      {  // tiles free?  (the consumer drains them at the very start of its step; this wave has just spent 64 MFMAs)
+        volatile HMA_LDS(int)* flag = (volatile HMA_LDS(int)*)(lds + TB_FLAG + pair * 16);
+        while (*flag < g) __builtin_amdgcn_s_sleep(1);
       }
-      const int64_t base_now = base;
-      if (h == 7 && tl + 1 < nt) {  // (xh is dead for this tile: the next tile's rows land behind the attention)
-        base = tbase(tl + 1);
-        load_x(base);
+      TPROF_MARK(4);
+      {  // q | k | v rows of the head (for the backward kernels)
+        lds_put(oa + out_off(lr, 2 * hi), pack8r(Q, 0));
+        lds_put(oa + out_off(lr, 2 * hi + 1), pack8r(Q, 8));
+        lds_put(oa + 2048 + out_off(lr, 2 * hi), pack8r(K, 0));
+        lds_put(oa + 2048 + out_off(lr, 2 * hi + 1), pack8r(K, 8));
+        lds_put(oa + 4096 + out_off(lr, 2 * hi), pack8r(V, 0));
+        lds_put(oa + 4096 + out_off(lr, 2 * hi + 1), pack8r(V, 8));
       }
       // S^T[key][query] over the pair's 32 tokens; contraction index of k-step e: channels 16 kg + 8 e + i
       f32x16_t ST;
@@ -227,27 +290,24 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
       OT = mfma32(as_frag(pack8r(VT, 0)), pb0, OT);
       OT = mfma32(as_frag(pack8r(VT, 8)), pb1, OT);
       // o of the head: lane (token, hi) holds channels 16 hi + r -> the consumer's B operand, and the saved o rows
-      const uint4 o0 = pack8r(OT, 0), o1 = pack8r(OT, 8);
-      HMA_LDS(char)* xc = lds + TB_XCH + pair * 4096 + (g & 1) * 2048 + lane * 16;
-      lds_put(xc, o0);
-      lds_put(xc + 1024, o1);
-      {
-        uint16_t* dst = reinterpret_cast<uint16_t*>(p.o) + base_now * 256 + (loff * 256u + 32 * h + 16 * hi);
-        *reinterpret_cast<uint4*>(dst) = o0;
-        *reinterpret_cast<uint4*>(dst + 8) = o1;
-      }
+      lds_put(oa + 6144 + out_off(lr, 2 * hi), pack8r(OT, 0));
+      lds_put(oa + 6144 + out_off(lr, 2 * hi + 1), pack8r(OT, 8));
+      TPROF_MARK(5);
     }
+    TPROF_FLUSH();
   } else {
     // ================================================================ consumer: x += Wproj o + b (+ LayerNorm of the new row)
     f32x16_t Y[8];
     bf16x8_t wp[8];   // projection fragments straight from L2, half a head at a time (output blocks 0..3 are loaded a step ahead)
-    HMA_LDS(char)* stg = lds + TB_STG + pair * 8192;
-    const uint32_t stg_b = lds_b + TB_STG + pair * 8192;
+    HMA_LDS(char)* stg = lds + TB_STG + pair * 4096;
+    const uint32_t stg_b = lds_b + TB_STG + pair * 4096;
+    HMA_LDS(char)* oa = lds + TB_OUT + pair * TB_OUT_PAIR;
     const int prow_ = lane >> 3, pchunk_ = lane & 7;
     const char* wq = reinterpret_cast<const char*>(p.wqkvp) + pair * 12288 + lane * 16;
     auto issue = [&](int b) __attribute__((always_inline)) {  // this wave's 12 of the 48 pieces of bundle b
       const uint32_t base = lds_b + (b & 1) * TB_SLOT + pair * 12288;
       const char* src = wq + (int64_t)(b & 7) * TB_SLOT;
+      if (TB_ABL & 2) return;
       glds16x4(src, base);
       glds16x4(src + 4096, base + 4096);
       glds16x4(src + 8192, base + 8192);
@@ -263,60 +323,84 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
       xoff[i] = ro + ((pchunk_ ^ ((r >> 1) & 7)) << 2);   // fp32 piece: 32 columns, 4 per chunk
       hoff[i] = ro + ((pchunk_ ^ ((r >> 1) & 7)) << 3);   // bf16 piece: 64 columns, 8 per chunk
     }
+    // row-major reads of a 2 KB tile: lane -> row 16 part + (lane >> 2), chunk position lane & 3 (logical chunk = position ^ swizzle)
+    uint32_t qoff[2], ooff[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const int n = 16 * part + (lane >> 2);
+      const uint32_t ro = (uint32_t)((n & 15) * SA + (n >> 4));
+      const uint32_t ch = (uint32_t)(((lane & 3) ^ ((n >> 1) & 3)) << 3);
+      qoff[part] = ro * 768u + ch;
+      ooff[part] = ro * 256u + ch;
+    }
+    int64_t base_h = 0;  // first row of the tile whose heads are being drained
     auto issue_x = [&](int64_t base, int cb) __attribute__((always_inline)) {
       const float* sb = p.x + base * 256 + cb * 32;
+      if (TB_ABL & 4) return;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16s(sb, xoff[i] * 4u, stg_b + (cb & 1) * 4096 + i * 1024);
+      for (int i = 0; i < 4; ++i) glds16s(sb, xoff[i] * 4u, stg_b + i * 1024);
     };
     auto load_w = [&](int h, int half) __attribute__((always_inline)) {
       const char* src = reinterpret_cast<const char*>(p.wprojp) + (int64_t)h * 16384 + half * 8192 + lane * 16;
 #pragma unroll
-      for (int f = 0; f < 8; ++f) wp[f] = as_frag(*reinterpret_cast<const uint4*>(src + f * 1024));
+      for (int f = 0; f < 8; ++f)
+        wp[f] = (TB_ABL & 8) ? as_frag(make_uint4(f, lane, h, half)) : as_frag(*reinterpret_cast<const uint4*>(src + f * 1024));
     };
     int64_t base = tbase(0);
+    TPROF_DECL;
     issue(0);
-    issue_x(base, 0);
-    load_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int g = 0; g <= nsteps; ++g) {
-      // everything this wave issued in the previous step has landed: the ring bundle the producers read next, the staged
-      // residual block, the projection fragments
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // No vmcnt wait here: vmcnt also counts stores, loads and stores complete out of order with each other (only vmcnt(0)
+      // is safe), and a wait right behind this wave's stores would sit out their acknowledgement at HBM pace -- measured as
+      // 11 k cycles per step against 4.6 k without the stores.  So a step issues ALL its loads first, waits once in mid-step
+      // (by then the previous step's stores have had half a step to drain), computes, and stores LAST.
+      TPROF_MARK(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TPROF_MARK(1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (g == 0 && nsteps > 1) issue(1);
+      TPROF_MARK(2);
+      if (g + 1 < nsteps) issue(g + 1);   // the ring bundle of the next step: landed by the mid-step wait, a barrier before its use
+      if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (g >= 1) {
         const int gc = g - 1, h = gc & 7, tl = gc >> 3;
         if (h == 0) {
+          base_h = base;
 #pragma unroll
           for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) Y[cb][e] = 0.f;
         }
-        HMA_LDS(char)* xc = lds + TB_XCH + pair * 4096 + (gc & 1) * 2048 + lane * 16;
-        const bf16x8_t o0 = lds_frag(xc), o1 = lds_frag(xc + 1024);
+        issue_x(base_h, h);               // residual block h of this tile (the piece was read in the previous step)
+        load_w(h, 0);                     // projection fragments, output blocks 0..3
+        // the head's o as this wave's B operand and its q | k | v | o rows into registers: the producer gets its tiles back now
+        const bf16x8_t o0 = lds_frag(oa + 6144 + out_off(lr, 2 * hi)), o1 = lds_frag(oa + 6144 + out_off(lr, 2 * hi + 1));
+        uint4 rv[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            rv[2 * w + part] = __builtin_bit_cast(uint4, lds_f4(oa + w * 2048 + (16 * part + (lane >> 2)) * 64 + ((lane & 3) << 4)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *(volatile HMA_LDS(int)*)(lds + TB_FLAG + pair * 16) = g;   // drained: the producer may write step g's tiles
+        // every load of this step (ring bundle, residual block, fragments) and the previous step's stores.  The builtin, not
+        // asm: the compiler must know that its own fragment loads are complete.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
           Y[mb] = mfma32(wp[2 * mb], o0, Y[mb]);
           Y[mb] = mfma32(wp[2 * mb + 1], o1, Y[mb]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_w(h, 1);                       // output blocks 4..7 of this head; the ring issue below covers their latency
+        load_w(h, 1);                       // output blocks 4..7 (an L2 round trip; nothing else of this wave is in flight)
         __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < nsteps) issue(g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          Y[4 + mb] = mfma32(wp[2 * mb], o0, Y[4 + mb]);
-          Y[4 + mb] = mfma32(wp[2 * mb + 1], o1, Y[4 + mb]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (g < nsteps) load_w(g & 7, 0);   // blocks 0..3 of the head the next step processes
-        __builtin_amdgcn_sched_barrier(0);
-        {  // residual block h (staged during the previous step)
+        {  // residual block h while the fragments arrive
           float xv[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 v = lds_f4(stg + (h & 1) * 4096 + stg_off(lr, 4 * hi + q));
+            const float4 v = lds_f4(stg + stg_off(lr, 4 * hi + q));
             xv[4 * q + 0] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
           }
 #pragma unroll
@@ -326,10 +410,26 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
               for (int e = 0; e < 16; ++e) Y[cb][e] += xv[e];
             }
         }
-        if (h < 7) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (piece (h + 1) & 1 was read a step ago; this orders the reads above)
-          issue_x(base, h + 1);
-        } else {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          Y[4 + mb] = mfma32(wp[2 * mb], o0, Y[4 + mb]);
+          Y[4 + mb] = mfma32(wp[2 * mb + 1], o1, Y[4 + mb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(TB_ABL & 1)) {  // the head's q | k | v | o rows: 16 rows x 64 B per store instruction, last thing in the step
+          uint16_t* qt = reinterpret_cast<uint16_t*>(p.qkv) + base_h * 768 + 32 * h;
+          uint16_t* ot = reinterpret_cast<uint16_t*>(p.o) + base_h * 256 + 32 * h;
+#pragma unroll
+          for (int part = 0; part < 2; ++part) {
+            *reinterpret_cast<uint4*>(qt + qoff[part]) = rv[part];
+            *reinterpret_cast<uint4*>(qt + 256 + qoff[part]) = rv[2 + part];
+            *reinterpret_cast<uint4*>(qt + 512 + qoff[part]) = rv[4 + part];
+            *reinterpret_cast<uint4*>(ot + ooff[part]) = rv[6 + part];
+          }
+        }
+        TPROF_MARK(3);
+        if (h == 7) {
           // ---- tile epilogue: + bias, LayerNorm statistics, rows out through the staging pieces (whole cache lines)
           HMA_LDS(char)* b2p = lds + TB_BPROJ + 16 * hi * 4;
           int prow = prow_, pchunk = pchunk_;
@@ -351,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
               sum += d;
               sq = __builtin_fmaf(d, d, sq);
             }
-            HMA_LDS(char)* sb = stg + (cb & 1) * 4096;
+            HMA_LDS(char)* sb = stg;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               lds_put(sb + stg_off(lr, 4 * hi + q), __builtin_bit_cast(uint4, make_float4(Y[cb][4 * q], Y[cb][4 * q + 1], Y[cb][4 * q + 2], Y[cb][4 * q + 3])));
@@ -359,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
             for (int i = 0; i < 4; ++i) {
               const int r = 8 * i + prow;
               const float4 v = lds_f4(sb + r * 128 + (pchunk << 4));
-              *reinterpret_cast<float4*>(xt + cb * 32 + xoff[i]) = v;
+              if (!(TB_ABL & 32)) *reinterpret_cast<float4*>(xt + cb * 32 + xoff[i]) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -373,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cp = 0; cp < 4; ++cp) {
-              HMA_LDS(char)* sb = stg + (cp & 1) * 4096;
+              HMA_LDS(char)* sb = stg;
 #pragma unroll
               for (int k = 0; k < 2; ++k) {
                 float o[16];
@@ -387,20 +487,18 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
               for (int i = 0; i < 4; ++i) {
                 const int r = 8 * i + prow;
                 const uint4 v = __builtin_bit_cast(uint4, lds_f4(sb + r * 128 + (pchunk << 4)));
-                *reinterpret_cast<uint4*>(ht + cp * 64 + hoff[i]) = v;
+                if (!(TB_ABL & 32)) *reinterpret_cast<uint4*>(ht + cp * 64 + hoff[i]) = v;
               }
               __builtin_amdgcn_sched_barrier(0);
             }
             if (hi == 0) p.ln_rstd[grow(base, lr)] = rstd;
           }
-          if (tl + 1 < nt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            base = tbase(tl + 1);
-            issue_x(base, 0);
-          }
+          if (tl + 1 < nt) base = tbase(tl + 1);
+          TPROF_MARK(4);
         }
       }
     }
+    TPROF_FLUSH();
   }
 }
 
@@ -427,6 +525,13 @@ int num_cus() {
 }
 
 }  // namespace
+
+#ifdef TB_PROF
+extern "C" int hma_tblock_debug_prof(unsigned long long* out64) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tb_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 extern "C" int hma_tblock_pack(void* stream, const float* src, void* dst, int32_t kind, int32_t batch, int64_t src_batch_stride,
                                int64_t dst_batch_stride) {
