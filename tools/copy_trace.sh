@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/ctrace
 rm -rf $OUT; mkdir -p $OUT
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o q -- python3 bench.py --steps 2 --warmup 1 --layers 4 --no-cpu-baseline --no-kernel-timing > $OUT/bench.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o q -- python3 bench.py --steps 2 --warmup 1 --layers 4 --mode train --no-cpu-baseline --no-kernel-timing > $OUT/bench.log 2>&1 < /dev/null
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY' | tee $OUT/summary.txt
 import csv, sys, collections

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/qprof
 rm -rf $OUT; mkdir -p $OUT
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o q -- python3 bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-kernel-timing ${BENCH_ARGS:-} > $OUT/bench.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o q -- python3 bench.py --steps ${STEPS:-3} --warmup 1 --mode train --no-cpu-baseline --no-kernel-timing ${BENCH_ARGS:-} > $OUT/bench.log 2>&1 < /dev/null
 echo "rc=$?"; tail -2 $OUT/bench.log | cut -c1-300
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY' | tee $OUT/stats.txt
