@@ -250,6 +250,8 @@ def decode_bench(args, dev, steps=None, warmup=None, batch=None):
     B, T, P, iters = args.batch, args.frames, 4, 8
     model, domains, d_actions = build_model(args.domains, T, args.layers)
     model = model.to(dev).eval()
+    if os.environ.get("HMA_FUSED_MLP_MIN_ROWS"):  # measurement only: policy threshold of the fused MLP block
+        model._get_engine(dev).fused_mlp_min_rows = int(os.environ["HMA_FUSED_MLP_MIN_ROWS"])
     g = torch.Generator().manual_seed(5)
     prompt = torch.randint(0, 8192, (B, P * 256), generator=g).to(dev)
     acts = torch.randn(B, T, d_actions[0], generator=g).to(dev)
