@@ -526,6 +526,70 @@ class MarTrainer:
     def reduced_loss(self) -> torch.Tensor:
         return self.last_loss_info[0] / self.last_loss_info[1]
 
+    # ------------------------------------------------------------------ resume: the same Accelerate-layout files as `Trainer`
+    def _locate(self, name: str):
+        """(moment buffers, offset, numel, shape, updates applied) of a named parameter, or None if it is never stepped."""
+        eng, own = self.engine, self.own
+        if name in own["names"]:
+            i = own["names"].index(name)
+            pv = own["pviews"][i]
+            off = (pv.data_ptr() - own["P"].data_ptr()) // 4
+            return own["M"], own["V"], off, pv.numel(), tuple(pv.shape), int(own["steps"][own["calls"] & 1].item())
+        e = eng.layout.entries.get(name)
+        if e is None or e.region == "frozen" or eng.M is None:
+            return None
+        k = eng.dom_steps.get(e.region[4:], 0) if e.region.startswith("dom:") else eng.opt_step
+        return eng.M, eng.V, e.offset, e.numel, tuple(e.shape), k
+
+    def save_state(self, directory) -> None:
+        """`config.json` + `model.safetensors` + `optimizer.bin` + `scheduler.bin` as `accelerator.save_state` leaves them
+        (hma/train_multi.py:310-321): the optimizer file is torch AdamW's state dict for the reference's two parameter groups."""
+        import os
+        self.model.save_pretrained(directory)
+        names = [n for n, _ in self.model.named_parameters()]
+        loc = {n: self._locate(n) for n in names}
+        steps = lambda n: 0 if loc[n] is None else loc[n][5]
+
+        def moments(n):
+            M, V, off, numel, shape, _ = loc[n]
+            return M[off:off + numel].detach().cpu().clone().view(shape), V[off:off + numel].detach().cpu().clone().view(shape)
+
+        lr_now = lr_at(self.completed, self.lr, self.warmup)
+        torch.save(build_optimizer_state_dict(names, moments, steps, lr_now, self.lr, self.betas, self.eps, self.wd),
+                   os.path.join(str(directory), "optimizer.bin"))
+        torch.save(build_scheduler_state_dict(self.completed, self.reducer.world, lr_now, self.lr),
+                   os.path.join(str(directory), "scheduler.bin"))
+
+    def load_state(self, directory) -> None:
+        import os
+        eng, own = self.engine, self.own
+        sd = torch.load(os.path.join(str(directory), "optimizer.bin"), map_location="cpu", weights_only=False)
+        names = [n for n, _ in self.model.named_parameters()]
+        order = sum(reference_param_groups(names), [])
+        if eng.M is None:
+            eng.M, eng.V = torch.zeros_like(eng.P), torch.zeros_like(eng.P)
+        dense, doms, own_k = 0, {}, 0
+        for idx, st in sd["state"].items():
+            name = order[int(idx)]
+            k = int(float(st["step"]))
+            if name in own["names"]:
+                M, V, off, numel, _, _ = self._locate(name)
+                own_k = max(own_k, k)
+            else:
+                e = eng.layout.entries[name]
+                M, V, off, numel = eng.M, eng.V, e.offset, e.numel
+                if e.region.startswith("dom:"):
+                    doms[e.region[4:]] = max(doms.get(e.region[4:], 0), k)
+                else:
+                    dense = max(dense, k)
+            M[off:off + numel].copy_(st["exp_avg"].reshape(-1))
+            V[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1))
+        eng.set_steps(dense, doms)
+        own["steps"][own["calls"] & 1] = own_k
+        sch_path = os.path.join(str(directory), "scheduler.bin")
+        self.completed = (int(torch.load(sch_path, map_location="cpu", weights_only=False)["last_epoch"]) // max(self.reducer.world, 1)
+                          if os.path.exists(sch_path) else dense)
+
 
 class FusedAdamW:
     """torch.optim-shaped facade over the engine's fused clip + AdamW for the autograd (drop-in) path:

@@ -109,7 +109,8 @@ def main(argv=None):
         model, lr=lr, betas=(args.adam_beta_1, args.adam_beta_2), eps=args.adam_eps, weight_decay=args.weight_decay,
         max_grad_norm=args.max_grad_norm, warmup_steps=args.num_warmup_steps, grad_accum=accum)
     start_step = 0
-    if not continuous and args.resume_from_checkpoint and os.path.exists(os.path.join(args.resume_from_checkpoint, Trainer.STATE_FILE)):
+    if args.resume_from_checkpoint and (os.path.exists(os.path.join(args.resume_from_checkpoint, "optimizer.bin")) or
+                                        os.path.exists(os.path.join(args.resume_from_checkpoint, Trainer.STATE_FILE))):
         trainer.load_state(args.resume_from_checkpoint)  # Adam moments + step counts (train_multi.py:484-533)
         start_step = trainer.completed
 
@@ -124,7 +125,7 @@ def main(argv=None):
     steps_per_epoch = max(len(sampler) // group, 1)         # (every rank gets the same number of batches per epoch)
     max_steps = args.max_train_steps or args.num_train_epochs * steps_per_epoch
     out_dir = Path(args.output_dir)
-    save = (lambda d: model.save_pretrained(d)) if continuous else trainer.save_state
+    save = trainer.save_state
     step, t0, tokens = start_step, time.time(), 0
     # resume: skip what the finished steps consumed (train_multi.py:519-528, 547-549) instead of replaying epoch 0
     first_epoch, skip_steps = divmod(start_step, steps_per_epoch)

@@ -181,3 +181,34 @@ def test_two_adamw_steps_match_reference():
         worst = max(worst, err / moved)
         # Adam turns a gradient into +-lr steps: an element whose gradient is bf16 rounding noise can land one step away
         assert err <= 0.35 * moved, (name, err, moved)
+
+
+def test_mar_trainer_resume_roundtrip(tmp_path):
+    """`MarTrainer.save_state` / `load_state`: Accelerate-layout optimizer.bin / scheduler.bin (train_multi.py:310-321) carry the Adam
+    moments of both flat ranges and the update counts; a resumed trainer takes the same next step."""
+    from hma_amd.train import MarTrainer, reference_param_groups
+    m = build()
+    m.load_state_dict(seeded_state(m.state_dict()))
+    m = m.to(DEV).train()
+    tr = MarTrainer(m, lr=1e-3, warmup_steps=0)
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    kw = dict(input_ids=inp["latents"], labels=inp["latents"], action_ids=inp["actions_domA"], domain=["domA"] * 2,
+              masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=inp["t"], diffusion_noise=inp["noise"])
+    for _ in range(2):
+        tr.step(**kw)
+    tr.save_state(tmp_path)
+    assert {"optimizer.bin", "scheduler.bin", "model.safetensors", "config.json"} <= set(os.listdir(tmp_path))
+    osd = torch.load(tmp_path / "optimizer.bin", weights_only=False)
+    order = sum(reference_param_groups([n for n, _ in m.named_parameters()]), [])
+    st = {order[i]: v for i, v in osd["state"].items()}
+    assert float(st["diffloss.net.cond_embed.weight"]["step"]) == 2.0 and float(st["decoder.layers.0.mlp.fc1.weight"]["step"]) == 2.0
+    assert not any(n.startswith("action_diff_losses.") or ".domB." in n or n == "action_mask_tokens" for n in st)
+    m2 = STMAR.from_pretrained(tmp_path).to(DEV).train()
+    tr2 = MarTrainer(m2, lr=1e-3, warmup_steps=0)
+    tr2.load_state(tmp_path)
+    assert tr2.completed == 2 and tr2.engine.opt_step == 2 and tr2.engine.dom_steps == {"domA": 2}
+    assert torch.equal(tr2.own["M"], tr.own["M"]) and torch.equal(tr2.own["V"], tr.own["V"])
+    tr.step(**kw)
+    tr2.step(**kw)
+    worst = max((p1.detach() - p2.detach()).abs().max().item() for (_, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()))
+    assert worst <= 2.1e-3  # at most one Adam step apart where a gradient element is rounding noise
