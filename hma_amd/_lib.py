@@ -106,6 +106,7 @@ _PROTOS = {
     "hma_gate_bwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32],
     "hma_diff_loss": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i32],
     "hma_diff_p_sample": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64, c_i32],
+    "hma_diff_p_sample_cfg": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_i64, c_i32, c_f32],
     "hma_mar_patchify": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32],
     "hma_mar_mask_token_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32],
     "hma_mar_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32],

@@ -267,12 +267,18 @@ __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict_
 // ---------------------------------------------------------------- one reverse step of the sampler
 __global__ __launch_bounds__(256) void p_sample_kernel(const float* __restrict__ out, int64_t ldo, float* __restrict__ x,
                                                        const float* __restrict__ noise, Sched sc, int ti, float temperature,
-                                                       int clip, int64_t n, int C) {
+                                                       int clip, int64_t n, int C, int64_t half, float cfg) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n * C) return;
   const int64_t row = i / C;
   const int c = (int)(i % C);
-  const float eps = out[row * ldo + c], v = out[row * ldo + C + c], x_t = x[i];
+  float eps = out[row * ldo + c];
+  if (half) {  // forward_with_cfg (diffloss.py:235-243): rows [0, half) conditional, [half, 2 half) unconditional
+    const int64_t r = row >= half ? row - half : row;
+    const float cond = out[r * ldo + c], uncond = out[(r + half) * ldo + c];
+    eps = uncond + cfg * (cond - uncond);
+  }
+  const float v = out[row * ldo + C + c], x_t = x[i];
   const float frac = (v + 1.f) * 0.5f;
   const float L = frac * sc.log_betas[ti] + (1.f - frac) * sc.post_logvar[ti];
   float px0 = sc.sqrt_recip_ac[ti] * x_t - sc.sqrt_recipm1_ac[ti] * eps;
@@ -375,7 +381,20 @@ extern "C" int hma_diff_p_sample(void* stream, const float* out, int64_t ldo, fl
   if (n <= 0) return 0;
   const Sched sc{tables6, tables6 + n_steps, tables6 + 2 * n_steps, tables6 + 3 * n_steps, tables6 + 4 * n_steps, tables6 + 5 * n_steps};
   hipLaunchKernelGGL(p_sample_kernel, dim3((unsigned)((n * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, ldo, x, noise, sc,
-                     (int)step, temperature, (int)clip_denoised, n, (int)C);
+                     (int)step, temperature, (int)clip_denoised, n, (int)C, (int64_t)0, 1.0f);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_diff_p_sample_cfg(void* stream, const float* out, int64_t ldo, float* x, const float* noise, const float* tables6,
+                                     int32_t n_steps, int32_t step, float temperature, int32_t clip_denoised, int64_t n, int32_t C,
+                                     float cfg_scale) {
+  if (!out || !x || !tables6 || step < 0 || step >= n_steps || C < 1 || ldo < 2 * C || (n & 1)) return HMA_EINVAL;
+  if (step != 0 && !noise) return HMA_EINVAL;
+  if (n <= 0) return 0;
+  const Sched sc{tables6, tables6 + n_steps, tables6 + 2 * n_steps, tables6 + 3 * n_steps, tables6 + 4 * n_steps, tables6 + 5 * n_steps};
+  hipLaunchKernelGGL(p_sample_kernel, dim3((unsigned)((n * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, ldo, x, noise, sc,
+                     (int)step, temperature, (int)clip_denoised, n, (int)C, n / 2, cfg_scale);
   HMA_CHECK_LAUNCH();
   return 0;
 }

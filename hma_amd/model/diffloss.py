@@ -386,24 +386,36 @@ class DiffLoss(nn.Module):
     @torch.no_grad()
     def sample(self, z, temperature=1.0, cfg=1.0, clip_denoised=False, *, noise0: Optional[torch.Tensor] = None,
                step_noises: Optional[torch.Tensor] = None):
-        """p_sample_loop over the respaced chain (diffloss.py:37-59, gaussian_diffusion.py:396-493)."""
-        if cfg != 1.0:
-            raise NotImplementedError("classifier-free guidance (cfg != 1) is not built")
+        """p_sample_loop over the respaced chain (diffloss.py:37-59, gaussian_diffusion.py:396-493).  cfg != 1 is the
+        reference's guidance branch (:39-43, forward_with_cfg :235-243): z = [cond | uncond], the start noise (`noise0`:
+        [N/2, C]) is duplicated, the network sees the first half of x twice and eps is mixed inside the reverse-step kernel."""
         dev = z.device
         N, Cc = z.shape[0], self.in_channels
+        guided = float(cfg) != 1.0
+        if guided and N % 2:
+            raise ValueError("classifier-free guidance needs an even batch: z = [cond | uncond]")
         sch = self._gen.on(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         Wb, _, bias = self._weights(stream, False)
         zc = z.detach().contiguous()
         zc = zc if zc.dtype in (F32, BF16) else zc.float()
-        x = (torch.randn(N, Cc, device=dev) if noise0 is None else noise0.to(dev, F32)).contiguous().clone()
+        if guided:
+            half0 = torch.randn(N // 2, Cc, device=dev) if noise0 is None else noise0.to(dev, F32)
+            x = torch.cat([half0, half0], dim=0).contiguous()
+        else:
+            x = (torch.randn(N, Cc, device=dev) if noise0 is None else noise0.to(dev, F32)).contiguous().clone()
         xt_pad = torch.empty(N, _PAD, dtype=BF16, device=dev)
         tfreq = torch.empty(N, 256, dtype=BF16, device=dev)
         for k, i in enumerate(reversed(range(self._gen.n))):
             t = torch.full((N,), i, dtype=torch.long, device=dev)
-            _lib.call("hma_diff_prepare", stream, ptr(x), None, ptr(t), None, None, ptr(sch["tmap"]), None, ptr(xt_pad), ptr(tfreq), N, Cc, _PAD)
+            xin = torch.cat([x[: N // 2], x[: N // 2]], dim=0) if guided else x
+            _lib.call("hma_diff_prepare", stream, ptr(xin), None, ptr(t), None, None, ptr(sch["tmap"]), None, ptr(xt_pad), ptr(tfreq), N, Cc, _PAD)
             out, _ = self._net_forward(stream, Wb, bias, xt_pad, tfreq, zc, keep=False)
             nz = torch.randn(N, Cc, device=dev) if step_noises is None else step_noises[k].to(dev, F32).contiguous()
-            _lib.call("hma_diff_p_sample", stream, ptr(out), _PAD, ptr(x), ptr(nz), ptr(sch["t6"]), self._gen.n, i, float(temperature),
-                      1 if clip_denoised else 0, N, Cc)
+            if guided:
+                _lib.call("hma_diff_p_sample_cfg", stream, ptr(out), _PAD, ptr(x), ptr(nz), ptr(sch["t6"]), self._gen.n, i,
+                          float(temperature), 1 if clip_denoised else 0, N, Cc, float(cfg))
+            else:
+                _lib.call("hma_diff_p_sample", stream, ptr(out), _PAD, ptr(x), ptr(nz), ptr(sch["t6"]), self._gen.n, i,
+                          float(temperature), 1 if clip_denoised else 0, N, Cc)
         return x

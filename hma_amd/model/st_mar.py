@@ -10,7 +10,8 @@ modules and their parameters are shared with an internal `STMaskGIT` whose flat 
 `hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
 `DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
 `maskgit_generate` / `generate` are the MAR decode (st_mar.py:277-452) with `DiffLoss.sample`.
-Not built: `jointly_predict_actions`, classifier-free guidance (cfg != 1), diffusion_batch_mul > 1.
+Not built: `jointly_predict_actions`, diffusion_batch_mul > 1, and cfg != 1 in the MAR decode (the reference's own branch,
+st_mar.py:417-418, indexes bs rows of latents with a 2 bs mask and cannot run; `DiffLoss.sample(cfg=...)` itself is built).
 """
 from __future__ import annotations
 
@@ -262,7 +263,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         import numpy as np
         assert out_t, "maskgit_generate requires out_t > 0"
         if cfg != 1.0:
-            raise NotImplementedError("classifier-free guidance (cfg != 1) is not built")
+            raise NotImplementedError("cfg != 1 in the MAR decode: the reference branch (st_mar.py:417-418) cannot run; DiffLoss.sample(cfg=) is built")
         dev = prompt_THW.device
         x = self.patchify(prompt_THW).clone()
         B, T, h_, w_, pc = x.shape

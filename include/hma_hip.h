@@ -260,6 +260,13 @@ int hma_diff_loss(void* stream, const float* out, int64_t ldo, const float* x0, 
 /* One reverse step x <- mean(x, out) + [step != 0] exp(logvar / 2) noise temperature  (p_sample, :358-394) */
 int hma_diff_p_sample(void* stream, const float* out, int64_t ldo, float* x, const float* noise, const float* tables6,
                       int32_t n_steps, int32_t step, float temperature, int32_t clip_denoised, int64_t n, int32_t C);
+/* The same step under classifier-free guidance (DiffLoss.sample's cfg != 1 branch, diffloss.py:39-43, with
+ * SimpleMLPAdaLN.forward_with_cfg :235-243): n is even, `out` is the network on [x[:n/2] | x[:n/2]] with conditions
+ * [cond | uncond]; every row's eps becomes uncond + cfg_scale (cond - uncond) of its half-batch partner pair, the
+ * variance channels stay the row's own. */
+int hma_diff_p_sample_cfg(void* stream, const float* out, int64_t ldo, float* x, const float* noise, const float* tables6,
+                          int32_t n_steps, int32_t step, float temperature, int32_t clip_denoised, int64_t n, int32_t C,
+                          float cfg_scale);
 
 /* ---- STMAR (continuous latents, hma/model/st_mar.py) input / output stages around the ST-transformer trunk --------------
  * hma_mar_patchify: latents [frames, H, W, C] -> patches [frames * H/p * W/p, p*p*C] in (p, q, c) channel order

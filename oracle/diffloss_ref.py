@@ -153,13 +153,24 @@ def diffloss_forward(P, target, z, mask, t, noise, depth):
 
 
 @torch.no_grad()
-def diffloss_sample(P, z, noise0, step_noises, depth, temperature=1.0, num_sampling_steps="100", clip_denoised=False):
-    """DiffLoss.sample (cfg = 1): p_sample_loop over the respaced process; step_noises[k] is the k-th randn_like."""
+def diffloss_sample(P, z, noise0, step_noises, depth, temperature=1.0, num_sampling_steps="100", clip_denoised=False, cfg=1.0):
+    """DiffLoss.sample (diffloss.py:37-59): p_sample_loop over the respaced process; step_noises[k] is the k-th randn_like.
+    cfg != 1: noise0 holds the half-batch start noise (duplicated, :40-41) and every step runs forward_with_cfg (:235-243) --
+    the network sees the FIRST half of x twice (conditions z = [cond | uncond]), eps of both halves becomes
+    uncond + cfg * (cond - uncond), the variance channels stay per row."""
     tb = Tables.sampling(num_sampling_steps)
-    x = noise0
+    x = noise0 if cfg == 1.0 else torch.cat([noise0, noise0], dim=0)
+    C = x.shape[1]
     for k, i in enumerate(reversed(range(tb.n))):
         t = torch.full((x.shape[0],), i, dtype=torch.long)
-        out = net_forward(P, x, torch.tensor(tb.timestep_map)[t], z, depth)
+        tm = torch.tensor(tb.timestep_map)[t]
+        if cfg == 1.0:
+            out = net_forward(P, x, tm, z, depth)
+        else:
+            h = x.shape[0] // 2
+            out = net_forward(P, torch.cat([x[:h], x[:h]], dim=0), tm, z, depth)
+            eps = out[h:, :C] + cfg * (out[:h, :C] - out[h:, :C])
+            out = torch.cat([torch.cat([eps, eps], dim=0), out[:, C:]], dim=1)
         mean, logvar, _ = p_mean_logvar(tb, x, t, out, clip_denoised)
         nz = 0.0 if i == 0 else 1.0
         x = mean + nz * torch.exp(0.5 * logvar) * step_noises[k] * temperature

@@ -64,5 +64,28 @@ try:
 finally:
     torch.randn_like = orig
 out.update({"s.z": zs, "s.noise0": noise0, "s.draws": torch.stack(draws), "s.sample": smp})
+
+# classifier-free guidance (diffloss.py:39-43 + forward_with_cfg :235-243): DiffLoss.sample's own cfg != 1 branch, its
+# torch.randn(...).cuda() start noise replaced by a seeded CPU draw (no GPU in the build container)
+CFG = 2.5
+zg = torch.randn(ns, ZC, generator=g)
+half0 = torch.randn(ns // 2, C, generator=g)
+draws_g = []
+def rec_g(x, *a, **k):
+    v = torch.randn(x.shape, generator=g)
+    draws_g.append(v)
+    return v
+class _Start:  # what `torch.randn(n, c).cuda()` returns inside DiffLoss.sample
+    def __init__(self, v): self.v = v
+    def cuda(self): return self.v
+orig_randn = torch.randn
+torch.randn_like = rec_g
+torch.randn = lambda *a, **k: _Start(half0) if "generator" not in k else orig_randn(*a, **k)
+try:
+    with torch.no_grad():
+        smp_g = dl.sample(zg, temperature=0.9, cfg=CFG)
+finally:
+    torch.randn_like, torch.randn = orig, orig_randn
+out.update({"g.z": zg, "g.half0": half0, "g.draws": torch.stack(draws_g), "g.sample": smp_g, "g.cfg": torch.tensor([CFG])})
 save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "g9_diffloss.safetensors"))
 print("wrote g9_diffloss:", len(out), "tensors,", os.path.getsize(os.path.join(HERE, "g9_diffloss.safetensors")) // 1024, "KB; loss", float(loss))

@@ -42,3 +42,10 @@ def test_training_loss_and_gradients_match_reference():
 def test_sampling_loop_matches_reference():
     x = R.diffloss_sample(params(), G["s.z"], G["s.noise0"], list(G["s.draws"]), DEPTH, temperature=0.9, num_sampling_steps="10")
     assert torch.allclose(x, G["s.sample"], rtol=1e-4, atol=1e-4)
+
+
+def test_sampling_with_classifier_free_guidance_matches_reference():
+    x = R.diffloss_sample(params(), G["g.z"], G["g.half0"], list(G["g.draws"]), DEPTH, temperature=0.9, num_sampling_steps="10",
+                          cfg=float(G["g.cfg"]))
+    assert x.shape == G["g.sample"].shape and not torch.equal(x[:32], x[32:])  # the halves draw their own step noise
+    assert torch.allclose(x, G["g.sample"], rtol=1e-4, atol=1e-4)

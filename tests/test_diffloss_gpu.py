@@ -61,3 +61,12 @@ def test_sampling_chain():
     x = m.sample(G["s.z"].to(DEV), temperature=0.9, noise0=G["s.noise0"].to(DEV), step_noises=G["s.draws"].to(DEV))
     assert x.shape == G["s.sample"].shape
     assert rel(x, G["s.sample"]) < 1.5e-2                        # measured 4.6e-3 after 10 reverse steps
+
+
+def test_sampling_chain_with_classifier_free_guidance():
+    m = build()
+    x = m.sample(G["g.z"].to(DEV), temperature=0.9, cfg=float(G["g.cfg"]), noise0=G["g.half0"].to(DEV), step_noises=G["g.draws"].to(DEV))
+    assert x.shape == G["g.sample"].shape
+    assert rel(x, G["g.sample"]) < 2.5e-2                        # guidance scale 2.5 amplifies the bf16 eps difference
+    with pytest.raises(ValueError):
+        m.sample(G["g.z"][:5].to(DEV), cfg=2.0)
