@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhma_hip.so")
 
-A_BF16, A_F32, A_BF16_AFFINE = 0, 1, 2
+A_BF16, A_F32, A_BF16_AFFINE, A_BF16_FRAG32 = 0, 1, 2, 3
 EPI_BF16, EPI_F32, EPI_RESID, EPI_GELU2, EPI_SILU2, EPI_DGELU, EPI_DSILU, EPI_ATOMIC_F32 = range(8)
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

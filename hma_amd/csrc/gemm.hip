@@ -1494,6 +1494,7 @@ struct tn_prob {
   int splits, gn, gk;
   int nb;            // workgroups of this problem
   int colsum;        // write the column-sum partials
+  int yfrag, afrag;  // operand stored in the fused-MLP fragment order (HMA_A_BF16_FRAG32): only the DMA source address differs
 };
 struct tn_pair_args {
   tn_prob q[2];      // problem 1's workgroup ids follow problem 0's (q[1].nb == 0: a single problem)
@@ -1555,8 +1556,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
       const int rl = q * 2 + (lane >> 5);                 // row & 3 (4 w is a multiple of 4)
       const int lc = (lane & 31) ^ (rl << 2);             // logical chunk that lands in this lane's slot
       const int64_t m = m0 + wave * 4 + rl;
-      const uint16_t* ys = Yb + m * p.ldy + lc * 8;  // host: no row groups on this path
-      const uint16_t* as = Ab + m * p.lda + lc * 8;
+      // HMA_A_BF16_FRAG32: (128-row tile, 32-column block, 32-row group) -> 2 KB = [columns 8..15 / 24..31 ? 1 : 0][column >= 16]
+      // [row][8 columns] -- what hma_mlp_bwd's producers store with one contiguous 1 KB per wave instruction
+      auto frag_at = [&](const uint16_t* base, int64_t ld, int64_t col) __attribute__((always_inline)) {
+        return base + (((((m >> 7) * (ld >> 5) + (col >> 5)) << 2) + ((m >> 5) & 3)) << 10) + (((col >> 3) & 1) << 9) +
+               (((((col >> 4) & 1) << 5) + (m & 31)) << 3);
+      };
+      const uint16_t* ys = p.yfrag ? frag_at(reinterpret_cast<const uint16_t*>(p.dY), p.ldy, n0 + lc * 8)
+                                   : Yb + m * p.ldy + lc * 8;  // host: no row groups on this path
+      const uint16_t* as = p.afrag ? frag_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8) : Ab + m * p.lda + lc * 8;
       glds16(ys, slot_b + (wave * 4 + q * 2) * 512);
       glds16(as, slot_b + DM_TILE_BYTES + (wave * 4 + q * 2) * 512);
     }
@@ -2313,8 +2321,11 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
 
 // ---- LDS-DMA ring weight gradients: eligibility, split planning and launch of one or two problems
 static bool tn_dma_eligible(const hma_gemm_tn_t& q) {
-  return q.N % WT == 0 && q.K % WT == 0 && q.y_kind == HMA_A_BF16 && (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE) &&
-         q.M > 0 && q.M % DM_ROWS == 0 && q.y_group_rows <= 0 && q.a_group_rows <= 0 && q.ldy % 8 == 0 && q.lda % 8 == 0 &&
+  const bool yf = q.y_kind == HMA_A_BF16_FRAG32, af = q.a_kind == HMA_A_BF16_FRAG32;
+  if ((yf || af) && q.batch > 1) return false;
+  if ((yf && q.ldy != q.N) || (af && q.lda != q.K)) return false;  // the fragment order has no row pitch: the operand is the whole matrix
+  return q.N % WT == 0 && q.K % WT == 0 && (q.y_kind == HMA_A_BF16 || yf) &&
+         (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE || af) && q.M > 0 && q.M % DM_ROWS == 0 && q.y_group_rows <= 0 && q.a_group_rows <= 0 && q.ldy % 8 == 0 && q.lda % 8 == 0 &&
          q.sY % 8 == 0 && q.sA % 8 == 0 && (reinterpret_cast<uintptr_t>(q.dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.A) & 15) == 0;
 }
 // splits for a problem that may use at most `budget` workgroups; 0 if it cannot take the two-stage path
@@ -2334,6 +2345,8 @@ static tn_prob tn_make_prob(const hma_gemm_tn_t& q, float* ws, int splits) {
   t.splits = splits; t.gn = (int)(q.N / WT); t.gk = (int)(q.K / WT);
   t.nb = splits * t.gn * t.gk * (q.batch > 0 ? q.batch : 1);
   t.colsum = (q.dBias != nullptr) || q.a_kind == HMA_A_BF16_AFFINE;
+  t.yfrag = q.y_kind == HMA_A_BF16_FRAG32;
+  t.afrag = q.a_kind == HMA_A_BF16_FRAG32;
   return t;
 }
 template <bool TR>
@@ -2408,7 +2421,7 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     const dim3 rgrid((unsigned)(WT * WT / 512), (unsigned)(gn * gk * nb));
     // bf16 x bf16 with a workspace: the LDS-DMA ring kernel
     const bool bias_room = q.ws && q.ws_elems >= (int64_t)nblocks * (WT * WT + WT);
-    if (q.ws && tn_dma_eligible(q) && (bias_room || (!q.dBias && q.a_kind == HMA_A_BF16))) {
+    if (q.ws && tn_dma_eligible(q) && (bias_room || (!q.dBias && q.a_kind != HMA_A_BF16_AFFINE))) {
       tn_pair_args args;
       args.q[0] = tn_make_prob(q, q.ws, splits);
       args.q[1] = args.q[0];

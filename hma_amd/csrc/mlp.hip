@@ -616,21 +616,25 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
     uint16_t* sp_du = nullptr;
     bool sv_ok = false;
     float s2acc = 0.f;
+    MPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {
+      MPROF_MARK(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      MPROF_MARK(1);
       if (g > 0 && sv_ok && !(MLP_ABL & 128)) {
         *reinterpret_cast<uint4*>(sp_hg) = sv[0];
-        *reinterpret_cast<uint4*>(sp_hg + 8) = sv[1];
+        *reinterpret_cast<uint4*>(sp_hg + 512) = sv[1];
         *reinterpret_cast<uint4*>(sp_du) = sv[2];
-        *reinterpret_cast<uint4*>(sp_du + 8) = sv[3];
+        *reinterpret_cast<uint4*>(sp_du + 512) = sv[3];
       }
+      MPROF_MARK(2);
       if (g < nsteps) {
         const int s = g & 31;
         const int64_t row = tile_row0(g >> 5) + lr;
         const int64_t rowc = row < p.M ? row : p.M - 1;
-        if (s == 0) {
+        if (s == 0 && (!(MLP_ABL & 2048) || g == 0)) {
           const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.xhat) + rowc * 256 + 16 * hi;
           const uint16_t* ds = reinterpret_cast<const uint16_t*>(p.dy) + rowc * 256 + 16 * hi;
 #pragma unroll
@@ -645,6 +649,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           asm volatile("" : "+v"(rs));
           if (hi == 0) ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lr] = rs;  // the consumer reads it one step later
         }
+        MPROF_MARK(3);
         HMA_LDS(char)* wb = lds + (g % MB_NSLOT) * MB_SLOT + lane * 16;
         f32x16_t U, D;
 #pragma unroll
@@ -668,6 +673,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             for (int i = 0; i < 4; ++i) fa[i] = fb[i];
           }
         }
+        MPROF_MARK(4);
         HMA_LDS(char)* bp = lds + MB_B1 + (32 * s + 16 * hi) * 4;
         // (two halves of 8: the staged GELU holds ~8 values per element in flight)
 #pragma unroll
@@ -693,8 +699,13 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           sv[2 + half] = pack8(du);
         }
         sv_ok = row < p.M;
-        sp_hg = reinterpret_cast<uint16_t*>(p.hg) + rowc * 1024 + 32 * s + 16 * hi;
-        sp_du = reinterpret_cast<uint16_t*>(p.du) + rowc * 1024 + 32 * s + 16 * hi;
+        {  // HMA_A_BF16_FRAG32: (tile, hidden block, pair) -> 2 KB = [the lane's units 0..7 | 8..15][64 lanes][8 units]: each of
+           // the four store instructions of a step writes 1 KB of contiguous memory (row-major, a lane's 16 bytes sit in a
+           // 2 KB-pitch row: 32 partial cache lines per instruction, which held up the LDS-DMA issue behind them)
+          const int64_t blk = ((((int64_t)blockIdx.x + (int64_t)(g >> 5) * gridDim.x) * 32 + s) * 4 + pair) * 1024 + lane * 8;
+          sp_hg = reinterpret_cast<uint16_t*>(p.hg) + blk;
+          sp_du = reinterpret_cast<uint16_t*>(p.du) + blk;
+        }
         HMA_LDS(char)* xc = lds + MB_XCH + pair * 4096 + (g & 1) * 2048 + lane * 16;
         lds_put(xc, sv[2]);
         lds_put(xc + 1024, sv[3]);
@@ -703,8 +714,10 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           if (hi == 0) ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256))[lr] = t2;
           s2acc = 0.f;
         }
+        MPROF_MARK(5);
       }
     }
+    MPROF_FLUSH(1);
   } else {
     // ---------------------------------------------------------------- consumer
     f32x16_t G[8];
@@ -759,22 +772,26 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
     issue(0);
     int pend = 0;            // loads issued after the newest bundle (they are younger than it: vmcnt(pend) = bundle complete)
     float invr = 1.f, rstd = 1.f, sumold = 0.f;
+    MPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {
+      MPROF_MARK(0);
       wait_vm(pend);
+      MPROF_MARK(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      MPROF_MARK(2);
       if (g + 1 <= nsteps) issue(g + 1);
       pend = 0;
       if (g >= 1) {
         const int gc = g - 1, s = gc & 31, tl = gc >> 5;
         // staged row blocks, issued AFTER the bundle (so that the bundle wait of the next step does not wait for HBM):
         // dx block cb at s = 4 cb (added at s = 4 cb + 2), xhat pieces 0 / 1 at s = 28 / 30 (used by the epilogue)
-        if ((s & 3) == 0) {
+        if ((s & 3) == 0 && !(MLP_ABL & 256)) {
           issue_rows(reinterpret_cast<const char*>(p.dx) + (s >> 2) * 128, 1024, tl, (s >> 2) & 1);
           pend += 4;
         }
-        if (s == 28) {
+        if (s == 28 && !(MLP_ABL & 1024)) {
           issue_rows(reinterpret_cast<const char*>(p.xhat), 512, tl, 0);
           pend += 4;
         }
@@ -783,6 +800,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           invr = 1.0f / rstd;
           sumold = 0.f;
         }
+        MPROF_MARK(3);
         HMA_LDS(char)* xc = lds + MB_XCH + pair * 4096 + (gc & 1) * 2048 + lane * 16;
         const bf16x8_t d0 = lds_frag(xc);
         const bf16x8_t d1 = lds_frag(xc + 1024);
@@ -808,6 +826,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             for (int i = 0; i < 4; ++i) fa[i] = fb[i];
           }
         }
+        MPROF_MARK(4);
         if ((s & 3) == 2 && !(MLP_ABL & 64)) {  // dx block issued two steps ago (older than the bundle waited for above)
           const int cbx = s >> 2;
           float xv[16];
@@ -825,10 +844,11 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
               for (int e = 0; e < 16; ++e) G[kb][e] += xv[e];
             }
         }
-        if (s == 30) {  // (after the last dx block left staging piece 1)
+        if (s == 30 && !(MLP_ABL & 1024)) {  // (after the last dx block left staging piece 1)
           issue_rows(reinterpret_cast<const char*>(p.xhat) + 128, 512, tl, 1);
           pend += 4;
         }
+        MPROF_MARK(5);
         if (s == 31 && (MLP_ABL & 64)) {
 #pragma unroll
           for (int kb = 0; kb < 8; ++kb)
@@ -865,7 +885,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
 #pragma unroll
               for (int e = 0; e < 16; ++e) G[2 * cp + k][e] = __builtin_fmaf(-s2, xf[e], G[2 * cp + k][e]);
             }
-            if (cp < 2) {
+            if (cp < 2 && !(MLP_ABL & 1024)) {
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's reads of the piece are done before it is refilled)
               issue_rows(reinterpret_cast<const char*>(p.xhat) + (cp + 2) * 128, 512, tl, cp & 1);
             }
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
               for (int i = 0; i < 4; ++i) {
                 const int r = 8 * i + prow;
                 const float4 v = lds_f4(sb + r * 128 + (pchunk << 4));
-                if (r0 + r < p.M) *reinterpret_cast<float4*>(p.dx + (r0 + r) * 256 + kb * 32 + ((pchunk ^ ((r >> 1) & 7)) << 2)) = v;
+                if (r0 + r < p.M && !(MLP_ABL & 512)) *reinterpret_cast<float4*>(p.dx + (r0 + r) * 256 + kb * 32 + ((pchunk ^ ((r >> 1) & 7)) << 2)) = v;
               }
               qb[2 * k] = pack8(o);
               qb[2 * k + 1] = pack8(o + 8);
@@ -905,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             for (int i = 0; i < 4; ++i) {
               const int r = 8 * i + prow;
               const uint4 v = __builtin_bit_cast(uint4, lds_f4(sb + r * 128 + (pchunk << 4)));
-              if (r0 + r < p.M)
+              if (r0 + r < p.M && !(MLP_ABL & 512))
                 *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.dx_bf16) + (r0 + r) * 256 + cp * 64 + ((pchunk ^ ((r >> 1) & 7)) << 3)) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -916,8 +936,10 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             for (int e = 0; e < 16; ++e) G[kb][e] = 0.f;
           pend = 63;  // every load of this wave is complete (vmcnt(0) above); the stores need no wait
         }
+        MPROF_MARK(6);
       }
     }
+    MPROF_FLUSH(1);
   }
 }
 

@@ -20,7 +20,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
+from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
 from .ops import make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
@@ -302,6 +302,8 @@ class STEngine:
         """Whether a pass over `rows` token rows runs the fused MLP block (see __init__)."""
         if not self.fused_mlp:
             return False
+        if train and rows % 32:  # hma_mlp_bwd hands gelu(u) / dL/du to the weight gradients in the HMA_A_BF16_FRAG32 order (LDS-DMA path only)
+            return False
         return rows >= self.fused_mlp_min_rows and (self.fused_mlp_train or not train)
 
     def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
@@ -356,8 +358,9 @@ class STEngine:
             buf("dxb", (M, 256), BF16)  # bf16 copy of dx: operand of the dgrad / wgrad GEMMs that read it
             if fused:
                 buf("dxb2", (M, 256), BF16)   # hma_mlp_bwd writes the new copy while the fc2 weight gradient still reads the old one
-                buf("hg1", (M, 1024), BF16)   # gelu(u) and dL/du of the layer in flight (operands of its two weight gradients)
-                buf("du1", (M, 1024), BF16)
+                Mt = (M + 127) // 128 * 128    # gelu(u) and dL/du of the layer in flight (operands of its two weight gradients),
+                buf("hg1", (Mt, 1024), BF16)   # in hma_mlp_bwd's fragment order (HMA_A_BF16_FRAG32: whole 128-row tiles)
+                buf("du1", (Mt, 1024), BF16)
             if float(getattr(self.cfg, "mlp_drop", 0.0) or 0.0) > 0.0:
                 buf("dxm", (M, 256), BF16)  # dx behind the Dropout that follows fc2
             buf("t256", (M, 256), BF16)
@@ -560,9 +563,9 @@ class STEngine:
                 pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
                            w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
                            b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du)
-                pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024,
+                pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16_FRAG32, M=M, N=256, K=1024,
                                      dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
-                                dict(dY=du, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
+                                dict(dY=du, ldy=1024, y_kind=A_BF16_FRAG32, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
                                      gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
                                      K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias),
                                      w_master=self._lw(l, "mlp.fc1.weight", "p"), dgamma=gw("norm2.weight"),

@@ -23,7 +23,12 @@ extern "C" {
 #define HMA_EINVAL (-10001) /* unsupported shape / null pointer */
 
 /* A-operand element type / prologue and epilogue selectors of the two GEMM entry points */
-enum { HMA_A_BF16 = 0, HMA_A_F32 = 1, HMA_A_BF16_AFFINE = 2 };
+enum { HMA_A_BF16 = 0, HMA_A_F32 = 1, HMA_A_BF16_AFFINE = 2,
+       /* hma_gemm_tn / hma_gemm_tn_pair operands only (workspace path, ld == the matrix width, batch 1): bf16 [M, ld] in the order
+        * hma_mlp_bwd stores gelu(u) / dL/du -- element (m, c) at ((((m / 128) (ld / 32) + c / 32) 4 + (m / 32) % 4) 1024 +
+        * ((c / 8) % 2) 512 + (((c / 16) % 2) 32 + m % 32) 8 + c % 8: every (128-row tile, 32-column block, 32-row group) is 2 KB that
+        * one wave writes with two contiguous 1 KB store instructions.  Allocate ceil(M / 128) 128 rows. */
+       HMA_A_BF16_FRAG32 = 3 };
 enum {
   HMA_EPI_BF16 = 0,      /* C(bf16)  = acc (+bias)                                            */
   HMA_EPI_F32 = 1,       /* C(f32)   = acc (+bias)                                            */
@@ -346,8 +351,9 @@ typedef struct {
 } hma_mlp_fwd_t;
 int hma_mlp_fwd(void* stream, const hma_mlp_fwd_t* p);
 /* Backward of the block above from dy = bf16 gradient wrt its output (the bf16 copy of the residual gradient dx):
- * u is recomputed from xhat; hg = gelu(u) and du = (dy fc2.weight) * gelu'(u) are written (bf16 [M, 1024]) for the two
- * weight gradients (hma_gemm_tn_pair: fc2 from dy / hg, fc1 from du / xhat with the affine + dgamma / dbeta);
+ * u is recomputed from xhat; hg = gelu(u) and du = (dy fc2.weight) * gelu'(u) are written (bf16, ceil(M / 128) 128 rows of
+ * 1024, in the HMA_A_BF16_FRAG32 order) for the two weight gradients (hma_gemm_tn_pair: fc2 from dy / hg as a_kind =
+ * HMA_A_BF16_FRAG32, fc1 from du as y_kind = HMA_A_BF16_FRAG32 / xhat with the affine + dgamma / dbeta);
  * dx += LayerNorm-backward(du fc1.weight * gamma) (rstd = the saved 1 / sigma of norm2) and dx_bf16 = bf16(new dx),
  * which must not alias dy (the fc2 weight gradient still reads dy). */
 typedef struct {

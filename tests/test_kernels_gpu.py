@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from hma_amd import _lib, ops  # noqa: E402
-from hma_amd._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID,
+from hma_amd._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID,
                           EPI_SILU2)  # noqa: E402
 from oracle import st_maskgit_ref as R  # noqa: E402
 
@@ -697,6 +697,13 @@ def test_mlp_fwd_fused(M, with_ln):
         close(ln_r, torch.rsqrt(var + 1e-5), 2e-3, "rstd")
 
 
+def _from_frag32(t, M):
+    """[Mt, ld] in the HMA_A_BF16_FRAG32 order (include/hma_hip.h) -> row-major [M, ld]."""
+    Mt, ld = t.shape
+    v = t.reshape(Mt // 128, ld // 32, 4, 2, 2, 32, 8)        # tile, block, row group, (c / 8) % 2, (c / 16) % 2, row, c % 8
+    return v.permute(0, 2, 5, 1, 4, 3, 6).reshape(Mt, ld)[:M]  # tile, group, row | block, c/16, c/8, c%8
+
+
 @pytest.mark.parametrize("M", [128, 1000, 40960])
 def test_mlp_bwd_fused(M):
     w1, b1, w2, b2, gam, bet = _mlp_weights(200)
@@ -711,8 +718,9 @@ def test_mlp_bwd_fused(M):
     xhd, dyd, rsd = xh.to(DEV).bfloat16(), dy.to(DEV).bfloat16(), rstd.reshape(-1).to(DEV)
     dxd = dx0.to(DEV).clone()
     dxb = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
-    hg = torch.empty(M, 1024, dtype=torch.bfloat16, device=DEV)
-    du = torch.empty(M, 1024, dtype=torch.bfloat16, device=DEV)
+    Mt = (M + 127) // 128 * 128
+    hg = torch.zeros(Mt, 1024, dtype=torch.bfloat16, device=DEV)  # HMA_A_BF16_FRAG32 order
+    du = torch.zeros(Mt, 1024, dtype=torch.bfloat16, device=DEV)
     a = ops.make_mlp_bwd(M=M, xhat=ops.ptr(xhd), rstd=ops.ptr(rsd), dy=ops.ptr(dyd), dx=ops.ptr(dxd), dx_bf16=ops.ptr(dxb),
                          w1p=ops.ptr(pk["w1p"]), w2tp=ops.ptr(pk["w2tp"]), w1tp=ops.ptr(pk["w1tp"]), b1=ops.ptr(b1f),
                          hg=ops.ptr(hg), du=ops.ptr(du))
@@ -725,8 +733,25 @@ def test_mlp_bwd_fused(M):
     hgr = u * cdf
     dhg = dy @ rb(w2)
     dur = dhg * (cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi))
-    close(hg, hgr, 2 * BF, "hg")
-    close(du, dur, 2 * BF, "du")
+    close(_from_frag32(hg, M), hgr, 2 * BF, "hg")
+    close(_from_frag32(du, M), dur, 2 * BF, "du")
+    if M % 32 == 0:  # the two weight gradients read that order directly (LDS-DMA source addressing)
+        dW2 = torch.zeros(256, 1024, device=DEV)
+        dW1 = torch.zeros(1024, 256, device=DEV)
+        dB1 = torch.zeros(1024, device=DEV)
+        ws = torch.empty(256 * (65536 + 256), device=DEV)
+        one, zero = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+        ta = ops.make_gemm_tn(dY=ops.ptr(dyd), ldy=256, y_kind=A_BF16, A=ops.ptr(hg), lda=1024, a_kind=A_BF16_FRAG32, M=M, N=256,
+                              K=1024, dW=ops.ptr(dW2), lddw=1024, ws=ops.ptr(ws), ws_elems=ws.numel())
+        tb = ops.make_gemm_tn(dY=ops.ptr(du), ldy=1024, y_kind=A_BF16_FRAG32, A=ops.ptr(xhd), lda=256, a_kind=A_BF16_AFFINE, M=M,
+                              N=1024, K=256, dW=ops.ptr(dW1), lddw=256, dBias=ops.ptr(dB1), gamma=ops.ptr(one), beta=ops.ptr(zero),
+                              ws=ops.ptr(ws), ws_elems=ws.numel())
+        _lib.call("hma_gemm_tn_pair", ops.stream_ptr(), C.byref(ta), C.byref(tb))
+        torch.cuda.synchronize()
+        hb, db = _from_frag32(hg, M).float().cpu(), _from_frag32(du, M).float().cpu()
+        close(dW2, dy.t() @ hb, 2e-2, "dW2 from FRAG32 hg")
+        close(dW1, db.t() @ xh, 2e-2, "dW1 from FRAG32 du")
+        close(dB1, db.sum(0), 2e-2, "db1 from FRAG32 du")
     gk = rb(dur) @ w1f  # dxhat with gamma folded (the kernel multiplies the bf16-rounded du it hands to the wgrad)
     s1 = gk.mean(1, keepdim=True)
     s2 = (gk * xh).mean(1, keepdim=True)

@@ -21,6 +21,9 @@ else
   : > gpurun_out/mlp_variants.txt
   timeout 120 python3 tools/mlp_bench.py 2>&1 | tail -1 | tee -a gpurun_out/mlp_variants.txt
   for so in variants/libhma_*.so; do
-    HMA_LIB=$so timeout 120 python3 tools/mlp_bench.py 2>&1 | tail -1 | tee -a gpurun_out/mlp_variants.txt
+    case $so in
+      *prof*) HMA_LIB=$so MLP_PROF=1 timeout 120 python3 tools/mlp_bench.py 2>&1 | tail -21 | tee -a gpurun_out/mlp_variants.txt ;;
+      *) HMA_LIB=$so timeout 120 python3 tools/mlp_bench.py 2>&1 | tail -1 | tee -a gpurun_out/mlp_variants.txt ;;
+    esac
   done
 fi
