@@ -727,13 +727,20 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
     const char* g1 = reinterpret_cast<const char*>(p.w1p) + pair * 4096 + lane * 16;
     const char* g2 = reinterpret_cast<const char*>(p.w2tp) + pair * 4096 + lane * 16;
     const char* g3 = reinterpret_cast<const char*>(p.w1tp) + pair * 4096 + lane * 16;
-    auto issue = [&](int b) __attribute__((always_inline)) {
+    // this wave's 12 KB of bundle b, in three parts (issued between the MFMA groups of the step: a burst of twelve 1 KB
+    // pieces right behind the barrier held the wave at the issue for as long as the MFMAs it had not started yet)
+    auto issue_part = [&](int b, int part) __attribute__((always_inline)) {
       const uint32_t base = lds_b + (b % MB_NSLOT) * MB_SLOT + pair * 4096;
       const int s1 = b & 31, s2 = (b + 31) & 31;
       if (MLP_ABL & 1) return;
-      glds16x4(g1 + s1 * 16384, base);
-      glds16x4(g2 + s1 * 16384, base + 16384);
-      glds16x4(g3 + s2 * 16384, base + 32768);
+      if (part == 0) glds16x4(g1 + s1 * 16384, base);
+      if (part == 1) glds16x4(g2 + s1 * 16384, base + 16384);
+      if (part == 2) glds16x4(g3 + s2 * 16384, base + 32768);
+    };
+    auto issue = [&](int b) __attribute__((always_inline)) {
+      issue_part(b, 0);
+      issue_part(b, 1);
+      issue_part(b, 2);
     };
     // one 32-row x 128-byte block of a row-major matrix (fp32 dx: 32 columns; bf16 xhat: 64 columns) -> staging piece `buf`
     auto issue_rows = [&](const char* base, int64_t row_bytes, int tl, int buf) __attribute__((always_inline)) {
@@ -781,20 +788,12 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
       if (!(MLP_ABL & 8)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       MPROF_MARK(2);
-      if (g + 1 <= nsteps) issue(g + 1);
+      const bool nxt = g + 1 <= nsteps;
       pend = 0;
+      if (g == 0 && nxt) issue(g + 1);
       if (g >= 1) {
         const int gc = g - 1, s = gc & 31, tl = gc >> 5;
-        // staged row blocks, issued AFTER the bundle (so that the bundle wait of the next step does not wait for HBM):
-        // dx block cb at s = 4 cb (added at s = 4 cb + 2), xhat pieces 0 / 1 at s = 28 / 30 (used by the epilogue)
-        if ((s & 3) == 0 && !(MLP_ABL & 256)) {
-          issue_rows(reinterpret_cast<const char*>(p.dx) + (s >> 2) * 128, 1024, tl, (s >> 2) & 1);
-          pend += 4;
-        }
-        if (s == 28 && !(MLP_ABL & 1024)) {
-          issue_rows(reinterpret_cast<const char*>(p.xhat), 512, tl, 0);
-          pend += 4;
-        }
+        if (nxt) issue_part(g + 1, 0);
         if (s == 0) {
           rstd = ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lr];  // published by the producer at its s == 0
           invr = 1.0f / rstd;
@@ -820,6 +819,20 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
             for (int i = 0; i < 4; ++i) {
               const int kb = 4 * (grp & 1) + i;
               G[kb] = mfma32a(fa[i], (grp >> 1) ? d1 : d0, G[kb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp < 2 && nxt) issue_part(g + 1, grp + 1);
+            if (grp == 2) {
+              // staged row blocks, issued AFTER the bundle (so that the bundle wait of the next step does not wait for HBM):
+              // dx block cb at s = 4 cb (added at s = 4 cb + 2), xhat pieces 0 / 1 at s = 28 / 30 (used by the epilogue)
+              if ((s & 3) == 0 && !(MLP_ABL & 256)) {
+                issue_rows(reinterpret_cast<const char*>(p.dx) + (s >> 2) * 128, 1024, tl, (s >> 2) & 1);
+                pend += 4;
+              }
+              if (s == 28 && !(MLP_ABL & 1024)) {
+                issue_rows(reinterpret_cast<const char*>(p.xhat), 512, tl, 0);
+                pend += 4;
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -871,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           const float s2 = ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256))[lr] * (1.0f / 256.0f);
           // xhat pieces: piece cp holds columns 64 cp .. 64 cp + 63 (blocks kb = 2 cp, 2 cp + 1); 0 and 1 are in flight since
           // s = 28 / 30, 2 and 3 are issued as the buffers free up.  This wave's queue: [piece 1]? [bundle g + 1 (12)] ...
-          wait_vm(12);  // pieces 0 and 1 (older than this step's bundle)
+          wait_vm(nxt ? 12 : 0);  // pieces 0 and 1 (older than this step's bundle; the last step issues none)
 #pragma unroll
           for (int cp = 0; cp < 4; ++cp) {
             if (cp == 2) wait_vm(4);   // piece 2 (piece 3 is younger)

@@ -67,8 +67,8 @@ if os.environ.get("MLP_PROF"):
     _lib.call("hma_mlp_bwd", torch.cuda.current_stream().cuda_stream, C.byref(b))
     torch.cuda.synchronize()
     lib.hma_mlp_debug_prof(buf)
-    print("bwd phases, block 0.  producer: [loop, barrier, store-issue, tile-load, mfma, gelu/xch];  consumer: [loop, vmcnt-wait, barrier, "
-          "bundle+row issue, mfma, dx-add, epilogue]")
+    print("bwd phases, block 0.  producer: [loop, barrier, store-issue, tile-load, mfma, gelu/xch];  "
+          "consumer: [loop, vmcnt-wait, barrier, first bundle part, MFMAs + bundle parts + row DMA, dx-add, epilogue]")
     for w in range(8):
         v = [buf[64 + w * 8 + i] for i in range(8)]
         print(f"  wave {w} ({'producer' if w < 4 else 'consumer'}): " + " ".join(f"{x:9d}" for x in v[:7]) + f"   sum {sum(v)}")
