@@ -843,30 +843,8 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   const int64_t bz = slab_id / slabs_n;
   const int64_t bn = (int64_t)(slab_id % slabs_n) * 256;
 
-  {  // park the weight slab: chunk ch of row n goes to position ch ^ (5 * (((n >> 3) ^ (n >> 4)) & 1))  (bank spread, see below)
-    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
-    for (int c = tid; c < 256 * 32; c += 64 * NWAVES) {
-      const int n = c >> 5, ch = c & 31;
-      *reinterpret_cast<uint4*>(&Wsl[n * TW_LD + ((ch ^ (5 * (((n >> 3) ^ (n >> 4)) & 1))) << 3)]) =
-          *reinterpret_cast<const uint4*>(Wb + (int64_t)n * p.ldw + ch * 8);
-    }
-    if (AKIND == HMA_A_BF16_AFFINE) {
-      for (int c = tid; c < 256; c += 64 * NWAVES) { gb[c] = p.gamma[c]; gb[256 + c] = p.beta[c]; }
-    }
-    if (EPI == HMA_EPI_GELU2 || EPI == HMA_EPI_DGELU) {
-      for (int c = tid; c < 2 * GT_N; c += 64 * NWAVES) {
-        const uint32_t bits = (uint32_t)(GT_A0 + (c % GT_N)) | (c >= GT_N ? 0x8000u : 0u);
-        const float u = __uint_as_float(bits << 16);
-        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
-        gtab[c] = EPI == HMA_EPI_GELU2 ? cdf : cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
-      }
-    }
-  }
-  __syncthreads();  // the only barrier
-
   const int64_t tiles = (p.M + 15) / 16;
   const int64_t gw = (int64_t)slot * NWAVES + wave, nw = (int64_t)per_slab * NWAVES;
-  if (gw >= tiles) return;
 
   const char* Ab = reinterpret_cast<const char*>(p.A) + bz * p.sA * (AKIND == HMA_A_F32 ? 4 : 2);
   // A rows of one tile as MFMA B operands: a[j] = chunk 4 j + g of token row (tile * 16 + tok)
@@ -894,6 +872,40 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
       for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(row + (4 * j + g) * 8));
     }
   };
+  // the first tile's rows are requested before the slab: their latency passes under the fill
+  bf16x8_t a[8], an[8];
+  if (gw < tiles) load_a(gw, an);
+
+  // park the weight slab by LDS-DMA (132 pieces of 1 KB = 256 rows x 33 slots; all of a wave's pieces in flight at once --
+  // through registers the fill was 16 dependent rounds per thread, most of a small-M launch): slot L = 33 n + pos holds
+  // chunk pos ^ (5 * (((n >> 3) ^ (n >> 4)) & 1)) of row n (bank spread, see below); pos = 32 is the row padding.
+  {
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(p.W) + bz * p.sW + bn * p.ldw;
+    const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(HMA_LDS(char)*)smem);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    for (int piece = wv; piece < 132; piece += NWAVES) {
+      const int L = piece * 64 + lane;
+      const int n = L / 33, pos = L - 33 * n;
+      const int ch = (pos < 32 ? pos : 0) ^ (5 * (((n >> 3) ^ (n >> 4)) & 1));
+      glds16(Wb + (int64_t)n * p.ldw + ch * 8, lds_b + piece * 1024);
+    }
+    if (AKIND == HMA_A_BF16_AFFINE) {
+      for (int c = tid; c < 256; c += 64 * NWAVES) { gb[c] = p.gamma[c]; gb[256 + c] = p.beta[c]; }
+    }
+    if (EPI == HMA_EPI_GELU2 || EPI == HMA_EPI_DGELU) {
+      for (int c = tid; c < 2 * GT_N; c += 64 * NWAVES) {
+        const uint32_t bits = (uint32_t)(GT_A0 + (c % GT_N)) | (c >= GT_N ? 0x8000u : 0u);
+        const float u = __uint_as_float(bits << 16);
+        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+        gtab[c] = EPI == HMA_EPI_GELU2 ? cdf : cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // the only barrier
+
+  if (gw >= tiles) return;
+
   auto affine_a = [&](bf16x8_t (&a)[8]) __attribute__((always_inline)) {
     if (AKIND == HMA_A_BF16_AFFINE) {
 #pragma unroll
@@ -919,8 +931,6 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
   const uint16_t* wbase = Wsl + (8 * (i16 >> 2) + (i16 & 3)) * TW_LD + (g ^ jsw) * 8;
   const float* bias = p.bias ? p.bias + bz * p.sBias + bn : nullptr;
 
-  bf16x8_t a[8], an[8];
-  load_a(gw, an);
   for (int64_t tile = gw; tile < tiles; tile += nw) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = an[j];
