@@ -283,44 +283,48 @@ __global__ __launch_bounds__(128, 2) void attn_t_bwd_kernel(const uint16_t* __re
   store_column(dqkv, LD, sm, QLD, 0, LD / 8, row0, n_s, T, tid);
 }
 
-// Incremental decode: only frame t_query is new.  One lane per (column, head): q from the cache row of frame
-// t_query, K/V rows of frames 0..t_query streamed straight from the per-layer cache (64 B per head and frame).
-// Rows of the cache are (b, t, s) with T_cache frames per sample; o holds frame t_query only, rows (b, s).
-__global__ __launch_bounds__(64) void attn_t_decode_kernel(const uint16_t* __restrict__ cache, uint16_t* __restrict__ o,
-                                                           int64_t cols, int t_query, int T_cache, int n_s, float c_log2) {
-  const int lane = threadIdx.x;
-  const int64_t col = (int64_t)blockIdx.x * 8 + (lane >> 3);
-  const int h = lane & 7;
+// Incremental decode: only frame t_query is new.  One WAVE per column: q, and the K and V rows of frames 0..t_query, are read
+// as whole 512-byte rows (8 bytes per lane: lane 8 h + i holds channels 4 i .. 4 i + 3 of head h), every load of a column in
+// flight at once; a head's score is a 4-channel partial dot reduced over its 8 lanes, the softmax runs redundantly in them, and
+// each lane accumulates its 4 output channels.  (One lane per (column, head) with 64-byte pieces -- the first version -- had every
+// load instruction touch 64 cache lines for 1 KB.)  Rows of the cache are (b, t, s) with T_cache frames per sample; o holds frame
+// t_query only, rows (b, s).
+__global__ __launch_bounds__(256) void attn_t_decode_kernel(const uint16_t* __restrict__ cache, uint16_t* __restrict__ o,
+                                                            int64_t cols, int t_query, int T_cache, int n_s, float c_log2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (col >= cols) return;
   const int64_t b = col / n_s, s_idx = col % n_s;
-  const uint16_t* base = cache + ((b * T_cache) * n_s + s_idx) * LD + h * 32;
-  uint32_t q[16];
-  ld16(base + (int64_t)t_query * n_s * LD, q);
+  const int64_t fs = (int64_t)n_s * LD;
+  const uint16_t* base = cache + ((b * T_cache) * n_s + s_idx) * LD + lane * 4;
+  const uint2 qw = *reinterpret_cast<const uint2*>(base + (int64_t)t_query * fs);
+  uint2 kw[TM], vw[TM];
+#pragma unroll
+  for (int tp = 0; tp < TM; ++tp) {
+    kw[tp] = make_uint2(0u, 0u), vw[tp] = make_uint2(0u, 0u);
+    if (tp <= t_query) {
+      kw[tp] = *reinterpret_cast<const uint2*>(base + (int64_t)tp * fs + DM);
+      vw[tp] = *reinterpret_cast<const uint2*>(base + (int64_t)tp * fs + 2 * DM);
+    }
+  }
+  const float q0 = bf16_lo(qw.x), q1 = bf16_hi(qw.x), q2 = bf16_lo(qw.y), q3 = bf16_hi(qw.y);
   float s[TM];
 #pragma unroll
   for (int tp = 0; tp < TM; ++tp) {
-    s[tp] = 0.f;
-    if (tp <= t_query) {
-      uint32_t k[16];
-      ld16(base + (int64_t)tp * n_s * LD + DM, k);
-      s[tp] = dot32(q, k) * c_log2;
-    }
+    float d = q0 * bf16_lo(kw[tp].x) + q1 * bf16_hi(kw[tp].x) + q2 * bf16_lo(kw[tp].y) + q3 * bf16_hi(kw[tp].y);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    s[tp] = d * c_log2;
   }
   causal_softmax(s, t_query, t_query + 1);
-#pragma unroll
-  for (int tp = 0; tp < TM; ++tp) s[tp] = from_bf16(to_bf16(s[tp]));  // P enters the PV product as bf16, as in the MFMA kernels
-  float out[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) out[i] = 0.f;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
   for (int tp = 0; tp < TM; ++tp) {
-    if (tp <= t_query) {
-      uint32_t v[16];
-      ld16(base + (int64_t)tp * n_s * LD + 2 * DM, v);
-      axpy32(out, s[tp], v);
-    }
+    const float pr = from_bf16(to_bf16(s[tp]));  // P enters the PV product as bf16, as in the MFMA kernels
+    o0 += pr * bf16_lo(vw[tp].x), o1 += pr * bf16_hi(vw[tp].x), o2 += pr * bf16_lo(vw[tp].y), o3 += pr * bf16_hi(vw[tp].y);
   }
-  st32(o + col * DM + h * 32, out, 1.0f);
+  *reinterpret_cast<uint2*>(o + col * DM + lane * 4) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -349,7 +353,7 @@ extern "C" int hma_attn_temporal_cached(void* stream, const void* qkv_cache, voi
                        (uint16_t*)o, (int)T, (int)n_s, scale * LOG2E, (int64_t)T_cache * n_s);
   } else {
     if (t_query >= T_cache) return HMA_EINVAL;
-    hipLaunchKernelGGL(attn_t_decode_kernel, dim3((unsigned)((batch * n_s + 7) / 8)), dim3(64), 0, s,
+    hipLaunchKernelGGL(attn_t_decode_kernel, dim3((unsigned)((batch * n_s + 3) / 4)), dim3(256), 0, s,
                        (const uint16_t*)qkv_cache, (uint16_t*)o, batch * n_s, (int)t_query, (int)T_cache, (int)n_s,
                        scale * LOG2E);
   }
