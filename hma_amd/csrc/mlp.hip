@@ -795,7 +795,9 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
         const int gc = g - 1, s = gc & 31, tl = gc >> 5;
         if (nxt) issue_part(g + 1, 0);
         if (s == 0) {
-          rstd = ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lr];  // published by the producer at its s == 0
+          int lro = lr;
+          asm volatile("" : "+v"(lro));  // (opaque: hoisted out of the loop this address is spilled, and reloaded behind a vmcnt(0))
+          rstd = ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lro];  // published by the producer at its s == 0
           invr = 1.0f / rstd;
           sumold = 0.f;
         }
