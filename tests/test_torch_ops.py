@@ -1,0 +1,100 @@
+"""`torch.ops.hma.*` (hma_amd/torch_ops.py): registration, fake-tensor shapes (CPU) and values / gradients through the custom
+ops against plain PyTorch fp32 math on the same bf16-rounded operands (GPU)."""
+import math
+
+import pytest
+import torch
+
+import hma_amd.torch_ops as T
+
+BF = 2.0 ** -8
+
+
+def test_ops_registered_with_fake_kernels():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in T.OPS:
+        assert hasattr(torch.ops.hma, name), name
+    with FakeTensorMode():
+        x = torch.empty(512, 256, dtype=torch.bfloat16, device="cuda")
+        w = torch.empty(768, 256, dtype=torch.bfloat16, device="cuda")
+        y = torch.ops.hma.linear(x, w, None)
+        assert y.shape == (512, 768) and y.dtype == torch.bfloat16
+        o, lse = torch.ops.hma.attn_spatial(y, 2, 256, 0.17)
+        assert o.shape == (512, 256) and lse.shape == (512, 8)
+        assert torch.ops.hma.attn_temporal(y, 2, 4, 64, 0.17).shape == (512, 256)
+        xh, rs = torch.ops.hma.layer_norm(torch.empty(512, 256, device="cuda"), 1e-5)
+        assert xh.dtype == torch.bfloat16 and rs.shape == (512,)
+
+
+def test_cpu_tensors_are_refused():
+    with pytest.raises(Exception):
+        torch.ops.hma.linear(torch.zeros(16, 256, dtype=torch.bfloat16), torch.zeros(256, 256, dtype=torch.bfloat16), None)
+
+
+def _close(a, b, tol, what):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs().max().item()
+    assert err <= tol * (b.abs().max().item() + 1e-12), f"{what}: {err:.3e} vs scale {b.abs().max().item():.3e}"
+
+
+@pytest.mark.gpu
+def test_linear_forward_and_autograd():
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(640, 256, generator=g)).bfloat16()
+    w = (torch.randn(768, 256, generator=g) * 0.05).bfloat16()
+    b = torch.randn(768, generator=g) * 0.1
+    xd = x.cuda().requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True)
+    y = torch.ops.hma.linear(xd, wd, bd)
+    ref = x.float() @ w.float().t() + b
+    _close(y, ref, 2 * BF, "linear")
+    dy = (torch.randn(640, 768, generator=g) * 0.1).bfloat16()
+    y.backward(dy.cuda())
+    _close(xd.grad, dy.float() @ w.float(), 2 * BF, "dx")
+    _close(wd.grad, dy.float().t() @ x.float(), 2e-2, "dW")
+    _close(bd.grad, dy.float().sum(0), 2e-2, "dbias")
+
+
+@pytest.mark.gpu
+def test_attention_ops_and_autograd():
+    g = torch.Generator().manual_seed(1)
+    frames, n = 4, 320
+    qkv = (torch.randn(frames * n, 768, generator=g) * 0.5).bfloat16()
+    scale = 1.0 / math.sqrt(32)
+    qd = qkv.cuda().requires_grad_(True)
+    o, _ = torch.ops.hma.attn_spatial(qd, frames, n, scale)
+    q, k, v = [t.reshape(frames, n, 8, 32).permute(0, 2, 1, 3) for t in qkv.float().requires_grad_(True).chunk(3, dim=1)]
+    leaf = qkv.float().requires_grad_(True)
+    q, k, v = [t.reshape(frames, n, 8, 32).permute(0, 2, 1, 3) for t in leaf.chunk(3, dim=1)]
+    ref = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(frames * n, 256)
+    _close(o, ref, 3 * BF, "attn_spatial")
+    d_o = (torch.randn(frames * n, 256, generator=g) * 0.1).bfloat16()
+    o.backward(d_o.cuda())
+    ref.backward(d_o.float())
+    _close(qd.grad, leaf.grad, 3e-2, "attn_spatial dqkv")
+    # temporal: rows (b, t, s), causal over t
+    B, Tn, S = 2, 8, 40
+    qkv = (torch.randn(B * Tn * S, 768, generator=g) * 0.5).bfloat16()
+    qd = qkv.cuda().requires_grad_(True)
+    o = torch.ops.hma.attn_temporal(qd, B, Tn, S, scale)
+    leaf = qkv.float().requires_grad_(True)
+    q, k, v = [t.reshape(B, Tn, S, 8, 32).permute(0, 2, 3, 1, 4) for t in leaf.chunk(3, dim=1)]  # b s h t c
+    sc = q @ k.transpose(-1, -2) * scale
+    sc = sc.masked_fill(torch.triu(torch.ones(Tn, Tn, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ v).permute(0, 3, 1, 2, 4).reshape(B * Tn * S, 256)
+    _close(o, ref, 3 * BF, "attn_temporal")
+    d_o = (torch.randn(B * Tn * S, 256, generator=g) * 0.1).bfloat16()
+    o.backward(d_o.cuda())
+    ref.backward(d_o.float())
+    _close(qd.grad, leaf.grad, 3e-2, "attn_temporal dqkv")
+
+
+@pytest.mark.gpu
+def test_layer_norm_op():
+    x = torch.randn(1000, 256, generator=torch.Generator().manual_seed(2)) * 2 + 0.5
+    xh, rs = torch.ops.hma.layer_norm(x.cuda(), 1e-5)
+    ref = torch.nn.functional.layer_norm(x, (256,), eps=1e-5)
+    _close(xh, ref, 2 * BF, "xhat")
+    _close(rs, torch.rsqrt(x.var(1, unbiased=False) + 1e-5), 1e-4, "rstd")
