@@ -407,7 +407,7 @@ def main():
             one(k)
         torch.cuda.synchronize()
         timer, eng.timer = eng.timer, None
-        timed_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer.pairs)
+        timed_ms = sum(p[2].elapsed_time(p[3]) for p in timer.pairs)
         inst_steps = min(total, args.warmup + 3) - args.warmup
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -439,21 +439,32 @@ def main():
             for name, sm in summ.items():
                 if sm["ms"] <= 0:
                     continue
-                ach = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
-                fams[name] = {"achieved": ach, "frac": ach / 2500.0, "launches": sm["launches"], "avg_launch_us": 1e3 * sm["ms"] / sm["launches"],
-                              "flops_per_launch": sm["flops"] / sm["launches"], "share_of_step_time": (sm["ms"] / inst_steps) / step_ms}
-            # `roofline` = the family with the largest share of the step
+                sec = sm["ms"] * 1e-3
+                ach = sm["flops"] / sec / 1e12
+                gbs = sm["bytes"] / sec / 1e9
+                # the roofline that bounds the family: arithmetic intensity against the machine balance 2500 TFLOP/s / 8 TB/s
+                ai = sm["flops"] / sm["bytes"] if sm["bytes"] > 0 else float("inf")
+                fams[name] = {"bound": "hbm" if ai < MFMA_PEAK / 8e12 else "mfma", "achieved": ach, "frac": ach / 2500.0,
+                              "hbm_achieved_gbs": gbs, "hbm_frac": gbs / 8000.0, "flop_per_byte": ai,
+                              "launches": sm["launches"], "avg_launch_us": 1e3 * sm["ms"] / sm["launches"],
+                              "flops_per_launch": sm["flops"] / sm["launches"], "bytes_per_launch": sm["bytes"] / sm["launches"],
+                              "share_of_step_time": (sm["ms"] / inst_steps) / step_ms}
+            # `roofline` = the family with the largest share of the step, against the roof its arithmetic intensity puts it under
             dom_name = max(fams, key=lambda k: fams[k]["share_of_step_time"]) if fams else None
             if dom_name:
                 d0 = fams[dom_name]
                 traffic = pmc_traffic_per_launch({"hma_gemm_nt": "gemm_nt", "hma_mlp_bwd": "mlp_bwd", "hma_mlp_fwd": "mlp_fwd",
                                                   "hma_gemm_tn_pair": "gemm_tn"}.get(dom_name, dom_name))
-                avg_s = 1e-6 * d0["avg_launch_us"]
-                out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s",
-                                   "frac": d0["frac"], "traffic": traffic,
-                                   "hbm": None if not traffic else {"achieved": traffic / avg_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                                    "frac": traffic / avg_s / 8e12},
-                                   "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes (profiles/pmc_hbm_*.json)",
+                mfma = {"achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s", "frac": d0["frac"]}
+                hbm = {"achieved": d0["hbm_achieved_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": d0["hbm_frac"]}
+                top = hbm if d0["bound"] == "hbm" else mfma
+                out["roofline"] = {"bound": d0["bound"], "kernel": dom_name, "achieved": top["achieved"], "peak": top["peak"],
+                                   "unit": top["unit"], "frac": top["frac"], "traffic": traffic,
+                                   "flop_per_byte": d0["flop_per_byte"], "mfma": mfma, "hbm": hbm,
+                                   "bytes_per_launch": d0["bytes_per_launch"],
+                                   "traffic_note": "traffic = measured HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
+                                                   "(profiles/pmc_hbm_*.json); achieved = ALGORITHMIC bytes (every operand once, every result once) / "
+                                                   "launch time; bound = hbm when FLOP per algorithmic byte < 2500e12 / 8e12",
                                    "launches": d0["launches"], "avg_launch_us": d0["avg_launch_us"], "flops_per_launch": d0["flops_per_launch"],
                                    "share_of_step_time": d0["share_of_step_time"],
                                    "measured": f"HIP events around every launch of the MFMA kernel families in {inst_steps} eager steps run "

@@ -37,17 +37,33 @@ class Plan:
     def __init__(self):
         self.calls: List[Tuple[Callable, str, tuple]] = []
         self.flops: List[float] = []   # algorithmic FLOPs of each call (0 for non-GEMM launches)
+        self.bytes: List[float] = []   # algorithmic HBM bytes of each call: every operand read once, every result written once
         self.marks: Dict[str, int] = {}
         self.keep: list = []
 
-    def add(self, name: str, *args, flops: float = 0.0) -> None:
+    def add(self, name: str, *args, flops: float = 0.0, nbytes: float = 0.0) -> None:
         self.calls.append((getattr(_lib.load(), name), name, args))
         self.flops.append(flops)
+        self.bytes.append(nbytes)
+
+    @staticmethod
+    def _nt_bytes(g) -> float:
+        """A once + the weight + what the epilogue reads and writes."""
+        b = max(g.batch, 1)
+        mn = float(g.M) * g.N * b
+        out = {EPI_BF16: 2, EPI_F32: 4, EPI_RESID: 8, EPI_GELU2: 4, EPI_SILU2: 4, EPI_DGELU: 4, EPI_DSILU: 4, EPI_ATOMIC_F32: 8}[g.epi]
+        extra = (2 if (g.epi == EPI_RESID and g.C2) else 0) + (2 if g.ln_xhat else 0) + (2 if g.ln_xm else 0)
+        return float(g.M) * g.K * b * (4 if g.a_kind == A_F32 else 2) + 2.0 * g.N * g.K * b + mn * (out + extra)
+
+    @staticmethod
+    def _tn_bytes(g) -> float:
+        b = max(g.batch, 1)
+        return b * (float(g.M) * g.N * (4 if g.y_kind == A_F32 else 2) + float(g.M) * g.K * (4 if g.a_kind == A_F32 else 2) + 4.0 * g.N * g.K)
 
     def gemm_nt(self, **kw) -> None:
         g = make_gemm_nt(**kw)
         self.keep.append(g)
-        self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
+        self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._nt_bytes(g))
 
     def gemm_tn(self, **kw) -> None:
         if Plan.tn_workspace is not None:
@@ -55,7 +71,7 @@ class Plan:
             kw.setdefault("ws_elems", Plan.tn_workspace.numel())
         g = make_gemm_tn(**kw)
         self.keep.append(g)
-        self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1))
+        self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._tn_bytes(g))
 
     def gemm_tn_pair(self, kw0: dict, kw1: dict) -> None:
         """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair)."""
@@ -67,17 +83,18 @@ class Plan:
             gs.append(make_gemm_tn(**kw))
         self.keep.extend(gs)
         self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
-                 flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs))
+                 flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
 
     def mlp_fwd(self, M: int, **kw) -> None:
         g = make_mlp_fwd(M=M, **kw)
         self.keep.append(g)
-        self.add("hma_mlp_fwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2)
+        self.add("hma_mlp_fwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2, nbytes=3072.0 * M)  # xhat 512 + x 1024 in, x 1024 + xhat 512 out
 
     def mlp_bwd(self, M: int, **kw) -> None:
         g = make_mlp_bwd(M=M, **kw)
         self.keep.append(g)
-        self.add("hma_mlp_bwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2)  # algorithmic dgrad FLOPs (the recompute is not counted)
+        # algorithmic dgrad FLOPs (the recompute is not counted); xhat 2 x 512 + dy 512 + dx 1024 in, dx 1024 + dxb 512 + hg / du 2 x 2048 out
+        self.add("hma_mlp_bwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2, nbytes=8192.0 * M)
 
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
@@ -97,7 +114,7 @@ class Plan:
                 e0.record()
                 rc = fn(stream, *args)
                 e1.record()
-                timer.pairs.append((name, self.flops[i], e0, e1))
+                timer.pairs.append((name, self.flops[i], e0, e1, self.bytes[i]))
             else:
                 rc = fn(stream, *args)
             if rc != 0:
@@ -113,11 +130,12 @@ class LaunchTimer:
 
     def summary(self) -> Dict[str, Dict[str, float]]:
         out: Dict[str, Dict[str, float]] = {}
-        for name, flops, e0, e1 in self.pairs:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for name, flops, e0, e1, nbytes in self.pairs:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
+            d["bytes"] += nbytes
         return out
 
 
@@ -396,7 +414,8 @@ class STEngine:
             pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
         pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
                    epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
-        pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale, flops=4.0 * Fr * SA * SA * 256)
+        pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale, flops=4.0 * Fr * SA * SA * 256,
+               nbytes=(1536.0 + 512 + 32) * Fr * SA)
         # (the LayerNorm / modulate prologue of the NEXT sub-block is fused into this projection's epilogue)
         fuse = dict(ln_xhat=b["xhm"], ln_rstd=b["rstdm"], ln_eps=1e-6, ln_ss=b["ss"], ln_xm=b["xm"], ln_rows_per_frame=SA) if use_mod else {}
         pl.gemm_nt(A=b["o_s"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
@@ -410,7 +429,7 @@ class STEngine:
         if kv is None:
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
                        K=256, epi=EPI_BF16, Cp=b["qkv_t"], ldc=768, bias=qb("temporal_attn"))
-            pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256)
+            pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256, nbytes=2048.0 * M)
         else:
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
                        K=256, epi=EPI_BF16, Cp=kv["cache"] + kv["row_off"] * 768 * 2, ldc=768, c_group=kv["c_group"],
@@ -591,7 +610,7 @@ class STEngine:
                        dxb)
             # ---- temporal attention
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256)
+            pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256, nbytes=3584.0 * M)
             # projection and qkv weight gradients in one launch (dxb is not updated before the dqkv dgrad below)
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
@@ -611,7 +630,8 @@ class STEngine:
             # ---- spatial attention
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale,
-                   flops=10.0 * Fr * SA * SA * 256)  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
+                   flops=10.0 * Fr * SA * SA * 256,  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
+                   nbytes=(1536.0 + 512 + 512 + 32 + 1536) * Fr * SA)  # qkv, o, dO, lse read once; dqkv written
             # projection and qkv weight gradients in one launch (dxb is next updated by the LayerNorm backward below)
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
