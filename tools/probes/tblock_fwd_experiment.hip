@@ -418,6 +418,17 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(TB_ABL & 1)) {  // the head's q | k | v | o rows: 16 rows x 64 B per store instruction, last thing in the step
+#ifdef TB_STORE_LINEAR
+          // timing experiment: the same bytes as 1 KB of contiguous memory per store instruction (a fragment-order layout; the
+          // results are not readable by the row-major consumers)
+          const int64_t tix = (base_h / ((int64_t)p.T * SA)) * (SA >> 3) + (base_h % ((int64_t)p.T * SA)) / 8;
+          char* ql = reinterpret_cast<char*>(p.qkv) + ((tix * 8 + h) * 4 + pair) * 6144 + lane * 16;
+          char* ol = reinterpret_cast<char*>(p.o) + ((tix * 8 + h) * 4 + pair) * 2048 + lane * 16;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) *reinterpret_cast<uint4*>(ql + k * 1024) = rv[k];
+          *reinterpret_cast<uint4*>(ol) = rv[6];
+          *reinterpret_cast<uint4*>(ol + 1024) = rv[7];
+#else
           uint16_t* qt = reinterpret_cast<uint16_t*>(p.qkv) + base_h * 768 + 32 * h;
           uint16_t* ot = reinterpret_cast<uint16_t*>(p.o) + base_h * 256 + 32 * h;
 #pragma unroll
@@ -427,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void tblock_fwd_kernel(hma_tblock_fwd_t p) 
             *reinterpret_cast<uint4*>(qt + 512 + qoff[part]) = rv[4 + part];
             *reinterpret_cast<uint4*>(ot + ooff[part]) = rv[6 + part];
           }
+#endif
         }
         TPROF_MARK(3);
         if (h == 7) {
