@@ -69,6 +69,31 @@ class MlpBwd(C.Structure):
     ]
 
 
+class ChainWeights(C.Structure):
+    _fields_ = [("seg", c_vp * 4), ("bundles", c_i32 * 4)]
+
+
+class ChainAFwd(C.Structure):
+    _fields_ = [
+        ("w", ChainWeights),
+        ("o", c_vp), ("x", c_vp), ("ss", c_vp),
+        ("b_proj", c_vp), ("b_lin", c_vp), ("b_qkv", c_vp),
+        ("xhat", c_vp), ("xm", c_vp), ("rstd", c_vp), ("x_bf16", c_vp),
+        ("qkv", c_vp), ("ldq", c_i64), ("q_group_rows", c_i64), ("q_group_stride", c_i64),
+        ("M", c_i64), ("rows_per_frame", c_i32), ("use_mod", c_i32),
+    ]
+
+
+class ChainABwd(C.Structure):
+    _fields_ = [
+        ("w", ChainWeights),
+        ("dqkv", c_vp), ("ldq", c_i64), ("dx", c_vp),
+        ("xhat", c_vp), ("rstd", c_vp), ("ss", c_vp),
+        ("dx2_bf16", c_vp), ("dx1_bf16", c_vp), ("d_o", c_vp), ("dss", c_vp),
+        ("M", c_i64), ("rows_per_frame", c_i32), ("use_mod", c_i32),
+    ]
+
+
 _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
@@ -120,6 +145,10 @@ _PROTOS = {
     "hma_mlp_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64],
     "hma_mlp_fwd": [c_vp, C.POINTER(MlpFwd)],
     "hma_mlp_bwd": [c_vp, C.POINTER(MlpBwd)],
+    "hma_chain_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64],
+    "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
+    "hma_chain_a_bwd": [c_vp, C.POINTER(ChainABwd)],
+    "hma_zero_f32": [c_vp, c_vp, c_i64],
     "hma_abi_version": [],
 }
 

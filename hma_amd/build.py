@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhma_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "embed.hip", "loss.hip", "optim.hip", "collate.hip", "diffusion.hip", "mar.hip", "mlp.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn_spatial.hip", "attn_temporal.hip", "embed.hip", "loss.hip", "optim.hip", "collate.hip", "diffusion.hip", "mar.hip", "mlp.hip", "chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 
 

@@ -1,0 +1,641 @@
+// Row-local chains of an STBlock for gfx950: everything between two attentions in ONE launch.
+// Reference: STBlock.forward (hma/model/st_transformer.py:85-112), ModulateLayer.forward (hma/model/st_mask_git.py:66-76),
+// SelfAttention's qkv / proj Linears (hma/model/attention.py:39,60) and their autograd mirrors.
+//
+// Structure:
+//   * 512 threads: seven COMPUTE waves and one LOADER wave.  A compute wave owns 16 token rows of the 112-row tile for the whole
+//     chain.  Lane (tok = lane & 15, g = lane >> 4) holds chunks 4 j + g (8 columns each) of its token row: as the B operand of
+//     v_mfma_f32_16x16x32_bf16 (weights = A operand) and -- because the weight rows of a 32-column block are permuted -- as
+//     what the MFMAs leave in its accumulators: acc[2 pr + o][r] = column 32 pr + 8 g + 4 o + r.  So the output of one GEMM,
+//     packed to bf16, IS the B operand of the next one: no LDS round trip, no shuffles, and every global access of a lane is
+//     16 (bf16) or 32 (fp32) contiguous bytes, 64 contiguous bytes per token row and instruction.
+//   * Only the weights move through LDS: pre-packed in fragment order (hma_chain_pack: a 16 KB bundle = 32 output columns x 256 k
+//     = 16 lane-linear 1 KB fragments), streamed by the loader wave through a four-slot ring with LDS-DMA, one raw s_barrier per
+//     bundle.  The loader has no stores in its queue, so its counted vmcnt waits see the bundles only; the compute waves issue no
+//     loads inside the steps (biases and the per-frame shift / scale rows sit in LDS), so they never wait behind their own stores:
+//     their only loads are the next tile's rows, requested a stage ahead straight into the registers that will hold them.
+//   * The L2 -> LDS path is not the limit of this organisation (tools/probes/l2_stream.hip: 56 B/clk per CU by LDS-DMA from two
+//     waves on, against ~10 B/clk that a chain needs).
+#include "hma_common.h"
+#include "../../include/hma_hip.h"
+
+using namespace hma;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+constexpr int NCW = 7;                       // compute waves; wave NCW is the loader
+constexpr int NS = 4;                        // ring slots
+constexpr int SLOT = 16384;                  // one bundle
+constexpr int TILE_ROWS = 16 * NCW;          // 112
+constexpr int L_BIAS = NS * SLOT;            // 2048 floats of bias vectors
+constexpr int L_SS = L_BIAS + 8192;          // 2 tiles x NCW waves x 2 KB: the frames' shift | scale rows
+constexpr int SMEM = L_SS + 2 * NCW * 2048;  // 102400 B
+
+__device__ __forceinline__ bf16x8_t lds_frag(HMA_LDS(char)* p) { return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(u32x4_t)*)p); }
+__device__ __forceinline__ float4 lds_f4(HMA_LDS(char)* p) {
+  const f32x4v_t v = *(HMA_LDS(f32x4v_t)*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ f32x4v_t lds_f4v(HMA_LDS(char)* p) { return *(HMA_LDS(f32x4v_t)*)p; }
+__device__ __forceinline__ int64_t remap_row(int64_t r, int64_t group_rows, int64_t group_stride) {
+  return group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) : r;
+}
+__device__ __forceinline__ f32x4v_t mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4v_t& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8_t as_frag(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+#define CH_BARRIER()                    \
+  do {                                  \
+    __builtin_amdgcn_s_barrier();       \
+    asm volatile("" ::: "memory");      \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
+                                                         const float* __restrict__ rscale, const float* __restrict__ cscale,
+                                                         uint16_t* __restrict__ dst, int kind, int nbundles, int64_t sstride,
+                                                         int64_t dstride) {
+  const int64_t bz = blockIdx.y;
+  src += bz * sstride;
+  if (rscale) rscale += bz * sstride;
+  if (cscale) cscale += bz * sstride;
+  dst += bz * dstride;
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (bundle, fragment, lane)
+  if (idx >= nbundles * 1024) return;
+  const int lane = idx & 63, frag = (idx >> 6) & 15, b = idx >> 10;
+  const int i = lane & 15, g = lane >> 4;
+  int row, col0;
+  if (kind == 0) {
+    const int j = frag >> 1, o = frag & 1;
+    row = 32 * b + 8 * (i >> 2) + (i & 3) + 4 * o;
+    col0 = 8 * (4 * j + g);
+  } else {
+    row = 32 * (frag >> 1) + 8 * (i >> 2) + (i & 3) + 4 * (frag & 1);
+    col0 = 32 * b + 8 * g;
+  }
+  const float rsc = rscale ? rscale[row] : 1.0f;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = col0 + e;
+    float w = src[(int64_t)row * rs + (int64_t)c * cs] * rsc;
+    if (cscale) w *= cscale[c];
+    v[e] = w;
+  }
+  *reinterpret_cast<uint4*>(dst + (int64_t)idx * 8) = pack8(v);
+}
+
+// ------------------------------------------------------------------------------------------------ the loader wave
+// Streams the chain's bundles, `per_tile` per tile and `nt` tiles, through the ring: bundle s goes to slot s % NS and is
+// complete (this wave's vmcnt) before the wave arrives at barrier s; the slot it frees -- the compute waves are past their
+// reads of bundle s - 1 when they arrive at barrier s -- is refilled right behind the barrier.  In front of a tile's first
+// bundle go the shift / scale rows of the frames its seven 16-row groups lie in (2 KB each).
+struct ring_src {
+  const char *s0, *s1, *s2, *s3;
+  int n0, n1, n2, n3;
+};
+__device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
+                                           int64_t M, int rows_per_frame) {
+  const int total = per_tile * nt;
+  int issued = 0, seg = 0, left = ws.n0, tl_issue = 0, slot_issue = 0;
+  const char* cur = ws.s0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    if (seg == 0 && left == ws.n0 && ss) {  // a tile's first bundle: its shift / scale rows first
+      const int64_t t = (int64_t)blockIdx.x + (int64_t)tl_issue * gridDim.x;
+#pragma unroll 1
+      for (int w = 0; w < NCW; ++w) {
+        int64_t r0 = (t * NCW + w) * 16;
+        r0 = r0 < M ? r0 : M - 1;
+        const char* s = reinterpret_cast<const char*>(ss) + (r0 / rows_per_frame) * 2048 + lane * 16;
+        const uint32_t d = __builtin_amdgcn_readfirstlane(lds_b + L_SS + ((tl_issue & 1) * NCW + w) * 2048);
+        glds16(s, d);
+        glds16(s + 1024, d + 1024);
+      }
+    }
+    const char* s = cur + lane * 16;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(lds_b + slot_issue * SLOT);
+    glds16x4(s, d);
+    glds16x4(s + 4096, d + 4096);
+    glds16x4(s + 8192, d + 8192);
+    glds16x4(s + 12288, d + 12288);
+    ++issued;
+    slot_issue = (slot_issue + 1) & (NS - 1);
+    cur += SLOT;
+    if (--left == 0) {
+      ++seg;
+      int nn = seg == 1 ? ws.n1 : seg == 2 ? ws.n2 : seg == 3 ? ws.n3 : 0;
+      if (nn == 0) {
+        seg = 0;
+        nn = ws.n0;
+        ++tl_issue;
+      }
+      cur = seg == 0 ? ws.s0 : seg == 1 ? ws.s1 : seg == 2 ? ws.s2 : ws.s3;
+      left = nn;
+    }
+  };
+#pragma unroll 1
+  for (int b = 0; b < NS - 1 && b < total; ++b) issue();
+#pragma unroll 1
+  for (int s = 0; s < total; ++s) {
+    const int ahead = issued - 1 - s;  // bundles issued after bundle s (each 16 pieces; shift / scale pieces only make the wait stricter)
+    if (ahead >= 2)
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (ahead == 1)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CH_BARRIER();
+    if (issued < total) issue();
+  }
+}
+
+// one N-block bundle against the wave's rows: c0 / c1 += W[32 columns] . a   (16 MFMAs)
+__device__ __forceinline__ void nb_mma(HMA_LDS(char)* wb, const bf16x8_t (&a)[8], f32x4v_t& c0, f32x4v_t& c1) {
+  bf16x8_t f[4], fn[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f[q] = lds_frag(wb + q * 1024);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    if (h < 3) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fn[q] = lds_frag(wb + (4 * h + 4 + q) * 1024);
+    }
+    c0 = mfma16(f[0], a[2 * h], c0);
+    c1 = mfma16(f[1], a[2 * h], c1);
+    c0 = mfma16(f[2], a[2 * h + 1], c0);
+    c1 = mfma16(f[3], a[2 * h + 1], c1);
+    __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting every fragment read: it spills)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = fn[q];
+  }
+}
+
+__device__ __forceinline__ void add4(f32x4v_t& c, const float4& b) { c[0] += b.x; c[1] += b.y; c[2] += b.z; c[3] += b.w; }
+__device__ __forceinline__ uint4 pack_pair(const f32x4v_t& c0, const f32x4v_t& c1) {
+  return make_uint4(pack_bf16(c0[0], c0[1]), pack_bf16(c0[2], c0[3]), pack_bf16(c1[0], c1[1]), pack_bf16(c1[2], c1[3]));
+}
+__device__ __forceinline__ f32x4v_t ld4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return f32x4v_t{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4v_t& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+// (opaque use of prefetched registers at the end of a loop body: hipcc then places the counted vmcnt wait there, in straight-line
+// code behind the stores it can count, instead of a vmcnt(0) at the loop head)
+#define CH_TOUCH_A(a) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) asm volatile("" : "+v"(a[j_]))
+#define CH_TOUCH_ACC(c) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) asm volatile("" : "+v"(c[j_]))
+
+// ------------------------------------------------------------------------------------------------ chain A, forward
+template <bool MOD>
+__global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
+  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  {
+    HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | lin 256..511 | qkv 512..1279
+    for (int i = tid; i < 1280; i += 512) {
+      float v = 0.f;
+      if (i < 256) v = p.b_proj ? p.b_proj[i] : 0.f;
+      else if (i < 512) v = (MOD && p.b_lin) ? p.b_lin[i - 256] : 0.f;
+      else v = p.b_qkv ? p.b_qkv[i - 512] : 0.f;
+      bl[i] = v;
+    }
+  }
+  __syncthreads();
+  constexpr int PER_TILE = MOD ? 40 : 32;
+  if (wave == NCW) {
+    const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
+                         reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
+                         p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
+    loader_run(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    return;
+  }
+  const int tok = lane & 15, g = lane >> 4;
+  auto row_of = [&](int tl) __attribute__((always_inline)) {
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16 + tok;
+  };
+  bf16x8_t a0[8], a1[8];
+  f32x4v_t acc[16];
+  auto prefetch = [&](int tl) __attribute__((always_inline)) {
+    int64_t m = row_of(tl);
+    m = m < p.M ? m : p.M - 1;
+    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
+    const float* xrow = p.x + m * 256 + 8 * g;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      acc[2 * pr] = ld4(xrow + 32 * pr);
+      acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+    }
+  };
+  prefetch(0);
+  int slot = 0;
+  HMA_LDS(char)* ring = lds + lane * 16;
+  HMA_LDS(char)* bias = lds + L_BIAS + 32 * g;
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t m = row_of(tl);
+    const bool ok = m < p.M;
+    const int64_t mc = ok ? m : p.M - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+    // ---- x1 = x + o Wproj^T + b
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      CH_BARRIER();
+      nb_mma(ring + slot * SLOT, a0, acc[2 * pr], acc[2 * pr + 1]);
+      slot = (slot + 1) & (NS - 1);
+      add4(acc[2 * pr], lds_f4(bias + 128 * pr));
+      add4(acc[2 * pr + 1], lds_f4(bias + 128 * pr + 16));
+    }
+    if (MOD) {
+      // ---- LayerNorm (no affine) of the row the four lanes tok, tok + 16, tok + 32, tok + 48 hold, then the modulation
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / 256.0f);
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[t][r] - mean;
+          sq = __builtin_fmaf(d, d, sq);
+        }
+      }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
+      const float nb = -mean * rstd;
+      HMA_LDS(char)* ssl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 32 * g;
+      uint16_t* xh = p.xhat ? reinterpret_cast<uint16_t*>(p.xhat) + mc * 256 + 8 * g : nullptr;
+      uint16_t* xm = p.xm ? reinterpret_cast<uint16_t*>(p.xm) + mc * 256 + 8 * g : nullptr;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        float h[8], mm[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
+        const float4 sh0 = lds_f4(ssl + 128 * pr), sh1 = lds_f4(ssl + 128 * pr + 16);
+        const float4 sc0 = lds_f4(ssl + 1024 + 128 * pr), sc1 = lds_f4(ssl + 1024 + 128 * pr + 16);
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        // (the modulation is applied to the bf16-ROUNDED xhat: what the backward re-reads, as the unfused epilogue does)
+        const uint4 hq = pack8(h);
+        float hr[8];
+        unpack8(hq, hr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(hr[e], 1.0f + sc[e], sh[e]);
+        const uint4 mq = pack8(mm);
+        a1[pr] = as_frag(mq);
+        if (ok && xh) *reinterpret_cast<uint4*>(xh + 32 * pr) = hq;
+        if (ok && xm) *reinterpret_cast<uint4*>(xm + 32 * pr) = mq;
+      }
+      if (ok && g == 0 && p.rstd) p.rstd[mc] = rstd;
+    }
+    // ---- x2 = x1 + xm Wlin^T + b: the new residual row, its bf16 copy = the qkv GEMM's operand
+    float* xrow = p.x + mc * 256 + 8 * g;
+    uint16_t* xb = p.x_bf16 ? reinterpret_cast<uint16_t*>(p.x_bf16) + mc * 256 + 8 * g : nullptr;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      if (MOD) {
+        CH_BARRIER();
+        nb_mma(ring + slot * SLOT, a1, acc[2 * pr], acc[2 * pr + 1]);
+        slot = (slot + 1) & (NS - 1);
+        add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
+        add4(acc[2 * pr + 1], lds_f4(bias + 1024 + 128 * pr + 16));
+      }
+      const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
+      a0[pr] = as_frag(q);
+      if (ok) {
+        st4(xrow + 32 * pr, acc[2 * pr]);
+        st4(xrow + 32 * pr + 4, acc[2 * pr + 1]);
+        if (xb) *reinterpret_cast<uint4*>(xb + 32 * pr) = q;
+      }
+    }
+    // ---- qkv = bf16(x2) Wqkv^T + b; the next tile's rows are requested here, 24 steps before they are used
+    prefetch(tl + 1 < nt ? tl + 1 : tl);
+    uint16_t* qrow = reinterpret_cast<uint16_t*>(p.qkv) + remap_row(mc, p.q_group_rows, p.q_group_stride) * p.ldq + 8 * g;
+#pragma unroll
+    for (int pq = 0; pq < 24; ++pq) {
+      CH_BARRIER();
+      f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * pq), c1 = lds_f4v(bias + 2048 + 128 * pq + 16);
+      nb_mma(ring + slot * SLOT, a0, c0, c1);
+      slot = (slot + 1) & (NS - 1);
+      if (ok) *reinterpret_cast<uint4*>(qrow + 32 * pq) = pack_pair(c0, c1);
+    }
+    CH_TOUCH_A(a1);
+    CH_TOUCH_ACC(acc);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ chain A, backward
+// Sum over the 16 token lanes of a lane group of 64 per-lane values, transposed on the way: step b exchanges halves with lane
+// tok ^ (1 << b) and keeps the half its bit b selects, so after four steps lane tok holds the 16-lane sums of the FOUR values
+// c = q + 4 b3 + 8 b2 + 16 b1 + 32 b0 (b_i = bit i of tok): 60 exchanges instead of 256, and every lane ends with its own columns.
+template <typename F>
+__device__ __forceinline__ void colsum16(F&& val, int tok, float (&out)[4]) {
+  float w[32];
+  const bool b0 = tok & 1, b1 = tok & 2, b2 = tok & 4, b3 = tok & 8;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float lo = val(c), hi = val(c + 32);
+    w[c] = (b0 ? hi : lo) + __shfl_xor(b0 ? lo : hi, 1, 64);
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w[c] = (b1 ? w[c + 16] : w[c]) + __shfl_xor(b1 ? w[c] : w[c + 16], 2, 64);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) w[c] = (b2 ? w[c + 8] : w[c]) + __shfl_xor(b2 ? w[c] : w[c + 8], 4, 64);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[c] = (b3 ? w[c + 4] : w[c]) + __shfl_xor(b3 ? w[c] : w[c + 4], 8, 64);
+}
+
+template <bool MOD>
+__global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
+  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  constexpr int PER_TILE = MOD ? 40 : 32;
+  if (wave == NCW) {
+    const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
+                         reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
+                         p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
+    loader_run(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    return;
+  }
+  const int tok = lane & 15, g = lane >> 4;
+  auto row0_of = [&](int tl) __attribute__((always_inline)) {
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+  };
+  bf16x8_t dq[3][8], xr[8], a1[8];
+  f32x4v_t acc[16];
+  float rs = 0.f;
+  auto load_chunk = [&](int64_t mc, int c, bf16x8_t (&d)[8]) __attribute__((always_inline)) {
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(p.dqkv) + mc * p.ldq + 256 * c + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
+  };
+  auto prefetch = [&](int tl) __attribute__((always_inline)) {
+    int64_t m = row0_of(tl) + tok;
+    m = m < p.M ? m : p.M - 1;
+    load_chunk(m, 0, dq[0]);
+    const float* xrow = p.dx + m * 256 + 8 * g;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      acc[2 * pr] = ld4(xrow + 32 * pr);
+      acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+    }
+    if (MOD) {
+      const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
+      rs = p.rstd[m];
+    }
+  };
+  prefetch(0);
+  int slot = 0;
+  HMA_LDS(char)* ring = lds + lane * 16;
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t r0 = row0_of(tl), m = r0 + tok;
+    const bool ok = m < p.M;
+    const int64_t mc = ok ? m : p.M - 1;
+    // ---- dx2 = dx + dqkv Wqkv (k = 768 in three chunks; chunk c + 1 is requested while chunk c is multiplied)
+    load_chunk(mc, 1, dq[1]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (c == 1) load_chunk(mc, 2, dq[2]);
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        CH_BARRIER();
+        nb_mma(ring + slot * SLOT, dq[c], acc[2 * pr], acc[2 * pr + 1]);
+        slot = (slot + 1) & (NS - 1);
+      }
+    }
+    float* xrow = p.dx + mc * 256 + 8 * g;
+    if (MOD) {
+      uint16_t* d2 = reinterpret_cast<uint16_t*>(p.dx2_bf16) + mc * 256 + 8 * g;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
+        a1[pr] = as_frag(q);
+        if (ok) *reinterpret_cast<uint4*>(d2 + 32 * pr) = q;
+      }
+      // ---- dxm = bf16(dx2) Wlin
+      f32x4v_t dm[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        CH_BARRIER();
+        nb_mma(ring + slot * SLOT, a1, dm[2 * pr], dm[2 * pr + 1]);
+        slot = (slot + 1) & (NS - 1);
+      }
+      // ---- modulate + LayerNorm backward.  Rows past M contribute nothing to the frame sums.
+      if (!ok) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+      }
+      HMA_LDS(char)* scl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 1024 + 32 * g;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        float xh[8];
+        unpack8(__builtin_bit_cast(uint4, xr[pr]), xh);
+        const float4 sc0 = lds_f4(scl + 128 * pr), sc1 = lds_f4(scl + 128 * pr + 16);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gq = dm[2 * pr + (e >> 2)][e & 3] * (1.0f + sc[e]);
+          s1 += gq;
+          s2 = __builtin_fmaf(gq, xh[e], s2);
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      s1 *= (1.0f / 256.0f);
+      s2 *= (1.0f / 256.0f);
+      if (r0 < p.M) {  // d shift = column sums of dxm, d scale = column sums of dxm xhat over the frame's rows
+        float* dssf = p.dss + (r0 / p.rows_per_frame) * 512 + 8 * g;
+        float o4[4];
+        const int cb = ((tok >> 3) & 1) * 4 + ((tok >> 2) & 1) * 8 + ((tok >> 1) & 1) * 16 + (tok & 1) * 32;
+        colsum16([&](int c) __attribute__((always_inline)) { return dm[2 * (c >> 3) + ((c >> 2) & 1)][c & 3]; }, tok, o4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unsafeAtomicAdd(dssf + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o4[q]);
+        colsum16([&](int c) __attribute__((always_inline)) {
+          const uint32_t wv = __builtin_bit_cast(u32x4_t, xr[c >> 3])[(c >> 1) & 3];
+          return dm[2 * (c >> 3) + ((c >> 2) & 1)][c & 3] * ((c & 1) ? bf16_hi(wv) : bf16_lo(wv));
+        }, tok, o4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unsafeAtomicAdd(dssf + 256 + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o4[q]);
+      }
+      uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + mc * 256 + 8 * g;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        float xh[8];
+        unpack8(__builtin_bit_cast(uint4, xr[pr]), xh);
+        const float4 sc0 = lds_f4(scl + 128 * pr), sc1 = lds_f4(scl + 128 * pr + 16);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gq = dm[2 * pr + (e >> 2)][e & 3] * (1.0f + sc[e]);
+          acc[2 * pr + (e >> 2)][e & 3] += rs * (gq - s1 - xh[e] * s2);
+        }
+        const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
+        a1[pr] = as_frag(q);
+        if (ok) {
+          st4(xrow + 32 * pr, acc[2 * pr]);
+          st4(xrow + 32 * pr + 4, acc[2 * pr + 1]);
+          *reinterpret_cast<uint4*>(d1 + 32 * pr) = q;
+        }
+      }
+    } else {
+      uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + mc * 256 + 8 * g;
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
+        a1[pr] = as_frag(q);
+        if (ok) {
+          st4(xrow + 32 * pr, acc[2 * pr]);
+          st4(xrow + 32 * pr + 4, acc[2 * pr + 1]);
+          *reinterpret_cast<uint4*>(d1 + 32 * pr) = q;
+        }
+      }
+    }
+    // ---- d_o = bf16(dx1) Wproj; the next tile's rows are requested here
+    prefetch(tl + 1 < nt ? tl + 1 : tl);
+    uint16_t* orow = reinterpret_cast<uint16_t*>(p.d_o) + mc * 256 + 8 * g;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      CH_BARRIER();
+      f32x4v_t c0 = f32x4v_t{0.f, 0.f, 0.f, 0.f}, c1 = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+      nb_mma(ring + slot * SLOT, a1, c0, c1);
+      slot = (slot + 1) & (NS - 1);
+      if (ok) *reinterpret_cast<uint4*>(orow + 32 * pr) = pack_pair(c0, c1);
+    }
+    CH_TOUCH_A(dq[0]);
+    CH_TOUCH_ACC(acc);
+    if (MOD) {
+      CH_TOUCH_A(xr);
+      asm volatile("" : "+v"(rs));
+    }
+  }
+}
+
+template <auto Kern>
+int set_lds(int bytes) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return -(int)e;
+    done = true;
+  }
+  return 0;
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+bool weights_ok(const hma_chain_weights_t& w, int expect) {
+  int sum = 0;
+  bool ended = false;
+  for (int i = 0; i < 4; ++i) {
+    if (w.bundles[i] < 0) return false;
+    if (w.bundles[i] == 0) { ended = true; continue; }
+    if (ended || !w.seg[i]) return false;
+    sum += w.bundles[i];
+  }
+  return sum == expect;
+}
+
+int chain_grid(int64_t M) {
+  const int64_t ntiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+  return (int)(ntiles < num_cus() ? ntiles : num_cus());
+}
+
+}  // namespace
+
+extern "C" int hma_chain_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
+                              const float* col_scale, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t batch,
+                              int64_t src_batch_stride, int64_t dst_batch_stride) {
+  if (!src || !dst || batch < 1) return HMA_EINVAL;
+  int nb;
+  if (kind == 0) {
+    if (cols != 256 || rows <= 0 || rows % 32) return HMA_EINVAL;
+    nb = rows / 32;
+  } else if (kind == 1) {
+    if (rows != 256 || cols <= 0 || cols % 32) return HMA_EINVAL;
+    nb = cols / 32;
+  } else {
+    return HMA_EINVAL;
+  }
+  hipLaunchKernelGGL(chain_pack_kernel, dim3(nb * 4, batch), dim3(256), 0, (hipStream_t)stream, src, row_stride, col_stride,
+                     row_scale, col_scale, reinterpret_cast<uint16_t*>(dst), (int)kind, nb, src_batch_stride, dst_batch_stride);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_a_fwd(void* stream, const hma_chain_a_fwd_t* p) {
+  if (!p || !p->o || !p->x || !p->qkv || p->M <= 0 || p->ldq < 768) return HMA_EINVAL;
+  if (!weights_ok(p->w, p->use_mod ? 40 : 32)) return HMA_EINVAL;
+  if (p->use_mod && (!p->ss || p->rows_per_frame <= 0 || p->rows_per_frame % 16)) return HMA_EINVAL;
+  const int grid = chain_grid(p->M);
+  if (p->use_mod) {
+    if (int rc = set_lds<chain_a_fwd_kernel<true>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_a_fwd_kernel<true>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+  } else {
+    if (int rc = set_lds<chain_a_fwd_kernel<false>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_a_fwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+  }
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p) {
+  if (!p || !p->dqkv || !p->dx || !p->dx1_bf16 || !p->d_o || p->M <= 0 || p->ldq < 768) return HMA_EINVAL;
+  if (!weights_ok(p->w, p->use_mod ? 40 : 32)) return HMA_EINVAL;
+  if (p->use_mod && (!p->ss || !p->xhat || !p->rstd || !p->dx2_bf16 || !p->dss || p->rows_per_frame <= 0 || p->rows_per_frame % 16))
+    return HMA_EINVAL;
+  const int grid = chain_grid(p->M);
+  if (p->use_mod) {
+    if (int rc = set_lds<chain_a_bwd_kernel<true>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_a_bwd_kernel<true>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+  } else {
+    if (int rc = set_lds<chain_a_bwd_kernel<false>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_a_bwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+  }
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_zero_f32(void* stream, float* p, int64_t n) {
+  if (!p || n < 0) return HMA_EINVAL;
+  if (n == 0) return 0;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)n * 4, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : -(int)e;
+}

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, GemmNT, GemmTN, MlpBwd, MlpFwd)
+                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, GemmNT, GemmTN, MlpBwd, MlpFwd)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -95,6 +95,53 @@ def make_mlp_bwd(*, M: int, xhat: int, rstd: int, dy: int, dx: int, dx_bf16: int
     g = MlpBwd()
     g.xhat, g.rstd, g.dy, g.dx, g.dx_bf16 = xhat, rstd, dy, dx, dx_bf16
     g.w1p, g.w2tp, g.w1tp, g.b1, g.hg, g.du, g.M = w1p, w2tp, w1tp, b1, hg, du, M
+    return g
+
+
+def chain_pack(src: torch.Tensor, *, kind: int, rows: int, cols: int, row_stride: int, col_stride: int,
+               row_scale: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Bundles of one logical [rows][cols] matrix (hma_chain_pack) in the chains' streaming order; bf16, 8192 elements per bundle."""
+    nb = (rows if kind == 0 else cols) // 32
+    if out is None:
+        out = torch.empty(nb * 8192, dtype=BF16, device=src.device)
+    _lib.call("hma_chain_pack", stream_ptr(), ptr(src), row_stride, col_stride, ptr(row_scale), ptr(col_scale), ptr(out), kind,
+              rows, cols, 1, 0, 0)
+    return out
+
+
+def _chain_weights(w, segs) -> None:
+    for i in range(4):
+        w.seg[i] = segs[i][0] if i < len(segs) else None
+        w.bundles[i] = segs[i][1] if i < len(segs) else 0
+
+
+def make_chain_a_fwd(*, M: int, segs, o: int, x: int, qkv: int, ldq: int = 768, ss: Optional[int] = None,
+                     b_proj: Optional[int] = None, b_lin: Optional[int] = None, b_qkv: Optional[int] = None,
+                     xhat: Optional[int] = None, xm: Optional[int] = None, rstd: Optional[int] = None,
+                     x_bf16: Optional[int] = None, q_group=(0, 0), rows_per_frame: int = 0, use_mod: bool = True) -> ChainAFwd:
+    """segs: [(device pointer, bundles)] of the packed proj (8), linear_out (8, use_mod only) and qkv (24) weights."""
+    g = ChainAFwd()
+    _chain_weights(g.w, segs)
+    g.o, g.x, g.ss = o, x, ss
+    g.b_proj, g.b_lin, g.b_qkv = b_proj, b_lin, b_qkv
+    g.xhat, g.xm, g.rstd, g.x_bf16 = xhat, xm, rstd, x_bf16
+    g.qkv, g.ldq = qkv, ldq
+    g.q_group_rows, g.q_group_stride = q_group
+    g.M, g.rows_per_frame, g.use_mod = M, rows_per_frame, 1 if use_mod else 0
+    return g
+
+
+def make_chain_a_bwd(*, M: int, segs, dqkv: int, dx: int, dx1_bf16: int, d_o: int, ldq: int = 768, xhat: Optional[int] = None,
+                     rstd: Optional[int] = None, ss: Optional[int] = None, dx2_bf16: Optional[int] = None,
+                     dss: Optional[int] = None, rows_per_frame: int = 0, use_mod: bool = True) -> ChainABwd:
+    """segs: packed qkv^T (3 x 8), linear_out^T (8, use_mod only), proj^T (8)."""
+    g = ChainABwd()
+    _chain_weights(g.w, segs)
+    g.dqkv, g.ldq, g.dx = dqkv, ldq, dx
+    g.xhat, g.rstd, g.ss = xhat, rstd, ss
+    g.dx2_bf16, g.dx1_bf16, g.d_o, g.dss = dx2_bf16, dx1_bf16, d_o, dss
+    g.M, g.rows_per_frame, g.use_mod = M, rows_per_frame, 1 if use_mod else 0
     return g
 
 

@@ -365,6 +365,63 @@ typedef struct {
 } hma_mlp_bwd_t;
 int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p);
 
+/* ---- Row-local chains of an STBlock (st_transformer.py:85-112): everything between two attentions in ONE launch ----------
+ * A layer is two attentions plus two row-local chains; a chain keeps a token row on chip from the attention output to the
+ * next attention's qkv input.  Kernel structure (csrc/chain.hip): 7 compute waves own 16 token rows each (lane = a token's
+ * quarter row, v_mfma_f32_16x16x32_bf16 with the weights as the A operand: what a GEMM leaves in a lane's accumulators is,
+ * packed to bf16, the next GEMM's B operand), an 8th wave streams the chain's packed weights through a 4-slot LDS-DMA
+ * ring (16 KB bundles = 32 output columns x 256 k), one s_barrier per bundle.
+ *
+ * hma_chain_pack: weight bundles in streaming order.  Logical matrix A[r][c] = src[r * row_stride + c * col_stride] *
+ * (row_scale ? row_scale[r] : 1) * (col_scale ? col_scale[c] : 1), rounded to bf16.
+ *   kind 0 ("N-block"): A is [rows][256]; bundle b = rows 32 b .. 32 b + 31: 16 fragments (j, o) at 2 j + o, lane (i, g) holds
+ *                       A[32 b + 8 (i >> 2) + (i & 3) + 4 o][8 (4 j + g) .. + 7]          (rows / 32 bundles)
+ *   kind 1 ("K-slice"): A is [256][cols]; bundle b = columns 32 b .. 32 b + 31: 16 fragments t, lane (i, g) holds
+ *                       A[32 (t >> 1) + 8 (i >> 2) + (i & 3) + 4 (t & 1)][32 b + 8 g .. + 7]  (cols / 32 bundles)
+ * `batch` matrices `src_batch_stride` floats apart (the scales move with them), outputs `dst_batch_stride` bf16 apart. */
+int hma_chain_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
+                   const float* col_scale, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t batch,
+                   int64_t src_batch_stride, int64_t dst_batch_stride);
+/* The packed weights of one chain: up to 4 segments of bundles, consumed in order once per 112-row tile. */
+typedef struct { const void* seg[4]; int32_t bundles[4]; } hma_chain_weights_t;
+
+/* Chain A forward (st_transformer.py:86 proj, :102-104 ModulateLayer = st_mask_git.py:66-76, :111 qkv of attention.py:39):
+ *   x1 = x + o Wproj^T + b_proj;  xhat = LN(x1, 1e-6, no affine);  xm = xhat (1 + scale[f]) + shift[f];
+ *   x2 = x1 + xm Wlin^T + b_lin;  qkv = bf16(x2) Wqkv^T + b_qkv
+ * in: o [M,256] bf16 (spatial attention output), x [M,256] fp32 (updated in place to x2), ss [frames,512] = shift | scale;
+ * out: xhat, xm, x_bf16 = bf16(x2) [M,256] bf16 and rstd [M] (saved for backward; each may be NULL), qkv [.,768] bf16 at
+ * row remap(m) (q_group_* as in hma_gemm_nt: the decode K/V cache).  weights: N-block bundles of proj (8), lin (8), qkv (24).
+ * rows_per_frame % 16 == 0.  use_mod == 0 skips the modulate stage (no action tokens): x2 = x1, weights = proj (8), qkv (24). */
+typedef struct {
+  hma_chain_weights_t w;
+  const void* o; float* x; const float* ss;
+  const float* b_proj; const float* b_lin; const float* b_qkv;
+  void* xhat; void* xm; float* rstd; void* x_bf16;
+  void* qkv; int64_t ldq; int64_t q_group_rows, q_group_stride;
+  int64_t M; int32_t rows_per_frame; int32_t use_mod;
+} hma_chain_a_fwd_t;
+int hma_chain_a_fwd(void* stream, const hma_chain_a_fwd_t* p);
+
+/* Chain A backward (autograd mirror of the above):
+ *   dx2 = dx + dqkv Wqkv;  dxm = bf16(dx2) Wlin;  g = dxm (1 + scale[f]);
+ *   dx1 = dx2 + rstd (g - mean(g) - xhat mean(g xhat));  d_o = bf16(dx1) Wproj
+ *   dss[f] += [sum_rows dxm | sum_rows dxm xhat]   (fp32 atomics: zero dss first)
+ * in: dqkv [M,768] bf16, dx [M,256] fp32 (updated in place to dx1), xhat / rstd saved by the forward, ss;
+ * out: dx2_bf16 (dY of the linear_out weight gradient), dx1_bf16 (dY of the projection's), d_o [M,256] bf16.
+ * weights: N-block bundles of Wqkv^T in three k-chunks (3 x 8: chunk c = rows 256 c .. of qkv.weight, A[n][k] = W[256 c + k][n]),
+ * Wlin^T (8), Wproj^T (8). */
+typedef struct {
+  hma_chain_weights_t w;
+  const void* dqkv; int64_t ldq; float* dx;
+  const void* xhat; const float* rstd; const float* ss;
+  void* dx2_bf16; void* dx1_bf16; void* d_o; float* dss;
+  int64_t M; int32_t rows_per_frame; int32_t use_mod;
+} hma_chain_a_bwd_t;
+int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p);
+
+/* n floats at p = 0 (captured in graphs in front of kernels that accumulate with atomics) */
+int hma_zero_f32(void* stream, float* p, int64_t n);
+
 /* library identity, for the loader: returns 0x484d4102 */
 int hma_abi_version(void);
 

@@ -1,0 +1,158 @@
+"""Kernel-level parity of the row-local chain kernels (csrc/chain.hip) against fp32 math on the bf16-rounded operands
+the kernels multiply (GPU box only).  Reference arithmetic: hma/model/st_transformer.py:85-112, hma/model/st_mask_git.py:66-76."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hma_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+BF = 2.0 ** -8
+
+
+def rb(t):
+    return t.to(torch.bfloat16).float()
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(a, b, rtol, what=""):
+    a = a.float().cpu().double()
+    b = b.float().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= rtol * ref, f"{what}: max err {err:.3e} vs ref scale {ref:.3e} (rtol {rtol})"
+
+
+def rms(a, b):
+    a = a.float().cpu().double()
+    b = b.float().cpu().double()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+def _weights(seed):
+    wp = rb(torch.randn(256, 256, generator=g(seed)) * 0.06)
+    wl = rb(torch.randn(256, 256, generator=g(seed + 1)) * 0.06)
+    wq = rb(torch.randn(768, 256, generator=g(seed + 2)) * 0.06)
+    bp = torch.randn(256, generator=g(seed + 3)) * 0.1
+    bl = torch.randn(256, generator=g(seed + 4)) * 0.1
+    bq = torch.randn(768, generator=g(seed + 5)) * 0.1
+    return wp, wl, wq, bp, bl, bq
+
+
+def _pack_nt(w):  # forward: A[n][k] = W[n][k]
+    wd = w.to(DEV).contiguous()
+    return ops.chain_pack(wd, kind=0, rows=w.shape[0], cols=256, row_stride=256, col_stride=1)
+
+
+def _pack_t(w, c=0):  # input gradient: A[n][k] = W[256 c + k][n]
+    wd = w.to(DEV).contiguous()
+    return ops.chain_pack(wd[256 * c:], kind=0, rows=256, cols=256, row_stride=1, col_stride=256)
+
+
+@pytest.mark.parametrize("M,rpf,mod", [(112, 16, True), (1000 // 16 * 16, 16, True), (320 * 7, 320, True), (40960, 320, True),
+                                       (1000, 0, False), (2560, 0, False)])
+def test_chain_a_fwd(M, rpf, mod):
+    wp, wl, wq, bp, bl, bq = _weights(300)
+    o = rb(torch.randn(M, 256, generator=g(1)))
+    x = torch.randn(M, 256, generator=g(2)) * 1.5 + 0.2
+    frames = M // rpf if mod else 1
+    ss = torch.randn(frames, 512, generator=g(3)) * 0.3
+    # reference
+    x1 = x + o @ wp.t() + bp
+    if mod:
+        xh = rb(F.layer_norm(x1, (256,), eps=1e-6))
+        f = torch.arange(M) // rpf
+        xm = rb(xh * (1 + ss[f, 256:]) + ss[f, :256])
+        x2 = x1 + xm @ wl.t() + bl
+        rstd = torch.rsqrt(x1.var(dim=1, unbiased=False) + 1e-6)
+    else:
+        x2 = x1
+    qkv = rb(x2) @ wq.t() + bq
+    # kernel
+    segs = [(_pack_nt(wp), 8)] + ([(_pack_nt(wl), 8)] if mod else []) + [(_pack_nt(wq), 24)]
+    xd = x.to(DEV).clone()
+    od = o.to(DEV).bfloat16()
+    ssd = ss.to(DEV)
+    bpd, bld, bqd = bp.to(DEV), bl.to(DEV), bq.to(DEV)
+    xhat_o = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    xm_o = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    rstd_o = torch.zeros(M, dtype=torch.float32, device=DEV)
+    xb_o = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    qkv_o = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
+    a = ops.make_chain_a_fwd(M=M, segs=[(ops.ptr(t), n) for t, n in segs], o=ops.ptr(od), x=ops.ptr(xd), qkv=ops.ptr(qkv_o),
+                             ss=ops.ptr(ssd) if mod else None, b_proj=ops.ptr(bpd), b_lin=ops.ptr(bld) if mod else None,
+                             b_qkv=ops.ptr(bqd), xhat=ops.ptr(xhat_o), xm=ops.ptr(xm_o), rstd=ops.ptr(rstd_o),
+                             x_bf16=ops.ptr(xb_o), rows_per_frame=rpf, use_mod=mod)
+    _lib.call("hma_chain_a_fwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    close(xd, x2, 2e-3, "x2")
+    assert rms(xd.cpu() - x, x2 - x) < 4e-3
+    close(xb_o, x2, 2 * BF, "x2 bf16")
+    close(qkv_o, qkv, 3 * BF, "qkv")
+    assert rms(qkv_o, qkv) < 4e-3
+    if mod:
+        close(xhat_o, xh, 2 * BF, "xhat")
+        close(xm_o, xm, 3 * BF, "xm")
+        close(rstd_o, rstd, 1e-4, "rstd")
+    # asymmetric check: a permuted row or column block would pass a symmetric statistic
+    assert (qkv_o.float().cpu() - qkv).abs().max() < 0.2 * (qkv_o.float().cpu() - qkv.flip(1)).abs().max()
+
+
+@pytest.mark.parametrize("M,rpf,mod", [(112, 16, True), (320 * 7, 320, True), (40960, 320, True), (1000, 0, False)])
+def test_chain_a_bwd(M, rpf, mod):
+    wp, wl, wq, _, _, _ = _weights(400)
+    dqkv = rb(torch.randn(M, 768, generator=g(11)) * 0.02)
+    dx = torch.randn(M, 256, generator=g(12)) * 0.02
+    x1 = torch.randn(M, 256, generator=g(13)) * 1.5 + 0.2
+    frames = M // rpf if mod else 1
+    ss = torch.randn(frames, 512, generator=g(14)) * 0.3
+    # reference
+    dx2 = dx + dqkv @ wq
+    if mod:
+        mean, var = x1.mean(1, keepdim=True), x1.var(1, unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + 1e-6)
+        xh = rb((x1 - mean) * rstd)
+        f = torch.arange(M) // rpf
+        dxm = rb(dx2) @ wl
+        gq = dxm * (1 + ss[f, 256:])
+        dx1 = dx2 + rstd * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))
+        dss = torch.zeros(frames, 512)
+        dss[:, :256].index_add_(0, f, dxm)
+        dss[:, 256:].index_add_(0, f, dxm * xh)
+    else:
+        dx1 = dx2
+    d_o = rb(dx1) @ wp
+    # kernel
+    segs = [(_pack_t(wq, c), 8) for c in range(3)]
+    wq_t = torch.cat([s[0] for s in segs])
+    segs = [(wq_t, 24)] + ([(_pack_t(wl), 8)] if mod else []) + [(_pack_t(wp), 8)]
+    dxd = dx.to(DEV).clone()
+    dqd = dqkv.to(DEV).bfloat16()
+    d2 = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    d1 = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    do = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    kw = {}
+    if mod:
+        xhd, rsd, ssd = xh.to(DEV).bfloat16(), rstd.reshape(-1).to(DEV).contiguous(), ss.to(DEV)
+        dssd = torch.zeros(frames, 512, dtype=torch.float32, device=DEV)
+        kw = dict(xhat=ops.ptr(xhd), rstd=ops.ptr(rsd), ss=ops.ptr(ssd), dx2_bf16=ops.ptr(d2), dss=ops.ptr(dssd))
+    a = ops.make_chain_a_bwd(M=M, segs=[(ops.ptr(t), n) for t, n in segs], dqkv=ops.ptr(dqd), dx=ops.ptr(dxd), dx1_bf16=ops.ptr(d1),
+                             d_o=ops.ptr(do), rows_per_frame=rpf, use_mod=mod, **kw)
+    _lib.call("hma_chain_a_bwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    close(dxd, dx1, 3e-3, "dx1")
+    assert rms(dxd, dx1) < 3e-3
+    close(d1, dx1, 2 * BF, "dx1 bf16")
+    close(do, d_o, 3 * BF, "d_o")
+    assert rms(do, d_o) < 5e-3
+    if mod:
+        close(d2, dx2, 2 * BF, "dx2 bf16")
+        close(dssd, dss, 3e-3, "dss")
+    assert (do.float().cpu() - d_o).abs().max() < 0.2 * (do.float().cpu() - d_o.flip(1)).abs().max()
