@@ -21,6 +21,11 @@
 
 using namespace hma;
 
+// Debug builds only (tools/chain_variants.sh, -DCH_ABL=bits): 1 no global stores, 2 no row loads, 4 no MFMA, 8 no barrier,
+// 16 no weight DMA
+#ifndef CH_ABL
+#define CH_ABL 0
+#endif
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
@@ -44,14 +49,19 @@ __device__ __forceinline__ int64_t remap_row(int64_t r, int64_t group_rows, int6
   return group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) : r;
 }
 __device__ __forceinline__ f32x4v_t mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4v_t& c) {
+  if (CH_ABL & 4) {
+    f32x4v_t r = c;
+    r[0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4_t, a)[0] ^ __builtin_bit_cast(u32x4_t, b)[1]);
+    return r;
+  }
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ bf16x8_t as_frag(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-#define CH_BARRIER()                    \
-  do {                                  \
-    __builtin_amdgcn_s_barrier();       \
-    asm volatile("" ::: "memory");      \
+#define CH_BARRIER()                                      \
+  do {                                                    \
+    if (!(CH_ABL & 8)) __builtin_amdgcn_s_barrier();      \
+    asm volatile("" ::: "memory");                        \
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -118,10 +128,12 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
     }
     const char* s = cur + lane * 16;
     const uint32_t d = __builtin_amdgcn_readfirstlane(lds_b + slot_issue * SLOT);
-    glds16x4(s, d);
-    glds16x4(s + 4096, d + 4096);
-    glds16x4(s + 8192, d + 8192);
-    glds16x4(s + 12288, d + 12288);
+    if (!(CH_ABL & 16)) {
+      glds16x4(s, d);
+      glds16x4(s + 4096, d + 4096);
+      glds16x4(s + 8192, d + 8192);
+      glds16x4(s + 12288, d + 12288);
+    }
     ++issued;
     slot_issue = (slot_issue + 1) & (NS - 1);
     cur += SLOT;
@@ -184,13 +196,56 @@ __device__ __forceinline__ f32x4v_t ld4(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, const f32x4v_t& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 
+// ---- whole-line stores.  In the accumulator layout a store instruction writes, per token row, the 64 bytes of the row's four
+// lanes (bf16) or four 16-byte pieces 32 bytes apart (fp32): sixteen half-filled 128-byte lines per instruction, and stores of
+// that shape were what the first version of these kernels spent two thirds of its time on (ablation: 266 -> 85 us without them).
+// Two 16-byte pieces q0 | q1 of a lane that are 64 (bf16: the blocks pr, pr + 1) or 16 (fp32: the block's halves) bytes apart are
+// therefore traded across the two halves of the lane group first (DPP row_ror:8: lane tok <-> tok ^ 8): instruction A then writes
+// rows 0..7 of the wave's tile, instruction B rows 8..15, each row as ONE full 128-byte line from eight lanes.
+__device__ __forceinline__ uint4 dpp_swap8(const uint4& v) {
+  uint4 r;
+  r.x = __builtin_amdgcn_mov_dpp(v.x, 0x128, 0xf, 0xf, true);
+  r.y = __builtin_amdgcn_mov_dpp(v.y, 0x128, 0xf, 0xf, true);
+  r.z = __builtin_amdgcn_mov_dpp(v.z, 0x128, 0xf, 0xf, true);
+  r.w = __builtin_amdgcn_mov_dpp(v.w, 0x128, 0xf, 0xf, true);
+  return r;
+}
+struct line_offs {
+  int a, b;  // byte offsets from the tile's first row: this lane's piece in rows 0..7 (instruction A) / rows 8..15 (instruction B)
+  bool lo;
+};
+// pitch = row pitch in bytes; g16 = byte offset of the lane group's q0 inside the 128-byte line; d = distance of q1 behind q0
+__device__ __forceinline__ line_offs make_lines(int pitch, int tok, int g16, int d) {
+  line_offs L;
+  L.lo = tok < 8;
+  L.a = (tok & 7) * pitch + g16 + (L.lo ? 0 : d);
+  L.b = ((tok & 7) + 8) * pitch + g16 + (L.lo ? d : 0);
+  return L;
+}
+__device__ __forceinline__ void store_lines(void* tile_base, const line_offs& L, int off, const uint4& q0, const uint4& q1) {
+  if (CH_ABL & 1) return;
+  const uint4 r = dpp_swap8(q1);
+  uint4 da, db;
+  da.x = L.lo ? q0.x : r.x; da.y = L.lo ? q0.y : r.y; da.z = L.lo ? q0.z : r.z; da.w = L.lo ? q0.w : r.w;
+  db.x = L.lo ? r.x : q0.x; db.y = L.lo ? r.y : q0.y; db.z = L.lo ? r.z : q0.z; db.w = L.lo ? r.w : q0.w;
+  char* b = reinterpret_cast<char*>(tile_base);
+  *reinterpret_cast<uint4*>(b + (L.a + off)) = da;
+  *reinterpret_cast<uint4*>(b + (L.b + off)) = db;
+}
+__device__ __forceinline__ uint4 as_u4(const f32x4v_t& v) { return __builtin_bit_cast(uint4, v); }
+
 // (opaque use of prefetched registers at the end of a loop body: hipcc then places the counted vmcnt wait there, in straight-line
 // code behind the stores it can count, instead of a vmcnt(0) at the loop head)
 #define CH_TOUCH_A(a) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) asm volatile("" : "+v"(a[j_]))
 #define CH_TOUCH_ACC(c) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) asm volatile("" : "+v"(c[j_]))
 
 // ------------------------------------------------------------------------------------------------ chain A, forward
-template <bool MOD>
+// M % 16 == 0 (checked by the launcher): a wave's 16 rows are all inside the matrix or all outside it, so the tile body has
+// no per-lane predication at all -- every store is unconditional straight-line code, which lets hipcc COUNT the stores
+// issued behind the next tile's row loads (s_waitcnt vmcnt(24) instead of a drain of the store queue).  A wave whose rows
+// lie past M only keeps the barriers company.
+
+template <bool MOD, bool SAVE>
 __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
@@ -219,13 +274,15 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
     return;
   }
   const int tok = lane & 15, g = lane >> 4;
-  auto row_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16 + tok;
+  auto row0_of = [&](int tl) __attribute__((always_inline)) {
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
   };
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
+  uint4 hqs[8];  // packed xhat of the tile in flight (stored during the next stage)
   auto prefetch = [&](int tl) __attribute__((always_inline)) {
-    int64_t m = row_of(tl);
+    if (CH_ABL & 2) return;
+    int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
 #pragma unroll
@@ -237,15 +294,30 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
       acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
     }
   };
+  if (CH_ABL & 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = as_frag(make_uint4(lane, j, lane, j));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
+  }
   prefetch(0);
-  int slot = 0;
+  CH_TOUCH_A(a1);     // (waited for HERE: a load still pending at the loop head would make hipcc drain the stores of every tile there)
+  CH_TOUCH_ACC(acc);
   HMA_LDS(char)* ring = lds + lane * 16;
   HMA_LDS(char)* bias = lds + L_BIAS + 32 * g;
+  const line_offs Lb = make_lines(512, tok, 16 * g, 64);                 // bf16 [., 256] outputs: the blocks pr | pr + 1
+  const line_offs Lf = make_lines(1024, tok, 32 * g, 16);                // fp32 [., 256]: the two halves of a block
+  const line_offs Lq = make_lines((int)p.ldq * 2, tok, 16 * g, 64);      // qkv
+  int slot = 0;
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
-    const int64_t m = row_of(tl);
-    const bool ok = m < p.M;
-    const int64_t mc = ok ? m : p.M - 1;
+    const int64_t r0 = row0_of(tl);
+    if (r0 >= p.M) {  // (whole wave past the matrix: possible in a workgroup's last tile only)
+#pragma unroll 1
+      for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
+      continue;
+    }
+    const int64_t m = r0 + tok;
 #pragma unroll
     for (int j = 0; j < 8; ++j) a0[j] = a1[j];
     // ---- x1 = x + o Wproj^T + b
@@ -279,8 +351,6 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
       const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
       const float nb = -mean * rstd;
       HMA_LDS(char)* ssl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 32 * g;
-      uint16_t* xh = p.xhat ? reinterpret_cast<uint16_t*>(p.xhat) + mc * 256 + 8 * g : nullptr;
-      uint16_t* xm = p.xm ? reinterpret_cast<uint16_t*>(p.xm) + mc * 256 + 8 * g : nullptr;
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         float h[8], mm[8];
@@ -298,14 +368,24 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
         for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(hr[e], 1.0f + sc[e], sh[e]);
         const uint4 mq = pack8(mm);
         a1[pr] = as_frag(mq);
-        if (ok && xh) *reinterpret_cast<uint4*>(xh + 32 * pr) = hq;
-        if (ok && xm) *reinterpret_cast<uint4*>(xm + 32 * pr) = mq;
+        if (SAVE) hqs[pr] = hq;
       }
-      if (ok && g == 0 && p.rstd) p.rstd[mc] = rstd;
+      if (SAVE && !(CH_ABL & 1)) p.rstd[m] = rstd;  // (the row's four lanes write the same value)
     }
-    // ---- x2 = x1 + xm Wlin^T + b: the new residual row, its bf16 copy = the qkv GEMM's operand
-    float* xrow = p.x + mc * 256 + 8 * g;
-    uint16_t* xb = p.x_bf16 ? reinterpret_cast<uint16_t*>(p.x_bf16) + mc * 256 + 8 * g : nullptr;
+    // ---- x2 = x1 + xm Wlin^T + b: the new residual row, its bf16 copy = the qkv GEMM's operand.
+    // Every output row leaves as ONE burst of back-to-back store instructions (its whole 512 / 1024 bytes within a few hundred
+    // cycles): pieces of a row written steps apart reach DRAM as separate 128-byte writes.
+    float* xt = p.x + r0 * 256;
+    uint16_t* xb = reinterpret_cast<uint16_t*>(p.x_bf16) + r0 * 256;
+    if (MOD && SAVE) {
+      uint16_t* xh = reinterpret_cast<uint16_t*>(p.xhat) + r0 * 256;
+      uint16_t* xm = reinterpret_cast<uint16_t*>(p.xm) + r0 * 256;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) store_lines(xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+        store_lines(xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+    }
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
       if (MOD) {
@@ -315,50 +395,58 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
         add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
         add4(acc[2 * pr + 1], lds_f4(bias + 1024 + 128 * pr + 16));
       }
-      const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
-      a0[pr] = as_frag(q);
-      if (ok) {
-        st4(xrow + 32 * pr, acc[2 * pr]);
-        st4(xrow + 32 * pr + 4, acc[2 * pr + 1]);
-        if (xb) *reinterpret_cast<uint4*>(xb + 32 * pr) = q;
-      }
+      a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
     }
-    // ---- qkv = bf16(x2) Wqkv^T + b; the next tile's rows are requested here, 24 steps before they are used
-    prefetch(tl + 1 < nt ? tl + 1 : tl);
-    uint16_t* qrow = reinterpret_cast<uint16_t*>(p.qkv) + remap_row(mc, p.q_group_rows, p.q_group_stride) * p.ldq + 8 * g;
 #pragma unroll
-    for (int pq = 0; pq < 24; ++pq) {
-      CH_BARRIER();
-      f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * pq), c1 = lds_f4v(bias + 2048 + 128 * pq + 16);
-      nb_mma(ring + slot * SLOT, a0, c0, c1);
-      slot = (slot + 1) & (NS - 1);
-      if (ok) *reinterpret_cast<uint4*>(qrow + 32 * pq) = pack_pair(c0, c1);
+    for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+    if (SAVE) {
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+        store_lines(xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
+    }
+    // ---- qkv = bf16(x2) Wqkv^T + b, stored as three 512-byte row pieces (q | k | v); the next tile's rows are requested here
+    prefetch(tl + 1 < nt ? tl + 1 : tl);
+    // (r0 is a multiple of 16 and so is a row group: the tile's 16 rows stay consecutive under the remap)
+    uint16_t* qt = reinterpret_cast<uint16_t*>(p.qkv) + remap_row(r0, p.q_group_rows, p.q_group_stride) * p.ldq;
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      uint4 qb[8];
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const int pq = 8 * part + pr;
+        CH_BARRIER();
+        f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * pq), c1 = lds_f4v(bias + 2048 + 128 * pq + 16);
+        nb_mma(ring + slot * SLOT, a0, c0, c1);
+        slot = (slot + 1) & (NS - 1);
+        qb[pr] = pack_pair(c0, c1);
+      }
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) store_lines(qt, Lq, 512 * part + 128 * pp, qb[2 * pp], qb[2 * pp + 1]);
     }
     CH_TOUCH_A(a1);
     CH_TOUCH_ACC(acc);
   }
 }
 
-
 // ------------------------------------------------------------------------------------------------ chain A, backward
-// Sum over the 16 token lanes of a lane group of 64 per-lane values, transposed on the way: step b exchanges halves with lane
-// tok ^ (1 << b) and keeps the half its bit b selects, so after four steps lane tok holds the 16-lane sums of the FOUR values
-// c = q + 4 b3 + 8 b2 + 16 b1 + 32 b0 (b_i = bit i of tok): 60 exchanges instead of 256, and every lane ends with its own columns.
+// Sum over the 16 token lanes of a lane group of 32 per-lane values, transposed on the way: step b exchanges halves with lane
+// tok ^ (1 << b) and keeps the half its bit b selects, so after four steps lane tok holds the 16-lane sums of the TWO values
+// c = q + 2 b3 + 4 b2 + 8 b1 + 16 b0 (b_i = bit i of tok): 30 exchanges instead of 128, and every lane ends with its own columns.
 template <typename F>
-__device__ __forceinline__ void colsum16(F&& val, int tok, float (&out)[4]) {
-  float w[32];
+__device__ __forceinline__ void colsum16(F&& val, int tok, float (&out)[2]) {
+  float w[16];
   const bool b0 = tok & 1, b1 = tok & 2, b2 = tok & 4, b3 = tok & 8;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const float lo = val(c), hi = val(c + 32);
+  for (int c = 0; c < 16; ++c) {
+    const float lo = val(c), hi = val(c + 16);
     w[c] = (b0 ? hi : lo) + __shfl_xor(b0 ? lo : hi, 1, 64);
   }
 #pragma unroll
-  for (int c = 0; c < 16; ++c) w[c] = (b1 ? w[c + 16] : w[c]) + __shfl_xor(b1 ? w[c] : w[c + 16], 2, 64);
+  for (int c = 0; c < 8; ++c) w[c] = (b1 ? w[c + 8] : w[c]) + __shfl_xor(b1 ? w[c] : w[c + 8], 2, 64);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) w[c] = (b2 ? w[c + 8] : w[c]) + __shfl_xor(b2 ? w[c] : w[c + 8], 4, 64);
+  for (int c = 0; c < 4; ++c) w[c] = (b2 ? w[c + 4] : w[c]) + __shfl_xor(b2 ? w[c] : w[c + 4], 4, 64);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) out[c] = (b3 ? w[c + 4] : w[c]) + __shfl_xor(b3 ? w[c] : w[c + 4], 8, 64);
+  for (int c = 0; c < 2; ++c) out[c] = (b3 ? w[c + 2] : w[c]) + __shfl_xor(b3 ? w[c] : w[c + 2], 8, 64);
 }
 
 template <bool MOD>
@@ -386,6 +474,11 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
   f32x4v_t acc[16];
   float rs = 0.f;
   auto load_chunk = [&](int64_t mc, int c, bf16x8_t (&d)[8]) __attribute__((always_inline)) {
+    if (CH_ABL & 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] = as_frag(make_uint4(lane, j, c, j));
+      return;
+    }
     const uint16_t* row = reinterpret_cast<const uint16_t*>(p.dqkv) + mc * p.ldq + 256 * c + 8 * g;
 #pragma unroll
     for (int j = 0; j < 8; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
@@ -394,32 +487,42 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
     int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     load_chunk(m, 0, dq[0]);
+    if (CH_ABL & 2) return;
     const float* xrow = p.dx + m * 256 + 8 * g;
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
       acc[2 * pr] = ld4(xrow + 32 * pr);
       acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
     }
-    if (MOD) {
-      const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
-      rs = p.rstd[m];
-    }
   };
+  if (CH_ABL & 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
+    rs = 1.f;
+  }
   prefetch(0);
+  CH_TOUCH_A(dq[0]);
+  CH_TOUCH_ACC(acc);
   int slot = 0;
   HMA_LDS(char)* ring = lds + lane * 16;
+  const line_offs Lb = make_lines(512, tok, 16 * g, 64);
+  const line_offs Lf = make_lines(1024, tok, 32 * g, 16);
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
-    const int64_t r0 = row0_of(tl), m = r0 + tok;
-    const bool ok = m < p.M;
-    const int64_t mc = ok ? m : p.M - 1;
+    const int64_t r0 = row0_of(tl);
+    if (r0 >= p.M) {
+#pragma unroll 1
+      for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
+      continue;
+    }
+    const int64_t m = r0 + tok;
     // ---- dx2 = dx + dqkv Wqkv (k = 768 in three chunks; chunk c + 1 is requested while chunk c is multiplied)
-    load_chunk(mc, 1, dq[1]);
+    load_chunk(m, 1, dq[1]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if (c == 1) load_chunk(mc, 2, dq[2]);
+      if (c == 1) load_chunk(m, 2, dq[2]);
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         CH_BARRIER();
@@ -427,16 +530,25 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
         slot = (slot + 1) & (NS - 1);
       }
     }
-    float* xrow = p.dx + mc * 256 + 8 * g;
+    float* xt = p.dx + r0 * 256;
+    uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + r0 * 256;
+    uint4 qk0;
     if (MOD) {
-      uint16_t* d2 = reinterpret_cast<uint16_t*>(p.dx2_bf16) + mc * 256 + 8 * g;
+      uint16_t* d2 = reinterpret_cast<uint16_t*>(p.dx2_bf16) + r0 * 256;
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
         a1[pr] = as_frag(q);
-        if (ok) *reinterpret_cast<uint4*>(d2 + 32 * pr) = q;
+        if (pr & 1) store_lines(d2, Lb, 64 * (pr - 1), qk0, q);
+        else qk0 = q;
       }
-      // ---- dxm = bf16(dx2) Wlin
+      // ---- dxm = bf16(dx2) Wlin (the saved xhat row and 1 / sigma are requested here, eight steps before they are used)
+      if (!(CH_ABL & 2)) {
+        const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
+        rs = p.rstd[m];
+      }
       f32x4v_t dm[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
@@ -446,11 +558,7 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
         nb_mma(ring + slot * SLOT, a1, dm[2 * pr], dm[2 * pr + 1]);
         slot = (slot + 1) & (NS - 1);
       }
-      // ---- modulate + LayerNorm backward.  Rows past M contribute nothing to the frame sums.
-      if (!ok) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-      }
+      // ---- modulate + LayerNorm backward
       HMA_LDS(char)* scl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 1024 + 32 * g;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -472,21 +580,34 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
       s2 += __shfl_xor(s2, 32, 64);
       s1 *= (1.0f / 256.0f);
       s2 *= (1.0f / 256.0f);
-      if (r0 < p.M) {  // d shift = column sums of dxm, d scale = column sums of dxm xhat over the frame's rows
+      // (opaque: otherwise the unpacked xhat and the scaled gradient of this pass -- 128 registers -- are kept for the passes below)
+      CH_TOUCH_A(xr);
+      CH_TOUCH_ACC(dm);
+      asm volatile("" ::: "memory");
+      {  // d shift = column sums of dxm, d scale = column sums of dxm xhat over the frame's rows (two halves of 128 columns)
         float* dssf = p.dss + (r0 / p.rows_per_frame) * 512 + 8 * g;
-        float o4[4];
-        const int cb = ((tok >> 3) & 1) * 4 + ((tok >> 2) & 1) * 8 + ((tok >> 1) & 1) * 16 + (tok & 1) * 32;
-        colsum16([&](int c) __attribute__((always_inline)) { return dm[2 * (c >> 3) + ((c >> 2) & 1)][c & 3]; }, tok, o4);
+        const int cb = ((tok >> 3) & 1) * 2 + ((tok >> 2) & 1) * 4 + ((tok >> 1) & 1) * 8 + (tok & 1) * 16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) unsafeAtomicAdd(dssf + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o4[q]);
-        colsum16([&](int c) __attribute__((always_inline)) {
-          const uint32_t wv = __builtin_bit_cast(u32x4_t, xr[c >> 3])[(c >> 1) & 3];
-          return dm[2 * (c >> 3) + ((c >> 2) & 1)][c & 3] * ((c & 1) ? bf16_hi(wv) : bf16_lo(wv));
-        }, tok, o4);
+        for (int h = 0; h < 2; ++h) {
+          float o2[2];
+          colsum16([&](int c) __attribute__((always_inline)) { return dm[8 * h + 2 * (c >> 3) + ((c >> 2) & 1)][c & 3]; }, tok, o2);
+          if (!(CH_ABL & 1)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) unsafeAtomicAdd(dssf + 256 + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o4[q]);
+            for (int q = 0; q < 2; ++q) unsafeAtomicAdd(dssf + 128 * h + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o2[q]);
+          }
+          colsum16([&](int c) __attribute__((always_inline)) {
+            const uint32_t wv = __builtin_bit_cast(u32x4_t, xr[4 * h + (c >> 3)])[(c >> 1) & 3];
+            return dm[8 * h + 2 * (c >> 3) + ((c >> 2) & 1)][c & 3] * ((c & 1) ? bf16_hi(wv) : bf16_lo(wv));
+          }, tok, o2);
+          if (!(CH_ABL & 1)) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) unsafeAtomicAdd(dssf + 256 + 128 * h + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o2[q]);
+          }
+        }
       }
-      uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + mc * 256 + 8 * g;
+      CH_TOUCH_A(xr);
+      CH_TOUCH_ACC(dm);
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         float xh[8];
@@ -500,42 +621,35 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
         }
         const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
         a1[pr] = as_frag(q);
-        if (ok) {
-          st4(xrow + 32 * pr, acc[2 * pr]);
-          st4(xrow + 32 * pr + 4, acc[2 * pr + 1]);
-          *reinterpret_cast<uint4*>(d1 + 32 * pr) = q;
-        }
+        store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+        if (pr & 1) store_lines(d1, Lb, 64 * (pr - 1), qk0, q);
+        else qk0 = q;
       }
     } else {
-      uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + mc * 256 + 8 * g;
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
         a1[pr] = as_frag(q);
-        if (ok) {
-          st4(xrow + 32 * pr, acc[2 * pr]);
-          st4(xrow + 32 * pr + 4, acc[2 * pr + 1]);
-          *reinterpret_cast<uint4*>(d1 + 32 * pr) = q;
-        }
+        store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+        if (pr & 1) store_lines(d1, Lb, 64 * (pr - 1), qk0, q);
+        else qk0 = q;
       }
     }
     // ---- d_o = bf16(dx1) Wproj; the next tile's rows are requested here
     prefetch(tl + 1 < nt ? tl + 1 : tl);
-    uint16_t* orow = reinterpret_cast<uint16_t*>(p.d_o) + mc * 256 + 8 * g;
+    uint16_t* ot = reinterpret_cast<uint16_t*>(p.d_o) + r0 * 256;
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
       CH_BARRIER();
       f32x4v_t c0 = f32x4v_t{0.f, 0.f, 0.f, 0.f}, c1 = f32x4v_t{0.f, 0.f, 0.f, 0.f};
       nb_mma(ring + slot * SLOT, a1, c0, c1);
       slot = (slot + 1) & (NS - 1);
-      if (ok) *reinterpret_cast<uint4*>(orow + 32 * pr) = pack_pair(c0, c1);
+      const uint4 q = pack_pair(c0, c1);
+      if (pr & 1) store_lines(ot, Lb, 64 * (pr - 1), qk0, q);
+      else qk0 = q;
     }
     CH_TOUCH_A(dq[0]);
     CH_TOUCH_ACC(acc);
-    if (MOD) {
-      CH_TOUCH_A(xr);
-      asm volatile("" : "+v"(rs));
-    }
   }
 }
 
@@ -601,23 +715,29 @@ extern "C" int hma_chain_pack(void* stream, const float* src, int64_t row_stride
 }
 
 extern "C" int hma_chain_a_fwd(void* stream, const hma_chain_a_fwd_t* p) {
-  if (!p || !p->o || !p->x || !p->qkv || p->M <= 0 || p->ldq < 768) return HMA_EINVAL;
+  if (!p || !p->o || !p->x || !p->qkv || p->M <= 0 || p->M % 16 || p->ldq < 768) return HMA_EINVAL;
+  const bool save = p->x_bf16 != nullptr;  // training: every saved activation, or none of them (inference / decode)
+  if (save ? (p->use_mod && (!p->xhat || !p->xm || !p->rstd)) : (p->xhat || p->xm || p->rstd)) return HMA_EINVAL;
   if (!weights_ok(p->w, p->use_mod ? 40 : 32)) return HMA_EINVAL;
   if (p->use_mod && (!p->ss || p->rows_per_frame <= 0 || p->rows_per_frame % 16)) return HMA_EINVAL;
   const int grid = chain_grid(p->M);
+#define CH_LAUNCH_A(MOD_, SAVE_)                                                                                          \
+  do {                                                                                                                   \
+    if (int rc = set_lds<chain_a_fwd_kernel<MOD_, SAVE_>>(SMEM)) return rc;                                              \
+    hipLaunchKernelGGL((chain_a_fwd_kernel<MOD_, SAVE_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);         \
+  } while (0)
   if (p->use_mod) {
-    if (int rc = set_lds<chain_a_fwd_kernel<true>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_a_fwd_kernel<true>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    if (save) CH_LAUNCH_A(true, true); else CH_LAUNCH_A(true, false);
   } else {
-    if (int rc = set_lds<chain_a_fwd_kernel<false>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_a_fwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    if (save) CH_LAUNCH_A(false, true); else CH_LAUNCH_A(false, false);
   }
+#undef CH_LAUNCH_A
   HMA_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p) {
-  if (!p || !p->dqkv || !p->dx || !p->dx1_bf16 || !p->d_o || p->M <= 0 || p->ldq < 768) return HMA_EINVAL;
+  if (!p || !p->dqkv || !p->dx || !p->dx1_bf16 || !p->d_o || p->M <= 0 || p->M % 16 || p->ldq < 768) return HMA_EINVAL;
   if (!weights_ok(p->w, p->use_mod ? 40 : 32)) return HMA_EINVAL;
   if (p->use_mod && (!p->ss || !p->xhat || !p->rstd || !p->dx2_bf16 || !p->dss || p->rows_per_frame <= 0 || p->rows_per_frame % 16))
     return HMA_EINVAL;

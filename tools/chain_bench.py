@@ -1,0 +1,93 @@
+"""Isolated timing of the chain kernels at the bench shape (M = 163840) beside the launches they replace.
+HMA_LIB=<path> selects a variant build."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hma_amd import _lib, ops  # noqa: E402
+from hma_amd._lib import A_BF16, EPI_BF16, EPI_RESID  # noqa: E402
+
+if os.environ.get("HMA_LIB"):
+    _lib.LIB_PATH = os.environ["HMA_LIB"]
+M = int(os.environ.get("M", 163840))
+RPF = 320
+dev = "cuda"
+torch.manual_seed(0)
+bf = torch.bfloat16
+mk = lambda *s: torch.randn(*s, device=dev)
+SKEW = int(os.environ.get("SKEW", 0))  # bytes of extra offset between consecutive activation arrays (0: back to back, as torch packs them)
+_pool = torch.empty(4 << 30, dtype=torch.uint8, device=dev) if SKEW else None
+_off = [0]
+
+
+def carve(shape, dtype):
+    if _pool is None:
+        return torch.empty(*shape, device=dev, dtype=dtype)
+    n = 1
+    for d in shape:
+        n *= d
+    nbytes = n * torch.empty(0, dtype=dtype).element_size()
+    t = _pool[_off[0]:_off[0] + nbytes].view(dtype).view(*shape)
+    _off[0] += (nbytes + SKEW + 255) // 256 * 256
+    return t
+
+
+o = carve((M, 256), bf).copy_(mk(M, 256))
+x = carve((M, 256), torch.float32).copy_(mk(M, 256))
+ss = mk(M // RPF, 512) * 0.3
+wp, wl, wq = mk(256, 256) * 0.05, mk(256, 256) * 0.05, mk(768, 256) * 0.05
+bp, bl, bq = mk(256), mk(256), mk(768)
+xhat, xm, xb = (carve((M, 256), bf) for _ in range(3))
+rstd = torch.empty(M, device=dev)
+qkv = carve((M, 768), bf)
+pk = lambda w: ops.chain_pack(w.contiguous(), kind=0, rows=w.shape[0], cols=256, row_stride=256, col_stride=1)
+pkt = lambda w, c=0: ops.chain_pack(w.contiguous()[256 * c:], kind=0, rows=256, cols=256, row_stride=1, col_stride=256)
+pwp, pwl, pwq = pk(wp), pk(wl), pk(wq)
+fa = ops.make_chain_a_fwd(M=M, segs=[(pwp.data_ptr(), 8), (pwl.data_ptr(), 8), (pwq.data_ptr(), 24)], o=o.data_ptr(), x=x.data_ptr(),
+                          qkv=qkv.data_ptr(), ss=ss.data_ptr(), b_proj=bp.data_ptr(), b_lin=bl.data_ptr(), b_qkv=bq.data_ptr(),
+                          xhat=xhat.data_ptr(), xm=xm.data_ptr(), rstd=rstd.data_ptr(), x_bf16=xb.data_ptr(), rows_per_frame=RPF)
+dqkv = carve((M, 768), bf).copy_(mk(M, 768) * 0.02)
+dx = carve((M, 256), torch.float32).copy_(mk(M, 256) * 0.02)
+d2, d1, do = (carve((M, 256), bf) for _ in range(3))
+dss = torch.zeros(M // RPF, 512, device=dev)
+twq = torch.cat([pkt(wq, c) for c in range(3)])
+twl, twp = pkt(wl), pkt(wp)
+rstd.fill_(1.0)
+ba = ops.make_chain_a_bwd(M=M, segs=[(twq.data_ptr(), 24), (twl.data_ptr(), 8), (twp.data_ptr(), 8)], dqkv=dqkv.data_ptr(),
+                          dx=dx.data_ptr(), dx1_bf16=d1.data_ptr(), d_o=do.data_ptr(), xhat=xhat.data_ptr(), rstd=rstd.data_ptr(),
+                          ss=ss.data_ptr(), dx2_bf16=d2.data_ptr(), dss=dss.data_ptr(), rows_per_frame=RPF)
+
+
+def timeit(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+st = torch.cuda.current_stream().cuda_stream
+t_f = timeit(lambda: _lib.call("hma_chain_a_fwd", st, C.byref(fa)))
+t_b = timeit(lambda: _lib.call("hma_chain_a_bwd", st, C.byref(ba)))
+# what they replace
+wpb, wlb, wqb = wp.to(bf), wl.to(bf), wq.to(bf)
+g1 = ops.make_gemm_nt(A=o.data_ptr(), lda=256, a_kind=A_BF16, W=wpb.data_ptr(), ldw=256, M=M, N=256, K=256, epi=EPI_RESID, Cp=x.data_ptr(),
+                      ldc=256, bias=bp.data_ptr(), ln_xhat=xhat.data_ptr(), ln_rstd=rstd.data_ptr(), ln_eps=1e-6, ln_ss=ss.data_ptr(),
+                      ln_xm=xm.data_ptr(), ln_rows_per_frame=RPF)
+g2 = ops.make_gemm_nt(A=xm.data_ptr(), lda=256, a_kind=A_BF16, W=wlb.data_ptr(), ldw=256, M=M, N=256, K=256, epi=EPI_RESID, Cp=x.data_ptr(),
+                      ldc=256, bias=bl.data_ptr(), C2=xb.data_ptr(), ldc2=256)
+g3 = ops.make_gemm_nt(A=xb.data_ptr(), lda=256, a_kind=A_BF16, W=wqb.data_ptr(), ldw=256, M=M, N=768, K=256, epi=EPI_BF16, Cp=qkv.data_ptr(),
+                      ldc=768, bias=bq.data_ptr())
+t_old = [timeit(lambda g=g: _lib.call("hma_gemm_nt", st, C.byref(g))) for g in (g1, g2, g3)]
+by_f = M * 5632.0
+print(f"skew {SKEW:8d} ", end="")
+print(f"{os.environ.get('HMA_LIB', 'default'):>24s}  chain A fwd {t_f:7.1f} us ({by_f / t_f / 1e6:5.2f} TB/s)  [3 launches: "
+      f"{' + '.join(f'{t:.0f}' for t in t_old)} = {sum(t_old):.0f} us]   chain A bwd {t_b:7.1f} us ({M * 5632.0 / t_b / 1e6:5.2f} TB/s)")
