@@ -16,6 +16,9 @@
 //     their only loads are the next tile's rows, requested a stage ahead straight into the registers that will hold them.
 //   * The L2 -> LDS path is not the limit of this organisation (tools/probes/l2_stream.hip: 56 B/clk per CU by LDS-DMA from two
 //     waves on, against ~10 B/clk that a chain needs).
+#include <type_traits>
+#include <utility>
+
 #include "hma_common.h"
 #include "../../include/hma_hip.h"
 
@@ -58,10 +61,27 @@ __device__ __forceinline__ f32x4v_t mfma16(const bf16x8_t& a, const bf16x8_t& b,
 }
 __device__ __forceinline__ bf16x8_t as_frag(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+// Debug builds only (-DCH_PROF): per-wave cycle counters summed per phase, workgroup 0 (tools/chain_bench.py CH_PROF=1)
+#ifdef CH_PROF
+__device__ unsigned long long g_ch_prof[2][8][8];
+#define CPROF_DECL unsigned long long pt_ = __builtin_readcyclecounter(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CPROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define CPROF_FLUSH(k, wv) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) g_ch_prof[k][wv][i_] = pacc_[i_]; } } while (0)
+#else
+#define CPROF_DECL
+#define CPROF_MARK(i)
+#define CPROF_FLUSH(k, wv)
+#endif
+#ifdef CH_FENCE
+#define CH_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define CH_SCHED_FENCE
+#endif
 #define CH_BARRIER()                                      \
   do {                                                    \
     if (!(CH_ABL & 8)) __builtin_amdgcn_s_barrier();      \
     asm volatile("" ::: "memory");                        \
+    CH_SCHED_FENCE                                        \
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ weight packing
@@ -108,6 +128,7 @@ struct ring_src {
   const char *s0, *s1, *s2, *s3;
   int n0, n1, n2, n3;
 };
+template <int PROF_K>
 __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
                                            int64_t M, int rows_per_frame) {
   const int total = per_tile * nt;
@@ -151,8 +172,10 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
   };
 #pragma unroll 1
   for (int b = 0; b < NS - 1 && b < total; ++b) issue();
+  CPROF_DECL;
 #pragma unroll 1
   for (int s = 0; s < total; ++s) {
+    CPROF_MARK(2);
     const int ahead = issued - 1 - s;  // bundles issued after bundle s (each 16 pieces; shift / scale pieces only make the wait stricter)
     if (ahead >= 2)
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -160,9 +183,13 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CPROF_MARK(0);
     CH_BARRIER();
+    CPROF_MARK(1);
     if (issued < total) issue();
   }
+  CPROF_MARK(2);
+  CPROF_FLUSH(PROF_K, NCW);
 }
 
 // one N-block bundle against the wave's rows: c0 / c1 += W[32 columns] . a   (16 MFMAs)
@@ -236,15 +263,32 @@ __device__ __forceinline__ uint4 as_u4(const f32x4v_t& v) { return __builtin_bit
 
 // (opaque use of prefetched registers at the end of a loop body: hipcc then places the counted vmcnt wait there, in straight-line
 // code behind the stores it can count, instead of a vmcnt(0) at the loop head)
+// compile-time step loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) -- the step index has to be
+// a constant EXPRESSION wherever it selects a register (an index that is only constant after unrolling leaves the arrays in scratch)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 #define CH_TOUCH_A(a) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) asm volatile("" : "+v"(a[j_]))
 #define CH_TOUCH_ACC(c) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) asm volatile("" : "+v"(c[j_]))
 
 // ------------------------------------------------------------------------------------------------ chain A, forward
 // M % 16 == 0 (checked by the launcher): a wave's 16 rows are all inside the matrix or all outside it, so the tile body has
 // no per-lane predication at all -- every store is unconditional straight-line code, which lets hipcc COUNT the stores
-// issued behind the next tile's row loads (s_waitcnt vmcnt(24) instead of a drain of the store queue).  A wave whose rows
+// issued behind the next tile's row loads (counted s_waitcnt vmcnt instead of a drain of the store queue).  A wave whose rows
 // lie past M only keeps the barriers company.
-
+//
+// Anti-phase stores.  Measured on the first version (tools/chain_variants.sh): loads + stores alone 188 us, MFMAs + LDS + barriers
+// alone 85 us, together 280 us -- the SUM.  A wave issues in order, so a store that waits for room in the memory pipeline (the
+// normal state of an HBM-bound kernel) holds the wave's MFMAs behind it, and with one barrier per step every wave of the chip is
+// in the same place.  The two waves of a SIMD therefore run the steps in opposite order: waves 0..3 ("early") multiply, then
+// store what the step produced; waves 4..6 ("late") first store what their PREVIOUS step produced, then multiply.  Behind
+// every barrier one wave of a SIMD is on the matrix pipe while the other one's stores drain.
 template <bool MOD, bool SAVE>
 __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -265,12 +309,13 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
     }
   }
   __syncthreads();
-  constexpr int PER_TILE = MOD ? 40 : 32;
+  constexpr int S3 = MOD ? 16 : 8;       // first qkv step
+  constexpr int PER_TILE = S3 + 24;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    loader_run<0>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
     return;
   }
   const int tok = lane & 15, g = lane >> 4;
@@ -279,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
   };
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
-  uint4 hqs[8];  // packed xhat of the tile in flight (stored during the next stage)
+  uint4 hqs[8];   // packed xhat of the tile in flight
+  uint4 qb[8];    // qkv blocks waiting for their burst (block pq in qb[pq & 7])
   auto prefetch = [&](int tl) __attribute__((always_inline)) {
     if (CH_ABL & 2) return;
     int64_t m = row0_of(tl) + tok;
@@ -309,6 +355,141 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
   const line_offs Lf = make_lines(1024, tok, 32 * g, 16);                // fp32 [., 256]: the two halves of a block
   const line_offs Lq = make_lines((int)p.ldq * 2, tok, 16 * g, 64);      // qkv
   int slot = 0;
+
+  // (ONE copy of the tile body; the late waves differ by two wave-uniform branches per step.  Two instantiations were tried first:
+  // every value the halves share became a spill candidate, ~110 spilled registers.)
+  const bool late = wave >= 4;
+  CPROF_DECL;
+  auto tile = [&](int tl, int64_t r0) __attribute__((always_inline)) {
+    float* xt = p.x + r0 * 256;
+    uint16_t* xb = reinterpret_cast<uint16_t*>(p.x_bf16) + r0 * 256;
+    uint16_t* xh = reinterpret_cast<uint16_t*>(p.xhat) + r0 * 256;
+    uint16_t* xm = reinterpret_cast<uint16_t*>(p.xm) + r0 * 256;
+    // (r0 is a multiple of 16 and so is a row group: the tile's 16 rows stay consecutive under the remap)
+    uint16_t* qt = reinterpret_cast<uint16_t*>(p.qkv) + remap_row(r0, p.q_group_rows, p.q_group_stride) * p.ldq;
+    // Output rows leave in BURSTS, one array at a time (xhat | xm rows after the LayerNorm, x | bf16(x) rows after linear_out,
+    // qkv in 512-byte pieces per row): the same stores issued a pair per step, arrays alternating, ran at 2.1 TB/s against
+    // 5.1 TB/s in bursts (tools/chain_variants.sh, stores alone).  The late waves issue each burst four steps after the early ones.
+    auto burst_ln = [&]() __attribute__((always_inline)) {
+      if constexpr (MOD && SAVE) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) store_lines(xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+          store_lines(xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+      }
+    };
+    auto burst_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+      if constexpr (SAVE) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+          store_lines(xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
+      }
+    };
+    // qkv blocks first .. first + 2 * npairs - 1 (block pq lives in qb[pq & 7])
+    auto burst_q = [&](auto first_, auto npairs_) __attribute__((always_inline)) {
+      constexpr int first = decltype(first_)::value, npairs = decltype(npairs_)::value;
+      static_for<npairs>([&](auto k_) __attribute__((always_inline)) {
+        constexpr int b = first + 2 * decltype(k_)::value;
+        store_lines(qt, Lq, 64 * b, qb[b & 7], qb[(b + 1) & 7]);
+      });
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+    static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      CPROF_MARK(3);
+      CH_BARRIER();
+      CPROF_MARK(0);
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = (slot + 1) & (NS - 1);
+      if constexpr (s < 8) {
+        // ---- x1 = x + o Wproj^T + b
+        nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
+        add4(acc[2 * s], lds_f4(bias + 128 * s));
+        add4(acc[2 * s + 1], lds_f4(bias + 128 * s + 16));
+        if constexpr (s == 7 && !MOD) {
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
+        }
+        if constexpr (s == 7 && MOD) {
+          // ---- LayerNorm (no affine) of the row the four lanes tok, tok + 16, tok + 32, tok + 48 hold, then the modulation
+          float sum = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          const float mean = sum * (1.0f / 256.0f);
+          float sq = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = acc[t][r] - mean;
+              sq = __builtin_fmaf(d, d, sq);
+            }
+          }
+          sq += __shfl_xor(sq, 16, 64);
+          sq += __shfl_xor(sq, 32, 64);
+          const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
+          const float nb = -mean * rstd;
+          HMA_LDS(char)* ssl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 32 * g;
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) {
+            float h[8], mm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
+            const float4 sh0 = lds_f4(ssl + 128 * pr), sh1 = lds_f4(ssl + 128 * pr + 16);
+            const float4 sc0 = lds_f4(ssl + 1024 + 128 * pr), sc1 = lds_f4(ssl + 1024 + 128 * pr + 16);
+            const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+            const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+            // (the modulation is applied to the bf16-ROUNDED xhat: what the backward re-reads, as the unfused epilogue does)
+            const uint4 hq = pack8(h);
+            float hr[8];
+            unpack8(hq, hr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(hr[e], 1.0f + sc[e], sh[e]);
+            a1[pr] = as_frag(pack8(mm));
+            if (SAVE) hqs[pr] = hq;
+          }
+          if (SAVE && !(CH_ABL & 1)) p.rstd[r0 + tok] = rstd;  // (the row's four lanes write the same value)
+        }
+      } else if constexpr (MOD && s < 16) {
+        // ---- x2 = x1 + xm Wlin^T + b: the new residual row; its bf16 copy is the qkv GEMM's operand
+        constexpr int pr = s - 8;
+        nb_mma(wb, a1, acc[2 * pr], acc[2 * pr + 1]);
+        add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
+        add4(acc[2 * pr + 1], lds_f4(bias + 1024 + 128 * pr + 16));
+        a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
+      } else {
+        // ---- qkv = bf16(x2) Wqkv^T + b
+        constexpr int pq = s - S3;
+        f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * pq), c1 = lds_f4v(bias + 2048 + 128 * pq + 16);
+        nb_mma(wb, a0, c0, c1);
+        qb[pq & 7] = pack_pair(c0, c1);
+      }
+      CPROF_MARK(2);
+      using I0 = std::integral_constant<int, 0>;
+      using I2 = std::integral_constant<int, 2>;
+      using I4 = std::integral_constant<int, 4>;
+      if constexpr (MOD && s == 7) { if (!late) burst_ln(); }
+      if constexpr (MOD && s == 11) { if (late) burst_ln(); }
+      if constexpr (s == S3 - 1) { if (!late) burst_x(); }
+      if constexpr (s == S3 + 3) { if (late) { burst_x(); burst_q(I0{}, I2{}); } }
+      if constexpr (s >= S3 && ((s - S3) & 7) == 7) { if (!late) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{}); }
+      if constexpr (s > S3 + 3 && s < S3 + 23 && ((s - S3) & 7) == 3) { if (late) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{}); }
+      if constexpr (s == S3 + 23) { if (late) burst_q(std::integral_constant<int, 20>{}, I2{}); }
+      CPROF_MARK(1);
+      if constexpr (s == S3 + 8) prefetch(tl + 1 < nt ? tl + 1 : tl);  // the next tile's rows, sixteen steps before they are used
+    });
+    CPROF_MARK(3);
+    CH_TOUCH_A(a1);
+    CH_TOUCH_ACC(acc);
+    CPROF_MARK(4);
+  };
+
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
@@ -317,115 +498,9 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
       for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
       continue;
     }
-    const int64_t m = r0 + tok;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
-    // ---- x1 = x + o Wproj^T + b
-#pragma unroll
-    for (int pr = 0; pr < 8; ++pr) {
-      CH_BARRIER();
-      nb_mma(ring + slot * SLOT, a0, acc[2 * pr], acc[2 * pr + 1]);
-      slot = (slot + 1) & (NS - 1);
-      add4(acc[2 * pr], lds_f4(bias + 128 * pr));
-      add4(acc[2 * pr + 1], lds_f4(bias + 128 * pr + 16));
-    }
-    if (MOD) {
-      // ---- LayerNorm (no affine) of the row the four lanes tok, tok + 16, tok + 32, tok + 48 hold, then the modulation
-      float sum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * (1.0f / 256.0f);
-      float sq = 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = acc[t][r] - mean;
-          sq = __builtin_fmaf(d, d, sq);
-        }
-      }
-      sq += __shfl_xor(sq, 16, 64);
-      sq += __shfl_xor(sq, 32, 64);
-      const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
-      const float nb = -mean * rstd;
-      HMA_LDS(char)* ssl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 32 * g;
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        float h[8], mm[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
-        const float4 sh0 = lds_f4(ssl + 128 * pr), sh1 = lds_f4(ssl + 128 * pr + 16);
-        const float4 sc0 = lds_f4(ssl + 1024 + 128 * pr), sc1 = lds_f4(ssl + 1024 + 128 * pr + 16);
-        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
-        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-        // (the modulation is applied to the bf16-ROUNDED xhat: what the backward re-reads, as the unfused epilogue does)
-        const uint4 hq = pack8(h);
-        float hr[8];
-        unpack8(hq, hr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(hr[e], 1.0f + sc[e], sh[e]);
-        const uint4 mq = pack8(mm);
-        a1[pr] = as_frag(mq);
-        if (SAVE) hqs[pr] = hq;
-      }
-      if (SAVE && !(CH_ABL & 1)) p.rstd[m] = rstd;  // (the row's four lanes write the same value)
-    }
-    // ---- x2 = x1 + xm Wlin^T + b: the new residual row, its bf16 copy = the qkv GEMM's operand.
-    // Every output row leaves as ONE burst of back-to-back store instructions (its whole 512 / 1024 bytes within a few hundred
-    // cycles): pieces of a row written steps apart reach DRAM as separate 128-byte writes.
-    float* xt = p.x + r0 * 256;
-    uint16_t* xb = reinterpret_cast<uint16_t*>(p.x_bf16) + r0 * 256;
-    if (MOD && SAVE) {
-      uint16_t* xh = reinterpret_cast<uint16_t*>(p.xhat) + r0 * 256;
-      uint16_t* xm = reinterpret_cast<uint16_t*>(p.xm) + r0 * 256;
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) store_lines(xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
-        store_lines(xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
-    }
-#pragma unroll
-    for (int pr = 0; pr < 8; ++pr) {
-      if (MOD) {
-        CH_BARRIER();
-        nb_mma(ring + slot * SLOT, a1, acc[2 * pr], acc[2 * pr + 1]);
-        slot = (slot + 1) & (NS - 1);
-        add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
-        add4(acc[2 * pr + 1], lds_f4(bias + 1024 + 128 * pr + 16));
-      }
-      a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
-    }
-#pragma unroll
-    for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
-    if (SAVE) {
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
-        store_lines(xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
-    }
-    // ---- qkv = bf16(x2) Wqkv^T + b, stored as three 512-byte row pieces (q | k | v); the next tile's rows are requested here
-    prefetch(tl + 1 < nt ? tl + 1 : tl);
-    // (r0 is a multiple of 16 and so is a row group: the tile's 16 rows stay consecutive under the remap)
-    uint16_t* qt = reinterpret_cast<uint16_t*>(p.qkv) + remap_row(r0, p.q_group_rows, p.q_group_stride) * p.ldq;
-#pragma unroll
-    for (int part = 0; part < 3; ++part) {
-      uint4 qb[8];
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        const int pq = 8 * part + pr;
-        CH_BARRIER();
-        f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * pq), c1 = lds_f4v(bias + 2048 + 128 * pq + 16);
-        nb_mma(ring + slot * SLOT, a0, c0, c1);
-        slot = (slot + 1) & (NS - 1);
-        qb[pr] = pack_pair(c0, c1);
-      }
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) store_lines(qt, Lq, 512 * part + 128 * pp, qb[2 * pp], qb[2 * pp + 1]);
-    }
-    CH_TOUCH_A(a1);
-    CH_TOUCH_ACC(acc);
+    tile(tl, r0);
   }
+  CPROF_FLUSH(0, wave);
 }
 
 // ------------------------------------------------------------------------------------------------ chain A, backward
@@ -458,21 +533,23 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
-  constexpr int PER_TILE = MOD ? 40 : 32;
+  constexpr int S3 = MOD ? 32 : 24;      // first d_o step
+  constexpr int PER_TILE = S3 + 8;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
     return;
   }
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
     return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
   };
-  bf16x8_t dq[3][8], xr[8], a1[8];
-  f32x4v_t acc[16];
-  float rs = 0.f;
+  bf16x8_t dq[3][8], xr[8], a1[8], a2[8];
+  f32x4v_t acc[16], dxr[16], dm[16];
+  uint4 qb[8];  // d_o blocks waiting for their burst
+  float rs = 1.f;
   auto load_chunk = [&](int64_t mc, int c, bf16x8_t (&d)[8]) __attribute__((always_inline)) {
     if (CH_ABL & 2) {
 #pragma unroll
@@ -483,32 +560,181 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
 #pragma unroll
     for (int j = 0; j < 8; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
   };
-  auto prefetch = [&](int tl) __attribute__((always_inline)) {
+  auto prefetch = [&](int tl) __attribute__((always_inline)) {  // the first k-chunk of the next tile's dqkv rows
     int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     load_chunk(m, 0, dq[0]);
-    if (CH_ABL & 2) return;
-    const float* xrow = p.dx + m * 256 + 8 * g;
-#pragma unroll
-    for (int pr = 0; pr < 8; ++pr) {
-      acc[2 * pr] = ld4(xrow + 32 * pr);
-      acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
-    }
   };
-  if (CH_ABL & 2) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
-    rs = 1.f;
-  }
   prefetch(0);
   CH_TOUCH_A(dq[0]);
-  CH_TOUCH_ACC(acc);
   int slot = 0;
   HMA_LDS(char)* ring = lds + lane * 16;
   const line_offs Lb = make_lines(512, tok, 16 * g, 64);
   const line_offs Lf = make_lines(1024, tok, 32 * g, 16);
+
+  // (ONE copy of the tile body; the late waves differ by two wave-uniform branches per step.  Two instantiations were tried first:
+  // every value the halves share became a spill candidate, ~110 spilled registers.)
+  const bool late = wave >= 4;
+  auto tile = [&](int tl, int64_t r0) __attribute__((always_inline)) {
+    const int64_t m = r0 + tok;
+    float* xt = p.dx + r0 * 256;
+    uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + r0 * 256;
+    uint16_t* d2 = reinterpret_cast<uint16_t*>(p.dx2_bf16) + r0 * 256;
+    uint16_t* ot = reinterpret_cast<uint16_t*>(p.d_o) + r0 * 256;
+    auto burst_d2 = [&]() __attribute__((always_inline)) {  // bf16(dx2), the dY of linear_out's weight gradient
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+        store_lines(d2, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+    };
+    auto burst_dx = [&]() __attribute__((always_inline)) {  // dx1, the new residual gradient, and its bf16 copy
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+        store_lines(d1, Lb, 128 * pp, __builtin_bit_cast(uint4, a2[2 * pp]), __builtin_bit_cast(uint4, a2[2 * pp + 1]));
+    };
+    auto burst_o = [&](auto first_) __attribute__((always_inline)) {  // d_o blocks first .. first + 3
+      constexpr int first = decltype(first_)::value;
+      store_lines(ot, Lb, 64 * first, qb[first], qb[first + 1]);
+      store_lines(ot, Lb, 64 * first + 128, qb[first + 2], qb[first + 3]);
+    };
+    load_chunk(m, 1, dq[1]);  // this tile's second k-chunk of dqkv
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+    static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      CH_BARRIER();
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = (slot + 1) & (NS - 1);
+      if constexpr (s < 24) {
+        // ---- dx2 = dx + dqkv Wqkv (k = 768 in three chunks; chunk c + 1 is requested while chunk c is multiplied)
+        constexpr int c = s >> 3, pr = s & 7;
+        if constexpr (s == 8) load_chunk(m, 2, dq[2]);
+        if constexpr (s == 16) {  // the residual gradient itself, added behind the product (eight steps from here)
+          if (!(CH_ABL & 2)) {
+            const float* xrow = p.dx + m * 256 + 8 * g;
+#pragma unroll
+            for (int pr2 = 0; pr2 < 8; ++pr2) {
+              dxr[2 * pr2] = ld4(xrow + 32 * pr2);
+              dxr[2 * pr2 + 1] = ld4(xrow + 32 * pr2 + 4);
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) dxr[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
+          }
+        }
+        nb_mma(wb, dq[c], acc[2 * pr], acc[2 * pr + 1]);
+        if constexpr (s == 23) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc[t] += dxr[t];
+#pragma unroll
+          for (int pr2 = 0; pr2 < 8; ++pr2) {
+            const bf16x8_t q = as_frag(pack_pair(acc[2 * pr2], acc[2 * pr2 + 1]));
+            if constexpr (MOD) a1[pr2] = q;
+            else a2[pr2] = q;
+          }
+        }
+      } else if constexpr (MOD && s < 32) {
+        // ---- dxm = bf16(dx2) Wlin (the saved xhat row and 1 / sigma are requested at its first step, eight steps before use)
+        constexpr int pr = s - 24;
+        if constexpr (s == 24) {
+          if (!(CH_ABL & 2)) {
+            const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
+            rs = p.rstd[m];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+        }
+        nb_mma(wb, a1, dm[2 * pr], dm[2 * pr + 1]);
+        if constexpr (s == 31) {
+          // ---- modulate + LayerNorm backward
+          HMA_LDS(char)* scl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 1024 + 32 * g;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int pr2 = 0; pr2 < 8; ++pr2) {
+            float xh[8];
+            unpack8(__builtin_bit_cast(uint4, xr[pr2]), xh);
+            const float4 sc0 = lds_f4(scl + 128 * pr2), sc1 = lds_f4(scl + 128 * pr2 + 16);
+            const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gq = dm[2 * pr2 + (e >> 2)][e & 3] * (1.0f + sc[e]);
+              s1 += gq;
+              s2 = __builtin_fmaf(gq, xh[e], s2);
+            }
+          }
+          s1 += __shfl_xor(s1, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 16, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          s1 *= (1.0f / 256.0f);
+          s2 *= (1.0f / 256.0f);
+          // (opaque: otherwise the unpacked xhat and the scaled gradient of this pass -- 128 registers -- are kept for the passes below)
+          CH_TOUCH_A(xr);
+          CH_TOUCH_ACC(dm);
+          asm volatile("" ::: "memory");
+          {  // d shift = column sums of dxm, d scale = column sums of dxm xhat over the frame's rows (two halves of 128 columns)
+            float* dssf = p.dss + (r0 / p.rows_per_frame) * 512 + 8 * g;
+            const int cb = ((tok >> 3) & 1) * 2 + ((tok >> 2) & 1) * 4 + ((tok >> 1) & 1) * 8 + (tok & 1) * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              float o2[2];
+              colsum16([&](int c) __attribute__((always_inline)) { return dm[8 * h + 2 * (c >> 3) + ((c >> 2) & 1)][c & 3]; }, tok, o2);
+              if (!(CH_ABL & 1)) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) unsafeAtomicAdd(dssf + 128 * h + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o2[q]);
+              }
+              colsum16([&](int c) __attribute__((always_inline)) {
+                const uint32_t wv = __builtin_bit_cast(u32x4_t, xr[4 * h + (c >> 3)])[(c >> 1) & 3];
+                return dm[8 * h + 2 * (c >> 3) + ((c >> 2) & 1)][c & 3] * ((c & 1) ? bf16_hi(wv) : bf16_lo(wv));
+              }, tok, o2);
+              if (!(CH_ABL & 1)) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) unsafeAtomicAdd(dssf + 256 + 128 * h + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o2[q]);
+              }
+            }
+          }
+          CH_TOUCH_A(xr);
+          CH_TOUCH_ACC(dm);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int pr2 = 0; pr2 < 8; ++pr2) {
+            float xh[8];
+            unpack8(__builtin_bit_cast(uint4, xr[pr2]), xh);
+            const float4 sc0 = lds_f4(scl + 128 * pr2), sc1 = lds_f4(scl + 128 * pr2 + 16);
+            const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gq = dm[2 * pr2 + (e >> 2)][e & 3] * (1.0f + sc[e]);
+              acc[2 * pr2 + (e >> 2)][e & 3] += rs * (gq - s1 - xh[e] * s2);
+            }
+            a2[pr2] = as_frag(pack_pair(acc[2 * pr2], acc[2 * pr2 + 1]));
+          }
+        }
+      } else {
+        // ---- d_o = bf16(dx1) Wproj
+        constexpr int pr = s - S3;
+        if constexpr (s == S3) prefetch(tl + 1 < nt ? tl + 1 : tl);
+        f32x4v_t c0 = f32x4v_t{0.f, 0.f, 0.f, 0.f}, c1 = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+        nb_mma(wb, a2, c0, c1);
+        qb[pr] = pack_pair(c0, c1);
+      }
+      using I0 = std::integral_constant<int, 0>;
+      using I4 = std::integral_constant<int, 4>;
+      if constexpr (MOD && s == 23) { if (!late) burst_d2(); }
+      if constexpr (MOD && s == 27) { if (late) burst_d2(); }
+      if constexpr (s == S3 - 1) { if (!late) burst_dx(); }
+      if constexpr (s == S3 + 3) { if (late) { burst_dx(); burst_o(I0{}); } }
+      if constexpr (s == S3 + 7) { if (!late) burst_o(I0{}); burst_o(I4{}); }
+    });
+    CH_TOUCH_A(dq[0]);
+  };
+
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
@@ -517,139 +743,7 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
       for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
       continue;
     }
-    const int64_t m = r0 + tok;
-    // ---- dx2 = dx + dqkv Wqkv (k = 768 in three chunks; chunk c + 1 is requested while chunk c is multiplied)
-    load_chunk(m, 1, dq[1]);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (c == 1) load_chunk(m, 2, dq[2]);
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        CH_BARRIER();
-        nb_mma(ring + slot * SLOT, dq[c], acc[2 * pr], acc[2 * pr + 1]);
-        slot = (slot + 1) & (NS - 1);
-      }
-    }
-    float* xt = p.dx + r0 * 256;
-    uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx1_bf16) + r0 * 256;
-    uint4 qk0;
-    if (MOD) {
-      uint16_t* d2 = reinterpret_cast<uint16_t*>(p.dx2_bf16) + r0 * 256;
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
-        a1[pr] = as_frag(q);
-        if (pr & 1) store_lines(d2, Lb, 64 * (pr - 1), qk0, q);
-        else qk0 = q;
-      }
-      // ---- dxm = bf16(dx2) Wlin (the saved xhat row and 1 / sigma are requested here, eight steps before they are used)
-      if (!(CH_ABL & 2)) {
-        const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
-        rs = p.rstd[m];
-      }
-      f32x4v_t dm[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        CH_BARRIER();
-        nb_mma(ring + slot * SLOT, a1, dm[2 * pr], dm[2 * pr + 1]);
-        slot = (slot + 1) & (NS - 1);
-      }
-      // ---- modulate + LayerNorm backward
-      HMA_LDS(char)* scl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 1024 + 32 * g;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        float xh[8];
-        unpack8(__builtin_bit_cast(uint4, xr[pr]), xh);
-        const float4 sc0 = lds_f4(scl + 128 * pr), sc1 = lds_f4(scl + 128 * pr + 16);
-        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gq = dm[2 * pr + (e >> 2)][e & 3] * (1.0f + sc[e]);
-          s1 += gq;
-          s2 = __builtin_fmaf(gq, xh[e], s2);
-        }
-      }
-      s1 += __shfl_xor(s1, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      s1 *= (1.0f / 256.0f);
-      s2 *= (1.0f / 256.0f);
-      // (opaque: otherwise the unpacked xhat and the scaled gradient of this pass -- 128 registers -- are kept for the passes below)
-      CH_TOUCH_A(xr);
-      CH_TOUCH_ACC(dm);
-      asm volatile("" ::: "memory");
-      {  // d shift = column sums of dxm, d scale = column sums of dxm xhat over the frame's rows (two halves of 128 columns)
-        float* dssf = p.dss + (r0 / p.rows_per_frame) * 512 + 8 * g;
-        const int cb = ((tok >> 3) & 1) * 2 + ((tok >> 2) & 1) * 4 + ((tok >> 1) & 1) * 8 + (tok & 1) * 16;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float o2[2];
-          colsum16([&](int c) __attribute__((always_inline)) { return dm[8 * h + 2 * (c >> 3) + ((c >> 2) & 1)][c & 3]; }, tok, o2);
-          if (!(CH_ABL & 1)) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) unsafeAtomicAdd(dssf + 128 * h + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o2[q]);
-          }
-          colsum16([&](int c) __attribute__((always_inline)) {
-            const uint32_t wv = __builtin_bit_cast(u32x4_t, xr[4 * h + (c >> 3)])[(c >> 1) & 3];
-            return dm[8 * h + 2 * (c >> 3) + ((c >> 2) & 1)][c & 3] * ((c & 1) ? bf16_hi(wv) : bf16_lo(wv));
-          }, tok, o2);
-          if (!(CH_ABL & 1)) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) unsafeAtomicAdd(dssf + 256 + 128 * h + 32 * ((cb + q) >> 3) + ((cb + q) & 7), o2[q]);
-          }
-        }
-      }
-      CH_TOUCH_A(xr);
-      CH_TOUCH_ACC(dm);
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        float xh[8];
-        unpack8(__builtin_bit_cast(uint4, xr[pr]), xh);
-        const float4 sc0 = lds_f4(scl + 128 * pr), sc1 = lds_f4(scl + 128 * pr + 16);
-        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gq = dm[2 * pr + (e >> 2)][e & 3] * (1.0f + sc[e]);
-          acc[2 * pr + (e >> 2)][e & 3] += rs * (gq - s1 - xh[e] * s2);
-        }
-        const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
-        a1[pr] = as_frag(q);
-        store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
-        if (pr & 1) store_lines(d1, Lb, 64 * (pr - 1), qk0, q);
-        else qk0 = q;
-      }
-    } else {
-#pragma unroll
-      for (int pr = 0; pr < 8; ++pr) {
-        const uint4 q = pack_pair(acc[2 * pr], acc[2 * pr + 1]);
-        a1[pr] = as_frag(q);
-        store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
-        if (pr & 1) store_lines(d1, Lb, 64 * (pr - 1), qk0, q);
-        else qk0 = q;
-      }
-    }
-    // ---- d_o = bf16(dx1) Wproj; the next tile's rows are requested here
-    prefetch(tl + 1 < nt ? tl + 1 : tl);
-    uint16_t* ot = reinterpret_cast<uint16_t*>(p.d_o) + r0 * 256;
-#pragma unroll
-    for (int pr = 0; pr < 8; ++pr) {
-      CH_BARRIER();
-      f32x4v_t c0 = f32x4v_t{0.f, 0.f, 0.f, 0.f}, c1 = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-      nb_mma(ring + slot * SLOT, a1, c0, c1);
-      slot = (slot + 1) & (NS - 1);
-      const uint4 q = pack_pair(c0, c1);
-      if (pr & 1) store_lines(ot, Lb, 64 * (pr - 1), qk0, q);
-      else qk0 = q;
-    }
-    CH_TOUCH_A(dq[0]);
-    CH_TOUCH_ACC(acc);
+    tile(tl, r0);
   }
 }
 
@@ -689,10 +783,20 @@ bool weights_ok(const hma_chain_weights_t& w, int expect) {
 
 int chain_grid(int64_t M) {
   const int64_t ntiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+#ifdef CH_GRID  // (debug builds: fewer workgroups than CUs)
+  return (int)(ntiles < CH_GRID ? ntiles : CH_GRID);
+#endif
   return (int)(ntiles < num_cus() ? ntiles : num_cus());
 }
 
 }  // namespace
+
+#ifdef CH_PROF
+extern "C" int hma_chain_debug_prof(unsigned long long* out128) {
+  if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_ch_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 extern "C" int hma_chain_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
                               const float* col_scale, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t batch,

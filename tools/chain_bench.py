@@ -91,3 +91,15 @@ by_f = M * 5632.0
 print(f"skew {SKEW:8d} ", end="")
 print(f"{os.environ.get('HMA_LIB', 'default'):>24s}  chain A fwd {t_f:7.1f} us ({by_f / t_f / 1e6:5.2f} TB/s)  [3 launches: "
       f"{' + '.join(f'{t:.0f}' for t in t_old)} = {sum(t_old):.0f} us]   chain A bwd {t_b:7.1f} us ({M * 5632.0 / t_b / 1e6:5.2f} TB/s)")
+
+if os.environ.get("CH_PROF"):
+    lib = _lib.load()
+    lib.hma_chain_debug_prof.argtypes = [C.c_void_p]
+    buf = (C.c_ulonglong * 128)()
+    _lib.call("hma_chain_a_fwd", st, C.byref(fa))
+    torch.cuda.synchronize()
+    lib.hma_chain_debug_prof(buf)
+    print("fwd, workgroup 0, cycles.  compute waves: [barrier wait, stores, compute, loop/prefetch, end-of-tile wait]; loader (wave 7): [vmcnt wait, barrier wait, issue]")
+    for w in range(8):
+        v = [buf[w * 8 + i] for i in range(8)]
+        print(f"  wave {w}: " + " ".join(f"{x:9d}" for x in v[:5]) + f"   sum {sum(v)}")
