@@ -38,7 +38,7 @@ FREQ = [20, 10, 20, 20, 5, 30, 2, 20, 20, 10, 2, 2, 10, 1, 10, 5, 5, 5, 10, 3, 1
 FLOP_PER_TOKEN_FWD_BWD = 3.104e8
 # every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
 FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_attn_spatial_fwd",
-            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd"]
+            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
 
 
@@ -81,12 +81,10 @@ def domain_sequence(n_domains, n_draws, seed=0):
 
 
 def pmc_traffic_per_launch(kernel_substr="gemm_nt"):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_hbm_r2.json, else _r1:
-    separate FETCH_SIZE / WRITE_SIZE runs of this bench on an 8-layer model; counters are in KB and, on gfx950,
-    FETCH_SIZE reports half of a wide coalesced read -- MI355X_MICROARCH.md section HBM -- so it is doubled)."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_r2.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "pmc_hbm_r1.json")
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_hbm_r3.json, else the
+    older rounds': separate FETCH_SIZE / WRITE_SIZE runs of this bench on an 8-layer model; counters are in KB and, on
+    gfx950, FETCH_SIZE reports half of a wide coalesced read -- MI355X_MICROARCH.md section HBM -- so it is doubled)."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (3, 2, 1)) if os.path.exists(q)), "")
     try:
         d = json.load(open(path))
         tot, launches = 0.0, 0
@@ -126,8 +124,10 @@ def _cpu_train_steps(sd, rc, names, domain, d_a, T, B, warm, timed):
 
 def cpu_baseline(model, domain, d_a, T, quick=False):
     """The CPU oracle (a port of the reference path, oracle/st_maskgit_ref.py) on the host cores, BASELINE.md section 3:
-    fp32, every host core, one optimizer step = fwd + bwd + clip + AdamW; B = 1: 2 warm-up + median of 5; B = 4 beside it
-    (1 warm-up + median of 2: a step is ~4x as long).  `quick`: one warm-up + one timed step at B = 1 only."""
+    fp32, every host core, one optimizer step = fwd + bwd + clip + AdamW; B = 1: 2 warm-up + median of 5.  Beside that protocol
+    figure: `best_threads` -- the same step at 8 / 16 / 32 / 64 threads (1 warm-up + median of 3 each; K = 256 matmuls do not
+    scale to 128 threads, the protocol figure understates what the host can do) -- and B = 4 at the best thread count
+    (1 warm-up + median of 5).  `quick`: one warm-up + one timed step at B = 1 only."""
     from oracle import st_maskgit_ref as R
 
     cfg = model.config
@@ -143,9 +143,25 @@ def cpu_baseline(model, domain, d_a, T, quick=False):
            "sample": f"CPU oracle (plain PyTorch fp32, {cores} threads), B=1 T={T} L={cfg.num_layers}, fwd+bwd+clip+AdamW, "
                      f"{w1} warm-up + median of {n1} steps ({med(t1):.2f} s/step)"}
     if not quick:
-        t4 = _cpu_train_steps(sd, rc, names, domain, d_a, T, 4, 1, 2)
-        out["b4"] = {"value": 4 * T * 256 / med(t4), "unit": "video-tokens/s",
-                     "sample": f"same, B=4, 1 warm-up + median of 2 steps ({med(t4):.2f} s/step)"}
+        sweep = {}
+        try:
+            for nthr in (8, 16, 32, 64):
+                if nthr >= cores:
+                    break
+                torch.set_num_threads(nthr)
+                sweep[nthr] = T * 256 / med(_cpu_train_steps(sd, rc, names, domain, d_a, T, 1, 1, 3))
+            best = max(sweep, key=sweep.get) if sweep else cores
+            if sweep and sweep[best] < out["value"]:
+                best = cores
+            torch.set_num_threads(best)
+            t4 = _cpu_train_steps(sd, rc, names, domain, d_a, T, 4, 1, 5)
+        finally:
+            torch.set_num_threads(cores)
+        out["best_threads"] = {"threads": best, "value": max([out["value"]] + list(sweep.values())), "unit": "video-tokens/s",
+                               "sweep": {str(k): v for k, v in sweep.items()},
+                               "sample": "same step, B=1, 1 warm-up + median of 3 per thread count"}
+        out["b4"] = {"value": 4 * T * 256 / med(t4), "unit": "video-tokens/s", "cores": best,
+                     "sample": f"same, B=4 at {best} threads, 1 warm-up + median of 5 steps ({med(t4):.2f} s/step)"}
     return out
 
 
@@ -163,11 +179,18 @@ def mar_bench(args, dev, steps=None, warmup=None):
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     B, T = (args.batch if args.batch != 32 else 16), args.frames
+    # hma/configs/mar_n32_h8_d256_action.json as shipped (mlp_drop 0.05: the MLP's two Dropout sites are live in training),
+    # use_mup as train_multi.py forces it, 30 action domains (the "1B" model, run_30datasets_mar_waction.sh)
     cfgd = dict(num_layers=args.layers, num_heads=8, d_model=256, T=T, S=1024, use_mup=True, action_network="concat+modulate",
-                num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.0, mlp_bias=False,
+                num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.05, mlp_bias=False,
                 patch_size=2, vae_embed_dim=4, diffloss_w=1024, diffloss_d=4, num_sampling_steps="100", attn_drop=0.0)
     m = STMAR(DiffusionGenieConfig(**cfgd))
-    m.init_action_projectors(["dom0", "dom1"], [14, 7], [[[0.0] * 7, [1.0] * 7]] * 2, cfgd["action_network"])
+    ndom = 30
+    doms = [f"dom{i}" for i in range(ndom)]
+    # (action strides capped at 9 steps: the per-domain action-diffusion heads the config also builds -- st_mar.py:89-100, never
+    # exercised without jointly_predict_actions -- take at most 64 target channels here)
+    m.init_action_projectors(doms, [14] + [7 * min(max(1, f // 2), 9) for f in FREQ[1:ndom]], [[[0.0] * 7, [1.0] * 7]] * ndom,
+                             cfgd["action_network"])
     with torch.no_grad():
         for p_ in m.parameters():
             if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
@@ -193,8 +216,10 @@ def mar_bench(args, dev, steps=None, warmup=None):
         "metric": "patch-tokens/sec (STMAR train step: fwd+bwd+clip+AdamW) HMA-MAR T=16 32x32x4 latents", "value": tokens / dt,
         "unit": "patch-tokens/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"HMA-MAR d256/h8/L{args.layers}, diffusion head 1024x4, synthetic latents T={T} 32x32x4 (+64 action "
-                               f"tokens/frame), batch {B}/GPU, eager launches (no hipGraph)", "global_batch": B, "parallelism": "dp1"},
+        "config": {"workload": f"HMA-MAR d256/h8/L{args.layers} (mar_n32_h8_d256_action.json: mlp_drop 0.05), {ndom} action domains "
+                               f"({sum(p_.numel() for p_ in m.parameters()) / 1e6:.0f}M params), diffusion head 1024x4, synthetic latents "
+                               f"T={T} 32x32x4 (+64 action tokens/frame), batch {B}/GPU, eager launches (no hipGraph)",
+                   "global_batch": B, "parallelism": "dp1"},
         "roofline": {"bound": "mfma", "kernel": "whole step (algorithmic FLOPs: trunk 3 x 1.04e8 + diffusion head 3 x 4.94e7 per patch token)",
                      "achieved": tokens / dt * MAR_FLOP_PER_TOKEN / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": tokens / dt * MAR_FLOP_PER_TOKEN / MFMA_PEAK, "traffic": None},
@@ -454,13 +479,16 @@ def main():
             if dom_name:
                 d0 = fams[dom_name]
                 traffic = pmc_traffic_per_launch({"hma_gemm_nt": "gemm_nt", "hma_mlp_bwd": "mlp_bwd", "hma_mlp_fwd": "mlp_fwd",
-                                                  "hma_gemm_tn_pair": "gemm_tn"}.get(dom_name, dom_name))
+                                                  "hma_gemm_tn_pair": "gemm_tn", "hma_chain_a_fwd": "chain_a_fwd",
+                                                  "hma_chain_a_bwd": "chain_a_bwd"}.get(dom_name, dom_name))
                 mfma = {"achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s", "frac": d0["frac"]}
                 hbm = {"achieved": d0["hbm_achieved_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": d0["hbm_frac"]}
-                top = hbm if d0["bound"] == "hbm" else mfma
-                out["roofline"] = {"bound": d0["bound"], "kernel": dom_name, "achieved": top["achieved"], "peak": top["peak"],
-                                   "unit": top["unit"], "frac": top["frac"], "traffic": traffic,
+                # headline = the MFMA roof (SURVEY.md 8d / north_star: dense contraction => MFMA); the HBM view of the same
+                # launches (algorithmic bytes / time) rides beside it as `hbm`
+                out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": mfma["achieved"], "peak": mfma["peak"],
+                                   "unit": mfma["unit"], "frac": mfma["frac"], "traffic": traffic,
                                    "flop_per_byte": d0["flop_per_byte"], "mfma": mfma, "hbm": hbm,
+                                   "bound_by_intensity": d0["bound"],
                                    "bytes_per_launch": d0["bytes_per_launch"],
                                    "traffic_note": "traffic = measured HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
                                                    "(profiles/pmc_hbm_*.json); achieved = ALGORITHMIC bytes (every operand once, every result once) / "

@@ -447,12 +447,9 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
             const float4 sc0 = lds_f4(ssl + 1024 + 128 * pr), sc1 = lds_f4(ssl + 1024 + 128 * pr + 16);
             const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
             const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
-            // (the modulation is applied to the bf16-ROUNDED xhat: what the backward re-reads, as the unfused epilogue does)
-            const uint4 hq = pack8(h);
-            float hr[8];
-            unpack8(hq, hr);
+            const uint4 hq = pack8(h);  // (saved for the backward; the modulation itself uses the fp32 value, like the reference)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(hr[e], 1.0f + sc[e], sh[e]);
+            for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(h[e], 1.0f + sc[e], sh[e]);
             a1[pr] = as_frag(pack8(mm));
             if (SAVE) hqs[pr] = hq;
           }

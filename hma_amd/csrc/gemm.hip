@@ -354,7 +354,11 @@ __device__ __forceinline__ void epilogue_oct(const hma_gemm_nt_t& p, int64_t bz,
 // ------------------------------------------------------------- NT, persistent, deferred epilogue
 // Same 8-wave, one-per-CU pipeline as gemm_nt_persist_kernel, with the epilogue as a template parameter,
 // 16-byte bf16 accesses (epilogue_oct) and the deferred, interleaved epilogue described inside.
-template <int AKIND, int EPI>
+// SHALLOW (K < 256: fewer than four K-steps per tile -- STMAR's token_embed and the diffusion head's input layer, K = 128): the
+// finished tile is written out at once.  The deferred epilogue below needs four steps of the NEXT tile to hide behind; with
+// fewer, a workgroup that owned two tiles lost parts of the first one, i.e. from M > 128 x #CUs = 32 768 rows (found in round 3
+// by the batch-decomposition property of tests/test_fulldepth_stmar_gpu.py).
+template <int AKIND, int EPI, bool SHALLOW = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int tiles_m, int tiles_n, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
     const uint16_t* As = smem + (it & 1) * P_STAGE;
     if (!(ablate & 4)) mma_tile(As, As + P_A, acc, wm, wn, lane);
     PROF_MARK(2);
-    if (!(ablate & 1)) emit_step(cur_kt);
+    if (!SHALLOW && !(ablate & 1)) emit_step(cur_kt);
     PROF_MARK(3);
     if (++cur_kt == KT) {
 #pragma unroll
@@ -534,6 +538,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(hma_gemm_nt_t p, int
 #pragma unroll
         for (int c = 0; c < 2; ++c) pacc[a][c] = acc[a][c];
       ptile = cur_tile;
+      if (SHALLOW && !(ablate & 1)) {
+        emit_part(I0{}, I0{});
+        emit_part(I0{}, I1{});
+        emit_part(I1{}, I0{});
+        emit_part(I1{}, I1{});
+        ptile = -1;
+      }
       zero_acc();
       cur_kt = 0;
       cur_tile += G;
@@ -2271,9 +2282,21 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
     HMA_CHECK_LAUNCH();                                                                               \
     return 0;                                                                                         \
   }
+#define HMA_NT3S_CASE(AK, EP)                                                                         \
+  if (p->a_kind == AK && p->epi == EP) {                                                              \
+    if ((rc = set_smem_bytes<gemm_nt_p3_kernel<AK, EP, true>>(P_SMEM_BYTES))) return rc;              \
+    hipLaunchKernelGGL((gemm_nt_p3_kernel<AK, EP, true>), p3grid, dim3(512), P_SMEM_BYTES, s, pa, tiles_m, tiles_n, total); \
+    HMA_CHECK_LAUNCH();                                                                               \
+    return 0;                                                                                         \
+  }
 #define HMA_NT3_ALL(AK)                                                                               \
   HMA_NT3_CASE(AK, HMA_EPI_BF16) HMA_NT3_CASE(AK, HMA_EPI_F32) HMA_NT3_CASE(AK, HMA_EPI_RESID)        \
   HMA_NT3_CASE(AK, HMA_EPI_ATOMIC_F32)
+      if (p->K < 4 * PK) {  // fewer than four K-steps per tile: the undeferred variant (see the kernel)
+        HMA_NT3S_CASE(HMA_A_BF16, HMA_EPI_BF16) HMA_NT3S_CASE(HMA_A_BF16, HMA_EPI_F32) HMA_NT3S_CASE(HMA_A_BF16, HMA_EPI_RESID)
+        HMA_NT3S_CASE(HMA_A_F32, HMA_EPI_BF16) HMA_NT3S_CASE(HMA_A_F32, HMA_EPI_F32) HMA_NT3S_CASE(HMA_A_F32, HMA_EPI_RESID)
+        return HMA_EINVAL;
+      }
       HMA_NT3_ALL(HMA_A_BF16)
       HMA_NT3_ALL(HMA_A_F32)
       HMA_NT3_ALL(HMA_A_BF16_AFFINE)

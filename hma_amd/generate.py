@@ -47,7 +47,7 @@ def get_model_step(checkpoint_dir) -> int:
     (generate.py:80-84), else `.../step_1234` -> 1234, else 0."""
     sch = os.path.join(str(checkpoint_dir), "scheduler.bin")
     if os.path.exists(sch):
-        return int(torch.load(sch, weights_only=False)["_step_count"])
+        return int(torch.load(sch, weights_only=True)["_step_count"])
     tail = os.path.basename(os.path.normpath(str(checkpoint_dir)))
     digits = "".join(ch for ch in tail.split("_")[-1] if ch.isdigit())
     return int(digits) if digits else 0

@@ -25,11 +25,32 @@ class SelfAttention(nn.Module):
         if self.qk_norm:
             self.norm = nn.LayerNorm(self.head_dim, eps=1e-05)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor, causal: bool = False) -> torch.Tensor:
-        """x (Bn, N, 256): spatial (causal=False, N in {64, 256, 320}) or temporal (causal=True, N <= 16)."""
+        """x (Bn, N, 256): spatial (causal=False, N in {64, 256, 320}) or temporal (causal=True, N <= 16).  With autograd on and
+        anything that requires a gradient in reach, the same kernels run as `torch.ops.hma.*` custom ops with their backward
+        formulas (hma_amd/torch_ops.py), so a caller that trains through the module gets gradients for x, qkv and proj."""
         if self.qk_norm or self.num_heads != 8 or self.head_dim != 32:
             raise NotImplementedError("kernels are built for 8 heads of 32 without qk_norm")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(x, causal)
+        with torch.no_grad():
+            return self._forward_inference(x, causal)
+
+    def _forward_autograd(self, x: torch.Tensor, causal: bool) -> torch.Tensor:
+        from .. import torch_ops  # noqa: F401  (registers torch.ops.hma.*)
+        Bn, N, Cd = x.shape
+        bf = torch.bfloat16
+        xb = x.reshape(Bn * N, Cd).to(bf)
+        qkv = torch.ops.hma.linear(xb, self.qkv.weight.to(bf), self.qkv.bias)
+        if causal:  # rows (t, column): one sample of N frames with Bn positions
+            o = torch.ops.hma.attn_temporal(qkv.view(Bn, N, 768).transpose(0, 1).reshape(-1, 768), 1, N, Bn, self.scale)
+            o = o.view(N, Bn, Cd).transpose(0, 1).reshape(Bn * N, Cd)
+        else:
+            o, _ = torch.ops.hma.attn_spatial(qkv, Bn, N, self.scale)
+        y = torch.ops.hma.linear(o, self.proj.weight.to(bf), self.proj.bias)
+        return y.view(Bn, N, Cd).to(x.dtype)
+
+    def _forward_inference(self, x: torch.Tensor, causal: bool) -> torch.Tensor:
         Bn, N, Cd = x.shape
         xf = x.reshape(Bn * N, Cd).contiguous().float()
         qkv = ops.linear(xf, self.qkv.weight.detach().to(torch.bfloat16), self.qkv.bias, epi=EPI_BF16)

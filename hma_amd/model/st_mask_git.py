@@ -420,9 +420,13 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
                     override = torch.rand(bs, h, w, device=prompt_THW.device).reshape(bs, S).contiguous()  # torch.rand_like, :435
             noise = None
             if sampled:
-                noise = (sample_draws[step].to(prompt_THW.device, torch.float32).reshape(bs, S, 2, 512).contiguous()
+                NV_, V_ = cfg.num_factored_vocabs, cfg.factored_vocab_size
+                if (NV_, V_) != (2, 512):
+                    raise NotImplementedError("the categorical MaskGIT step is built for the 2 x 512 factorised vocabulary")
+                noise = (sample_draws[step].to(prompt_THW.device, torch.float32).reshape(bs, S, NV_, V_).contiguous()
                          if sample_draws is not None else
-                         torch.empty(bs, S, 2, 512, device=prompt_THW.device, dtype=torch.float32).exponential_())
+                         torch.empty(bs, S, NV_, V_, device=prompt_THW.device, dtype=torch.float32).exponential_())
+                noise = noise.clamp_min(1e-30)  # (the draws divide the probabilities: an exact 0 would make inf / nan)
             eng.maskgit_step(work, unmasked, out_t, n, last, override, sample_noise=noise)
         prompt_THW.copy_(work.view(bs, t, h, w))
         samples_HW = work[:, out_t].view(bs, h, w).clone()

@@ -23,9 +23,22 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_dim, d_model, bias=mlp_bias)
         self.drop = nn.Dropout(mlp_drop)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """fc2(gelu(fc1 x)) (st_transformer.py:24-27; dropout p = 0 on this path)."""
+        """fc2(gelu(fc1 x)) (st_transformer.py:24-27; dropout p = 0 on this path).  With autograd on and anything that requires a
+        gradient in reach it runs as the `torch.ops.hma.mlp` custom op, whose backward gives x, fc1 and fc2 their gradients."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.training and self.drop.p > 0:
+                raise NotImplementedError("Mlp.forward with autograd and mlp_drop > 0: train through STMaskGIT / STMAR (hma_amd.train)")
+            from .. import torch_ops  # noqa: F401  (registers torch.ops.hma.*)
+            bf = torch.bfloat16
+            shp = x.shape
+            y, _, _ = torch.ops.hma.mlp(x.reshape(-1, shp[-1]).to(bf), self.fc1.weight.to(bf), self.fc1.bias, self.fc2.weight.to(bf),
+                                        self.fc2.bias)
+            return y.view(shp).to(x.dtype)
+        with torch.no_grad():
+            return self._forward_inference(x)
+
+    def _forward_inference(self, x: torch.Tensor) -> torch.Tensor:
         shp = x.shape
         xf = x.reshape(-1, shp[-1]).contiguous().float()
         hid = self.fc1.weight.shape[0]
@@ -34,6 +47,17 @@ class Mlp(nn.Module):
         ops.linear(xf, self.fc1.weight.detach().to(torch.bfloat16), self.fc1.bias, epi=EPI_GELU2, out=u, out2=h)
         y = ops.linear(h, self.fc2.weight.detach().to(torch.bfloat16), self.fc2.bias, epi=EPI_F32)
         return y.view(shp).to(x.dtype)
+
+
+
+def _refuse_autograd(what: str, x: torch.Tensor, module: nn.Module) -> None:
+    """The blocks run through the owning model's engine (recorded launch plans, no autograd graph).  A caller that would get no
+    gradients is told so instead of training on zeros."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
+        raise RuntimeError(
+            f"{what}.forward carries no autograd graph: train through STMaskGIT / STMAR.forward with hma_amd.train.Trainer / "
+            "MarTrainer (the engine's own backward), or call it under torch.no_grad() for inference.  SelfAttention and Mlp "
+            "do run under autograd (torch.ops.hma.*).")
 
 
 class STBlock(nn.Module):
@@ -55,9 +79,13 @@ class STBlock(nn.Module):
         self._owner = None
         self._index = -1
 
-    @torch.no_grad()
     def forward(self, x_TSC: torch.Tensor, action_ids: Optional[torch.Tensor] = None, domain=None) -> torch.Tensor:
-        """(B, T, S, C) -> same (st_transformer.py:79-114).  `action_ids` is the (B, T, C) action embedding."""
+        """(B, T, S, C) -> same (st_transformer.py:79-114).  `action_ids` is the (B, T, C) action embedding.  Inference only."""
+        _refuse_autograd("STBlock", x_TSC, self)
+        with torch.no_grad():
+            return self._forward_inference(x_TSC, action_ids, domain)
+
+    def _forward_inference(self, x_TSC, action_ids, domain):
         owner = self._owner() if self._owner is not None else None
         if owner is None:
             raise RuntimeError("STBlock runs through its STMaskGIT's engine; construct it via STMaskGIT")
@@ -97,8 +125,13 @@ class STTransformerDecoder(nn.Module):
             layer._owner = self._owner
             layer._index = i
 
-    @torch.no_grad()
     def forward(self, tgt: torch.Tensor, action_ids: Optional[torch.Tensor] = None, domain="") -> torch.Tensor:
+        """N x STBlock (st_transformer.py:172-177).  Inference only: see `_refuse_autograd`."""
+        _refuse_autograd("STTransformerDecoder", tgt, self)
+        with torch.no_grad():
+            return self._forward_inference(tgt, action_ids, domain)
+
+    def _forward_inference(self, tgt, action_ids, domain):
         owner = self._owner() if self._owner is not None else None
         if owner is None:
             raise RuntimeError("STTransformerDecoder runs through its STMaskGIT's engine; construct it via STMaskGIT")

@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import EPI_BF16
+from ._lib import EPI_BF16, EPI_DGELU, EPI_GELU2
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -166,4 +166,65 @@ def _at_backward(ctx, d_o):
 
 attn_temporal.register_autograd(_at_backward, setup_context=_at_setup)
 
-OPS = ("linear", "linear_wgrad", "layer_norm", "attn_spatial", "attn_spatial_bwd", "attn_temporal", "attn_temporal_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ Mlp (fc1 -> GELU -> fc2)
+@torch.library.custom_op("hma::mlp", mutates_args=(), device_types="cuda")
+def mlp(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor,
+        b2: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(y (M, d) bf16, u (M, hid) bf16, gelu(u) (M, hid) bf16) = fc2(gelu(fc1 x)) -- st_transformer.py:24-27 (dropout p = 0):
+    two hma_gemm_nt launches, the first with the HMA_EPI_GELU2 epilogue; u and gelu(u) are what the backward re-reads"""
+    _cuda(x, w1, b1, w2, b2)
+    u = torch.empty(x.shape[0], w1.shape[0], dtype=BF16, device=x.device)
+    h = torch.empty_like(u)
+    ops.linear(x.contiguous(), w1.contiguous(), b1, epi=EPI_GELU2, out=u, out2=h)
+    return ops.linear(h, w2.contiguous(), b2, epi=EPI_BF16), u, h
+
+
+@mlp.register_fake
+def _(x, w1, b1, w2, b2):
+    return (x.new_empty(x.shape[0], w2.shape[0], dtype=BF16), x.new_empty(x.shape[0], w1.shape[0], dtype=BF16),
+            x.new_empty(x.shape[0], w1.shape[0], dtype=BF16))
+
+
+@torch.library.custom_op("hma::mlp_bwd", mutates_args=(), device_types="cuda")
+def mlp_bwd(dy: torch.Tensor, x: torch.Tensor, u: torch.Tensor, h: torch.Tensor, w1: torch.Tensor,
+            w2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dx bf16, dW1, db1, dW2, db2 fp32): dU = (dy W2) gelu'(u) in the HMA_EPI_DGELU epilogue, then the two weight gradients
+    (hma_gemm_tn) and dx = dU W1"""
+    _cuda(dy, x, u, h, w1, w2)
+    dy = dy.contiguous()
+    dW2 = torch.zeros(w2.shape, dtype=F32, device=dy.device)
+    db2 = torch.zeros(w2.shape[0], dtype=F32, device=dy.device)
+    ops.linear_wgrad(dy, h, dW2, db2)
+    du = ops.linear(dy, w2.t().contiguous(), None, epi=EPI_DGELU, aux=u)
+    dW1 = torch.zeros(w1.shape, dtype=F32, device=dy.device)
+    db1 = torch.zeros(w1.shape[0], dtype=F32, device=dy.device)
+    ops.linear_wgrad(du, x.contiguous(), dW1, db1)
+    dx = ops.linear(du, w1.t().contiguous(), None, epi=EPI_BF16)
+    return dx, dW1, db1, dW2, db2
+
+
+@mlp_bwd.register_fake
+def _(dy, x, u, h, w1, w2):
+    return (torch.empty_like(x), w1.new_empty(w1.shape, dtype=F32), w1.new_empty(w1.shape[0], dtype=F32),
+            w2.new_empty(w2.shape, dtype=F32), w2.new_empty(w2.shape[0], dtype=F32))
+
+
+def _mlp_setup(ctx, inputs, output):
+    x, w1, b1, w2, b2 = inputs
+    _, u, h = output
+    ctx.save_for_backward(x, u, h, w1, w2)
+    ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+
+
+def _mlp_backward(ctx, dy, du_unused, dh_unused):
+    x, u, h, w1, w2 = ctx.saved_tensors
+    dx, dW1, db1, dW2, db2 = torch.ops.hma.mlp_bwd(dy.to(BF16).contiguous(), x, u, h, w1, w2)
+    return dx, dW1.to(w1.dtype), (db1 if ctx.has_b1 else None), dW2.to(w2.dtype), (db2 if ctx.has_b2 else None)
+
+
+mlp.register_autograd(_mlp_backward, setup_context=_mlp_setup)
+
+OPS = ("linear", "linear_wgrad", "layer_norm", "attn_spatial", "attn_spatial_bwd", "attn_temporal", "attn_temporal_bwd", "mlp",
+       "mlp_bwd")

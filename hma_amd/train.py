@@ -418,7 +418,7 @@ class Trainer:
         eng = self.engine
         opt_path = os.path.join(str(directory), "optimizer.bin")
         if os.path.exists(opt_path):
-            sd = torch.load(opt_path, map_location="cpu", weights_only=False)
+            sd = torch.load(opt_path, map_location="cpu", weights_only=True)
             names = [n for n, _ in self.model.named_parameters()]
             g0, g1 = reference_param_groups(names)
             order = g0 + g1
@@ -440,7 +440,7 @@ class Trainer:
             eng.set_steps(dense, doms)
             sch_path = os.path.join(str(directory), "scheduler.bin")
             if os.path.exists(sch_path):
-                sch = torch.load(sch_path, map_location="cpu", weights_only=False)
+                sch = torch.load(sch_path, map_location="cpu", weights_only=True)
                 self.completed = int(sch["last_epoch"]) // max(self.reducer.world, 1)
             else:
                 self.completed = dense
@@ -482,6 +482,7 @@ class MarTrainer:
         self.reducer = GradReducer(self.engine.layout, self.engine.G, layers_per_bucket)
         self.completed, self._micro = 0, 0
         self._active: List[str] = []
+        self._known = False
         self.loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
         self.last_loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
 
@@ -490,13 +491,22 @@ class MarTrainer:
         red = self.reducer
         domain = batch["domain"]
         dom = domain if isinstance(domain, str) else domain[0]
+        # Same rule as Trainer._announce: the set of domains that are reduced and stepped is either announced up front (every rank
+        # passes the same step_domains; a micro-batch of another domain is an error) or gathered with a collective that EVERY rank
+        # enters on EVERY micro-batch -- a rank that skipped it because its own domain was already known would pair the other
+        # ranks' all_gather with its own later all_reduce.
         if self._micro == 0:
-            self._active = red.order(step_domains) if step_domains is not None else red.active_domains(dom)
+            self._known = step_domains is not None
+            self._active = red.order(step_domains) if self._known else red.active_domains(dom)
             self.model.zero_grad()
             self.loss_info.zero_()
-        elif dom not in self._active:
-            fresh = [d for d in (red.active_domains(dom) if step_domains is None else [dom]) if d not in self._active]
-            self._active = red.order(list(self._active) + fresh)  # (model.zero_grad() zeroed every block: nothing stale to clear)
+        elif self._known:
+            if dom not in self._active:
+                raise RuntimeError(f"domain {dom!r} is not in the step_domains announced for this optimizer step")
+        else:
+            fresh = [d for d in red.active_domains(dom) if d not in self._active]
+            if fresh:
+                self._active = red.order(list(self._active) + fresh)  # (model.zero_grad() zeroed every block: nothing stale to clear)
         out = self.model(**batch)
         loss = out.loss.detach()
         ok = torch.isfinite(loss)
@@ -563,7 +573,7 @@ class MarTrainer:
     def load_state(self, directory) -> None:
         import os
         eng, own = self.engine, self.own
-        sd = torch.load(os.path.join(str(directory), "optimizer.bin"), map_location="cpu", weights_only=False)
+        sd = torch.load(os.path.join(str(directory), "optimizer.bin"), map_location="cpu", weights_only=True)
         names = [n for n, _ in self.model.named_parameters()]
         order = sum(reference_param_groups(names), [])
         if eng.M is None:
@@ -587,7 +597,7 @@ class MarTrainer:
         eng.set_steps(dense, doms)
         own["steps"][own["calls"] & 1] = own_k
         sch_path = os.path.join(str(directory), "scheduler.bin")
-        self.completed = (int(torch.load(sch_path, map_location="cpu", weights_only=False)["last_epoch"]) // max(self.reducer.world, 1)
+        self.completed = (int(torch.load(sch_path, map_location="cpu", weights_only=True)["last_epoch"]) // max(self.reducer.world, 1)
                           if os.path.exists(sch_path) else dense)
 
 

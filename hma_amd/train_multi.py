@@ -122,7 +122,12 @@ def main(argv=None):
     domain_of = lambda indices: domains[int(np.searchsorted(bounds, indices[0], side="right"))]  # one domain per batch
     collate = get_maskgit_collator_feature(config) if continuous else get_maskgit_collator(config)
     group = world * accum                                   # batches consumed by one optimizer step, all ranks together
-    steps_per_epoch = max(len(sampler) // group, 1)         # (every rank gets the same number of batches per epoch)
+    if len(sampler) < group:
+        raise ValueError(f"the dataset mix yields {len(sampler)} batches per epoch, fewer than the {group} one optimizer step consumes "
+                         f"(world {world} x gradient accumulation {accum}): lower the batch size / accumulation or add data")
+    # (the reference stops an epoch 8 iterations early, train_multi.py:554 `len(train_dataloader) - 8`; here an epoch is every
+    # whole group of batches -- a resume position computed from a reference-written step count can differ by that margin)
+    steps_per_epoch = len(sampler) // group                 # (every rank gets the same number of batches per epoch)
     max_steps = args.max_train_steps or args.num_train_epochs * steps_per_epoch
     out_dir = Path(args.output_dir)
     save = trainer.save_state

@@ -91,6 +91,34 @@ def mar_digest(model, losses):
     return out
 
 
+# mixed domains under gradient accumulation WITHOUT step_domains: micro-batch k of rank r
+MIXED = {0: [0, 0], 1: [0, 1]}  # rank 0: domA, domA; rank 1: domA, domB (a domain that is new on ONE rank in the second micro-batch)
+
+
+def main_mar_mixed(out_path):
+    import torch.distributed as dist
+    from safetensors.torch import save_file
+    from hma_amd.train import MarTrainer
+
+    rank = int(os.environ["RANK"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    model = build_mar()
+    tr = MarTrainer(model, lr=1e-3, warmup_steps=0, grad_accum=2)
+    losses = []
+    for step in range(2):
+        for k in range(2):
+            tr.micro_step(**mar_batch(MIXED[rank][k], 4 * step + 2 * k + rank))  # (every rank enters the domain gather every micro-batch)
+        assert tr._active == ["domA", "domB"], tr._active
+        tr.optimizer_step()
+        losses.append(tr.reduced_loss().detach().clone())
+    torch.cuda.synchronize()
+    if rank == 0:
+        save_file(mar_digest(model, losses), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main_mar(out_path):
     import torch.distributed as dist
     from safetensors.torch import save_file
@@ -115,6 +143,8 @@ def main_mar(out_path):
 def main():
     if len(sys.argv) > 3 and sys.argv[3] == "mar":
         return main_mar(sys.argv[1])
+    if len(sys.argv) > 3 and sys.argv[3] == "mar_mixed":
+        return main_mar_mixed(sys.argv[1])
     import torch.distributed as dist
     from safetensors.torch import save_file
     from hma_amd.train import Trainer

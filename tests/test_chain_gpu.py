@@ -67,9 +67,10 @@ def test_chain_a_fwd(M, rpf, mod):
     # reference
     x1 = x + o @ wp.t() + bp
     if mod:
-        xh = rb(F.layer_norm(x1, (256,), eps=1e-6))
+        xh32 = F.layer_norm(x1, (256,), eps=1e-6)
+        xh = rb(xh32)
         f = torch.arange(M) // rpf
-        xm = rb(xh * (1 + ss[f, 256:]) + ss[f, :256])
+        xm = rb(xh32 * (1 + ss[f, 256:]) + ss[f, :256])
         x2 = x1 + xm @ wl.t() + bl
         rstd = torch.rsqrt(x1.var(dim=1, unbiased=False) + 1e-6)
     else:

@@ -24,7 +24,7 @@ sys.path.insert(0, HERE)
 
 
 def _launch_pair(out_path, nan_step=-1, mode=None):
-    port = 29600 + os.getpid() % 1000 + (7 if nan_step >= 0 else 0) + (13 if mode else 0)
+    port = 29600 + os.getpid() % 1000 + (7 if nan_step >= 0 else 0) + ({None: 0, "mar": 13, "mar_mixed": 29}[mode])
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
@@ -127,3 +127,34 @@ def test_stmar_two_ranks_equal_one_rank_accumulating(tmp_path):
         f.write(f"worst rms |w_2ranks - w_1rank| / rms |w - w_init| over checked tensors: {worst:.3e}\n")
         for k, v in sorted(per.items()):
             f.write(f"  {k}: {v:.3e}\n")
+
+
+@pytest.mark.timeout(900)
+def test_stmar_mixed_domains_under_accumulation_without_step_domains(tmp_path):
+    """with gradient accumulation, world > 1 and no `step_domains`, every rank has to enter the domain gather on
+    every micro-batch (a rank whose own domain was already known used to skip it: the other rank's all_gather then paired with its
+    all_reduce).  Rank 0 sees domA twice, rank 1 domA then domB; the result must equal one process accumulating the four batches."""
+    import dp_child as C
+    from hma_amd.train import MarTrainer
+
+    two = _launch_pair(tmp_path / "marmix0.safetensors", mode="mar_mixed")
+    model = C.build_mar()
+    init = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()}
+    tr = MarTrainer(model, lr=1e-3, warmup_steps=0, grad_accum=4)
+    losses = []
+    for step in range(2):
+        for k in range(2):
+            for rank in range(2):
+                tr.micro_step(**C.mar_batch(C.MIXED[rank][k], 4 * step + 2 * k + rank))
+        tr.optimizer_step()
+        losses.append(tr.reduced_loss().detach().clone())
+    torch.cuda.synchronize()
+    one = C.mar_digest(model, losses)
+    assert abs(float(two["_losses"][0]) - float(one["_losses"][0])) <= 1e-5 * float(one["_losses"][0])
+    for name, w2 in two.items():
+        if name.startswith("_"):
+            continue
+        moved = (one[name] - init[name]).double().pow(2).mean().sqrt().item()
+        assert moved > 0, name
+        err = (w2 - one[name]).double().pow(2).mean().sqrt().item()
+        assert err <= (0.15 if w2.numel() <= 1024 else 3e-2) * moved, (name, err, moved)

@@ -786,3 +786,17 @@ def test_gemm_tn_folded_affine_grads():
     close(dW, P * gam + cs[:, None] * bet[None, :], 1e-2, "dW")  # bf16 partials
     close(dG, (w * P).sum(0), 1e-2, "dgamma")
     close(dBt, (w * cs[:, None]).sum(0), 1e-2, "dbeta")
+
+
+@pytest.mark.parametrize("K", [64, 128, 192])
+@pytest.mark.parametrize("M", [1000, 65536, 100000])
+def test_gemm_nt_shallow_k_many_tiles(M, K):
+    """K < 256 (fewer than four K-steps per tile: STMAR's token_embed has K = 128, hma/model/st_mar.py:160) at row counts where a
+    persistent workgroup would own more than one tile (M > 128 x 256): round 3 found the first tile of every such workgroup lost."""
+    x = rb(torch.randn(M, K, generator=g(31)))
+    w = rb(torch.randn(256, K, generator=g(32)) * 0.2)
+    y = ops.linear(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), None, epi=EPI_F32)
+    close(y, x @ w.t(), 1e-5, "shallow K, f32 out")
+    b = torch.randn(256, generator=g(33))
+    y = ops.linear(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV), epi=EPI_BF16)
+    close(y, x @ w.t() + b, BF, "shallow K, bf16 out")

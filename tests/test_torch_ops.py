@@ -98,3 +98,91 @@ def test_layer_norm_op():
     ref = torch.nn.functional.layer_norm(x, (256,), eps=1e-5)
     _close(xh, ref, 2 * BF, "xhat")
     _close(rs, torch.rsqrt(x.var(1, unbiased=False) + 1e-5), 1e-4, "rstd")
+
+
+def _rms(a, b):
+    a, b = a.float().cpu().double(), b.float().cpu().double()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+@pytest.mark.gpu
+def test_mlp_module_trains_through_autograd():
+    """`Mlp(x)` under autograd returns gradients (reference: hma/model/st_transformer.py:24-27)."""
+    from hma_amd.model import Mlp
+    g = torch.Generator().manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(256, 1024), torch.nn.GELU(), torch.nn.Linear(1024, 256))
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() == 2 else 0.1))
+    m = Mlp(256)
+    m.load_state_dict({"fc1.weight": ref[0].weight, "fc1.bias": ref[0].bias, "fc2.weight": ref[2].weight, "fc2.bias": ref[2].bias})
+    m = m.cuda().train()
+    x = torch.randn(3, 200, 256, generator=g)
+    r = torch.randn(3, 200, 256, generator=g) * 0.1
+    xd = x.cuda().requires_grad_(True)
+    y = m(xd)
+    assert y.requires_grad and y.shape == x.shape
+    (y * r.cuda()).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * r).sum().backward()
+    _close(y, yr, 1.5e-2, "Mlp forward")
+    assert _rms(xd.grad, xr.grad) < 2e-2
+    assert _rms(m.fc1.weight.grad, ref[0].weight.grad) < 2e-2
+    assert _rms(m.fc2.weight.grad, ref[2].weight.grad) < 2e-2
+    assert _rms(m.fc1.bias.grad, ref[0].bias.grad) < 2e-2
+    assert _rms(m.fc2.bias.grad, ref[2].bias.grad) < 2e-2
+    # without anything that requires a gradient in reach the module still runs (inference path, no graph)
+    with torch.no_grad():
+        assert not m(x.cuda()).requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("causal", [False, True])
+def test_self_attention_module_trains_through_autograd(causal):
+    """`SelfAttention(x, causal)` under autograd (reference: hma/model/attention.py:37-61, BasicSelfAttention)."""
+    from hma_amd.model import SelfAttention
+    g = torch.Generator().manual_seed(4)
+    att = SelfAttention(num_heads=8, d_model=256, qkv_bias=False, proj_bias=True, qk_norm=False, use_mup=True)
+    with torch.no_grad():
+        att.qkv.weight.copy_(torch.randn(768, 256, generator=g) * 0.06)
+        att.proj.weight.copy_(torch.randn(256, 256, generator=g) * 0.06)
+        att.proj.bias.copy_(torch.randn(256, generator=g) * 0.1)
+    wq, wp, bp = att.qkv.weight.detach().clone(), att.proj.weight.detach().clone(), att.proj.bias.detach().clone()
+    att = att.cuda().train()
+    Bn, N = (6, 16) if causal else (3, 320)
+    x = torch.randn(Bn, N, 256, generator=g)
+    r = torch.randn(Bn, N, 256, generator=g) * 0.1
+    xd = x.cuda().requires_grad_(True)
+    y = att(xd, causal=causal)
+    (y * r.cuda()).sum().backward()
+    # fp32 reference
+    xr, wqr, wpr = x.clone().requires_grad_(True), wq.clone().requires_grad_(True), wp.clone().requires_grad_(True)
+    q, k, v = [t.reshape(Bn, N, 8, 32).permute(0, 2, 1, 3) for t in (xr @ wqr.t()).chunk(3, dim=-1)]
+    sc = (q * att.scale) @ k.transpose(-1, -2)
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+    o = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(Bn, N, 256)
+    yr = o @ wpr.t() + bp
+    (yr * r).sum().backward()
+    _close(y, yr, 2e-2, "SelfAttention forward")
+    assert _rms(xd.grad, xr.grad) < 3e-2
+    assert _rms(att.qkv.weight.grad, wqr.grad) < 3e-2
+    assert _rms(att.proj.weight.grad, wpr.grad) < 3e-2
+
+
+@pytest.mark.gpu
+def test_engine_backed_blocks_refuse_autograd():
+    """STBlock / STTransformerDecoder run on recorded launch plans: with autograd on they raise instead of returning a tensor
+    that silently carries no graph; under torch.no_grad() they run."""
+    from tests.test_model_gpu import build_model
+    from tests.helpers import golden
+    g = golden("g5_stblock")
+    m = build_model(train=False)
+    x, a = g["x"].cuda(), g["a_emb"].cuda()
+    with pytest.raises(RuntimeError, match="no autograd graph"):
+        m.decoder(x, action_ids=a, domain="domB")
+    with pytest.raises(RuntimeError, match="no autograd graph"):
+        m.decoder.layers[0](x, action_ids=a, domain="domA")
+    with torch.no_grad():
+        assert m.decoder(x, action_ids=a, domain="domB").shape == x.shape
