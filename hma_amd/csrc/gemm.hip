@@ -2183,7 +2183,12 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
   static const int ablate = getenv("HMA_GEMM_ABLATE") ? atoi(getenv("HMA_GEMM_ABLATE")) : 0;  // debug build only
   pa._pad2 = ablate;
 #endif
-  if (p->N % PN == 0) {
+  // (K < 256 on the persistent 8-wave kernel needs its undeferred variant, instantiated for the plain epilogues of bf16 / fp32
+  // operands; anything else that shallow takes the tile-per-workgroup kernel at the bottom)
+  const bool plain_epi = p->epi == HMA_EPI_BF16 || p->epi == HMA_EPI_F32 || p->epi == HMA_EPI_RESID || p->epi == HMA_EPI_ATOMIC_F32;
+  const bool shallow_other = p->K < 4 * PK && plain_epi &&
+                             !((p->a_kind == HMA_A_BF16 || p->a_kind == HMA_A_F32) && p->epi != HMA_EPI_ATOMIC_F32);
+  if (p->N % PN == 0 && !shallow_other) {
     const int tiles_m = (int)((p->M + PM - 1) / PM), tiles_n = (int)(p->N / PN);
     const int total = tiles_m * tiles_n * (p->batch > 0 ? p->batch : 1);
     static int n_cu = 0;
