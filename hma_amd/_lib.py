@@ -94,6 +94,16 @@ class ChainABwd(C.Structure):
     ]
 
 
+class ChainBFwd(C.Structure):
+    _fields_ = [
+        ("w", ChainWeights),
+        ("o", c_vp), ("x", c_vp),
+        ("b_proj", c_vp), ("b1", c_vp), ("b2", c_vp), ("b_qkv", c_vp),
+        ("qkv", c_vp), ("ldq", c_i64),
+        ("M", c_i64), ("ln_eps", C.c_float), ("_pad", c_i32),
+    ]
+
+
 _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
@@ -145,7 +155,8 @@ _PROTOS = {
     "hma_mlp_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i64],
     "hma_mlp_fwd": [c_vp, C.POINTER(MlpFwd)],
     "hma_mlp_bwd": [c_vp, C.POINTER(MlpBwd)],
-    "hma_chain_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64],
+    "hma_chain_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32],
+    "hma_chain_b_fwd": [c_vp, C.POINTER(ChainBFwd)],
     "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
     "hma_chain_a_bwd": [c_vp, C.POINTER(ChainABwd)],
     "hma_zero_f32": [c_vp, c_vp, c_i64],

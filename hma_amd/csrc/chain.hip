@@ -88,7 +88,7 @@ __device__ unsigned long long g_ch_prof[2][8][8];
 __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
                                                          const float* __restrict__ rscale, const float* __restrict__ cscale,
                                                          uint16_t* __restrict__ dst, int kind, int nbundles, int64_t sstride,
-                                                         int64_t dstride) {
+                                                         int64_t dstride, int bundle_stride) {
   const int64_t bz = blockIdx.y;
   src += bz * sstride;
   if (rscale) rscale += bz * sstride;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict
     if (cscale) w *= cscale[c];
     v[e] = w;
   }
-  *reinterpret_cast<uint4*>(dst + (int64_t)idx * 8) = pack8(v);
+  *reinterpret_cast<uint4*>(dst + ((int64_t)b * bundle_stride * 1024 + (idx & 1023)) * 8) = pack8(v);
 }
 
 // ------------------------------------------------------------------------------------------------ the loader wave
@@ -736,6 +736,188 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
   }
 }
 
+// ------------------------------------------------------------------------------------------------ chain B, forward (inference)
+// one K-slice bundle against the wave's rows: acc[t] += W[16 columns of tile t][32 k] . h   (16 MFMAs, 16 accumulators)
+__device__ __forceinline__ void ks_mma(HMA_LDS(char)* wb, const bf16x8_t& h, f32x4v_t (&acc)[16]) {
+  bf16x8_t f[4], fn[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f[q] = lds_frag(wb + q * 1024);
+#pragma unroll
+  for (int hq = 0; hq < 4; ++hq) {
+    if (hq < 3) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fn[q] = lds_frag(wb + (4 * hq + 4 + q) * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[4 * hq + q] = mfma16(f[q], h, acc[4 * hq + q]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = fn[q];
+  }
+}
+
+// proj_t + residual -> LayerNorm (norm2, affine folded into fc1) -> fc1 -> GELU -> fc2 + residual -> [LayerNorm (the next block's norm1,
+// folded into its qkv) -> qkv]: the second row-local chain of a block (st_transformer.py:111-112 and :85-86 of the next block), for
+// passes that save nothing (inference / decode).  Steps per tile: 8 (proj) + 2 x 32 (a hidden block of 32 units: its fc1 rows,
+// then its fc2 columns) + 24 (qkv).  The hidden activation exists as ONE B-operand fragment per step.
+template <bool QKV>
+__global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
+  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  {
+    HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | fc2 256..511 | fc1 512..1535 | qkv 1536..2303
+    for (int i = tid; i < 2304; i += 512) {
+      float v = 0.f;
+      if (i < 256) v = p.b_proj ? p.b_proj[i] : 0.f;
+      else if (i < 512) v = p.b2 ? p.b2[i - 256] : 0.f;
+      else if (i < 1536) v = p.b1[i - 512];
+      else v = (QKV && p.b_qkv) ? p.b_qkv[i - 1536] : 0.f;
+      bl[i] = v;
+    }
+  }
+  __syncthreads();
+  constexpr int SM = 8, SQ = 8 + 64;           // first MLP step, first qkv step
+  constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
+  if (wave == NCW) {
+    const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
+                         reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
+                         p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
+    loader_run<0>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1);
+    return;
+  }
+  const int tok = lane & 15, g = lane >> 4;
+  auto row0_of = [&](int tl) __attribute__((always_inline)) {
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+  };
+  bf16x8_t a0[8], a1[8];
+  f32x4v_t acc[16];
+  uint4 qb[8];
+  auto prefetch = [&](int tl) __attribute__((always_inline)) {
+    int64_t m = row0_of(tl) + tok;
+    m = m < p.M ? m : p.M - 1;
+    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
+    const float* xrow = p.x + m * 256 + 8 * g;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      acc[2 * pr] = ld4(xrow + 32 * pr);
+      acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+    }
+  };
+  prefetch(0);
+  CH_TOUCH_A(a1);
+  CH_TOUCH_ACC(acc);
+  HMA_LDS(char)* ring = lds + lane * 16;
+  HMA_LDS(char)* bias = lds + L_BIAS + 32 * g;
+  const line_offs Lf = make_lines(1024, tok, 32 * g, 16);
+  const line_offs Lq = make_lines((int)p.ldq * 2, tok, 16 * g, 64);
+  int slot = 0;
+  // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand
+  auto ln_pack = [&](bf16x8_t (&dst)[8]) __attribute__((always_inline)) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / 256.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[t][r] - mean;
+        sq = __builtin_fmaf(d, d, sq);
+      }
+    }
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = rsqrtf(sq * (1.0f / 256.0f) + p.ln_eps);
+    const float nb = -mean * rstd;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      float h[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
+      dst[pr] = as_frag(pack8(h));
+    }
+  };
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t r0 = row0_of(tl);
+    if (r0 >= p.M) {
+#pragma unroll 1
+      for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
+      continue;
+    }
+    float* xt = p.x + r0 * 256;
+    uint16_t* qt = QKV ? reinterpret_cast<uint16_t*>(p.qkv) + r0 * p.ldq : nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+    bf16x8_t hf;
+    static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      CH_BARRIER();
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = (slot + 1) & (NS - 1);
+      if constexpr (s < SM) {
+        // ---- x1 = x + o Wproj^T + b
+        nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
+        add4(acc[2 * s], lds_f4(bias + 128 * s));
+        add4(acc[2 * s + 1], lds_f4(bias + 128 * s + 16));
+        if constexpr (s == SM - 1) {
+          ln_pack(a1);  // xhat2 (norm2's affine sits in the packed fc1 weights / bias)
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) {  // + fc2 bias, once
+            add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
+            add4(acc[2 * pr + 1], lds_f4(bias + 1024 + 128 * pr + 16));
+          }
+        }
+      } else if constexpr (s < SQ) {
+        constexpr int h = (s - SM) >> 1;
+        if constexpr (((s - SM) & 1) == 0) {
+          // ---- u = W1f[hidden block h] xhat2 + b1f; gelu; the lane's 8 hidden units are the next step's B operand
+          f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * h), c1 = lds_f4v(bias + 2048 + 128 * h + 16);
+          nb_mma(wb, a1, c0, c1);
+          float hv[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hv[e] = gelu_f(c0[e]);
+            hv[4 + e] = gelu_f(c1[e]);
+          }
+          hf = as_frag(pack8(hv));
+        } else {
+          // ---- x2 += W2[:, hidden block h] gelu(u)
+          ks_mma(wb, hf, acc);
+          if constexpr (s == SQ - 1) {
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+            if constexpr (QKV) ln_pack(a0);  // the next block's norm1 (affine folded into its qkv weights / bias)
+            prefetch(tl + 1 < nt ? tl + 1 : tl);
+          }
+        }
+      } else {
+        // ---- the next block's spatial qkv
+        constexpr int pq = s - SQ;
+        f32x4v_t c0 = lds_f4v(bias + 6144 + 128 * pq), c1 = lds_f4v(bias + 6144 + 128 * pq + 16);
+        nb_mma(wb, a0, c0, c1);
+        qb[pq & 7] = pack_pair(c0, c1);
+        if constexpr ((pq & 7) == 7) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) store_lines(qt, Lq, 64 * (pq - 7) + 128 * pp, qb[2 * pp], qb[2 * pp + 1]);
+        }
+      }
+    });
+    CH_TOUCH_A(a1);
+    CH_TOUCH_ACC(acc);
+  }
+}
+
 template <auto Kern>
 int set_lds(int bytes) {
   static bool done = false;
@@ -789,8 +971,8 @@ extern "C" int hma_chain_debug_prof(unsigned long long* out128) {
 
 extern "C" int hma_chain_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
                               const float* col_scale, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t batch,
-                              int64_t src_batch_stride, int64_t dst_batch_stride) {
-  if (!src || !dst || batch < 1) return HMA_EINVAL;
+                              int64_t src_batch_stride, int64_t dst_batch_stride, int32_t bundle_stride) {
+  if (!src || !dst || batch < 1 || bundle_stride < 1) return HMA_EINVAL;
   int nb;
   if (kind == 0) {
     if (cols != 256 || rows <= 0 || rows % 32) return HMA_EINVAL;
@@ -802,7 +984,8 @@ extern "C" int hma_chain_pack(void* stream, const float* src, int64_t row_stride
     return HMA_EINVAL;
   }
   hipLaunchKernelGGL(chain_pack_kernel, dim3(nb * 4, batch), dim3(256), 0, (hipStream_t)stream, src, row_stride, col_stride,
-                     row_scale, col_scale, reinterpret_cast<uint16_t*>(dst), (int)kind, nb, src_batch_stride, dst_batch_stride);
+                     row_scale, col_scale, reinterpret_cast<uint16_t*>(dst), (int)kind, nb, src_batch_stride, dst_batch_stride,
+                     (int)bundle_stride);
   HMA_CHECK_LAUNCH();
   return 0;
 }
@@ -841,6 +1024,24 @@ extern "C" int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p) {
   } else {
     if (int rc = set_lds<chain_a_bwd_kernel<false>>(SMEM)) return rc;
     hipLaunchKernelGGL(chain_a_bwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+  }
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
+  if (!p || !p->o || !p->x || !p->b1 || p->M <= 0 || p->M % 16) return HMA_EINVAL;
+  const bool qkv = p->qkv != nullptr;
+  if (qkv && p->ldq < 768) return HMA_EINVAL;
+  if (!weights_ok(p->w, qkv ? 96 : 72)) return HMA_EINVAL;
+  const int grid = chain_grid(p->M);
+  // (the bias area holds 2304 floats here: it runs into the shift / scale rows' space, which this chain does not use)
+  if (qkv) {
+    if (int rc = set_lds<chain_b_fwd_kernel<true>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_b_fwd_kernel<true>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+  } else {
+    if (int rc = set_lds<chain_b_fwd_kernel<false>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_b_fwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
   }
   HMA_CHECK_LAUNCH();
   return 0;

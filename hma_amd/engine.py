@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
-from .ops import make_chain_a_bwd, make_chain_a_fwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
+from .ops import make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -103,6 +103,13 @@ class Plan:
         # o 512 + x 1024 in; x 1024 + qkv 1536 out (+ xhat, xm, bf16(x): 512 each when they are saved)
         nbytes = (512 + 1024 + 1024 + 1536 + (512 * (3 if use_mod else 1) if save else 0)) * float(M)
         self.add("hma_chain_a_fwd", C.byref(g), flops=2.0 * M * 256 * n_out, nbytes=nbytes)
+
+    def chain_b_fwd(self, M: int, with_qkv: bool, **kw) -> None:
+        g = make_chain_b_fwd(M=M, **kw)
+        self.keep.append(g)
+        # o 512 + x 1024 in; x 1024 (+ qkv 1536) out
+        self.add("hma_chain_b_fwd", C.byref(g), flops=2.0 * M * 256 * (256 + 2048 + (768 if with_qkv else 0)),
+                 nbytes=(512 + 1024 + 1024 + (1536 if with_qkv else 0)) * float(M))
 
     def chain_a_bwd(self, M: int, use_mod: bool, **kw) -> None:
         g = make_chain_a_bwd(M=M, use_mod=use_mod, **kw)
@@ -221,6 +228,10 @@ class STEngine:
         self.chain_min_rows = 0
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN)}
+        # chain B (proj_t + norm2 + MLP + the next block's norm1 + qkv_s in one launch) for passes that save nothing
+        self.chain_b_ok = hid == 1024
+        if self.chain_b_ok:
+            self.CP.update({"proj_t": mk(L, 8 * BUN), "mlp": mk(L, 64 * BUN), "qkv_s": mk(L, 24 * BUN)})
         if self.modulate:
             for dom in self.domains:
                 self.CP[f"lin:{dom}"] = mk(L, 8 * BUN)
@@ -332,12 +343,22 @@ class STEngine:
                 BUN = 8192
                 pre = f"decoder.layers.{L - 1}."
                 wp, wq = self._p(pre + "spatial_attn.proj.weight"), self._p(pre + "temporal_attn.qkv.weight")
-                _lib.call("hma_chain_pack", stream, wp, d, 1, None, None, self.CP["proj_s"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN)
-                _lib.call("hma_chain_pack", stream, wp, 1, d, None, None, self.CP["proj_s_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN)
-                _lib.call("hma_chain_pack", stream, wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN)
+                _lib.call("hma_chain_pack", stream, wp, d, 1, None, None, self.CP["proj_s"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
+                _lib.call("hma_chain_pack", stream, wp, 1, d, None, None, self.CP["proj_s_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
+                _lib.call("hma_chain_pack", stream, wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN, 1)
                 for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
                     _lib.call("hma_chain_pack", stream, wq + 4 * c * d * d, 1, d, None, None,
-                              self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN)
+                              self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
+                if self.chain_b_ok:
+                    # chain B (inference): proj_t, the fc1 (norm2's gamma folded in) / fc2 bundles interleaved per hidden block, and the
+                    # spatial qkv with norm1's gamma folded in (consumed by the PREVIOUS block's chain)
+                    wpt, w1, w2 = self._p(pre + "temporal_attn.proj.weight"), self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight")
+                    wqs, g1, g2 = self._p(pre + "spatial_attn.qkv.weight"), self._p(pre + "norm1.weight"), self._p(pre + "norm2.weight")
+                    _lib.call("hma_chain_pack", stream, wpt, d, 1, None, None, self.CP["proj_t"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
+                    _lib.call("hma_chain_pack", stream, w1, d, 1, None, g2, self.CP["mlp"][L - 1].data_ptr(), 0, hid, d, L, ls, -64 * BUN, 2)
+                    _lib.call("hma_chain_pack", stream, w2, hid, 1, None, None, self.CP["mlp"][L - 1].data_ptr() + 2 * BUN, 1, d, hid, L, ls,
+                              -64 * BUN, 2)
+                    _lib.call("hma_chain_pack", stream, wqs, d, 1, None, g1, self.CP["qkv_s"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN, 1)
             self._wt_ok = True
         if domain is not None and self.modulate and domain not in self._dom_fresh:
             pre = f"decoder.layers.0.action_projectors.{domain}"
@@ -349,8 +370,8 @@ class STEngine:
                       self.WT[f"ada2:{domain}"].data_ptr(), 2 * d, d, L, 2 * d * d, 2 * d * d)
             if self.use_chain:
                 wl = self._p(f"{pre}.linear_out.weight")
-                _lib.call("hma_chain_pack", stream, wl, d, 1, None, None, self.CP[f"lin:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192)
-                _lib.call("hma_chain_pack", stream, wl, 1, d, None, None, self.CP[f"lin_T:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192)
+                _lib.call("hma_chain_pack", stream, wl, d, 1, None, None, self.CP[f"lin:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192, 1)
+                _lib.call("hma_chain_pack", stream, wl, 1, d, None, None, self.CP[f"lin_T:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192, 1)
             self._dom_fresh.add(domain)
 
     def weights_changed(self) -> None:
@@ -450,7 +471,8 @@ class STEngine:
 
     def _emit_layer(self, pl: Plan, l: int, x: int, b: Dict[str, int], M: int, Fr: int, B: int, T: int, SA: int,
                     use_mod: bool, domain: Optional[str], kv: Optional[dict] = None, train: bool = False,
-                    have_ln1: bool = False, ln_next: Optional[Tuple[int, int]] = None, fused: bool = False) -> None:
+                    have_ln1: bool = False, ln_next: Optional[Tuple[int, int]] = None, fused: bool = False,
+                    have_qkv_s: bool = False, chain_b: bool = False, next_qkv_s: Optional[int] = None) -> None:
         """One STBlock forward (st_transformer.py:79-114) on M rows = Fr frames of SA tokens.  `kv` redirects the
         temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
         "t_query": -1 | t, "T_cache": frames}."""
@@ -459,10 +481,11 @@ class STEngine:
         qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
         pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
         # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
-        if not have_ln1:  # (otherwise the previous block's fused MLP already wrote this block's LN1 output)
-            pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
-        pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
-                   epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
+        if not have_qkv_s:  # (otherwise the previous block's chain B already wrote this block's spatial qkv)
+            if not have_ln1:  # (otherwise the previous block's fused MLP already wrote this block's LN1 output)
+                pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
+            pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
+                       epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=self.BF["qkv_s"][l].data_ptr())  # norm1 folded into W / bias
         pl.add("hma_attn_spatial_fwd", b["qkv_s"], b["o_s"], b["lse_s"], Fr, SA, self.scale, flops=4.0 * Fr * SA * SA * 256,
                nbytes=(1536.0 + 512 + 32) * Fr * SA)
         qkv_dst = b["qkv_t"] if kv is None else kv["cache"] + kv["row_off"] * 768 * 2
@@ -496,6 +519,16 @@ class STEngine:
             pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256, nbytes=2048.0 * M)
         else:
             pl.add("hma_attn_temporal_cached", kv["cache"], b["o_t"], B, T, kv["t_query"], kv["T_cache"], SA, self.scale)
+        if chain_b:
+            # ---- chain B (csrc/chain.hip, passes that save nothing): proj_t + residual -> norm2 -> MLP + residual -> the next
+            # block's norm1 + spatial qkv, one launch
+            segs = [(self.CP["proj_t"][l].data_ptr(), 8), (self.CP["mlp"][l].data_ptr(), 64)]
+            if next_qkv_s is not None:
+                segs.append((self.CP["qkv_s"][l + 1].data_ptr(), 24))
+            pl.chain_b_fwd(M, next_qkv_s is not None, segs=segs, o=b["o_t"], x=x, b_proj=pb("temporal_attn"),
+                           b1=self.BF["fc1"][l].data_ptr(), b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
+                           b_qkv=self.BF["qkv_s"][l + 1].data_ptr() if next_qkv_s is not None else None, qkv=next_qkv_s)
+            return
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
         # MLP (its LayerNorm: fused above)                   st_transformer.py:112
@@ -582,8 +615,10 @@ class STEngine:
             if fused and l + 1 < l1:  # the MLP kernel also emits the next block's LN1 output
                 s1 = sl(l + 1)
                 ln_next = (dp(ws["xh1"], s1, ws["xh1"][0].numel()), dp(ws["rstd1"], s1, ws["rstd1"][0].numel()))
+            cb = (not train) and self.chain_b_ok and self._use_chain(M, SA)
             self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train,
-                             have_ln1=fused and l > l0, ln_next=ln_next, fused=fused)
+                             have_ln1=fused and l > l0, ln_next=ln_next, fused=fused, have_qkv_s=cb and l > l0, chain_b=cb,
+                             next_qkv_s=bufs["qkv_s"] if (cb and l + 1 < l1) else None)
         # readout on the image tokens only                      st_mask_git.py:681-683
         if readout:
           pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,
@@ -959,8 +994,10 @@ class STEngine:
                 bufs["ss"] = d["ss"].data_ptr() + l * B * 512 * 4
             kv = {"cache": d["cache"][l].data_ptr(), "row_off": t * SA, "c_group": (SA, T_total * SA), "t_query": t,
                   "T_cache": T_total}
+            cb = self.chain_b_ok and self._use_chain(M1, SA)
             self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv, have_ln1=fused and l > 0,
-                             ln_next=(d["xh1"].data_ptr(), d["rstd1"].data_ptr()) if fused and l + 1 < L else None, fused=fused)
+                             ln_next=(d["xh1"].data_ptr(), d["rstd1"].data_ptr()) if fused and l + 1 < L else None, fused=fused,
+                             have_qkv_s=cb and l > 0, chain_b=cb, next_qkv_s=bufs["qkv_s"] if (cb and l + 1 < L) else None)
         if readout:
             pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=B * S, N=1024,
                        K=256, epi=EPI_F32, Cp=d["logits"].data_ptr(), ldc=1024, bias=self._p("out_x_proj.bias"))

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, GemmNT, GemmTN, MlpBwd, MlpFwd)
+                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, ChainBFwd, GemmNT, GemmTN, MlpBwd, MlpFwd)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -100,13 +100,14 @@ def make_mlp_bwd(*, M: int, xhat: int, rstd: int, dy: int, dx: int, dx_bf16: int
 
 def chain_pack(src: torch.Tensor, *, kind: int, rows: int, cols: int, row_stride: int, col_stride: int,
                row_scale: Optional[torch.Tensor] = None, col_scale: Optional[torch.Tensor] = None,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Bundles of one logical [rows][cols] matrix (hma_chain_pack) in the chains' streaming order; bf16, 8192 elements per bundle."""
+               out: Optional[torch.Tensor] = None, bundle_stride: int = 1, bundle_offset: int = 0) -> torch.Tensor:
+    """Bundles of one logical [rows][cols] matrix (hma_chain_pack) in the chains' streaming order; bf16, 8192 elements per bundle.
+    Bundle b lands at bundle slot bundle_offset + b * bundle_stride of `out`."""
     nb = (rows if kind == 0 else cols) // 32
     if out is None:
-        out = torch.empty(nb * 8192, dtype=BF16, device=src.device)
-    _lib.call("hma_chain_pack", stream_ptr(), ptr(src), row_stride, col_stride, ptr(row_scale), ptr(col_scale), ptr(out), kind,
-              rows, cols, 1, 0, 0)
+        out = torch.empty((bundle_offset + (nb - 1) * bundle_stride + 1) * 8192, dtype=BF16, device=src.device)
+    _lib.call("hma_chain_pack", stream_ptr(), ptr(src), row_stride, col_stride, ptr(row_scale), ptr(col_scale),
+              out.data_ptr() + 2 * 8192 * bundle_offset, kind, rows, cols, 1, 0, 0, bundle_stride)
     return out
 
 
@@ -129,6 +130,17 @@ def make_chain_a_fwd(*, M: int, segs, o: int, x: int, qkv: int, ldq: int = 768, 
     g.qkv, g.ldq = qkv, ldq
     g.q_group_rows, g.q_group_stride = q_group
     g.M, g.rows_per_frame, g.use_mod = M, rows_per_frame, 1 if use_mod else 0
+    return g
+
+
+def make_chain_b_fwd(*, M: int, segs, o: int, x: int, b1: int, b_proj: Optional[int] = None, b2: Optional[int] = None,
+                     b_qkv: Optional[int] = None, qkv: Optional[int] = None, ldq: int = 768, ln_eps: float = 1e-5) -> ChainBFwd:
+    """segs: packed proj (8), the 64 alternating fc1 / fc2 bundles, and -- with `qkv` -- the next block's folded qkv (24)."""
+    g = ChainBFwd()
+    _chain_weights(g.w, segs)
+    g.o, g.x = o, x
+    g.b_proj, g.b1, g.b2, g.b_qkv = b_proj, b1, b2, b_qkv
+    g.qkv, g.ldq, g.M, g.ln_eps = qkv, ldq, M, ln_eps
     return g
 
 

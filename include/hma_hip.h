@@ -378,10 +378,11 @@ int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p);
  *                       A[32 b + 8 (i >> 2) + (i & 3) + 4 o][8 (4 j + g) .. + 7]          (rows / 32 bundles)
  *   kind 1 ("K-slice"): A is [256][cols]; bundle b = columns 32 b .. 32 b + 31: 16 fragments t, lane (i, g) holds
  *                       A[32 (t >> 1) + 8 (i >> 2) + (i & 3) + 4 (t & 1)][32 b + 8 g .. + 7]  (cols / 32 bundles)
- * `batch` matrices `src_batch_stride` floats apart (the scales move with them), outputs `dst_batch_stride` bf16 apart. */
+ * `batch` matrices `src_batch_stride` floats apart (the scales move with them), outputs `dst_batch_stride` bf16 apart; bundle b
+ * is written at bundle slot b * bundle_stride of the output (2: the fc1 / fc2 bundles of chain B interleave). */
 int hma_chain_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
                    const float* col_scale, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t batch,
-                   int64_t src_batch_stride, int64_t dst_batch_stride);
+                   int64_t src_batch_stride, int64_t dst_batch_stride, int32_t bundle_stride);
 /* The packed weights of one chain: up to 4 segments of bundles, consumed in order once per 112-row tile. */
 typedef struct { const void* seg[4]; int32_t bundles[4]; } hma_chain_weights_t;
 
@@ -418,6 +419,23 @@ typedef struct {
   int64_t M; int32_t rows_per_frame; int32_t use_mod;
 } hma_chain_a_bwd_t;
 int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p);
+
+/* Chain B forward, passes that save nothing (inference / decode): st_transformer.py:111 proj, :112 norm2 + Mlp (:24-27), and the
+ * NEXT block's :85-86 norm1 + qkv (attention.py:39):
+ *   x1 = x + o Wproj^T + b_proj;  x2 = x1 + fc2(gelu(fc1(LN(x1)))) ;  qkv = LN(x2) Wqkv'^T + b_qkv'
+ * in: o [M,256] bf16 (temporal attention output), x [M,256] fp32 (updated in place to x2); out: qkv [M, ldq] bf16 of the next
+ * block (NULL: last block, no qkv stage).  Both LayerNorms are affine-free here: their gamma / beta are folded into the
+ * weights / biases that follow (hma_chain_pack col_scale; hma_fold_ln_bf16's bias).  weights: N-block bundles of proj (8), then
+ * 64 bundles alternating fc1 (N-block of gamma-folded fc1.weight, hidden block h) and fc2 (K-slice of fc2.weight, the same h),
+ * then N-block bundles of the next block's gamma-folded qkv (24).  b1 = folded fc1 bias (1024), b2 = fc2.bias or NULL. */
+typedef struct {
+  hma_chain_weights_t w;
+  const void* o; float* x;
+  const float* b_proj; const float* b1; const float* b2; const float* b_qkv;
+  void* qkv; int64_t ldq;
+  int64_t M; float ln_eps; int32_t _pad;
+} hma_chain_b_fwd_t;
+int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p);
 
 /* n floats at p = 0 (captured in graphs in front of kernels that accumulate with atomics) */
 int hma_zero_f32(void* stream, float* p, int64_t n);

@@ -157,3 +157,47 @@ def test_chain_a_bwd(M, rpf, mod):
         close(d2, dx2, 2 * BF, "dx2 bf16")
         close(dssd, dss, 3e-3, "dss")
     assert (do.float().cpu() - d_o).abs().max() < 0.2 * (do.float().cpu() - d_o.flip(1)).abs().max()
+
+
+@pytest.mark.parametrize("M,with_qkv", [(112, True), (1008, True), (20480, True), (40960, True), (2560, False)])
+def test_chain_b_fwd(M, with_qkv):
+    """proj_t + residual -> norm2 -> fc1 -> GELU -> fc2 + residual -> the next block's norm1 -> qkv, one launch (inference form:
+    nothing saved).  Reference: hma/model/st_transformer.py:111-112, :24-27, :85-86; hma/model/attention.py:39,60."""
+    gq = lambda s_: torch.Generator().manual_seed(s_)
+    wp = rb(torch.randn(256, 256, generator=gq(500)) * 0.06)
+    w1 = torch.randn(1024, 256, generator=gq(501)) * 0.06
+    w2 = rb(torch.randn(256, 1024, generator=gq(502)) * 0.04)
+    wq = torch.randn(768, 256, generator=gq(503)) * 0.06
+    bp, b1, b2, bq = (torch.randn(n, generator=gq(504 + i)) * 0.1 for i, n in enumerate((256, 1024, 256, 768)))
+    g2, be2 = 1 + 0.1 * torch.randn(256, generator=gq(510)), 0.1 * torch.randn(256, generator=gq(511))
+    g1, be1 = 1 + 0.1 * torch.randn(256, generator=gq(512)), 0.1 * torch.randn(256, generator=gq(513))
+    o = rb(torch.randn(M, 256, generator=gq(1)))
+    x = torch.randn(M, 256, generator=gq(2)) * 1.5 + 0.2
+    # reference: the LayerNorm affines folded like the engine folds them (W diag(gamma) in bf16, bias + W beta in fp32)
+    w1f, b1f = rb(w1 * g2), b1 + w1 @ be2
+    wqf, bqf = rb(wq * g1), bq + wq @ be1
+    x1 = x + o @ wp.t() + bp
+    u = rb(F.layer_norm(x1, (256,), eps=1e-5)) @ w1f.t() + b1f
+    x2 = x1 + rb(F.gelu(u)) @ w2.t() + b2
+    qkv = rb(F.layer_norm(x2, (256,), eps=1e-5)) @ wqf.t() + bqf
+    # kernel
+    d = lambda t: t.to(DEV).contiguous()
+    pp = ops.chain_pack(d(wp), kind=0, rows=256, cols=256, row_stride=256, col_stride=1)
+    mlp = torch.empty(64 * 8192, dtype=torch.bfloat16, device=DEV)
+    ops.chain_pack(d(w1), kind=0, rows=1024, cols=256, row_stride=256, col_stride=1, col_scale=d(g2), out=mlp, bundle_stride=2)
+    ops.chain_pack(d(w2), kind=1, rows=256, cols=1024, row_stride=1024, col_stride=1, out=mlp, bundle_stride=2, bundle_offset=1)
+    pq = ops.chain_pack(d(wq), kind=0, rows=768, cols=256, row_stride=256, col_stride=1, col_scale=d(g1))
+    segs = [(ops.ptr(pp), 8), (ops.ptr(mlp), 64)] + ([(ops.ptr(pq), 24)] if with_qkv else [])
+    xd, od = d(x).clone(), d(o).bfloat16()
+    qo = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
+    bpd, b1d, b2d, bqd = d(bp), d(b1f), d(b2), d(bqf)
+    a = ops.make_chain_b_fwd(M=M, segs=segs, o=ops.ptr(od), x=ops.ptr(xd), b_proj=ops.ptr(bpd), b1=ops.ptr(b1d), b2=ops.ptr(b2d),
+                             b_qkv=ops.ptr(bqd) if with_qkv else None, qkv=ops.ptr(qo) if with_qkv else None)
+    _lib.call("hma_chain_b_fwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    close(xd, x2, 3e-3, "x2")
+    assert rms(xd.cpu() - x, x2 - x) < 5e-3
+    if with_qkv:
+        close(qo, qkv, 4 * BF, "next qkv")
+        assert rms(qo, qkv) < 6e-3
+        assert (qo.float().cpu() - qkv).abs().max() < 0.2 * (qo.float().cpu() - qkv.flip(1)).abs().max()
