@@ -128,7 +128,7 @@ struct ring_src {
   const char *s0, *s1, *s2, *s3;
   int n0, n1, n2, n3;
 };
-template <int PROF_K>
+template <int PROF_K, int NW = NCW>
 __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
                                            int64_t M, int rows_per_frame) {
   const int total = per_tile * nt;
@@ -138,8 +138,8 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
     if (seg == 0 && left == ws.n0 && ss) {  // a tile's first bundle: its shift / scale rows first
       const int64_t t = (int64_t)blockIdx.x + (int64_t)tl_issue * gridDim.x;
 #pragma unroll 1
-      for (int w = 0; w < NCW; ++w) {
-        int64_t r0 = (t * NCW + w) * 16;
+      for (int w = 0; w < NW; ++w) {
+        int64_t r0 = (t * NW + w) * 16;
         r0 = r0 < M ? r0 : M - 1;
         const char* s = reinterpret_cast<const char*>(ss) + (r0 / rows_per_frame) * 2048 + lane * 16;
         const uint32_t d = __builtin_amdgcn_readfirstlane(lds_b + L_SS + ((tl_issue & 1) * NCW + w) * 2048);
@@ -294,14 +294,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // in the same place.  The two waves of a SIMD therefore run the steps in opposite order: waves 0..3 ("early") multiply, then
 // store what the step produced; waves 4..6 ("late") first store what their PREVIOUS step produced, then multiply.  Behind
 // every barrier one wave of a SIMD is on the matrix pipe while the other one's stores drain.
-template <bool MOD, bool SAVE>
+// NW = compute waves per workgroup (7; 5 for passes of fewer than 7 x 16 x #CUs rows -- a decode frame pass of 20 480 rows is 256
+// tiles of 80 rows instead of 183 of 112: every CU gets one).  Waves NW .. 6 leave at once; wave 7 is the loader.
+template <bool MOD, bool SAVE, int NW = NCW>
 __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
+  const int64_t ntiles = (p.M + 16 * NW - 1) / (16 * NW);
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | lin 256..511 | qkv 512..1279
@@ -316,16 +318,17 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
   __syncthreads();
   constexpr int S3 = MOD ? 16 : 8;       // first qkv step
   constexpr int PER_TILE = S3 + 24;
+  if (wave >= NW && wave != NCW) return;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
     return;
   }
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
   };
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
@@ -760,14 +763,14 @@ __device__ __forceinline__ void ks_mma(HMA_LDS(char)* wb, const bf16x8_t& h, f32
 // folded into its qkv) -> qkv]: the second row-local chain of a block (st_transformer.py:111-112 and :85-86 of the next block), for
 // passes that save nothing (inference / decode).  Steps per tile: 8 (proj) + 2 x 32 (a hidden block of 32 units: its fc1 rows,
 // then its fc2 columns) + 24 (qkv).  The hidden activation exists as ONE B-operand fragment per step.
-template <bool QKV>
+template <bool QKV, int NW = NCW>
 __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
+  const int64_t ntiles = (p.M + 16 * NW - 1) / (16 * NW);
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | fc2 256..511 | fc1 512..1535 | qkv 1536..2303
@@ -783,16 +786,17 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
   __syncthreads();
   constexpr int SM = 8, SQ = 8 + 64;           // first MLP step, first qkv step
   constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
+  if (wave >= NW && wave != NCW) return;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1);
     return;
   }
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
   };
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
@@ -952,8 +956,14 @@ bool weights_ok(const hma_chain_weights_t& w, int expect) {
   return sum == expect;
 }
 
-int chain_grid(int64_t M) {
-  const int64_t ntiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+// compute waves for a pass of M rows: 5 when 7-wave tiles would leave CUs without a tile and 5-wave tiles fill more of them
+int chain_waves(int64_t M) {
+  const int64_t t7 = (M + 111) / 112, t5 = (M + 79) / 80;
+  return (t7 < num_cus() && t5 > t7) ? 5 : 7;
+}
+
+int chain_grid(int64_t M, int nw = NCW) {
+  const int64_t ntiles = (M + 16 * nw - 1) / (16 * nw);
 #ifdef CH_GRID  // (debug builds: fewer workgroups than CUs)
   return (int)(ntiles < CH_GRID ? ntiles : CH_GRID);
 #endif
@@ -996,16 +1006,17 @@ extern "C" int hma_chain_a_fwd(void* stream, const hma_chain_a_fwd_t* p) {
   if (save ? (p->use_mod && (!p->xhat || !p->xm || !p->rstd)) : (p->xhat || p->xm || p->rstd)) return HMA_EINVAL;
   if (!weights_ok(p->w, p->use_mod ? 40 : 32)) return HMA_EINVAL;
   if (p->use_mod && (!p->ss || p->rows_per_frame <= 0 || p->rows_per_frame % 16)) return HMA_EINVAL;
-  const int grid = chain_grid(p->M);
-#define CH_LAUNCH_A(MOD_, SAVE_)                                                                                          \
-  do {                                                                                                                   \
-    if (int rc = set_lds<chain_a_fwd_kernel<MOD_, SAVE_>>(SMEM)) return rc;                                              \
-    hipLaunchKernelGGL((chain_a_fwd_kernel<MOD_, SAVE_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);         \
+  const int nw = save ? NCW : chain_waves(p->M);
+  const int grid = chain_grid(p->M, nw);
+#define CH_LAUNCH_A(MOD_, SAVE_, NW_)                                                                                        \
+  do {                                                                                                                      \
+    if (int rc = set_lds<chain_a_fwd_kernel<MOD_, SAVE_, NW_>>(SMEM)) return rc;                                            \
+    hipLaunchKernelGGL((chain_a_fwd_kernel<MOD_, SAVE_, NW_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);       \
   } while (0)
   if (p->use_mod) {
-    if (save) CH_LAUNCH_A(true, true); else CH_LAUNCH_A(true, false);
+    if (save) CH_LAUNCH_A(true, true, 7); else if (nw == 5) CH_LAUNCH_A(true, false, 5); else CH_LAUNCH_A(true, false, 7);
   } else {
-    if (save) CH_LAUNCH_A(false, true); else CH_LAUNCH_A(false, false);
+    if (save) CH_LAUNCH_A(false, true, 7); else if (nw == 5) CH_LAUNCH_A(false, false, 5); else CH_LAUNCH_A(false, false, 7);
   }
 #undef CH_LAUNCH_A
   HMA_CHECK_LAUNCH();
@@ -1034,15 +1045,20 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
   const bool qkv = p->qkv != nullptr;
   if (qkv && p->ldq < 768) return HMA_EINVAL;
   if (!weights_ok(p->w, qkv ? 96 : 72)) return HMA_EINVAL;
-  const int grid = chain_grid(p->M);
+  const int nw = chain_waves(p->M);
+  const int grid = chain_grid(p->M, nw);
   // (the bias area holds 2304 floats here: it runs into the shift / scale rows' space, which this chain does not use)
+#define CH_LAUNCH_B(QKV_, NW_)                                                                                          \
+  do {                                                                                                                 \
+    if (int rc = set_lds<chain_b_fwd_kernel<QKV_, NW_>>(SMEM)) return rc;                                              \
+    hipLaunchKernelGGL((chain_b_fwd_kernel<QKV_, NW_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);         \
+  } while (0)
   if (qkv) {
-    if (int rc = set_lds<chain_b_fwd_kernel<true>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_b_fwd_kernel<true>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    if (nw == 5) CH_LAUNCH_B(true, 5); else CH_LAUNCH_B(true, 7);
   } else {
-    if (int rc = set_lds<chain_b_fwd_kernel<false>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_b_fwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, 7);
   }
+#undef CH_LAUNCH_B
   HMA_CHECK_LAUNCH();
   return 0;
 }
