@@ -38,7 +38,7 @@ FREQ = [20, 10, 20, 20, 5, 30, 2, 20, 20, 10, 2, 2, 10, 1, 10, 5, 5, 5, 10, 3, 1
 FLOP_PER_TOKEN_FWD_BWD = 3.104e8
 # every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
 FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_attn_spatial_fwd",
-            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd"]
+            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
 
 
@@ -480,7 +480,7 @@ def main():
                 d0 = fams[dom_name]
                 traffic = pmc_traffic_per_launch({"hma_gemm_nt": "gemm_nt", "hma_mlp_bwd": "mlp_bwd", "hma_mlp_fwd": "mlp_fwd",
                                                   "hma_gemm_tn_pair": "gemm_tn", "hma_chain_a_fwd": "chain_a_fwd",
-                                                  "hma_chain_a_bwd": "chain_a_bwd"}.get(dom_name, dom_name))
+                                                  "hma_chain_a_bwd": "chain_a_bwd", "hma_chain_b_fwd": "chain_b_fwd"}.get(dom_name, dom_name))
                 mfma = {"achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s", "frac": d0["frac"]}
                 hbm = {"achieved": d0["hbm_achieved_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": d0["hbm_frac"]}
                 # headline = the MFMA roof (SURVEY.md 8d / north_star: dense contraction => MFMA); the HBM view of the same

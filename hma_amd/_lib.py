@@ -101,6 +101,7 @@ class ChainBFwd(C.Structure):
         ("b_proj", c_vp), ("b1", c_vp), ("b2", c_vp), ("b_qkv", c_vp),
         ("qkv", c_vp), ("ldq", c_i64),
         ("M", c_i64), ("ln_eps", C.c_float), ("_pad", c_i32),
+        ("xhat2", c_vp), ("rstd2", c_vp), ("xhat1n", c_vp), ("rstd1n", c_vp),
     ]
 
 

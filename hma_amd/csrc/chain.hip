@@ -763,7 +763,7 @@ __device__ __forceinline__ void ks_mma(HMA_LDS(char)* wb, const bf16x8_t& h, f32
 // folded into its qkv) -> qkv]: the second row-local chain of a block (st_transformer.py:111-112 and :85-86 of the next block), for
 // passes that save nothing (inference / decode).  Steps per tile: 8 (proj) + 2 x 32 (a hidden block of 32 units: its fc1 rows,
 // then its fc2 columns) + 24 (qkv).  The hidden activation exists as ONE B-operand fragment per step.
-template <bool QKV, int NW = NCW>
+template <bool QKV, int NW = NCW, bool SAVE = false>
 __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
@@ -822,8 +822,9 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
   const line_offs Lf = make_lines(1024, tok, 32 * g, 16);
   const line_offs Lq = make_lines((int)p.ldq * 2, tok, 16 * g, 64);
   int slot = 0;
-  // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand
-  auto ln_pack = [&](bf16x8_t (&dst)[8]) __attribute__((always_inline)) {
+  const line_offs Lb = make_lines(512, tok, 16 * g, 64);
+  // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand (training: also saved, with 1 / sigma, for the backward)
+  auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t r0) __attribute__((always_inline)) {
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
@@ -850,6 +851,13 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
       for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
       dst[pr] = as_frag(pack8(h));
     }
+    if constexpr (SAVE) {
+      uint16_t* xo = reinterpret_cast<uint16_t*>(xhat_out) + r0 * 256;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+        store_lines(xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
+      if (!(CH_ABL & 1)) rstd_out[r0 + tok] = rstd;
+    }
   };
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
         add4(acc[2 * s], lds_f4(bias + 128 * s));
         add4(acc[2 * s + 1], lds_f4(bias + 128 * s + 16));
         if constexpr (s == SM - 1) {
-          ln_pack(a1);  // xhat2 (norm2's affine sits in the packed fc1 weights / bias)
+          ln_pack(a1, p.xhat2, p.rstd2, r0);  // xhat2 (norm2's affine sits in the packed fc1 weights / bias)
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr) {  // + fc2 bias, once
             add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
           if constexpr (s == SQ - 1) {
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
-            if constexpr (QKV) ln_pack(a0);  // the next block's norm1 (affine folded into its qkv weights / bias)
+            if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, r0);  // the next block's norm1 (affine folded into its qkv weights / bias)
             prefetch(tl + 1 < nt ? tl + 1 : tl);
           }
         }
@@ -1045,7 +1053,9 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
   const bool qkv = p->qkv != nullptr;
   if (qkv && p->ldq < 768) return HMA_EINVAL;
   if (!weights_ok(p->w, qkv ? 96 : 72)) return HMA_EINVAL;
-  const int nw = chain_waves(p->M);
+  const bool save = p->xhat2 != nullptr;  // training: the two LayerNorm outputs are saved for the backward
+  if (save && (!p->rstd2 || (qkv && (!p->xhat1n || !p->rstd1n)))) return HMA_EINVAL;
+  const int nw = save ? NCW : chain_waves(p->M);
   const int grid = chain_grid(p->M, nw);
   // (the bias area holds 2304 floats here: it runs into the shift / scale rows' space, which this chain does not use)
 #define CH_LAUNCH_B(QKV_, NW_)                                                                                          \
@@ -1053,7 +1063,15 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
     if (int rc = set_lds<chain_b_fwd_kernel<QKV_, NW_>>(SMEM)) return rc;                                              \
     hipLaunchKernelGGL((chain_b_fwd_kernel<QKV_, NW_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);         \
   } while (0)
-  if (qkv) {
+  if (save) {
+    if (qkv) {
+      if (int rc = set_lds<chain_b_fwd_kernel<true, 7, true>>(SMEM)) return rc;
+      hipLaunchKernelGGL((chain_b_fwd_kernel<true, 7, true>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    } else {
+      if (int rc = set_lds<chain_b_fwd_kernel<false, 7, true>>(SMEM)) return rc;
+      hipLaunchKernelGGL((chain_b_fwd_kernel<false, 7, true>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    }
+  } else if (qkv) {
     if (nw == 5) CH_LAUNCH_B(true, 5); else CH_LAUNCH_B(true, 7);
   } else {
     if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, 7);

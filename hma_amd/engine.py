@@ -107,9 +107,10 @@ class Plan:
     def chain_b_fwd(self, M: int, with_qkv: bool, **kw) -> None:
         g = make_chain_b_fwd(M=M, **kw)
         self.keep.append(g)
-        # o 512 + x 1024 in; x 1024 (+ qkv 1536) out
+        # o 512 + x 1024 in; x 1024 (+ qkv 1536) out (+ the saved LayerNorm outputs, 512 each, in training)
+        saved = 512 * ((1 if kw.get("xhat2") else 0) + (1 if kw.get("xhat1n") else 0))
         self.add("hma_chain_b_fwd", C.byref(g), flops=2.0 * M * 256 * (256 + 2048 + (768 if with_qkv else 0)),
-                 nbytes=(512 + 1024 + 1024 + (1536 if with_qkv else 0)) * float(M))
+                 nbytes=(512 + 1024 + 1024 + (1536 if with_qkv else 0) + saved) * float(M))
 
     def chain_a_bwd(self, M: int, use_mod: bool, **kw) -> None:
         g = make_chain_a_bwd(M=M, use_mod=use_mod, **kw)
@@ -230,6 +231,7 @@ class STEngine:
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN)}
         # chain B (proj_t + norm2 + MLP + the next block's norm1 + qkv_s in one launch) for passes that save nothing
         self.chain_b_ok = hid == 1024
+        self.chain_b_train = True
         if self.chain_b_ok:
             self.CP.update({"proj_t": mk(L, 8 * BUN), "mlp": mk(L, 64 * BUN), "qkv_s": mk(L, 24 * BUN)})
         if self.modulate:
@@ -472,7 +474,8 @@ class STEngine:
     def _emit_layer(self, pl: Plan, l: int, x: int, b: Dict[str, int], M: int, Fr: int, B: int, T: int, SA: int,
                     use_mod: bool, domain: Optional[str], kv: Optional[dict] = None, train: bool = False,
                     have_ln1: bool = False, ln_next: Optional[Tuple[int, int]] = None, fused: bool = False,
-                    have_qkv_s: bool = False, chain_b: bool = False, next_qkv_s: Optional[int] = None) -> None:
+                    have_qkv_s: bool = False, chain_b: bool = False, next_qkv_s: Optional[int] = None,
+                    next_ln1: Optional[Tuple[int, int]] = None) -> None:
         """One STBlock forward (st_transformer.py:79-114) on M rows = Fr frames of SA tokens.  `kv` redirects the
         temporal qkv into the per-layer decode cache: {"cache": ptr, "row_off": rows, "c_group": (rows, stride),
         "t_query": -1 | t, "T_cache": frames}."""
@@ -525,9 +528,14 @@ class STEngine:
             segs = [(self.CP["proj_t"][l].data_ptr(), 8), (self.CP["mlp"][l].data_ptr(), 64)]
             if next_qkv_s is not None:
                 segs.append((self.CP["qkv_s"][l + 1].data_ptr(), 24))
+            sv = {}
+            if train:  # the two LayerNorm outputs are saved for the backward (norm2 of this block, norm1 of the next one)
+                sv = dict(xhat2=b["xh2"], rstd2=b["rstd2"])
+                if next_qkv_s is not None:
+                    sv.update(xhat1n=next_ln1[0], rstd1n=next_ln1[1])
             pl.chain_b_fwd(M, next_qkv_s is not None, segs=segs, o=b["o_t"], x=x, b_proj=pb("temporal_attn"),
                            b1=self.BF["fc1"][l].data_ptr(), b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
-                           b_qkv=self.BF["qkv_s"][l + 1].data_ptr() if next_qkv_s is not None else None, qkv=next_qkv_s)
+                           b_qkv=self.BF["qkv_s"][l + 1].data_ptr() if next_qkv_s is not None else None, qkv=next_qkv_s, **sv)
             return
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
@@ -615,10 +623,16 @@ class STEngine:
             if fused and l + 1 < l1:  # the MLP kernel also emits the next block's LN1 output
                 s1 = sl(l + 1)
                 ln_next = (dp(ws["xh1"], s1, ws["xh1"][0].numel()), dp(ws["rstd1"], s1, ws["rstd1"][0].numel()))
-            cb = (not train) and self.chain_b_ok and self._use_chain(M, SA)
+            # chain B: every pass that saves nothing, and training passes that would take the fused MLP block (no dropout)
+            cb = self.chain_b_ok and self._use_chain(M, SA) and ((not train) or (fused and self.chain_b_train))
+            nxt = None
+            if cb and l + 1 < l1:
+                s1 = sl(l + 1)
+                nxt = (dp(ws["qkv_s"], s1, ws["qkv_s"][0].numel()), dp(ws["xh1"], s1, ws["xh1"][0].numel()),
+                       dp(ws["rstd1"], s1, ws["rstd1"][0].numel()))
             self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train,
                              have_ln1=fused and l > l0, ln_next=ln_next, fused=fused, have_qkv_s=cb and l > l0, chain_b=cb,
-                             next_qkv_s=bufs["qkv_s"] if (cb and l + 1 < l1) else None)
+                             next_qkv_s=nxt[0] if nxt else None, next_ln1=(nxt[1], nxt[2]) if nxt else None)
         # readout on the image tokens only                      st_mask_git.py:681-683
         if readout:
           pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=Mi, N=1024, K=256,

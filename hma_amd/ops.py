@@ -134,13 +134,16 @@ def make_chain_a_fwd(*, M: int, segs, o: int, x: int, qkv: int, ldq: int = 768, 
 
 
 def make_chain_b_fwd(*, M: int, segs, o: int, x: int, b1: int, b_proj: Optional[int] = None, b2: Optional[int] = None,
-                     b_qkv: Optional[int] = None, qkv: Optional[int] = None, ldq: int = 768, ln_eps: float = 1e-5) -> ChainBFwd:
+                     b_qkv: Optional[int] = None, qkv: Optional[int] = None, ldq: int = 768, ln_eps: float = 1e-5,
+                     xhat2: Optional[int] = None, rstd2: Optional[int] = None, xhat1n: Optional[int] = None,
+                     rstd1n: Optional[int] = None) -> ChainBFwd:
     """segs: packed proj (8), the 64 alternating fc1 / fc2 bundles, and -- with `qkv` -- the next block's folded qkv (24)."""
     g = ChainBFwd()
     _chain_weights(g.w, segs)
     g.o, g.x = o, x
     g.b_proj, g.b1, g.b2, g.b_qkv = b_proj, b1, b2, b_qkv
     g.qkv, g.ldq, g.M, g.ln_eps = qkv, ldq, M, ln_eps
+    g.xhat2, g.rstd2, g.xhat1n, g.rstd1n = xhat2, rstd2, xhat1n, rstd1n
     return g
 
 

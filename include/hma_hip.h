@@ -434,6 +434,9 @@ typedef struct {
   const float* b_proj; const float* b1; const float* b2; const float* b_qkv;
   void* qkv; int64_t ldq;
   int64_t M; float ln_eps; int32_t _pad;
+  /* training (all NULL in inference): xhat2 = LN(x1) bf16 [M,256] and rstd2 [M] (norm2, what hma_mlp_bwd re-reads), xhat1n / rstd1n
+   * = LN(x2) and its 1 / sigma (the next block's norm1; required with qkv) */
+  void* xhat2; float* rstd2; void* xhat1n; float* rstd1n;
 } hma_chain_b_fwd_t;
 int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p);
 

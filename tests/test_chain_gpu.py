@@ -159,8 +159,9 @@ def test_chain_a_bwd(M, rpf, mod):
     assert (do.float().cpu() - d_o).abs().max() < 0.2 * (do.float().cpu() - d_o.flip(1)).abs().max()
 
 
-@pytest.mark.parametrize("M,with_qkv", [(112, True), (1008, True), (20480, True), (40960, True), (2560, False)])
-def test_chain_b_fwd(M, with_qkv):
+@pytest.mark.parametrize("M,with_qkv,save", [(112, True, False), (1008, True, True), (20480, True, False), (40960, True, True),
+                                             (2560, False, False), (2560, False, True)])
+def test_chain_b_fwd(M, with_qkv, save):
     """proj_t + residual -> norm2 -> fc1 -> GELU -> fc2 + residual -> the next block's norm1 -> qkv, one launch (inference form:
     nothing saved).  Reference: hma/model/st_transformer.py:111-112, :24-27, :85-86; hma/model/attention.py:39,60."""
     gq = lambda s_: torch.Generator().manual_seed(s_)
@@ -191,8 +192,15 @@ def test_chain_b_fwd(M, with_qkv):
     xd, od = d(x).clone(), d(o).bfloat16()
     qo = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
     bpd, b1d, b2d, bqd = d(bp), d(b1f), d(b2), d(bqf)
+    kw = {}
+    if save:
+        xh2o, xh1o = (torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        rs2o, rs1o = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+        kw = dict(xhat2=ops.ptr(xh2o), rstd2=ops.ptr(rs2o))
+        if with_qkv:
+            kw.update(xhat1n=ops.ptr(xh1o), rstd1n=ops.ptr(rs1o))
     a = ops.make_chain_b_fwd(M=M, segs=segs, o=ops.ptr(od), x=ops.ptr(xd), b_proj=ops.ptr(bpd), b1=ops.ptr(b1d), b2=ops.ptr(b2d),
-                             b_qkv=ops.ptr(bqd) if with_qkv else None, qkv=ops.ptr(qo) if with_qkv else None)
+                             b_qkv=ops.ptr(bqd) if with_qkv else None, qkv=ops.ptr(qo) if with_qkv else None, **kw)
     _lib.call("hma_chain_b_fwd", ops.stream_ptr(), C.byref(a))
     torch.cuda.synchronize()
     close(xd, x2, 3e-3, "x2")
@@ -201,3 +209,9 @@ def test_chain_b_fwd(M, with_qkv):
         close(qo, qkv, 4 * BF, "next qkv")
         assert rms(qo, qkv) < 6e-3
         assert (qo.float().cpu() - qkv).abs().max() < 0.2 * (qo.float().cpu() - qkv.flip(1)).abs().max()
+    if save:  # what the backward re-reads
+        close(xh2o, F.layer_norm(x1, (256,), eps=1e-5), 2 * BF, "xhat2")
+        close(rs2o, torch.rsqrt(x1.var(dim=1, unbiased=False) + 1e-5), 1e-4, "rstd2")
+        if with_qkv:
+            close(xh1o, F.layer_norm(x2, (256,), eps=1e-5), 3 * BF, "next xhat1")
+            close(rs1o, torch.rsqrt(x2.var(dim=1, unbiased=False) + 1e-5), 3e-3, "next rstd1")

@@ -103,3 +103,32 @@ if os.environ.get("CH_PROF"):
     for w in range(8):
         v = [buf[w * 8 + i] for i in range(8)]
         print(f"  wave {w}: " + " ".join(f"{x:9d}" for x in v[:5]) + f"   sum {sum(v)}")
+
+# ---- chain B forward (training form: the two LayerNorm outputs saved) beside proj_t + LN GEMM, hma_mlp_fwd, qkv_s GEMM
+w1, w2 = mk(1024, 256) * 0.05, mk(256, 1024) * 0.05
+g2 = torch.ones(256, device=dev)
+mlpw = torch.empty(64 * 8192, dtype=bf, device=dev)
+ops.chain_pack(w1.contiguous(), kind=0, rows=1024, cols=256, row_stride=256, col_stride=1, col_scale=g2, out=mlpw, bundle_stride=2)
+ops.chain_pack(w2.contiguous(), kind=1, rows=256, cols=1024, row_stride=1024, col_stride=1, out=mlpw, bundle_stride=2, bundle_offset=1)
+b1v, b2v = mk(1024) * 0.1, mk(256) * 0.1
+xh2, xh1n = (carve((M, 256), bf) for _ in range(2))
+rs2, rs1n = torch.empty(M, device=dev), torch.empty(M, device=dev)
+fb = ops.make_chain_b_fwd(M=M, segs=[(pwp.data_ptr(), 8), (mlpw.data_ptr(), 64), (pwq.data_ptr(), 24)], o=o.data_ptr(), x=x.data_ptr(),
+                          b_proj=bp.data_ptr(), b1=b1v.data_ptr(), b2=b2v.data_ptr(), b_qkv=bq.data_ptr(), qkv=qkv.data_ptr(),
+                          xhat2=xh2.data_ptr(), rstd2=rs2.data_ptr(), xhat1n=xh1n.data_ptr(), rstd1n=rs1n.data_ptr())
+fbi = ops.make_chain_b_fwd(M=M, segs=[(pwp.data_ptr(), 8), (mlpw.data_ptr(), 64), (pwq.data_ptr(), 24)], o=o.data_ptr(), x=x.data_ptr(),
+                           b_proj=bp.data_ptr(), b1=b1v.data_ptr(), b2=b2v.data_ptr(), b_qkv=bq.data_ptr(), qkv=qkv.data_ptr())
+t_bt = timeit(lambda: _lib.call("hma_chain_b_fwd", st, C.byref(fb)))
+t_bi = timeit(lambda: _lib.call("hma_chain_b_fwd", st, C.byref(fbi)))
+from hma_amd._lib import A_BF16 as _A  # noqa: E402
+gp = ops.make_gemm_nt(A=o.data_ptr(), lda=256, a_kind=A_BF16, W=wpb.data_ptr(), ldw=256, M=M, N=256, K=256, epi=EPI_RESID, Cp=x.data_ptr(),
+                      ldc=256, bias=bp.data_ptr(), ln_xhat=xh2.data_ptr(), ln_rstd=rs2.data_ptr(), ln_eps=1e-5)
+wpk = {k: (torch.randn(512 * 512, device=dev) * 0.05).to(bf) for k in ("w1p", "w2p")}
+mf = ops.make_mlp_fwd(M=M, xhat=xh2.data_ptr(), x=x.data_ptr(), w1p=wpk["w1p"].data_ptr(), w2p=wpk["w2p"].data_ptr(), b1=b1v.data_ptr(),
+                      b2=b2v.data_ptr(), ln_xhat=xh1n.data_ptr(), ln_rstd=rs1n.data_ptr(), ln_eps=1e-5)
+gq = ops.make_gemm_nt(A=xh1n.data_ptr(), lda=256, a_kind=A_BF16, W=wqb.data_ptr(), ldw=256, M=M, N=768, K=256, epi=EPI_BF16,
+                      Cp=qkv.data_ptr(), ldc=768, bias=bq.data_ptr())
+t_o = [timeit(lambda: _lib.call("hma_gemm_nt", st, C.byref(gp))), timeit(lambda: _lib.call("hma_mlp_fwd", st, C.byref(mf))),
+       timeit(lambda: _lib.call("hma_gemm_nt", st, C.byref(gq)))]
+print(f"chain B fwd (train, saves xhat2 / xhat1') {t_bt:7.1f} us, (inference) {t_bi:7.1f} us   [3 launches: "
+      f"{' + '.join(f'{t:.0f}' for t in t_o)} = {sum(t_o):.0f} us]   {2.0 * M * 256 * 3072 / t_bt / 1e6:6.0f} TFLOP/s")
