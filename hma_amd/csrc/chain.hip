@@ -34,8 +34,17 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
-constexpr int NCW = 7;                       // compute waves; wave NCW is the loader
-constexpr int NS = 4;                        // ring slots
+// (measurement builds: -DCH_NCW=3 -DCH_NS=3 makes 4-wave workgroups of 48-row tiles, two per CU -- tools/chain_variants.sh)
+#ifndef CH_NCW
+#define CH_NCW 7
+#endif
+#ifndef CH_NS
+#define CH_NS 4
+#endif
+constexpr int NCW = CH_NCW;                  // compute waves; wave NCW is the loader
+constexpr int CH_THREADS = 64 * (NCW + 1);
+constexpr int WGS_PER_CU = NCW <= 3 ? 2 : 1;
+constexpr int NS = CH_NS;                    // ring slots
 constexpr int SLOT = 16384;                  // one bundle
 constexpr int TILE_ROWS = 16 * NCW;          // 112
 constexpr int L_BIAS = NS * SLOT;            // 2048 floats of bias vectors
@@ -156,7 +165,7 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
       glds16x4(s + 12288, d + 12288);
     }
     ++issued;
-    slot_issue = (slot_issue + 1) & (NS - 1);
+    slot_issue = slot_issue + 1 == NS ? 0 : slot_issue + 1;
     cur += SLOT;
     if (--left == 0) {
       ++seg;
@@ -297,7 +306,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // NW = compute waves per workgroup (7; 5 for passes of fewer than 7 x 16 x #CUs rows -- a decode frame pass of 20 480 rows is 256
 // tiles of 80 rows instead of 183 of 112: every CU gets one).  Waves NW .. 6 leave at once; wave 7 is the loader.
 template <bool MOD, bool SAVE, int NW = NCW>
-__global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p) {
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | lin 256..511 | qkv 512..1279
-    for (int i = tid; i < 1280; i += 512) {
+    for (int i = tid; i < 1280; i += CH_THREADS) {
       float v = 0.f;
       if (i < 256) v = p.b_proj ? p.b_proj[i] : 0.f;
       else if (i < 512) v = (MOD && p.b_lin) ? p.b_lin[i - 256] : 0.f;
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void chain_a_fwd_kernel(hma_chain_a_fwd_t p
       CH_BARRIER();
       CPROF_MARK(0);
       HMA_LDS(char)* wb = ring + slot * SLOT;
-      slot = (slot + 1) & (NS - 1);
+      slot = slot + 1 == NS ? 0 : slot + 1;
       if constexpr (s < 8) {
         // ---- x1 = x + o Wproj^T + b
         nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
@@ -521,7 +530,7 @@ __device__ __forceinline__ void colsum16(F&& val, int tok, float (&out)[2]) {
 }
 
 template <bool MOD>
-__global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p) {
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void chain_a_bwd_kernel(hma_chain_a_bwd_t p
       constexpr int s = decltype(sc_)::value;
       CH_BARRIER();
       HMA_LDS(char)* wb = ring + slot * SLOT;
-      slot = (slot + 1) & (NS - 1);
+      slot = slot + 1 == NS ? 0 : slot + 1;
       if constexpr (s < 24) {
         // ---- dx2 = dx + dqkv Wqkv (k = 768 in three chunks; chunk c + 1 is requested while chunk c is multiplied)
         constexpr int c = s >> 3, pr = s & 7;
@@ -764,7 +773,7 @@ __device__ __forceinline__ void ks_mma(HMA_LDS(char)* wb, const bf16x8_t& h, f32
 // passes that save nothing (inference / decode).  Steps per tile: 8 (proj) + 2 x 32 (a hidden block of 32 units: its fc1 rows,
 // then its fc2 columns) + 24 (qkv).  The hidden activation exists as ONE B-operand fragment per step.
 template <bool QKV, int NW = NCW, bool SAVE = false>
-__global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p) {
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | fc2 256..511 | fc1 512..1535 | qkv 1536..2303
-    for (int i = tid; i < 2304; i += 512) {
+    for (int i = tid; i < 2304; i += CH_THREADS) {
       float v = 0.f;
       if (i < 256) v = p.b_proj ? p.b_proj[i] : 0.f;
       else if (i < 512) v = p.b2 ? p.b2[i - 256] : 0.f;
@@ -876,7 +885,7 @@ __global__ __launch_bounds__(512, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p
       constexpr int s = decltype(sc_)::value;
       CH_BARRIER();
       HMA_LDS(char)* wb = ring + slot * SLOT;
-      slot = (slot + 1) & (NS - 1);
+      slot = slot + 1 == NS ? 0 : slot + 1;
       if constexpr (s < SM) {
         // ---- x1 = x + o Wproj^T + b
         nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
@@ -966,6 +975,7 @@ bool weights_ok(const hma_chain_weights_t& w, int expect) {
 
 // compute waves for a pass of M rows: 5 when 7-wave tiles would leave CUs without a tile and 5-wave tiles fill more of them
 int chain_waves(int64_t M) {
+  if (NCW != 7) return NCW;
   const int64_t t7 = (M + 111) / 112, t5 = (M + 79) / 80;
   return (t7 < num_cus() && t5 > t7) ? 5 : 7;
 }
@@ -975,7 +985,8 @@ int chain_grid(int64_t M, int nw = NCW) {
 #ifdef CH_GRID  // (debug builds: fewer workgroups than CUs)
   return (int)(ntiles < CH_GRID ? ntiles : CH_GRID);
 #endif
-  return (int)(ntiles < num_cus() ? ntiles : num_cus());
+  const int slots = num_cus() * WGS_PER_CU;
+  return (int)(ntiles < slots ? ntiles : slots);
 }
 
 }  // namespace
@@ -1019,12 +1030,12 @@ extern "C" int hma_chain_a_fwd(void* stream, const hma_chain_a_fwd_t* p) {
 #define CH_LAUNCH_A(MOD_, SAVE_, NW_)                                                                                        \
   do {                                                                                                                      \
     if (int rc = set_lds<chain_a_fwd_kernel<MOD_, SAVE_, NW_>>(SMEM)) return rc;                                            \
-    hipLaunchKernelGGL((chain_a_fwd_kernel<MOD_, SAVE_, NW_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);       \
+    hipLaunchKernelGGL((chain_a_fwd_kernel<MOD_, SAVE_, NW_>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);       \
   } while (0)
   if (p->use_mod) {
-    if (save) CH_LAUNCH_A(true, true, 7); else if (nw == 5) CH_LAUNCH_A(true, false, 5); else CH_LAUNCH_A(true, false, 7);
+    if (save) CH_LAUNCH_A(true, true, NCW); else if (nw == 5) CH_LAUNCH_A(true, false, 5); else CH_LAUNCH_A(true, false, NCW);
   } else {
-    if (save) CH_LAUNCH_A(false, true, 7); else if (nw == 5) CH_LAUNCH_A(false, false, 5); else CH_LAUNCH_A(false, false, 7);
+    if (save) CH_LAUNCH_A(false, true, NCW); else if (nw == 5) CH_LAUNCH_A(false, false, 5); else CH_LAUNCH_A(false, false, NCW);
   }
 #undef CH_LAUNCH_A
   HMA_CHECK_LAUNCH();
@@ -1039,10 +1050,10 @@ extern "C" int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p) {
   const int grid = chain_grid(p->M);
   if (p->use_mod) {
     if (int rc = set_lds<chain_a_bwd_kernel<true>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_a_bwd_kernel<true>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(chain_a_bwd_kernel<true>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
   } else {
     if (int rc = set_lds<chain_a_bwd_kernel<false>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_a_bwd_kernel<false>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(chain_a_bwd_kernel<false>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
   }
   HMA_CHECK_LAUNCH();
   return 0;
@@ -1061,20 +1072,20 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
 #define CH_LAUNCH_B(QKV_, NW_)                                                                                          \
   do {                                                                                                                 \
     if (int rc = set_lds<chain_b_fwd_kernel<QKV_, NW_>>(SMEM)) return rc;                                              \
-    hipLaunchKernelGGL((chain_b_fwd_kernel<QKV_, NW_>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);         \
+    hipLaunchKernelGGL((chain_b_fwd_kernel<QKV_, NW_>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);         \
   } while (0)
   if (save) {
     if (qkv) {
-      if (int rc = set_lds<chain_b_fwd_kernel<true, 7, true>>(SMEM)) return rc;
-      hipLaunchKernelGGL((chain_b_fwd_kernel<true, 7, true>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+      if (int rc = set_lds<chain_b_fwd_kernel<true, NCW, true>>(SMEM)) return rc;
+      hipLaunchKernelGGL((chain_b_fwd_kernel<true, NCW, true>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
     } else {
-      if (int rc = set_lds<chain_b_fwd_kernel<false, 7, true>>(SMEM)) return rc;
-      hipLaunchKernelGGL((chain_b_fwd_kernel<false, 7, true>), dim3(grid), dim3(512), SMEM, (hipStream_t)stream, *p);
+      if (int rc = set_lds<chain_b_fwd_kernel<false, NCW, true>>(SMEM)) return rc;
+      hipLaunchKernelGGL((chain_b_fwd_kernel<false, NCW, true>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
     }
   } else if (qkv) {
-    if (nw == 5) CH_LAUNCH_B(true, 5); else CH_LAUNCH_B(true, 7);
+    if (nw == 5) CH_LAUNCH_B(true, 5); else CH_LAUNCH_B(true, NCW);
   } else {
-    if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, 7);
+    if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, NCW);
   }
 #undef CH_LAUNCH_B
   HMA_CHECK_LAUNCH();
