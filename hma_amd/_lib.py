@@ -66,6 +66,7 @@ class MlpBwd(C.Structure):
         ("w1p", c_vp), ("w2tp", c_vp), ("w1tp", c_vp), ("b1", c_vp),
         ("hg", c_vp), ("du", c_vp),
         ("M", c_i64),
+        ("drop_p", C.c_float), ("drop_salt", c_i32), ("drop_seed", c_vp), ("dy_drop", c_vp),
     ]
 
 
@@ -102,6 +103,7 @@ class ChainBFwd(C.Structure):
         ("qkv", c_vp), ("ldq", c_i64),
         ("M", c_i64), ("ln_eps", C.c_float), ("_pad", c_i32),
         ("xhat2", c_vp), ("rstd2", c_vp), ("xhat1n", c_vp), ("rstd1n", c_vp),
+        ("drop_p", C.c_float), ("drop_salt", c_i32), ("drop_seed", c_vp),
     ]
 
 

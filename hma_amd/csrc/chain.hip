@@ -772,7 +772,7 @@ __device__ __forceinline__ void ks_mma(HMA_LDS(char)* wb, const bf16x8_t& h, f32
 // folded into its qkv) -> qkv]: the second row-local chain of a block (st_transformer.py:111-112 and :85-86 of the next block), for
 // passes that save nothing (inference / decode).  Steps per tile: 8 (proj) + 2 x 32 (a hidden block of 32 units: its fc1 rows,
 // then its fc2 columns) + 24 (qkv).  The hidden activation exists as ONE B-operand fragment per step.
-template <bool QKV, int NW = NCW, bool SAVE = false>
+template <bool QKV, int NW = NCW, bool SAVE = false, bool DROP = false>
 __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_fwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
@@ -832,6 +832,15 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   const line_offs Lq = make_lines((int)p.ldq * 2, tok, 16 * g, 64);
   int slot = 0;
   const line_offs Lb = make_lines(512, tok, 16 * g, 64);
+  // mlp_drop > 0 (training): the two nn.Dropout masks of Mlp.forward, counter-based like the GEMM epilogues' (hma_common.h drop_keep)
+  uint32_t dseed = 0, dth = 0;
+  float dsc = 1.f;
+  f32x4v_t x1[DROP ? 16 : 1];  // (DROP: the residual is kept apart from the branch output, which is masked before the add)
+  if constexpr (DROP) {
+    dseed = *p.drop_seed;
+    dth = drop_thresh(p.drop_p);
+    dsc = 1.0f / (1.0f - p.drop_p);
+  }
   // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand (training: also saved, with 1 / sigma, for the backward)
   auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t r0) __attribute__((always_inline)) {
     float sum = 0.f;
@@ -893,6 +902,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
         add4(acc[2 * s + 1], lds_f4(bias + 128 * s + 16));
         if constexpr (s == SM - 1) {
           ln_pack(a1, p.xhat2, p.rstd2, r0);  // xhat2 (norm2's affine sits in the packed fc1 weights / bias)
+          if constexpr (DROP) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              x1[t] = acc[t];
+              acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+            }
+          }
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr) {  // + fc2 bias, once
             add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
@@ -911,11 +927,27 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
             hv[e] = gelu_f(c0[e]);
             hv[4 + e] = gelu_f(c1[e]);
           }
+          if constexpr (DROP) {
+            const int64_t e0 = (r0 + tok) * 1024 + 32 * h + 8 * g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = drop_keep(dseed, p.drop_salt, e0 + e, dth) ? hv[e] * dsc : 0.f;
+          }
           hf = as_frag(pack8(hv));
         } else {
           // ---- x2 += W2[:, hidden block h] gelu(u)
           ks_mma(wb, hf, acc);
           if constexpr (s == SQ - 1) {
+            if constexpr (DROP) {
+              const int64_t e0 = (r0 + tok) * 256 + 8 * g;
+#pragma unroll
+              for (int t = 0; t < 16; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const bool keep = drop_keep(dseed, p.drop_salt + 1, e0 + 32 * (t >> 1) + 4 * (t & 1) + r, dth);
+                  acc[t][r] = x1[t][r] + (keep ? acc[t][r] * dsc : 0.f);
+                }
+              }
+            }
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
             if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, r0);  // the next block's norm1 (affine folded into its qkv weights / bias)
@@ -1066,6 +1098,8 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
   if (!weights_ok(p->w, qkv ? 96 : 72)) return HMA_EINVAL;
   const bool save = p->xhat2 != nullptr;  // training: the two LayerNorm outputs are saved for the backward
   if (save && (!p->rstd2 || (qkv && (!p->xhat1n || !p->rstd1n)))) return HMA_EINVAL;
+  const bool drop = p->drop_p != 0.f;
+  if (drop && (!(p->drop_p > 0.f && p->drop_p < 1.f) || !p->drop_seed || !save)) return HMA_EINVAL;
   const int nw = save ? NCW : chain_waves(p->M);
   const int grid = chain_grid(p->M, nw);
   // (the bias area holds 2304 floats here: it runs into the shift / scale rows' space, which this chain does not use)
@@ -1074,7 +1108,15 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
     if (int rc = set_lds<chain_b_fwd_kernel<QKV_, NW_>>(SMEM)) return rc;                                              \
     hipLaunchKernelGGL((chain_b_fwd_kernel<QKV_, NW_>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);         \
   } while (0)
-  if (save) {
+  if (drop) {
+    if (qkv) {
+      if (int rc = set_lds<chain_b_fwd_kernel<true, NCW, true, true>>(SMEM)) return rc;
+      hipLaunchKernelGGL((chain_b_fwd_kernel<true, NCW, true, true>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+    } else {
+      if (int rc = set_lds<chain_b_fwd_kernel<false, NCW, true, true>>(SMEM)) return rc;
+      hipLaunchKernelGGL((chain_b_fwd_kernel<false, NCW, true, true>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+    }
+  } else if (save) {
     if (qkv) {
       if (int rc = set_lds<chain_b_fwd_kernel<true, NCW, true>>(SMEM)) return rc;
       hipLaunchKernelGGL((chain_b_fwd_kernel<true, NCW, true>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);

@@ -580,6 +580,10 @@ constexpr int MB_ST2 = MB_B1 + 4096;         // per pair: 32 floats (sum_h du (W
 constexpr int MB_STG = MB_ST2 + 1024;        // per pair: 2 staging pieces of 4 KB
 constexpr int MB_SMEM = MB_STG + 4 * 8192;   // 152576 B
 
+// DROP (mlp_drop > 0): the forward's two masks re-created from the counter-based hash (hma_common.h drop_keep; chain B forward or the
+// GELU2 / RESID epilogues applied them): dy is masked as it is loaded (and written out for the fc2 weight gradient), hg and the
+// gradient entering gelu' carry the activation mask.
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
@@ -616,6 +620,13 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
     uint16_t* sp_du = nullptr;
     bool sv_ok = false;
     float s2acc = 0.f;
+    uint32_t dseed = 0, dth = 0;
+    float dsc = 1.f;
+    if constexpr (DROP) {
+      dseed = *p.drop_seed;
+      dth = drop_thresh(p.drop_p);
+      dsc = 1.0f / (1.0f - p.drop_p);
+    }
     MPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {
       MPROF_MARK(0);
@@ -648,6 +659,20 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(xh[j]), "+v"(dy[j]));
           asm volatile("" : "+v"(rs));
           if (hi == 0) ((HMA_LDS(float)*)(lds + MB_ST2 + pair * 256 + 128))[lr] = rs;  // the consumer reads it one step later
+          if constexpr (DROP) {  // the Dropout behind fc2: dy * keep / (1 - p), also written out for the fc2 weight / bias gradient
+            uint16_t* dd = reinterpret_cast<uint16_t*>(p.dy_drop) + row * 256 + 16 * hi;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int c0 = 32 * (j >> 1) + 8 * (j & 1);
+              float v[8];
+              unpack8(__builtin_bit_cast(uint4, dy[j]), v);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = drop_keep(dseed, p.drop_salt + 1, row * 256 + 16 * hi + c0 + e, dth) ? v[e] * dsc : 0.f;
+              const uint4 pk = pack8(v);
+              dy[j] = as_frag(pk);
+              if (row < p.M) *reinterpret_cast<uint4*>(dd + c0) = pk;
+            }
+          }
         }
         MPROF_MARK(3);
         HMA_LDS(char)* wb = lds + (g % MB_NSLOT) * MB_SLOT + lane * 16;
@@ -687,11 +712,24 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) dd[e] = D[8 * half + e];
+          bool keep[8];
+          if constexpr (DROP) {  // the Dropout behind the GELU: the gradient passes the same mask before gelu'
+            const int64_t e0 = row * 1024 + 32 * s + 16 * hi + 8 * half;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              keep[e] = drop_keep(dseed, p.drop_salt, e0 + e, dth);
+              dd[e] = keep[e] ? dd[e] * dsc : 0.f;
+            }
+          }
           if (MLP_ABL & 4) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) hg[e] = u[e], du[e] = dd[e];
           } else {
             gelu_bwd_n<8>(u, dd, hg, du);
+          }
+          if constexpr (DROP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hg[e] = keep[e] ? hg[e] * dsc : 0.f;
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) s2acc = __builtin_fmaf(du[e], U[8 * half + e], s2acc);  // du (W1f xhat): the pre-bias accumulator
@@ -1019,10 +1057,18 @@ extern "C" int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p) {
   if (!p || !p->xhat || !p->rstd || !p->dy || !p->dx || !p->dx_bf16 || !p->w1p || !p->w2tp || !p->w1tp || !p->b1 || !p->hg ||
       !p->du || p->M <= 0 || p->dy == p->dx_bf16)
     return HMA_EINVAL;
+  const bool drop = p->drop_p != 0.f;
+  if (drop && (!(p->drop_p > 0.f && p->drop_p < 1.f) || !p->drop_seed || !p->dy_drop || p->dy_drop == p->dx_bf16)) return HMA_EINVAL;
   const int64_t ntiles = (p->M + 127) >> 7;
   const int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
-  if (int rc = set_lds<mlp_bwd_kernel>(MB_SMEM)) return rc;
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(512), MB_SMEM, (hipStream_t)stream, *p);
+  if (drop) {
+    if (int rc = set_lds<mlp_bwd_kernel<true>>(MB_SMEM)) return rc;
+    hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(grid), dim3(512), MB_SMEM, (hipStream_t)stream, *p);
+    HMA_CHECK_LAUNCH();
+    return 0;
+  }
+  if (int rc = set_lds<mlp_bwd_kernel<false>>(MB_SMEM)) return rc;
+  hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(grid), dim3(512), MB_SMEM, (hipStream_t)stream, *p);
   HMA_CHECK_LAUNCH();
   return 0;
 }

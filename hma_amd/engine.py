@@ -210,7 +210,10 @@ class STEngine:
         # against 418 us for fc1 + fc2 + the next LayerNorm; backward 535-570 us against 379 us for dfc2 + dfc1 + LayerNorm
         # backward; the step as a whole comes out 1-2 % ahead with 1.4 GB less HBM traffic per layer.  Passes with fewer
         # rows than half a 128-row tile per CU keep the two GEMM launches.
-        self.fused_mlp = float(getattr(cfg, "mlp_drop", 0.0) or 0.0) == 0.0 and hid == 1024
+        # With mlp_drop > 0 a TRAINING pass is fused only where chain B runs its forward: chain B and hma_mlp_bwd carry the two
+        # nn.Dropout masks, hma_mlp_fwd does not.
+        self.mlp_drop = float(getattr(cfg, "mlp_drop", 0.0) or 0.0)
+        self.fused_mlp = hid == 1024
         self.fused_mlp_train = self.fused_mlp
         self.fused_mlp_min_rows = 128 * 128   # (the decode frame pass at B = 64, 20 480 rows = 160 tiles, is 17 % faster with it)
         if self.fused_mlp:
@@ -381,9 +384,11 @@ class STEngine:
         self._dom_fresh = set()
 
     # ------------------------------------------------------------------------------ workspace
-    def _use_fused(self, rows: int, train: bool) -> bool:
-        """Whether a pass over `rows` token rows runs the fused MLP block (see __init__)."""
+    def _use_fused(self, rows: int, train: bool, SA: int = 0) -> bool:
+        """Whether a pass over `rows` token rows (frames of SA rows) runs the fused MLP block (see __init__)."""
         if not self.fused_mlp:
+            return False
+        if train and self.mlp_drop > 0.0 and not (self.chain_b_ok and self.chain_b_train and SA > 0 and self._use_chain(rows, SA)):
             return False
         if train and rows % 32:  # hma_mlp_bwd hands gelu(u) / dL/du to the weight gradients in the HMA_A_BF16_FRAG32 order (LDS-DMA path only)
             return False
@@ -394,7 +399,7 @@ class STEngine:
         return self.use_chain and rows % 16 == 0 and SA % 16 == 0 and rows >= self.chain_min_rows
 
     def _workspace(self, B: int, T: int, S: int, A: int, train: bool) -> Dict[str, torch.Tensor]:
-        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train), self._use_chain(B * T * (S + A), S + A))
+        key = (B, T, S, A, train, self._use_fused(B * T * (S + A), train, S + A), self._use_chain(B * T * (S + A), S + A))
         if self._ws_key == key:
             return self._ws
         self._ws, self._plans = {}, {}
@@ -420,7 +425,7 @@ class STEngine:
         buf("lse_s", (Ls, M, 8), F32)
         buf("rstd1", (Ls, M), F32)
         buf("rstd2", (Ls, M), F32)
-        fused = self._use_fused(M, train)
+        fused = self._use_fused(M, train, SA)
         if not fused:  # the fused MLP block never materialises the hidden activation
             buf("u", (Ls, M, 1024), BF16)
             buf("hg", (Ls, M, 1024), BF16)
@@ -535,7 +540,8 @@ class STEngine:
                     sv.update(xhat1n=next_ln1[0], rstd1n=next_ln1[1])
             pl.chain_b_fwd(M, next_qkv_s is not None, segs=segs, o=b["o_t"], x=x, b_proj=pb("temporal_attn"),
                            b1=self.BF["fc1"][l].data_ptr(), b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
-                           b_qkv=self.BF["qkv_s"][l + 1].data_ptr() if next_qkv_s is not None else None, qkv=next_qkv_s, **sv)
+                           b_qkv=self.BF["qkv_s"][l + 1].data_ptr() if next_qkv_s is not None else None, qkv=next_qkv_s, **sv,
+                           **self._drop_fused(train, l))
             return
         pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
@@ -565,18 +571,24 @@ class STEngine:
             return {}
         return dict(drop_p=p, drop_salt=2 * l + which, drop_seed=self.drop_seed.data_ptr())
 
+    def _drop_fused(self, train: bool, l: int) -> dict:
+        """The same two sites for the kernels that hold both (chain B forward, hma_mlp_bwd): salts 2 l (activation), 2 l + 1 (output)."""
+        if not train or self.mlp_drop <= 0.0:
+            return {}
+        return dict(drop_p=self.mlp_drop, drop_salt=2 * l, drop_seed=self.drop_seed.data_ptr())
+
     def _forward_plan(self, B, T, S, A, train, domain, embed=True, l0=0, l1=None, readout=True, kv_cache=None,
                       T_cache=0) -> Plan:
         l1 = self.cfg.num_layers if l1 is None else l1
         # (T_cache is part of the key: a re-allocated cache of another length can land on the old one's address)
         key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else (kv_cache.data_ptr(), T_cache),
-               self._use_fused(B * T * (S + A), train), self._use_chain(B * T * (S + A), S + A))
+               self._use_fused(B * T * (S + A), train, S + A), self._use_chain(B * T * (S + A), S + A))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
         L = cfg.num_layers
         SA, M, Mi, Fr = S + A, B * T * (S + A), B * T * S, B * T
-        fused = self._use_fused(M, train)
+        fused = self._use_fused(M, train, SA)
         pl = Plan()
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         sl = (lambda l: l) if train else (lambda l: 0)
@@ -654,7 +666,7 @@ class STEngine:
         return pl
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
-        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True), self._use_chain(B * T * (S + A), S + A))
+        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -685,16 +697,20 @@ class STEngine:
             gw = lambda suffix: self._lw(l, suffix, "g")
             gb = lambda suffix, on=True: self._lw(l, suffix, "g") if on else None
             wt = lambda k: dp(self.WT[k], l, self.WT[k][0].numel())
-            if self._use_fused(M, True):
+            if self._use_fused(M, True, SA):
                 # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
                 # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
                 # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
                 dxb_new = ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr()
                 hg, du = ws["hg1"].data_ptr(), ws["du1"].data_ptr()
+                dkw = self._drop_fused(True, l)
+                dy2 = dxb  # dY of the fc2 weight gradient: behind the output Dropout when there is one (written by hma_mlp_bwd)
+                if dkw:
+                    dy2 = dkw["dy_drop"] = ws["dxm"].data_ptr()
                 pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
                            w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
-                           b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du)
-                pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16_FRAG32, M=M, N=256, K=1024,
+                           b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du, **dkw)
+                pl.gemm_tn_pair(dict(dY=dy2, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16_FRAG32, M=M, N=256, K=1024,
                                      dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
                                 dict(dY=du, ldy=1024, y_kind=A_BF16_FRAG32, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
                                      gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,

@@ -91,10 +91,12 @@ def make_mlp_fwd(*, M: int, xhat: int, x: int, w1p: int, w2p: int, b1: int, b2: 
 
 
 def make_mlp_bwd(*, M: int, xhat: int, rstd: int, dy: int, dx: int, dx_bf16: int, w1p: int, w2tp: int, w1tp: int, b1: int,
-                 hg: int, du: int) -> MlpBwd:
+                 hg: int, du: int, drop_p: float = 0.0, drop_salt: int = 0, drop_seed: Optional[int] = None,
+                 dy_drop: Optional[int] = None) -> MlpBwd:
     g = MlpBwd()
     g.xhat, g.rstd, g.dy, g.dx, g.dx_bf16 = xhat, rstd, dy, dx, dx_bf16
     g.w1p, g.w2tp, g.w1tp, g.b1, g.hg, g.du, g.M = w1p, w2tp, w1tp, b1, hg, du, M
+    g.drop_p, g.drop_salt, g.drop_seed, g.dy_drop = drop_p, drop_salt, drop_seed, dy_drop
     return g
 
 
@@ -136,7 +138,8 @@ def make_chain_a_fwd(*, M: int, segs, o: int, x: int, qkv: int, ldq: int = 768, 
 def make_chain_b_fwd(*, M: int, segs, o: int, x: int, b1: int, b_proj: Optional[int] = None, b2: Optional[int] = None,
                      b_qkv: Optional[int] = None, qkv: Optional[int] = None, ldq: int = 768, ln_eps: float = 1e-5,
                      xhat2: Optional[int] = None, rstd2: Optional[int] = None, xhat1n: Optional[int] = None,
-                     rstd1n: Optional[int] = None) -> ChainBFwd:
+                     rstd1n: Optional[int] = None, drop_p: float = 0.0, drop_salt: int = 0,
+                     drop_seed: Optional[int] = None) -> ChainBFwd:
     """segs: packed proj (8), the 64 alternating fc1 / fc2 bundles, and -- with `qkv` -- the next block's folded qkv (24)."""
     g = ChainBFwd()
     _chain_weights(g.w, segs)
@@ -144,6 +147,7 @@ def make_chain_b_fwd(*, M: int, segs, o: int, x: int, b1: int, b_proj: Optional[
     g.b_proj, g.b1, g.b2, g.b_qkv = b_proj, b1, b2, b_qkv
     g.qkv, g.ldq, g.M, g.ln_eps = qkv, ldq, M, ln_eps
     g.xhat2, g.rstd2, g.xhat1n, g.rstd1n = xhat2, rstd2, xhat1n, rstd1n
+    g.drop_p, g.drop_salt, g.drop_seed = drop_p, drop_salt, drop_seed
     return g
 
 

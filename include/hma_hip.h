@@ -327,7 +327,7 @@ int hma_transpose_cast_bf16(void* stream, const float* src, void* dst, int32_t r
 int hma_fold_ln_bf16(void* stream, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* bf,
                      int32_t rows, int32_t cols, int32_t batch, int64_t in_stride, int64_t wf_stride, int64_t bf_stride);
 
-/* ---- Fused MLP block (st_transformer.py:24-27 Mlp.forward as called from STBlock.forward :112; mlp_drop == 0) ----------
+/* ---- Fused MLP block (st_transformer.py:24-27 Mlp.forward as called from STBlock.forward :112; forward: mlp_drop == 0) ----------
  * hma_mlp_pack: a weight matrix rearranged into the MFMA-fragment order the fused kernels stream (512 fragments of 1 KB):
  *   kind 0: logical A[1024][256], kind 1: logical A[256][1024]; A[r][c] = src[r * row_stride + c * col_stride] *
  *   (row_scale ? row_scale[r] : 1) * (col_scale ? col_scale[c] : 1), rounded to bf16.  `batch` matrices, `src_batch_stride`
@@ -362,6 +362,10 @@ typedef struct {
   const void* w1p; const void* w2tp; const void* w1tp; const float* b1;
   void* hg; void* du;
   int64_t M;
+  /* mlp_drop > 0 (else 0 / NULL): the forward's two masks re-created (salts drop_salt: activation, drop_salt + 1: branch output,
+   * see hma_chain_b_fwd_t): dy is masked as it is loaded and the masked rows are written to dy_drop (bf16 [M,256]: what the fc2
+   * weight / bias gradient must read instead of dy), hg and du carry the activation mask. */
+  float drop_p; int32_t drop_salt; const uint32_t* drop_seed; void* dy_drop;
 } hma_mlp_bwd_t;
 int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p);
 
@@ -437,6 +441,10 @@ typedef struct {
   /* training (all NULL in inference): xhat2 = LN(x1) bf16 [M,256] and rstd2 [M] (norm2, what hma_mlp_bwd re-reads), xhat1n / rstd1n
    * = LN(x2) and its 1 / sigma (the next block's norm1; required with qkv) */
   void* xhat2; float* rstd2; void* xhat1n; float* rstd1n;
+  /* training with mlp_drop > 0 (drop_p in (0, 1), else 0 / NULL): the two nn.Dropout sites of Mlp.forward (st_transformer.py:25-26)
+   * with hma_gemm_nt_t's counter-based mask: gelu(u) * keep(drop_salt, row * 1024 + hidden unit) / (1 - p), then
+   * (fc2 output + b2) * keep(drop_salt + 1, row * 256 + column) / (1 - p) before the residual add.  Requires xhat2. */
+  float drop_p; int32_t drop_salt; const uint32_t* drop_seed;
 } hma_chain_b_fwd_t;
 int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p);
 

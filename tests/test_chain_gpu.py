@@ -162,6 +162,24 @@ def test_chain_a_bwd(M, rpf, mod):
 @pytest.mark.parametrize("M,with_qkv,save", [(112, True, False), (1008, True, True), (20480, True, False), (40960, True, True),
                                              (2560, False, False), (2560, False, True)])
 def test_chain_b_fwd(M, with_qkv, save):
+    _chain_b_case(M, with_qkv, save, 0.0)
+
+
+@pytest.mark.parametrize("M,with_qkv", [(1008, True), (4096, False)])
+def test_chain_b_fwd_dropout(M, with_qkv):
+    """mlp_drop > 0 (training): gelu(u) and the branch output pass nn.Dropout (st_transformer.py:25-26) with the counter-based masks
+    of the GEMM epilogues / hma_dropout_bf16 (salts s and s + 1), so hma_mlp_bwd can re-create them."""
+    _chain_b_case(M, with_qkv, True, 0.1)
+
+
+def _drop_mask(M, cols, p, seed, salt):
+    ones = torch.ones(M, cols, device=DEV)
+    out = torch.empty(M, cols, dtype=torch.bfloat16, device=DEV)
+    _lib.call("hma_dropout_bf16", ops.stream_ptr(), ones.data_ptr(), out.data_ptr(), M, cols, p, seed.data_ptr(), salt)
+    return (out.float() > 0).float().cpu() / (1.0 - p)
+
+
+def _chain_b_case(M, with_qkv, save, p_drop):
     """proj_t + residual -> norm2 -> fc1 -> GELU -> fc2 + residual -> the next block's norm1 -> qkv, one launch (inference form:
     nothing saved).  Reference: hma/model/st_transformer.py:111-112, :24-27, :85-86; hma/model/attention.py:39,60."""
     gq = lambda s_: torch.Generator().manual_seed(s_)
@@ -177,9 +195,14 @@ def test_chain_b_fwd(M, with_qkv, save):
     # reference: the LayerNorm affines folded like the engine folds them (W diag(gamma) in bf16, bias + W beta in fp32)
     w1f, b1f = rb(w1 * g2), b1 + w1 @ be2
     wqf, bqf = rb(wq * g1), bq + wq @ be1
+    m0, m1, dkw = 1.0, 1.0, {}
+    if p_drop > 0:
+        seed = torch.tensor([777], dtype=torch.int32, device=DEV)
+        m0, m1 = _drop_mask(M, 1024, p_drop, seed, 10), _drop_mask(M, 256, p_drop, seed, 11)
+        dkw = dict(drop_p=p_drop, drop_salt=10, drop_seed=seed.data_ptr())
     x1 = x + o @ wp.t() + bp
     u = rb(F.layer_norm(x1, (256,), eps=1e-5)) @ w1f.t() + b1f
-    x2 = x1 + rb(F.gelu(u)) @ w2.t() + b2
+    x2 = x1 + (rb(F.gelu(u) * m0) @ w2.t() + b2) * m1
     qkv = rb(F.layer_norm(x2, (256,), eps=1e-5)) @ wqf.t() + bqf
     # kernel
     d = lambda t: t.to(DEV).contiguous()
@@ -200,9 +223,13 @@ def test_chain_b_fwd(M, with_qkv, save):
         if with_qkv:
             kw.update(xhat1n=ops.ptr(xh1o), rstd1n=ops.ptr(rs1o))
     a = ops.make_chain_b_fwd(M=M, segs=segs, o=ops.ptr(od), x=ops.ptr(xd), b_proj=ops.ptr(bpd), b1=ops.ptr(b1d), b2=ops.ptr(b2d),
-                             b_qkv=ops.ptr(bqd) if with_qkv else None, qkv=ops.ptr(qo) if with_qkv else None, **kw)
+                             b_qkv=ops.ptr(bqd) if with_qkv else None, qkv=ops.ptr(qo) if with_qkv else None, **kw, **dkw)
     _lib.call("hma_chain_b_fwd", ops.stream_ptr(), C.byref(a))
     torch.cuda.synchronize()
+    if p_drop > 0:  # a dropped output element is the residual exactly; the masks do drop
+        gone = m1 == 0
+        assert 0.05 < gone.float().mean() < 0.15
+        assert (xd.cpu()[gone] - x1[gone]).abs().max() < 1e-5
     close(xd, x2, 3e-3, "x2")
     assert rms(xd.cpu() - x, x2 - x) < 5e-3
     if with_qkv:

@@ -706,6 +706,25 @@ def _from_frag32(t, M):
 
 @pytest.mark.parametrize("M", [128, 1000, 40960])
 def test_mlp_bwd_fused(M):
+    _mlp_bwd_case(M, 0.0)
+
+
+@pytest.mark.parametrize("M", [128, 4096 + 32])
+def test_mlp_bwd_fused_dropout(M):
+    """mlp_drop > 0: hma_mlp_bwd re-creates the forward's two masks (the hash of hma_dropout_bf16 / the GEMM epilogues): dy is masked
+    (and written to dy_drop for the fc2 weight gradient), hg and the gradient entering gelu' carry the activation mask."""
+    _mlp_bwd_case(M, 0.1)
+
+
+def _drop_mask(M, cols, p, seed, salt):
+    """keep / (1 - p) per element, from hma_dropout_bf16 applied to ones (1 / 0.9 is not exact in bf16: normalise)"""
+    ones = torch.ones(M, cols, device=DEV)
+    out = torch.empty(M, cols, dtype=torch.bfloat16, device=DEV)
+    _lib.call("hma_dropout_bf16", ops.stream_ptr(), ones.data_ptr(), out.data_ptr(), M, cols, p, seed.data_ptr(), salt)
+    return (out.float() > 0).float().cpu() / (1.0 - p)
+
+
+def _mlp_bwd_case(M, p_drop):
     w1, b1, w2, b2, gam, bet = _mlp_weights(200)
     x = torch.randn(M, 256, generator=g(17)) * 1.5 + 0.3
     mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
@@ -721,17 +740,29 @@ def test_mlp_bwd_fused(M):
     Mt = (M + 127) // 128 * 128
     hg = torch.zeros(Mt, 1024, dtype=torch.bfloat16, device=DEV)  # HMA_A_BF16_FRAG32 order
     du = torch.zeros(Mt, 1024, dtype=torch.bfloat16, device=DEV)
+    dkw, m0, m1 = {}, 1.0, 1.0
+    if p_drop > 0:
+        seed = torch.tensor([12345], dtype=torch.int32, device=DEV)
+        dyo = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+        dkw = dict(drop_p=p_drop, drop_salt=6, drop_seed=seed.data_ptr(), dy_drop=ops.ptr(dyo))
+        m0, m1 = _drop_mask(M, 1024, p_drop, seed, 6), _drop_mask(M, 256, p_drop, seed, 7)
+        assert 0.85 < (m0 > 0).float().mean() < 0.95 and 0.85 < (m1 > 0).float().mean() < 0.95
     a = ops.make_mlp_bwd(M=M, xhat=ops.ptr(xhd), rstd=ops.ptr(rsd), dy=ops.ptr(dyd), dx=ops.ptr(dxd), dx_bf16=ops.ptr(dxb),
                          w1p=ops.ptr(pk["w1p"]), w2tp=ops.ptr(pk["w2tp"]), w1tp=ops.ptr(pk["w1tp"]), b1=ops.ptr(b1f),
-                         hg=ops.ptr(hg), du=ops.ptr(du))
+                         hg=ops.ptr(hg), du=ops.ptr(du), **dkw)
     _lib.call("hma_mlp_bwd", ops.stream_ptr(), C.byref(a))
     torch.cuda.synchronize()
     # reference (fp32 math on the rounded operands)
     w1f = rb(w1 * gam)
     u = xh @ w1f.t() + (b1 + w1 @ bet)
     cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
-    hgr = u * cdf
-    dhg = dy @ rb(w2)
+    hgr = u * cdf * m0
+    if p_drop > 0:
+        dy = rb(dy * m1)  # the gradient behind the output Dropout
+        close(dyo, dy, BF, "dy_drop")
+        assert torch.equal(dyo.float().cpu() == 0, (m1 == 0) | (dy == 0))
+        dyd = dyo
+    dhg = (dy @ rb(w2)) * m0
     dur = dhg * (cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi))
     close(_from_frag32(hg, M), hgr, 2 * BF, "hg")
     close(_from_frag32(du, M), dur, 2 * BF, "du")

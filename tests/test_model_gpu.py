@@ -38,8 +38,8 @@ def _note(key, val):
         pass
 
 
-def build_model(train=True, initlike=False):
-    cfg = GenieConfig(**TINY["config"])
+def build_model(train=True, initlike=False, **cfg_over):
+    cfg = GenieConfig(**{**TINY["config"], **cfg_over})
     m = STMaskGIT(cfg)
     m.init_action_projectors(TINY["domains"], TINY["d_actions"], TINY["action_stats"], cfg.action_network)
     m.load_state_dict(tiny_state_dict(initlike=initlike), strict=True)
@@ -285,8 +285,8 @@ def test_clip_adamw_two_steps_vs_golden():
         assert abs(out.loss.item() - g[f"step{it}.loss"].item()) <= (5e-3 if it == 0 else 1.5e-2), it  # step 1 runs on weights that already took a sign-like Adam step
         norm = m._engine.grad_norm().item()
         _note(f"adamw.step{it}.grad_norm_rel_err", abs(norm - g[f"step{it}.grad_norm"].item()) / g[f"step{it}.grad_norm"].item())
-        assert abs(norm - g[f"step{it}.grad_norm"].item()) <= 3e-2 * g[f"step{it}.grad_norm"].item()
-    worst = 0.0
+        assert abs(norm - g[f"step{it}.grad_norm"].item()) <= 5e-3 * g[f"step{it}.grad_norm"].item()  # measured 1.1e-3 / 5e-4
+    worst, errs = 0.0, []
     for name, p in m.named_parameters():
         flat = p.detach().reshape(-1).cpu()
         idx = torch.linspace(0, flat.numel() - 1, 64).long()
@@ -300,8 +300,14 @@ def test_clip_adamw_two_steps_vs_golden():
         du, dr = flat[idx] - old, ref - old
         err = (du - dr).pow(2).mean().sqrt().item() / (dr.pow(2).mean().sqrt().item() + 1e-12)
         worst = max(worst, err)
-        assert err <= 0.35, f"{name}: update err {err:.3f}"
+        errs.append(err)
+        # measured worst 0.21 (one parameter whose sampled elements include near-zero gradients: a bf16-noise sign flip moves an
+        # element by 2 lr, i.e. one flipped element of 64 is an rms error of 2 / 8 = 0.25 of the update)
+        assert err <= 0.26, f"{name}: update err {err:.3f}"
+    errs.sort()
     _note("adamw.worst_update_rel_err", worst)
+    _note("adamw.median_update_rel_err", errs[len(errs) // 2])
+    assert errs[len(errs) // 2] <= 0.08, errs[len(errs) // 2]  # the typical parameter: no flipped element among the 64 sampled
 
 
 def test_trainer_step_equals_autograd_path_and_checkpoint_roundtrip(tmp_path):
@@ -433,3 +439,36 @@ def test_evaluator_loss_matches_plain_cross_entropy():
     want = torch.nn.functional.cross_entropy(logits, fl, reduction="none").sum(dim=1).mean().item()
     got = compute_loss(labels, logits.to(DEV))
     assert abs(got - want) <= 2e-5 * abs(want), (got, want)
+
+
+def test_mlp_dropout_fused_path_equals_epilogue_path():
+    """mlp_drop > 0 in training: chain B forward + hma_mlp_bwd re-create the SAME counter-based masks as the GELU2 / RESID epilogues +
+    hma_dropout_bf16 of the unfused path (salts 2 l, 2 l + 1 of one device seed), so the two paths give the same loss and gradients up
+    to bf16 rounding -- and both differ from the no-dropout loss."""
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    res = {}
+    for tag in ("fused", "unfused"):
+        m = build_model(mlp_drop=0.1)
+        eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+        eng.fused_mlp_min_rows = 0
+        if tag == "unfused":
+            eng.fused_mlp = False
+        out = m(input_ids=inp["input_ids"], labels=inp["labels"], action_ids=inp["actions_domA"], domain=["domA"] * 2)
+        out.loss.backward()
+        M = 2 * m.config.T * (256 + m.config.action_token_size)
+        assert eng._use_fused(M, True, 256 + m.config.action_token_size) == (tag == "fused")
+        res[tag] = (out.loss.item(), {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None})
+    (la, ga), (lb, gb) = res["fused"], res["unfused"]
+    _note("dropout.fused_vs_unfused.loss", [la, lb])
+    assert abs(la - lb) <= 2e-3 * abs(lb), (la, lb)
+    worst = 0.0
+    for n in gb:
+        den = gb[n].pow(2).mean().sqrt().item()
+        if den == 0:
+            continue
+        worst = max(worst, (ga[n] - gb[n]).pow(2).mean().sqrt().item() / den)
+    _note("dropout.fused_vs_unfused.worst_grad_rms", worst)
+    assert worst <= 3e-2, worst
+    m0 = build_model()
+    l0 = m0(input_ids=inp["input_ids"], labels=inp["labels"], action_ids=inp["actions_domA"], domain=["domA"] * 2).loss.item()
+    assert abs(la - l0) > 1e-4 * abs(l0)

@@ -180,7 +180,8 @@ def test_two_adamw_steps_match_reference():
         assert moved > 0, name
         worst = max(worst, err / moved)
         # Adam turns a gradient into +-lr steps: an element whose gradient is bf16 rounding noise can land one step away
-        assert err <= 0.35 * moved, (name, err, moved)
+        assert err <= 0.30 * moved, (name, err, moved)
+    print("stmar adamw worst update err / moved", worst)
 
 
 def test_mar_trainer_resume_roundtrip(tmp_path):
