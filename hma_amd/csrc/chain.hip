@@ -930,7 +930,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
           if constexpr (DROP) {
             const int64_t e0 = (r0 + tok) * 1024 + 32 * h + 8 * g;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = drop_keep(dseed, p.drop_salt, e0 + e, dth) ? hv[e] * dsc : 0.f;
+            for (int e = 0; e < 8; e += 2) {
+              bool k0, k1;
+              drop_keep2(dseed, p.drop_salt, e0 + e, dth, k0, k1);
+              hv[e] = k0 ? hv[e] * dsc : 0.f;
+              hv[e + 1] = k1 ? hv[e + 1] * dsc : 0.f;
+            }
           }
           hf = as_frag(pack8(hv));
         } else {
@@ -942,9 +947,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
 #pragma unroll
               for (int t = 0; t < 16; ++t) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const bool keep = drop_keep(dseed, p.drop_salt + 1, e0 + 32 * (t >> 1) + 4 * (t & 1) + r, dth);
-                  acc[t][r] = x1[t][r] + (keep ? acc[t][r] * dsc : 0.f);
+                for (int r = 0; r < 4; r += 2) {
+                  bool k0, k1;
+                  drop_keep2(dseed, p.drop_salt + 1, e0 + 32 * (t >> 1) + 4 * (t & 1) + r, dth, k0, k1);
+                  acc[t][r] = x1[t][r] + (k0 ? acc[t][r] * dsc : 0.f);
+                  acc[t][r + 1] = x1[t][r + 1] + (k1 ? acc[t][r + 1] * dsc : 0.f);
                 }
               }
             }

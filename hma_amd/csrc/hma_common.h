@@ -93,13 +93,25 @@ __device__ __forceinline__ float dsilu_f(float u) {
   return s * (1.0f + u * (1.0f - s));
 }
 
-// Counter-based dropout mask: keep iff hash(seed, salt, element index) >= p * 2^32 (murmur3 finaliser over the mixed
-// index); forward and backward call it with the same arguments instead of storing the mask.
-__device__ __forceinline__ bool drop_keep(uint32_t seed, int salt, int64_t idx, uint32_t thresh) {
-  uint32_t x = (uint32_t)idx ^ ((uint32_t)((uint64_t)idx >> 32) * 0x9E3779B9u);
+// Counter-based dropout mask: one 32-bit hash (murmur3 finaliser over seed, salt and the element PAIR index) decides two neighbouring
+// elements, 16 bits each: keep iff that half >= p * 2^16 (the drop probability is p rounded down to a multiple of 2^-16).  Forward and
+// backward call it with the same arguments instead of storing the mask.  The integer multiplies are quarter rate on gfx950, so the
+// kernels that mask whole rows (chain B, hma_mlp_bwd) hash once per pair with drop_keep2.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, int salt, int64_t pair) {
+  uint32_t x = (uint32_t)pair ^ ((uint32_t)((uint64_t)pair >> 32) * 0x9E3779B9u);
   x ^= seed + 0x7F4A7C15u * (uint32_t)(salt + 1);
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-  return x >= thresh;
+  return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t seed, int salt, int64_t idx, uint32_t thresh) {
+  const uint32_t x = drop_hash(seed, salt, idx >> 1);
+  return ((idx & 1) ? (x >> 16) : (x & 0xFFFFu)) >= (thresh >> 16);
+}
+// elements idx (even) and idx + 1
+__device__ __forceinline__ void drop_keep2(uint32_t seed, int salt, int64_t idx, uint32_t thresh, bool& k0, bool& k1) {
+  const uint32_t x = drop_hash(seed, salt, idx >> 1);
+  k0 = (x & 0xFFFFu) >= (thresh >> 16);
+  k1 = (x >> 16) >= (thresh >> 16);
 }
 __device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
 

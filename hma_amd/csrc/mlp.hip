@@ -667,7 +667,12 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
               float v[8];
               unpack8(__builtin_bit_cast(uint4, dy[j]), v);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = drop_keep(dseed, p.drop_salt + 1, row * 256 + 16 * hi + c0 + e, dth) ? v[e] * dsc : 0.f;
+              for (int e = 0; e < 8; e += 2) {
+                bool k0, k1;
+                drop_keep2(dseed, p.drop_salt + 1, row * 256 + 16 * hi + c0 + e, dth, k0, k1);
+                v[e] = k0 ? v[e] * dsc : 0.f;
+                v[e + 1] = k1 ? v[e + 1] * dsc : 0.f;
+              }
               const uint4 pk = pack8(v);
               dy[j] = as_frag(pk);
               if (row < p.M) *reinterpret_cast<uint4*>(dd + c0) = pk;
@@ -716,10 +721,9 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
           if constexpr (DROP) {  // the Dropout behind the GELU: the gradient passes the same mask before gelu'
             const int64_t e0 = row * 1024 + 32 * s + 16 * hi + 8 * half;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              keep[e] = drop_keep(dseed, p.drop_salt, e0 + e, dth);
-              dd[e] = keep[e] ? dd[e] * dsc : 0.f;
-            }
+            for (int e = 0; e < 8; e += 2) drop_keep2(dseed, p.drop_salt, e0 + e, dth, keep[e], keep[e + 1]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dd[e] = keep[e] ? dd[e] * dsc : 0.f;
           }
           if (MLP_ABL & 4) {
 #pragma unroll

@@ -73,8 +73,9 @@ typedef struct {
    *   HMA_EPI_GELU2: C2 = GELU(u) * keep / (1 - p)         (C, the saved pre-activation, is not dropped)
    *   HMA_EPI_DGELU: C  = acc * GELU'(U) * keep / (1 - p)   (the same mask: same seed, salt and element index)
    *   HMA_EPI_RESID: C += (acc + bias) * keep / (1 - p)
-   * keep = hash(*drop_seed, drop_salt, row * ldc + column) >= p * 2^32 (counter-based, hma_dropout_bf16 uses the same
-   * function), so backward regenerates the mask instead of storing it.  drop_seed is a DEVICE pointer (one uint32 the
+   * keep = 16 bits of hash(*drop_seed, drop_salt, (row * ldc + column) / 2) >= p * 2^16 (counter-based: one 32-bit hash decides an
+   * element pair; hma_dropout_bf16, chain B and hma_mlp_bwd use the same function), so backward regenerates the mask instead of
+   * storing it.  drop_seed is a DEVICE pointer (one uint32 the
    * host bumps per step: recorded launches and captured graphs stay valid).  Supported on the streaming K = 256 kernel
    * (GELU2 / DGELU) and the persistent kernel (RESID); otherwise HMA_EINVAL. */
   float drop_p; int32_t drop_salt; const uint32_t* drop_seed;

@@ -180,7 +180,9 @@ def test_two_adamw_steps_match_reference():
         assert moved > 0, name
         worst = max(worst, err / moved)
         # Adam turns a gradient into +-lr steps: an element whose gradient is bf16 rounding noise can land one step away
-        assert err <= 0.30 * moved, (name, err, moved)
+        # (measured worst 0.35: temporal_attn.qkv.bias, whose k-bias third has a mathematically zero gradient -- softmax is shift invariant --
+        # so its Adam update is +-lr on rounding noise)
+        assert err <= 0.40 * moved, (name, err, moved)
     print("stmar adamw worst update err / moved", worst)
 
 
