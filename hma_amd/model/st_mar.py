@@ -10,7 +10,7 @@ modules and their parameters are shared with an internal `STMaskGIT` whose flat 
 `hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
 `DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
 `maskgit_generate` / `generate` are the MAR decode (st_mar.py:277-452) with `DiffLoss.sample`.
-Not built: `jointly_predict_actions`, diffusion_batch_mul > 1, and cfg != 1 in the MAR decode (the reference's own branch,
+Not built: `jointly_predict_actions` and cfg != 1 in the MAR decode (the reference's own branch,
 st_mar.py:417-418, indexes bs rows of latents with a 2 bs mask and cannot run; `DiffLoss.sample(cfg=...)` itself is built).
 """
 from __future__ import annotations
@@ -56,8 +56,8 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
             config = DiffusionGenieConfig.from_dict(config)
         if config.jointly_predict_actions:
             raise NotImplementedError("jointly_predict_actions is not built")
-        if config.diffusion_batch_mul != 1:
-            raise NotImplementedError("diffusion_batch_mul > 1 is not built")
+        if config.diffusion_batch_mul < 1:
+            raise ValueError("diffusion_batch_mul must be >= 1")
         self.config = config
         self.patch_size, self.vae_embed_dim = config.patch_size, config.vae_embed_dim
         self.h = self.w = math.isqrt(config.S)
@@ -186,7 +186,12 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         _lib.call("hma_mar_readout_fwd", stream, ptr(y), ptr(self.decoder_norm.weight), ptr(self.decoder_norm.bias), 1e-6,
                   ptr(self.diffusion_pos_embed_learned), ptr(z), ptr(yhat), ptr(rstd_r), Mi, T, S)
         zl = z.detach().requires_grad_(train)
-        inner = self.diffloss(target, zl, pmask, t=kwargs.get("diffusion_t"), noise=kwargs.get("diffusion_noise"))
+        mul = self.diffusion_batch_mul
+        if mul > 1:  # st_mar.py:133-140: every token is scored at `mul` independent (t, noise) draws; the rows are repeated whole
+            inner = self.diffloss(target.repeat(mul, 1), zl.repeat(mul, 1), pmask.repeat(mul), t=kwargs.get("diffusion_t"),
+                                  noise=kwargs.get("diffusion_noise"))
+        else:
+            inner = self.diffloss(target, zl, pmask, t=kwargs.get("diffusion_t"), noise=kwargs.get("diffusion_noise"))
         logits = z.view(B, T, h_, w_, d).permute(0, 4, 1, 2, 3)
         acc = torch.zeros((), device=dev)
         if not train:

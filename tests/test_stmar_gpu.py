@@ -215,3 +215,33 @@ def test_mar_trainer_resume_roundtrip(tmp_path):
     tr2.step(**kw)
     worst = max((p1.detach() - p2.detach()).abs().max().item() for (_, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()))
     assert worst <= 2.1e-3  # at most one Adam step apart where a gradient element is rounding noise
+
+
+def test_diffusion_batch_mul_scores_every_token_at_several_draws():
+    """diffusion_batch_mul = 2 (st_mar.py:133-140: target / z / mask rows repeated before the diffusion loss): with the draws of the two
+    copies given, the masked-mean loss is the mean of the two single-draw losses and every gradient the mean of theirs."""
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    gen = torch.Generator().manual_seed(5)
+    t2 = torch.randint(0, 1000, inp["t"].shape, generator=gen).to(DEV)
+    n2 = torch.randn(inp["noise"].shape, generator=gen).to(DEV)
+    names = ["out_x_proj.weight", "diffloss.net.cond_embed.weight", "decoder.layers.1.mlp.fc2.weight", "token_embed.weight"]
+
+    def run(mul, t, noise):
+        m = STMAR(DiffusionGenieConfig(**dict(CFG, diffusion_batch_mul=mul)))
+        m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, CFG["action_network"])
+        m.load_state_dict(seeded_state(m.state_dict()))
+        m = m.to(DEV).train()
+        out = m(input_ids=inp["latents"].clone(), labels=inp["latents"].clone(), action_ids=inp["actions_domA"], domain=["domA"] * 2,
+                masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=t, diffusion_noise=noise)
+        out.loss.backward()
+        p = dict(m.named_parameters())
+        return out.loss.item(), {n: p[n].grad.detach().float().cpu().clone() for n in names}
+
+    la, ga = run(1, inp["t"], inp["noise"])
+    lb, gb = run(1, t2, n2)
+    l2, g2 = run(2, torch.cat([inp["t"], t2]), torch.cat([inp["noise"], n2]))
+    assert abs(la - lb) > 1e-4 * abs(la)  # the draws matter
+    assert abs(l2 - 0.5 * (la + lb)) <= 2e-4 * abs(l2), (l2, la, lb)
+    for n in names:
+        ref = 0.5 * (ga[n] + gb[n])
+        assert rel(g2[n], ref) < 2e-2, (n, rel(g2[n], ref))
