@@ -889,9 +889,11 @@ class STEngine:
             self._last = (B, T, S, A, domain)
         return ws
 
-    def trunk_train_backward(self, fill_dx: Callable[[dict], None], embed_bwd: Callable[[dict], None]) -> None:
+    def trunk_train_backward(self, fill_dx: Callable[[dict], None], embed_bwd: Callable[[dict], None],
+                             on_segment: Optional[Callable[[str], None]] = None, segment_layers: int = 0) -> None:
         """`fill_dx(ws)` writes d loss / d x_out into ws["dx"] (zeroed before) -> backward of the ST-blocks -> `embed_bwd(ws)`
-        consumes ws["dx"] (= d loss / d x_in) and adds the action rows' sum into ws["da_emb"] -> adaLN stacks and action stem."""
+        consumes ws["dx"] (= d loss / d x_in) and adds the action rows' sum into ws["da_emb"] -> adaLN stacks and action stem.
+        `on_segment(label)` as in `backward`: called after every `segment_layers` enqueued layers ('layer<l>', then 'end')."""
         B, T, S, A, domain = self._last
         ws = self._ws
         stream = torch.cuda.current_stream().cuda_stream
@@ -899,9 +901,20 @@ class STEngine:
         ws["da_emb"].zero_()
         fill_dx(ws)
         pl = self._backward_plan(B, T, S, A, domain)
-        pl.run(stream, pl.marks["post_readout"], pl.marks["embed"], timer=self.timer)
+        start = pl.marks["post_readout"]
+        if on_segment is not None and segment_layers > 0:
+            L = self.cfg.num_layers
+            for l in reversed(range(L)):
+                if (L - l) % segment_layers == 0 or l == 0:
+                    stop = pl.marks[f"layer{l}"]
+                    pl.run(stream, start, stop, timer=self.timer)
+                    start = stop
+                    on_segment(f"layer{l}")
+        pl.run(stream, start, pl.marks["embed"], timer=self.timer)
         embed_bwd(ws)
         pl.run(stream, pl.marks["post_embed"], None, timer=self.timer)
+        if on_segment is not None and segment_layers > 0:
+            on_segment("end")
 
     def run_trunk(self, x_BTSD: torch.Tensor, a_emb: Optional[torch.Tensor], domain: Optional[str], l0: int = 0,
                   l1: Optional[int] = None) -> torch.Tensor:

@@ -332,6 +332,9 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         eng = self._core._engine
         z0 = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
         sv["inner"].backward(grad_out)                       # DiffLoss: parameter grads + d loss / d z
+        hooks = self.__dict__.get("_bwd_hooks") or {}         # (a data-parallel driver: MarTrainer, last micro-batch of a step)
+        if hooks.get("after_head"):
+            hooks["after_head"]()                             # the head's gradients are final: their all-reduce can start now
         dz = sv["zl"].grad.contiguous()
         dy, dpos2, dg_n, db_n = z0(Mi, d), z0(self.diffusion_pos_embed_learned.shape), z0(d), z0(d)
         _lib.call("hma_mar_readout_bwd", stream, ptr(dz), ptr(sv["yhat"]), ptr(sv["rstd_r"]), ptr(self.decoder_norm.weight), ptr(dy), ptr(dpos2),
@@ -357,7 +360,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
             self._nt(stream, A=ptr(dxtok), lda=d, a_kind=A_F32, W=ptr(sv["wtok_t"]), ldw=d, M=Mi, N=_PAD, K=d, epi=EPI_F32, Cp=ptr(dpatch), ldc=_PAD)
             _lib.call("hma_mar_mask_token_bwd", stream, ptr(dpatch), _PAD, ptr(sv["mk"]), ptr(dmask_tok), Fr, H, W, Cc, p)
 
-        eng.trunk_train_backward(fill_dx, embed_bwd)
+        eng.trunk_train_backward(fill_dx, embed_bwd, on_segment=hooks.get("on_segment"), segment_layers=hooks.get("segment_layers", 0))
         self._grads_live = True
         with torch.no_grad():
             self._accum(self.out_x_proj.weight, dWo)
@@ -428,9 +431,20 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         self.__dict__["_own"] = own
         return own
 
-    def _own_gather_grads(self, own) -> None:
-        """Make the flat gradient buffer hold every own gradient (a caller may have produced fresh .grad tensors)."""
+    def _own_head_range(self, own):
+        """(start, stop) elements of the diffusion head's parameters inside the own flat range (they are consecutive in it)."""
+        idx = [i for i, n in enumerate(own["names"]) if n.startswith("diffloss.")]
+        assert idx == list(range(idx[0], idx[-1] + 1)), "the diffusion head's parameters are not consecutive"
+        a = (own["gviews"][idx[0]].data_ptr() - own["G"].data_ptr()) // 4
+        b = (own["gviews"][idx[-1]].data_ptr() - own["G"].data_ptr()) // 4 + own["gviews"][idx[-1]].numel()
+        return a, b
+
+    def _own_gather_grads(self, own, prefix: Optional[str] = None, skip: Optional[str] = None) -> None:
+        """Make the flat gradient buffer hold every own gradient (a caller may have produced fresh .grad tensors).  `prefix` /
+        `skip`: only the parameters whose names start with it / all but those."""
         for (n, p), gv in zip(self._own_named(), own["gviews"]):
+            if (prefix is not None and not n.startswith(prefix)) or (skip is not None and n.startswith(skip)):
+                continue
             if p.grad is None:
                 gv.zero_()
             elif p.grad.data_ptr() != gv.data_ptr():

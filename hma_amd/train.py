@@ -480,11 +480,14 @@ class MarTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm, self.warmup, self.accum = max_grad_norm, warmup_steps, grad_accum
         self.reducer = GradReducer(self.engine.layout, self.engine.G, layers_per_bucket)
+        self.layers_per_bucket = layers_per_bucket
         self.completed, self._micro = 0, 0
         self._active: List[str] = []
         self._known = False
         self.loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
         self.last_loss_info = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.force_overlap = False   # (tests: take the segmented / hooked backward on one rank too)
+        self.early_launches = 0      # reductions issued before the backward had finished (head range + trunk buckets)
 
     def micro_step(self, step_domains=None, **batch):
         """forward + backward of one micro-batch (`batch` = STMAR.forward's keyword arguments)."""
@@ -513,12 +516,35 @@ class MarTrainer:
         okf = ok.to(torch.float32)
         B = batch["input_ids"].shape[0]
         self.loss_info += torch.stack([torch.where(ok, loss, torch.zeros_like(loss)) * B, okf * B, 1.0 - okf, okf * 0.0])
-        (out.loss * (1.0 / (self.accum * red.world))).backward()
+        scaled = out.loss * (1.0 / (self.accum * red.world))
         self._micro += 1
-        if self._micro == self.accum and red.world > 1:
-            self.model._own_gather_grads(self.own)
+        if self._micro == self.accum and (red.world > 1 or self.force_overlap):
+            # Last micro-batch of the step: gradients become final in backward order -- the diffusion head first, then the trunk
+            # bucket by bucket, then the input / output stages -- and every finished range is all-reduced on the side stream
+            # while the backward goes on (the reference: DDP's bucketed reduction, train_multi.py:779, 990).
+            own, m = self.own, self.model
+            ha, hb = m._own_head_range(own)
             red.begin()
-            red.finish(self._active, extra=[self.own["G"], self.loss_info])
+
+            def after_head():
+                m._own_gather_grads(own, prefix="diffloss.")
+                red._launch_tensor(own["G"][ha:hb])
+                self.early_launches += 1
+
+            def on_segment(label):
+                n0 = red._next
+                red.on_segment(label)
+                self.early_launches += red._next - n0
+
+            m.__dict__["_bwd_hooks"] = dict(after_head=after_head, on_segment=on_segment, segment_layers=self.layers_per_bucket)
+            try:
+                scaled.backward()
+            finally:
+                m.__dict__["_bwd_hooks"] = None
+            m._own_gather_grads(own, skip="diffloss.")
+            red.finish(self._active, extra=[own["G"][:ha], own["G"][hb:], self.loss_info])
+        else:
+            scaled.backward()
         return out
 
     def optimizer_step(self) -> None:

@@ -128,12 +128,15 @@ def main_mar(out_path):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     model = build_mar()
-    tr = MarTrainer(model, lr=1e-3, warmup_steps=0)
+    tr = MarTrainer(model, lr=1e-3, warmup_steps=0, layers_per_bucket=1)
     losses = []
     for step in range(3):
         tr.step(step_domains=["domA", "domB"], **mar_batch(rank, step))
         losses.append(tr.reduced_loss().detach().clone())
     torch.cuda.synchronize()
+    # the bucketed path ran: per step the diffusion head's range and the two one-layer trunk buckets were all-reduced from inside
+    # the backward (before the input stage's gradients existed), the rest in finish()
+    assert tr.early_launches == 3 * 3, tr.early_launches
     if rank == 0:
         save_file(mar_digest(model, losses), out_path)
     dist.barrier()

@@ -245,3 +245,29 @@ def test_diffusion_batch_mul_scores_every_token_at_several_draws():
     for n in names:
         ref = 0.5 * (ga[n] + gb[n])
         assert rel(g2[n], ref) < 2e-2, (n, rel(g2[n], ref))
+
+
+def test_mar_trainer_segmented_backward_equals_plain():
+    """MarTrainer's data-parallel backward (hooks: the diffusion head's range reduced when the head backward is done, the trunk bucket
+    by bucket from `trunk_train_backward(on_segment=...)`, the input / output stages last) computes the same step as the plain one."""
+    from hma_amd.train import MarTrainer
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    kw = dict(input_ids=inp["latents"], labels=inp["latents"], action_ids=inp["actions_domA"], domain=["domA"] * 2,
+              masked_tokens_indicator=inp["masked"], h=[32, 32], w=[32, 32], diffusion_t=inp["t"], diffusion_noise=inp["noise"])
+    res = []
+    for overlap in (False, True):
+        m = build()
+        m.load_state_dict(seeded_state(m.state_dict()))
+        m = m.to(DEV).train()
+        tr = MarTrainer(m, lr=1e-3, warmup_steps=0, layers_per_bucket=1, grad_accum=2)
+        tr.force_overlap = overlap
+        for _ in range(2):
+            tr.micro_step(**kw)
+            tr.micro_step(**kw)
+            tr.optimizer_step()
+        assert tr.early_launches == (2 * 3 if overlap else 0)  # per step: head + two one-layer buckets, last micro-batch only
+        res.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    worst = max((res[0][n] - res[1][n]).abs().max().item() for n in res[0])
+    assert worst <= 2.1e-3, worst  # (atomics order: an Adam step of +-lr on a noise-level gradient element can flip)
+    same = sum(torch.equal(res[0][n], res[1][n]) for n in res[0]) / len(res[0])
+    assert same >= 0.5, same
