@@ -269,5 +269,11 @@ def test_mar_trainer_segmented_backward_equals_plain():
         res.append({n: p.detach().clone() for n, p in m.named_parameters()})
     worst = max((res[0][n] - res[1][n]).abs().max().item() for n in res[0])
     assert worst <= 2.1e-3, worst  # (atomics order: an Adam step of +-lr on a noise-level gradient element can flip)
-    same = sum(torch.equal(res[0][n], res[1][n]) for n in res[0]) / len(res[0])
-    assert same >= 0.5, same
+    m0 = build()
+    init = {k: v.to(DEV) for k, v in seeded_state(m0.state_dict()).items()}
+    for n in res[0]:
+        moved = (res[0][n] - init[n]).double().pow(2).mean().sqrt().item()
+        err = (res[0][n] - res[1][n]).double().pow(2).mean().sqrt().item()
+        # run-to-run noise of the fp32 atomics: far below the update itself, except for vectors whose gradient IS noise (the k third
+        # of temporal_attn.qkv.bias: softmax is shift invariant), where +-lr Adam steps flip
+        assert err <= (0.3 if res[0][n].numel() <= 1024 else 0.05) * moved + 1e-12, (n, err, moved)
