@@ -107,6 +107,17 @@ class ChainBFwd(C.Structure):
     ]
 
 
+class ReadoutCE(C.Structure):
+    _fields_ = [
+        ("w", ChainWeights),
+        ("x", c_vp), ("bias", c_vp),
+        ("input_ids", c_vp), ("labels", c_vp),
+        ("stats", c_vp), ("dlogits", c_vp), ("grad_scale_dev", c_vp),
+        ("rows", c_i64), ("mask_id", c_i64),
+        ("S", c_i32), ("SA", c_i32), ("T", c_i32), ("grad_scale", C.c_float), ("label_smoothing", C.c_float), ("_pad", c_i32),
+    ]
+
+
 _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
@@ -159,6 +170,7 @@ _PROTOS = {
     "hma_mlp_fwd": [c_vp, C.POINTER(MlpFwd)],
     "hma_mlp_bwd": [c_vp, C.POINTER(MlpBwd)],
     "hma_chain_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32],
+    "hma_readout_ce": [c_vp, C.POINTER(ReadoutCE)],
     "hma_chain_b_fwd": [c_vp, C.POINTER(ChainBFwd)],
     "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
     "hma_chain_a_bwd": [c_vp, C.POINTER(ChainABwd)],

@@ -978,6 +978,145 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ readout + cross-entropy
+// out_x_proj (st_mask_git.py:681-683) + the factorised cross-entropy (compute_video_loss_and_acc, :603-630) of the image rows in one
+// launch: the fp32 logits (2 x 512 per row) exist only as one factor's 128 accumulator registers per lane; what reaches HBM is the
+// bf16 gradient of the logits (the readout's weight gradient and input gradient read it) and three sums.  32 N-block bundles per
+// tile; after 16 of them a lane group holds a factor's 512 logits of its 16 rows (column 32 j + 8 g + 4 o + r in lg[2 j + o][r]).
+template <int NW = NCW>
+__global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_ce_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.rows + 16 * NW - 1) / (16 * NW);
+  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  {
+    HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);
+    for (int i = tid; i < 1024; i += CH_THREADS) bl[i] = p.bias ? p.bias[i] : 0.f;
+  }
+  __syncthreads();
+  if (wave >= NW && wave != NCW) return;
+  if (wave == NCW) {
+    const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
+                         reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
+                         p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
+    loader_run<0, NW>(ws, 32, nt, lds_b, lane, nullptr, p.rows, 1);
+    return;
+  }
+  const int tok = lane & 15, g = lane >> 4;
+  constexpr int V = 512;
+  const float wgt = p.grad_scale * (p.grad_scale_dev ? *p.grad_scale_dev : 1.0f) / p.stats[2];
+  const float eps = p.label_smoothing;
+  float loss_acc = 0.f, acc_acc = 0.f;
+  HMA_LDS(char)* ring = lds + lane * 16;
+  HMA_LDS(char)* bias = lds + L_BIAS + 32 * g;
+  const line_offs Ld = make_lines(2048, tok, 16 * g, 64);
+  int slot = 0;
+  bf16x8_t a[8];
+  f32x4v_t lg[32];
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t r0 = (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
+    if (r0 >= p.rows) {
+#pragma unroll 1
+      for (int s = 0; s < 32; ++s) CH_BARRIER();
+      continue;
+    }
+    const int64_t i = r0 + tok, frame = i / p.S;
+    const float* xrow = p.x + (frame * p.SA + (i - frame * p.S)) * 256 + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xrow + 32 * j), v1 = *reinterpret_cast<const float4*>(xrow + 32 * j + 4);
+      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      a[j] = as_frag(pack8(v));
+    }
+    const bool live = (int)(frame % p.T) >= 1 && p.input_ids[i] == p.mask_id;
+    const int64_t lab = p.labels[i];
+    float row_loss = 0.f;
+    bool ok = true;
+    char* dl = reinterpret_cast<char*>(p.dlogits) + r0 * 2048;
+    static_for<32>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int f = s >> 4, j = s & 15;
+      CH_BARRIER();
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      f32x4v_t c0 = lds_f4v(bias + 128 * s), c1 = lds_f4v(bias + 128 * s + 16);
+      nb_mma(wb, a, c0, c1);
+      lg[2 * j] = c0;
+      lg[2 * j + 1] = c1;
+      if constexpr (j == 15) {
+        const int target = (int)(f == 0 ? lab % V : (lab / V) % V);
+        float m = lg[0][0];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) m = fmaxf(fmaxf(m, fmaxf(lg[t][0], lg[t][1])), fmaxf(lg[t][2], lg[t][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        int arg = 1 << 30;
+        float se = 0.f, sx = 0.f, xt = 0.f;
+        const int tg1 = target - 8 * g;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int colg = 32 * (t >> 1) + 4 * (t & 1) + r;
+            const float x = lg[t][r];
+            if (x == m) arg = min(arg, colg);  // lowest index wins ties (torch.argmax on the reference path)
+            se += __expf(x - m);
+            sx += x;
+            xt += colg == tg1 ? x : 0.f;
+          }
+          if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler keeps all 128 exponentials in flight: spills)
+        }
+        arg += 8 * g;
+        arg = min(arg, __shfl_xor(arg, 16, 64));
+        arg = min(arg, __shfl_xor(arg, 32, 64));
+        se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+        sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
+        xt += __shfl_xor(xt, 16, 64); xt += __shfl_xor(xt, 32, 64);
+        const float lse = m + __logf(se);
+        row_loss += (1.f - eps) * (lse - xt) + eps * (lse - sx * (1.0f / V));
+        ok = ok && (arg == target);
+        if (p.dlogits) {
+          const float w = live ? wgt : 0.f;
+          int tg2 = target - 8 * g;
+          asm volatile("" : "+v"(tg2));  // (opaque: re-using the 128 compare masks of the loop above costs 256 SGPRs -> spills)
+          const float base = -eps * (1.0f / V) * w, hit = -(1.f - eps) * w;
+#pragma unroll
+          for (int jp = 0; jp < 8; ++jp) {
+#pragma unroll
+            for (int t = 4 * jp; t < 4 * jp + 4; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int colg = 32 * (t >> 1) + 4 * (t & 1) + r;
+                lg[t][r] = __builtin_fmaf(w, __expf(lg[t][r] - lse), base + (colg == tg2 ? hit : 0.f));
+              }
+            }
+            store_lines(dl, Ld, 1024 * f + 128 * jp, pack_pair(lg[4 * jp], lg[4 * jp + 1]), pack_pair(lg[4 * jp + 2], lg[4 * jp + 3]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    });
+    if (live && g == 0) {
+      loss_acc += row_loss;
+      acc_acc += ok ? 1.f : 0.f;
+    }
+  }
+  // one atomic pair per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    loss_acc += __shfl_xor(loss_acc, o, 64);
+    acc_acc += __shfl_xor(acc_acc, o, 64);
+  }
+  if (lane == 0 && (loss_acc != 0.f || acc_acc != 0.f)) {
+    atomicAdd(p.stats + 0, loss_acc);
+    atomicAdd(p.stats + 1, acc_acc);
+  }
+}
+
 template <auto Kern>
 int set_lds(int bytes) {
   static bool done = false;
@@ -1137,6 +1276,17 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
     if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, NCW);
   }
 #undef CH_LAUNCH_B
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_readout_ce(void* stream, const hma_readout_ce_t* p) {
+  if (!p || !p->x || !p->input_ids || !p->labels || !p->stats || p->rows <= 0 || p->rows % 16 || p->S <= 0 || p->SA < p->S || p->T <= 0)
+    return HMA_EINVAL;
+  if (!weights_ok(p->w, 32)) return HMA_EINVAL;
+  const int grid = chain_grid(p->rows, NCW);
+  if (int rc = set_lds<readout_ce_kernel<NCW>>(SMEM)) return rc;
+  hipLaunchKernelGGL((readout_ce_kernel<NCW>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
   HMA_CHECK_LAUNCH();
   return 0;
 }

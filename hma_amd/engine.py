@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
-from .ops import make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
+from .ops import make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_readout_ce, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -119,6 +119,12 @@ class Plan:
         # dqkv 1536 + dx 1024 (+ xhat 512) in; dx 1024 + bf16(dx1) 512 + d_o 512 (+ bf16(dx2) 512) out
         nbytes = (1536 + 1024 + 1024 + 512 + 512 + (1024 if use_mod else 0)) * float(M)
         self.add("hma_chain_a_bwd", C.byref(g), flops=2.0 * M * 256 * n_in, nbytes=nbytes)
+
+    def readout_ce(self, rows: int, **kw) -> None:
+        g = make_readout_ce(rows=rows, **kw)
+        self.keep.append(g)
+        # x 1024 in, dlogits 2048 out per image row (+ ids / labels); the logits themselves stay in registers
+        self.add("hma_readout_ce", C.byref(g), flops=2.0 * rows * 256 * 1024, nbytes=(1024.0 + (2048 if kw.get("dlogits") else 0) + 16) * rows)
 
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
@@ -232,6 +238,9 @@ class STEngine:
         self.chain_min_rows = 0
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN)}
+        # readout + cross-entropy in one launch (hma_readout_ce) for training steps that do not hand the logits to the caller
+        self.fused_ce = True
+        self.CP["out"] = mk(32 * BUN)
         # chain B (proj_t + norm2 + MLP + the next block's norm1 + qkv_s in one launch) for passes that save nothing
         self.chain_b_ok = hid == 1024
         self.chain_b_train = True
@@ -351,6 +360,8 @@ class STEngine:
                 _lib.call("hma_chain_pack", stream, wp, d, 1, None, None, self.CP["proj_s"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
                 _lib.call("hma_chain_pack", stream, wp, 1, d, None, None, self.CP["proj_s_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
                 _lib.call("hma_chain_pack", stream, wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN, 1)
+                _lib.call("hma_chain_pack", stream, self._p("out_x_proj.weight"), d, 1, None, None, self.CP["out"].data_ptr(), 0, 1024, d, 1, 0,
+                          0, 1)
                 for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
                     _lib.call("hma_chain_pack", stream, wq + 4 * c * d * d, 1, d, None, None,
                               self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
@@ -652,16 +663,27 @@ class STEngine:
         self._plans[key] = pl
         return pl
 
-    def _loss_plan(self, B, T, S, with_grad: bool) -> Plan:
-        key = ("loss", B, T, S, with_grad)
+    def _use_fused_ce(self, B: int, T: int, S: int) -> bool:
+        return self.fused_ce and self.use_chain and (B * T * S) % 16 == 0
+
+    def _loss_plan(self, B, T, S, with_grad: bool, fused: bool = False, A: int = 0) -> Plan:
+        """Masked-row count + cross-entropy (+ dlogits) from ws["logits"]; `fused`: readout and cross-entropy from ws["x"] in one launch
+        (hma_readout_ce: the logits are never written; the scale is fixed when the plan is built, hence part of the key)."""
+        key = ("loss", B, T, S, with_grad, fused, A if fused else 0, self.grad_scale.value if fused else None)
         if key in self._plans:
             return self._plans[key]
         ws, cfg = self._ws, self.cfg
         pl = Plan()
         pl.add("hma_count_masked", ws["ids"].data_ptr(), ws["stats"].data_ptr(), B, T, S, cfg.image_vocab_size)
-        pl.add("hma_ce_fwd_bwd", ws["logits"].data_ptr(), ws["ids"].data_ptr(), ws["labels"].data_ptr(), ws["stats"].data_ptr(),
-               ws["dlogits"].data_ptr() if with_grad else None, self.gscale.data_ptr(), self.grad_scale, B, T, S,
-               cfg.image_vocab_size, 0.01)
+        if fused:
+            pl.readout_ce(B * T * S, segs=[(self.CP["out"].data_ptr(), 32)], x=ws["x"].data_ptr(), bias=self._p("out_x_proj.bias"),
+                          input_ids=ws["ids"].data_ptr(), labels=ws["labels"].data_ptr(), stats=ws["stats"].data_ptr(),
+                          dlogits=ws["dlogits"].data_ptr() if with_grad else None, grad_scale_dev=self.gscale.data_ptr(),
+                          grad_scale=self.grad_scale.value, S=S, SA=S + A, T=T, mask_id=cfg.image_vocab_size, label_smoothing=0.01)
+        else:
+            pl.add("hma_ce_fwd_bwd", ws["logits"].data_ptr(), ws["ids"].data_ptr(), ws["labels"].data_ptr(), ws["stats"].data_ptr(),
+                   ws["dlogits"].data_ptr() if with_grad else None, self.gscale.data_ptr(), self.grad_scale, B, T, S,
+                   cfg.image_vocab_size, 0.01)
         self._plans[key] = pl
         return pl
 
@@ -827,10 +849,11 @@ class STEngine:
         return self._ws
 
     def forward(self, ids_BTS: torch.Tensor, labels: Optional[torch.Tensor], actions: Optional[torch.Tensor],
-                domain: Optional[str], train: bool, skip_normalization: bool = False, loss_grad: bool = False
-                ) -> Dict[str, torch.Tensor]:
+                domain: Optional[str], train: bool, skip_normalization: bool = False, loss_grad: bool = False,
+                need_logits: bool = True) -> Dict[str, torch.Tensor]:
         """Embeds, runs the trunk and the readout; with `labels` also the loss (and, with `loss_grad`, dlogits
-        scaled by `self.grad_scale * self.gscale`)."""
+        scaled by `self.grad_scale * self.gscale`).  `need_logits=False` (a training step that only wants the loss and the
+        gradient): readout and cross-entropy run as one launch and ws["logits"] is NOT written."""
         B, T, S = ids_BTS.shape
         A = self.cfg.action_token_size if (actions is not None and "concat" in self.cfg.action_network) else 0
         if actions is not None and A == 0:
@@ -853,12 +876,14 @@ class STEngine:
             ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
         if train:
             self.bump_dropout()
-        self._forward_plan(B, T, S, A, train, domain if A > 0 else None).run(stream, timer=self.timer)
+        fce = labels is not None and train and loss_grad and not need_logits and self._use_fused_ce(B, T, S)
+        self._forward_plan(B, T, S, A, train, domain if A > 0 else None, readout=not fce).run(stream, timer=self.timer)
         self._last = (B, T, S, A, domain if A > 0 else None)
+        self._last_fce = fce
         if labels is not None:
             ws["labels"].copy_(labels.reshape(B, T * S), non_blocking=True)
             ws["stats"].zero_()
-            self._loss_plan(B, T, S, train and loss_grad).run(stream)
+            self._loss_plan(B, T, S, train and loss_grad, fused=fce, A=A).run(stream, timer=self.timer)
         return ws
 
     # ------------------------------------------------------------------------------ trunk-only training (STMAR)
@@ -1126,7 +1151,7 @@ class STEngine:
             # dlogits were produced with the scale captured at forward time: redo the (cheap) CE pass
             self.grad_scale.value = grad_scale
             ws["stats"].zero_()
-            self._loss_plan(B, T, S, True).run(stream)
+            self._loss_plan(B, T, S, True, fused=getattr(self, "_last_fce", False), A=A).run(stream)
         lay = self.layout
         ws["dx"].zero_()
         if A > 0:

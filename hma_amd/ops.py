@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, ChainBFwd, GemmNT, GemmTN, MlpBwd, MlpFwd)
+                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, ChainBFwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -148,6 +148,17 @@ def make_chain_b_fwd(*, M: int, segs, o: int, x: int, b1: int, b_proj: Optional[
     g.qkv, g.ldq, g.M, g.ln_eps = qkv, ldq, M, ln_eps
     g.xhat2, g.rstd2, g.xhat1n, g.rstd1n = xhat2, rstd2, xhat1n, rstd1n
     g.drop_p, g.drop_salt, g.drop_seed = drop_p, drop_salt, drop_seed
+    return g
+
+
+def make_readout_ce(*, rows: int, segs, x: int, bias: Optional[int], input_ids: int, labels: int, stats: int, dlogits: Optional[int],
+                    grad_scale_dev: Optional[int], grad_scale: float, S: int, SA: int, T: int, mask_id: int,
+                    label_smoothing: float) -> ReadoutCE:
+    """segs: the 32 N-block bundles of out_x_proj.weight (chain_pack kind 0)."""
+    g = ReadoutCE()
+    _chain_weights(g.w, segs)
+    g.x, g.bias, g.input_ids, g.labels, g.stats, g.dlogits, g.grad_scale_dev = x, bias, input_ids, labels, stats, dlogits, grad_scale_dev
+    g.rows, g.mask_id, g.S, g.SA, g.T, g.grad_scale, g.label_smoothing = rows, mask_id, S, SA, T, grad_scale, label_smoothing
     return g
 
 

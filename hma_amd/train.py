@@ -247,7 +247,7 @@ class Trainer:
             ws = self._graphed_micro_step(input_ids.reshape(B, T, -1), labels, action_ids, dom)
             self._micro += 1
             return ws
-        ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True)
+        ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True, need_logits=False)
         self._book(ws, B)
         if last and red.world > 1:
             red.begin()
@@ -289,7 +289,7 @@ class Trainer:
         if graphs is None:
             n = self._seen.get(key, 0) + 1
             self._seen[key] = n
-            ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True)
+            ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True, need_logits=False)
             self._book(ws, B)
             if red.world > 1:
                 red.begin()
@@ -307,9 +307,10 @@ class Trainer:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         stream = torch.cuda.current_stream().cuda_stream
                         if i == 0:
-                            eng._forward_plan(Bq, Tq, Sq, A, True, domq).run(stream)
+                            fce = eng._use_fused_ce(Bq, Tq, Sq)
+                            eng._forward_plan(Bq, Tq, Sq, A, True, domq, readout=not fce).run(stream)
                             eng._ws["stats"].zero_()
-                            eng._loss_plan(Bq, Tq, Sq, True).run(stream)
+                            eng._loss_plan(Bq, Tq, Sq, True, fused=fce, A=A).run(stream)
                             eng._ws["dx"].zero_()
                             if A > 0:
                                 eng._ws["da_emb"].zero_()

@@ -449,6 +449,23 @@ typedef struct {
 } hma_chain_b_fwd_t;
 int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p);
 
+/* Readout + factorised cross-entropy of the image rows in one launch (st_mask_git.py:681-683 out_x_proj; :603-630
+ * compute_video_loss_and_acc with label_smoothing): what hma_gemm_nt (x -> fp32 logits) + hma_ce_fwd_bwd do, without the logits in
+ * HBM.  rows = B * T * S image rows (a multiple of 16); row i reads x row (i / S) * SA + i % S of the [*, 256] fp32 residual stream.
+ * w: 32 N-block bundles (hma_chain_pack kind 0) of out_x_proj.weight [1024][256]; bias [1024] or NULL.  A row counts when its frame
+ * index (i / S) % T >= 1 and input_ids[i] == mask_id.  stats[0] += sum of row losses, stats[1] += rows whose two factor arg-maxes
+ * both hit; stats[2] (the masked-row count, hma_count_masked) is read.  dlogits (bf16 [rows, 1024], or NULL) = grad_scale *
+ * *grad_scale_dev / stats[2] * (softmax - smoothed one-hot) per factor, zero for rows that do not count. */
+typedef struct {
+  hma_chain_weights_t w;
+  const float* x; const float* bias;
+  const int64_t* input_ids; const int64_t* labels;
+  float* stats; void* dlogits; const float* grad_scale_dev;
+  int64_t rows; int64_t mask_id;
+  int32_t S; int32_t SA; int32_t T; float grad_scale; float label_smoothing; int32_t _pad;
+} hma_readout_ce_t;
+int hma_readout_ce(void* stream, const hma_readout_ce_t* p);
+
 /* n floats at p = 0 (captured in graphs in front of kernels that accumulate with atomics) */
 int hma_zero_f32(void* stream, float* p, int64_t n);
 
