@@ -448,6 +448,202 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   }
 }
 
+// ------------------------------------------------------------------------------------- dQ, dK, dV in one kernel
+// One persistent workgroup per CU, NT tile waves + 2 dQ waves: tile wave w owns key tile w of a (frame, head) item and keeps its dK / dV accumulators in
+// registers.  Q, K, V and dO of the item's n tokens sit in LDS (4 x n x 80 B = 100 KB at n = 320): every operand is read from HBM once
+// (the two-kernel form read q / k / v / dO twice: 1039 -> 660 MB per layer at frames = 512), and the score tile S, P = exp(S - lse)
+// and dS = P (dP - delta) are formed ONCE per (query tile, key tile) -- 5 products of n^2 d instead of 7, half the exponentials.
+// The soft-max arithmetic, not the matrix pipe, bounds these kernels (16 v_exp per 8 MFMAs and lane).  The transposed use of dS (dQ
+// contracts over the keys, which are the LANES of the tile a wave has just computed) goes through LDS: every wave writes its dS
+// tile as [key][query] rows, and after the step's barrier one of the two dQ waves reads the NT tiles back with transposing reads
+// (ds_read_b64_tr_b16, like K^T) and forms dQ of that query tile (2 NT MFMAs) while the tile waves go on with the next query tile
+// (two dS buffers).  delta = rowsum(dO * O) is formed while the item is staged; the
+// NEXT item's rows are fetched into registers during the compute (one workgroup per CU: nothing else would hide the staging).
+#ifndef ATTN_ABL  // debug builds (timing only, results wrong): 1 no lse / delta reads, 2 no dQ job, 4 no exponentials, 8 no dS tile writes, 32 no compute at all (staging + stores)
+#define ATTN_ABL 0
+#endif
+// LDS-only barrier: waits for this wave's LDS operations, not for its global loads (the next item's rows stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT>
+struct FusedStage {
+  static constexpr int N = NT * 32, ITEMS = N * 4, THREADS = (NT + 2) * 64, R = (ITEMS + THREADS - 1) / THREADS;
+  // (vectors, not arrays: carried around the item loop as arrays, hipcc leaves three of them in scratch)
+  typedef uint32_t vec_t __attribute__((ext_vector_type(4 * R)));
+  vec_t rq, rk, rv, rg, ro;
+  float rl;
+  static __device__ __forceinline__ void put(vec_t& v, int i, const uint4& x) {
+    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+  }
+  static __device__ __forceinline__ uint4 get(const vec_t& v, int i) { return make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]); }
+  __device__ __forceinline__ void fetch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int64_t item,
+                                        int64_t frames, int tid) {
+    int64_t frame; int head;
+    decode_block(item, frames, frame, head);
+    const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
+    const uint16_t* gb = d_o + frame * N * DM + head * HD;
+    const uint16_t* ob = o + frame * N * DM + head * HD;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int c = min(tid + i * THREADS, ITEMS - 1);
+      const int64_t row = c >> 2;
+      const int ch = (c & 3) * 8;
+      put(rq, i, *reinterpret_cast<const uint4*>(base + row * QKV_LD + ch));
+      put(rk, i, *reinterpret_cast<const uint4*>(base + DM + row * QKV_LD + ch));
+      put(rv, i, *reinterpret_cast<const uint4*>(base + 2 * DM + row * QKV_LD + ch));
+      put(rg, i, *reinterpret_cast<const uint4*>(gb + row * DM + ch));
+      put(ro, i, *reinterpret_cast<const uint4*>(ob + row * DM + ch));
+    }
+    rl = lse[(frame * N + min(tid, N - 1)) * NH + head];
+  }
+  __device__ __forceinline__ void stage(uint16_t* Qs, uint16_t* Ks, uint16_t* Vs, uint16_t* Gs, float* L2s, float* Dls, float* delta,
+                                        int64_t item, int64_t frames, int tid) const {
+    int64_t frame; int head;
+    decode_block(item, frames, frame, head);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int c = min(tid + i * THREADS, ITEMS - 1);
+      const int off = (c >> 2) * LDR + (c & 3) * 8;
+      *reinterpret_cast<uint4*>(&Qs[off]) = get(rq, i);
+      *reinterpret_cast<uint4*>(&Ks[off]) = get(rk, i);
+      *reinterpret_cast<uint4*>(&Vs[off]) = get(rv, i);
+      *reinterpret_cast<uint4*>(&Gs[off]) = get(rg, i);
+      // delta of the row: the four 8-column pieces of a row sit in four neighbouring lanes
+      const uint32_t gw[4] = {rg[4 * i], rg[4 * i + 1], rg[4 * i + 2], rg[4 * i + 3]}, ow[4] = {ro[4 * i], ro[4 * i + 1], ro[4 * i + 2], ro[4 * i + 3]};
+      float dsum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dsum = __builtin_fmaf(__builtin_bit_cast(float, gw[e] << 16), __builtin_bit_cast(float, ow[e] << 16), dsum);
+        dsum = __builtin_fmaf(__builtin_bit_cast(float, gw[e] & 0xffff0000u), __builtin_bit_cast(float, ow[e] & 0xffff0000u), dsum);
+      }
+      dsum += __shfl_xor(dsum, 1, 64);
+      dsum += __shfl_xor(dsum, 2, 64);
+      if ((c & 3) == 0) {
+        Dls[c >> 2] = dsum;
+        delta[(frame * N + (c >> 2)) * NH + head] = dsum;
+      }
+    }
+    if (tid < N) L2s[tid] = rl;
+  }
+};
+
+template <int NT>
+__global__ __launch_bounds__((NT + 2) * 64, 1) void attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                                    const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                    float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                                    int64_t frames, float c_log2, float scale) {
+  constexpr int N = NT * 32;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Qs = smem;                 // [N][LDR]
+  uint16_t* Ks = Qs + N * LDR;
+  uint16_t* Vs = Ks + N * LDR;
+  uint16_t* Gs = Vs + N * LDR;         // dO
+  uint16_t* Ts = Gs + N * LDR;         // 2 x [N keys][LDR]: dS of one query tile, [key][query]
+  float* L2s = reinterpret_cast<float*>(Ts + 2 * N * LDR);  // [N]
+  float* Dls = L2s + N;                                      // [N]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int64_t nitems = frames * NH;
+  const int kt = wave;
+
+  FusedStage<NT> st;
+  int64_t item = blockIdx.x;
+  if (item < nitems) st.fetch(qkv, o, d_o, lse, item, frames, tid);
+#pragma unroll 1
+  for (; item < nitems; item += gridDim.x) {
+    st.stage(Qs, Ks, Vs, Gs, L2s, Dls, delta, item, frames, tid);
+    lds_barrier();  // (LDS-only barriers throughout: a __syncthreads would also drain the previous item's dqkv stores)
+    const int64_t nxt = item + gridDim.x;
+    if (nxt < nitems) st.fetch(qkv, o, d_o, lse, nxt, frames, tid);
+    int64_t frame; int head;
+    decode_block(item, frames, frame, head);
+    if (wave >= NT) {
+      // ---- the two dQ waves: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], wave NT + (qt & 1), while the
+      // tile waves work on query tile qt + 1 (which goes to the other dS buffer)
+#pragma unroll 1
+      for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+        lds_barrier();
+        if ((qt & 1) == wave - NT && !(ATTN_ABL & 2)) {
+          const uint16_t* Tq = Ts + (qt & 1) * N * LDR;
+          f32x16_t a0 = zero16(), a1 = zero16();
+          // 2 NT k-steps of 16 keys in groups of 4, the next group's transposing reads in flight behind this group's MFMAs (one read
+          // -> MFMA round trip per k-step made the job longer than the tile waves' step, and they wait for it at the next barrier)
+          static_assert((2 * NT) % 4 == 0, "groups of four k-steps");
+          bf16x8_t fa[4], fb[4], na[4], nb[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { fa[i] = frag_tr(Ks, LDR, 16 * i, lane); fb[i] = frag_tr(Tq, LDR, 16 * i, lane); }
+#pragma unroll
+          for (int grp = 0; grp < NT / 2; ++grp) {
+            if (grp + 1 < NT / 2) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                na[i] = frag_tr(Ks, LDR, 16 * (4 * grp + 4 + i), lane);
+                nb[i] = frag_tr(Tq, LDR, 16 * (4 * grp + 4 + i), lane);
+              }
+            }
+            a0 = mfma32(fa[0], fb[0], a0);
+            a1 = mfma32(fa[1], fb[1], a1);
+            a0 = mfma32(fa[2], fb[2], a0);
+            a1 = mfma32(fa[3], fb[3], a1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a0[e] += a1[e];
+          store_dt(dqkv + (frame * N + qt * 32) * QKV_LD + head * HD, QKV_LD, a0, scale, lane);
+        }
+      }
+    } else {
+      const bf16x8_t k0 = frag_rows(Ks, kt * 32, 0, lane), k1 = frag_rows(Ks, kt * 32, 1, lane);
+      const bf16x8_t v0 = frag_rows(Vs, kt * 32, 0, lane), v1 = frag_rows(Vs, kt * 32, 1, lane);
+      f32x16_t dk = zero16(), dv = zero16();
+#pragma unroll 1
+      for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+        // S[q][key], dP[q][key]: lane = key, rows = q
+        f32x16_t sc = mfma32(frag_rows(Qs, qt * 32, 0, lane), k0, zero16());
+        sc = mfma32(frag_rows(Qs, qt * 32, 1, lane), k1, sc);
+        f32x16_t dp = mfma32(frag_rows(Gs, qt * 32, 0, lane), v0, zero16());
+        dp = mfma32(frag_rows(Gs, qt * 32, 1, lane), v1, dp);
+        uint16_t* T = Ts + (qt & 1) * N * LDR + (kt * 32 + (lane & 31)) * LDR;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // rows 8 g + 4 hi + {0..3}: one 16-byte LDS read each for lse and delta
+          float4 l4 = make_float4(c_log2, scale, c_log2, scale), d4 = l4;
+          if (!(ATTN_ABL & 1)) {
+            l4 = *reinterpret_cast<const float4*>(&L2s[qt * 32 + 8 * g + 4 * hi]);
+            d4 = *reinterpret_cast<const float4*>(&Dls[qt * 32 + 8 * g + 4 * hi]);
+          }
+          const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float arg = sc[4 * g + e] * c_log2 - lq[e];
+            const float pr = (ATTN_ABL & 4) ? arg : fast_exp2(arg);
+            sc[4 * g + e] = pr;
+            dp[4 * g + e] = pr * (dp[4 * g + e] - dq4[e]);
+          }
+          // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
+          if (!(ATTN_ABL & 8))
+            *reinterpret_cast<uint2*>(T + 8 * g + 4 * hi) =
+                make_uint2(pack_bf16(dp[4 * g], dp[4 * g + 1]), pack_bf16(dp[4 * g + 2], dp[4 * g + 3]));
+        }
+        // (dS tile of query tile qt complete after this barrier; the buffer's previous reader -- the dQ job of qt - 2 -- is past its
+        // reads: it arrived at the barrier of qt - 1 only after them)
+        lds_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          dv = mfma32(frag_tr(Gs, LDR, qt * 32 + 16 * s2, lane), pack_acc_half(sc, s2), dv);
+          dk = mfma32(frag_tr(Qs, LDR, qt * 32 + 16 * s2, lane), pack_acc_half(dp, s2), dk);
+        }
+      }
+      const int64_t row0 = frame * N + kt * 32;
+      store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk, scale, lane);
+      store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv, 1.0f, lane);
+    }
+    lds_barrier();  // every wave is done with this item's LDS before the next one is staged
+  }
+}
+
 template <auto Kern>
 int set_lds(int bytes) {
   static bool done = false;
@@ -473,9 +669,38 @@ int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int64_t fram
   return 0;
 }
 
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int NT>
+int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                     int64_t frames, float scale) {
+  constexpr int N = NT * 32;
+  constexpr int bytes = 6 * N * LDR * 2 + 2 * N * 4;
+  int rc = set_lds<attn_bwd_fused_kernel<NT>>(bytes);
+  if (rc) return rc;
+  const int64_t items = frames * NH;
+  const int grid = (int)(items < cu_count() ? items : cu_count());
+  hipLaunchKernelGGL(attn_bwd_fused_kernel<NT>, dim3((unsigned)grid), dim3((NT + 2) * 64), bytes, s, (const uint16_t*)qkv, (const uint16_t*)o,
+                     (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NT>
 int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                void* dqkv, int64_t frames, float scale) {
+#ifndef ATTN_BWD_SPLIT  // (debug builds: the two-kernel form, tools/attn_bench.py compares)
+  if (NT >= 8) return launch_bwd_fused<NT>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
+#endif
   constexpr int N = NT * 32, LDV = N + 4;
   constexpr int bytes_dq = 2 * N * LDR * 2;
   constexpr int NRh = N / 2;
