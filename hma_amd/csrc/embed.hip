@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     an_out[r * d_a + i] = v;
   }
   __syncthreads();
-  // pre[j]: wave w covers j = w*64 .. +63, lanes split the d_a inputs
+  // pre[j]: wave w covers j = w*64 .. +63, lanes split the d_a inputs (8 outputs' weight rows in flight: one exposed L2 round trip
+  // per output made this kernel 88 us for the 64 rows of a decode frame pass)
+#pragma unroll 8
   for (int jj = 0; jj < 64; ++jj) {
     const int j = w * 64 + jj;
     float p = 0.f;
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   hs[tid] = hv;
   __syncthreads();
   const float4 h4 = *reinterpret_cast<const float4*>(hs + lane * 4);
+#pragma unroll 8
   for (int jj = 0; jj < 64; ++jj) {
     const int j = w * 64 + jj;
     const float4 w4 = *reinterpret_cast<const float4*>(W2 + (int64_t)j * D + lane * 4);

@@ -139,13 +139,31 @@ __global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ 
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* lg = logits + ((b * logits_T + logits_t) * (int64_t)S) * C;
+  // (a wave walks its tokens with the NEXT token's 4 KB of logits already in flight: one exposed HBM round trip per token made
+  // this kernel 170 us for 64 workgroups)
+  float xn[2][8];
+  if (w < S) {
+    load8(lg + (int64_t)w * C + V + lane * 8, xn[1]);
+    load8(lg + (int64_t)w * C + lane * 8, xn[0]);
+  }
   for (int s = w; s < S; s += 4) {
     int sample = 0;
     float c = 1.f;
+    float xc[2][8];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xc[f][j] = xn[f][j];
+    {
+      const int sn = s + 4 < S ? s + 4 : s;
+      load8(lg + (int64_t)sn * C + V + lane * 8, xn[1]);
+      load8(lg + (int64_t)sn * C + lane * 8, xn[0]);
+    }
 #pragma unroll
     for (int f = 1; f >= 0; --f) {  // flip(2): highest factor first (:408)
       float x[8];
-      load8(lg + (int64_t)s * C + f * V + lane * 8, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = xc[f][j];
       const FactorStats st = factor_stats(x, lane, -1);
       if (!sample_noise) {  // greedy (temperature <= 1e-8, :409-410)
         sample = sample * V + st.arg;
@@ -192,14 +210,22 @@ __global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ 
     prev_unm = unmasked[b * S + s] != 0;
     out = samp[s];
     if (conf_out) conf_out[b * S + s] = conf[s];
+  }
+  // the confidences the ranking uses (override, previously unmasked tokens pinned to +inf), once per token, through LDS
+  float c_eff = INFINITY;
+  if (active && !last) {
+    c_eff = conf_override ? conf_override[b * S + s] : conf[s];
+    if (prev_unm) c_eff = INFINITY;
+  }
+  __syncthreads();  // (everyone has read conf[s] / samp[s])
+  if (active) conf[s] = c_eff;
+  __syncthreads();
+  if (active) {
     if (!last) {
-      float c = conf_override ? conf_override[b * S + s] : conf[s];
-      if (prev_unm) c = INFINITY;
       int rank = 0;
       for (int j = 0; j < S; ++j) {
-        float cj = conf_override ? conf_override[b * S + j] : conf[j];
-        if (unmasked[b * S + j] != 0) cj = INFINITY;
-        rank += (cj < c || (cj == c && j < s)) ? 1 : 0;
+        const float cj = conf[j];
+        rank += (cj < c_eff || (cj == c_eff && j < s)) ? 1 : 0;
       }
       if (rank < n_mask) out = mask_id;
     }
