@@ -190,9 +190,11 @@ def st_block(sd: SD, cfg: RefConfig, l: int, x_btsd: torch.Tensor,
 
 
 def trunk_input(sd: SD, cfg: RefConfig, x_THW: torch.Tensor, action_ids: Optional[torch.Tensor],
-                domain: Optional[Sequence[str]], skip_normalization: bool = False
-                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """compute_logits up to the decoder call, hma/model/st_mask_git.py:640-672."""
+                domain: Optional[Sequence[str]], skip_normalization: bool = False,
+                action_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """compute_logits up to the decoder call, hma/model/st_mask_git.py:640-672.  `action_mask` (B, T), 1 = masked: with
+    jointly_predict_actions the concatenated action tokens of a masked frame are `action_mask_tokens[t]` (:656-660); the
+    modulation further down still sees the embedded actions."""
     B, T = x_THW.shape[:2]
     x = token_embed(sd, cfg, x_THW.reshape(B, T, -1))
     a_emb = None
@@ -200,6 +202,9 @@ def trunk_input(sd: SD, cfg: RefConfig, x_THW: torch.Tensor, action_ids: Optiona
         a_emb = action_stem(sd, cfg, action_ids, domain[0], skip_normalization)
         if "concat" in cfg.action_network:
             cond = a_emb[:, :T, None].expand(B, T, cfg.action_token_size, cfg.d_model)
+            if action_mask is not None:
+                m = action_mask[:, :T, None, None].to(cond.dtype)
+                cond = m * sd["action_mask_tokens"][:, :T] + (1 - m) * cond
             x = torch.cat([x, cond], dim=2)
     x = x + sd["pos_embed_TSC"][:, :T, : x.shape[2]]
     return x, a_emb
@@ -217,6 +222,35 @@ def compute_logits(sd: SD, cfg: RefConfig, x_THW: torch.Tensor, action_ids: Opti
     # FixedMuReadout at width_mult == 1, output_mult == 1 is a plain Linear (:784-789)
     logits = F.linear(x, sd["out_x_proj.weight"], sd["out_x_proj.bias"])  # (B,T,S,C)
     return logits.reshape(B, T, H, W, -1).permute(0, 4, 1, 2, 3)
+
+
+def compute_logits_and_actions(sd: SD, cfg: RefConfig, x_THW: torch.Tensor, action_ids: torch.Tensor, domain: Sequence[str],
+                               action_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """compute_logits with jointly_predict_actions (hma/model/st_mask_git.py:656-660, 676-683): also the action read-out -- the
+    mean of a frame's action tokens through `action_out_projectors[domain]` (a plain Linear at width_mult == 1) -> (B, T, d_action)."""
+    B, T, H, W = x_THW.shape
+    x, a_emb = trunk_input(sd, cfg, x_THW, action_ids, domain, action_mask=action_mask)
+    dom = domain[0]
+    for l in range(cfg.num_layers):
+        x = st_block(sd, cfg, l, x, a_emb, dom)
+    pooled = x[:, :, -cfg.action_token_size:].mean(dim=2)
+    actions = F.linear(pooled, sd[f"action_out_projectors.{dom}.weight"], sd[f"action_out_projectors.{dom}.bias"])
+    logits = F.linear(x[:, :, : H * W], sd["out_x_proj.weight"], sd["out_x_proj.bias"])
+    return logits.reshape(B, T, H, W, -1).permute(0, 4, 1, 2, 3), actions
+
+
+def forward_with_actions(sd: SD, cfg: RefConfig, input_ids: torch.Tensor, labels: torch.Tensor, action_ids: torch.Tensor,
+                         domain: Sequence[str], action_mask: torch.Tensor, H: int = 16, W: int = 16):
+    """STMaskGIT.forward with jointly_predict_actions, hma/model/st_mask_git.py:688-733, the (B, T) action mask given instead of
+    drawn (:704-710).  action_loss as the reference computes it: `mse_loss(action_labels, action_outputs, reduce="none")` goes
+    through the legacy-argument path, where any truthy `reduce` means the MEAN, so the "elementwise" loss is a scalar and
+    (scalar * mask).mean() = mean squared error (against the RAW action ids) x the fraction of masked frames (:725-726)."""
+    B = input_ids.shape[0]
+    x_THW = input_ids.reshape(B, cfg.T, H, W)
+    logits, actions = compute_logits_and_actions(sd, cfg, x_THW, action_ids, domain, action_mask)
+    loss, acc = video_loss_and_acc(cfg, logits, labels, x_THW)
+    action_loss = ((action_ids[:, : cfg.T] - actions) ** 2).mean() * action_mask.to(actions.dtype).mean()
+    return loss, acc, logits, action_loss, actions
 
 
 def video_loss_and_acc(cfg: RefConfig, logits_CTHW: torch.Tensor, labels_flat: torch.Tensor,

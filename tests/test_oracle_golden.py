@@ -96,6 +96,39 @@ def test_g6_forward_backward(tag):
     assert n_checked > 20
 
 
+@pytest.mark.parametrize("tag", ["domA", "domB"])
+def test_g16_jointly_predict_actions(tag):
+    """jointly_predict_actions=True (st_mask_git.py:656-660, 676-678, 724-733): masked action tokens, the pooled action read-out and the
+    reference's action loss (legacy `reduce="none"` = mean, times the masked fraction), gradients of loss + 0.5 action_loss."""
+    g = golden("g16_jpa")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    inp = tiny_inputs()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(params)
+    loss, acc, logits, aloss, actions = R.forward_with_actions(full, cfg, inp["input_ids"], inp["labels"], inp[f"actions_{tag}"], [tag] * 2,
+                                                               g[f"{tag}.action_mask"])
+    (loss + 0.5 * aloss).backward()
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5
+    assert abs(aloss.item() - g[f"{tag}.action_loss"].item()) < 1e-5 * max(1.0, abs(g[f"{tag}.action_loss"].item()))
+    assert acc.item() == g[f"{tag}.acc"].item()
+    assert rel_err(actions.detach(), g[f"{tag}.actions"]) < TOL
+    assert rel_err(logits.detach()[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) < TOL
+    seen = set()
+    for name, p in params.items():
+        key = f"{tag}.grad_samp.{name}"
+        if key not in g:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, name
+            continue
+        seen.add(name)
+        gf = p.grad.reshape(-1)
+        idx = torch.linspace(0, gf.numel() - 1, 64).long()
+        scale = g[f"{tag}.grad_abs.{name}"].item() / gf.numel() + 1e-12
+        assert (gf[idx] - g[key]).abs().max().item() < 5e-4 * scale + 1e-9, name
+    assert {"action_mask_tokens", f"action_out_projectors.{tag}.weight", f"action_out_projectors.{tag}.bias"} <= seen
+
+
 def test_g6b_initlike_forward_backward():
     g = golden("g6b_initlike")
     cfg = tiny_ref_config()
