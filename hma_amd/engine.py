@@ -177,8 +177,13 @@ class STEngine:
             raise NotImplementedError("qk_norm=True is not used by the shipped MagVit configs and is not built")
         if cfg.num_factored_vocabs != 2 or cfg.factored_vocab_size != 512:
             raise NotImplementedError("readout/loss kernels are built for the 2 x 512 factorised vocabulary")
-        if cfg.jointly_predict_actions:
-            raise NotImplementedError("jointly_predict_actions is outside the accelerated path")
+        # jointly_predict_actions (st_mask_git.py:656-660, 676-678, 724-733): the action tokens of masked frames are
+        # `action_mask_tokens[t]`, a frame's action tokens are mean-pooled after the trunk and read out per domain, and an action
+        # loss trains that head.  The trunk kernels are unchanged; the three small per-frame pieces ([B*T, 256] mixes, a 256 x d_a
+        # Linear, its MSE) are fp32 torch ops on the GPU between plan segments.
+        self.jpa = bool(cfg.jointly_predict_actions)
+        self._act: Optional[dict] = None
+        self.act_scale = 0.0   # d total / d action_loss of the backward in flight (0: the action loss is not part of the objective)
         _lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -453,6 +458,10 @@ class STEngine:
             buf("srstd", (Fr,), F32)
             buf("sh", (Fr, 256), F32)
             buf("a_emb", (Fr, 256), F32)
+            if self.jpa:
+                buf("a_tok", (Fr, 256), F32)    # what the concatenated action tokens carry: a_emb, or action_mask_tokens[t] on masked frames
+                buf("amask", (Fr, 1), F32)
+                buf("da_tok", (Fr, 256), F32)
         buf("logits", (Mi, 1024), F32)
         buf("stats", (4,), F32)
         if train:
@@ -619,6 +628,7 @@ class STEngine:
                    self._p(f"{am}.0.bias"), self._p(f"{am}.1.weight"), self._p(f"{am}.1.bias"), self._p(f"{am}.3.weight"),
                    self._p(f"{am}.3.bias"), ws["an"].data_ptr(), ws["sxhat"].data_ptr(), ws["srstd"].data_ptr(),
                    ws["sh"].data_ptr(), ws["a_emb"].data_ptr(), Fr, self.d_actions[dom], self._skip_norm)
+              pl.mark("post_stem")
             if self.modulate:
                 ap = f"decoder.layers.0.action_projectors.{dom}"
                 pl.gemm_nt(A=ws["a_emb"].data_ptr(), lda=256, a_kind=A_F32, W=self._wb(f"{ap}.adaLN_modulation.0.weight"),
@@ -632,8 +642,8 @@ class STEngine:
         if embed:
             pl.add("hma_embed_fwd", ws["ids"].data_ptr(), self._p("token_embed.factored_embeds.0.weight"),
                    self._p("token_embed.factored_embeds.1.weight"), self._p("token_embed.mask_token_embed"),
-                   self._p("pos_embed_TSC"), ws["a_emb"].data_ptr() if A > 0 else None, ws["x"].data_ptr(), B, T, S, A,
-                   cfg.S + cfg.action_token_size, cfg.factored_vocab_size, cfg.image_vocab_size)
+                   self._p("pos_embed_TSC"), (ws["a_tok"] if self.jpa else ws["a_emb"]).data_ptr() if A > 0 else None,
+                   ws["x"].data_ptr(), B, T, S, A, cfg.S + cfg.action_token_size, cfg.factored_vocab_size, cfg.image_vocab_size)
         x = ws["x"].data_ptr()
         for l in range(l0, l1):
             s = sl(l)
@@ -813,8 +823,8 @@ class STEngine:
         pl.mark("embed")
         pl.add("hma_embed_bwd", ws["ids"].data_ptr(), dx, self._g("token_embed.factored_embeds.0.weight"),
                self._g("token_embed.factored_embeds.1.weight"), self._g("token_embed.mask_token_embed"), self._g("pos_embed_TSC"),
-               ws["da_emb"].data_ptr() if A > 0 else None, B, T, S, A, cfg.S + cfg.action_token_size, cfg.factored_vocab_size,
-               cfg.image_vocab_size)
+               (ws["da_tok"] if self.jpa else ws["da_emb"]).data_ptr() if A > 0 else None, B, T, S, A,
+               cfg.S + cfg.action_token_size, cfg.factored_vocab_size, cfg.image_vocab_size)
         pl.mark("post_embed")
         if A > 0:
             dom = domain
@@ -850,7 +860,7 @@ class STEngine:
 
     def forward(self, ids_BTS: torch.Tensor, labels: Optional[torch.Tensor], actions: Optional[torch.Tensor],
                 domain: Optional[str], train: bool, skip_normalization: bool = False, loss_grad: bool = False,
-                need_logits: bool = True) -> Dict[str, torch.Tensor]:
+                need_logits: bool = True, action_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Embeds, runs the trunk and the readout; with `labels` also the loss (and, with `loss_grad`, dlogits
         scaled by `self.grad_scale * self.gscale`).  `need_logits=False` (a training step that only wants the loss and the
         gradient): readout and cross-entropy run as one launch and ws["logits"] is NOT written."""
@@ -877,7 +887,29 @@ class STEngine:
         if train:
             self.bump_dropout()
         fce = labels is not None and train and loss_grad and not need_logits and self._use_fused_ce(B, T, S)
-        self._forward_plan(B, T, S, A, train, domain if A > 0 else None, readout=not fce).run(stream, timer=self.timer)
+        pl = self._forward_plan(B, T, S, A, train, domain if A > 0 else None, readout=not fce)
+        self._act, self.act_scale = None, 0.0
+        if self.jpa and A > 0:
+            # action stem -> mix in the mask tokens -> everything else (the modulation keeps the embedded actions, :672)
+            pl.run(stream, 0, pl.marks["post_stem"], timer=self.timer)
+            m = ws["amask"]
+            m.zero_() if action_mask is None else m.copy_(action_mask.reshape(B * T, 1).to(F32))
+            mt = self.view("action_mask_tokens").reshape(-1, 256)[:T]
+            torch.where(m.bool(), mt.repeat(B, 1), ws["a_emb"], out=ws["a_tok"])
+            pl.run(stream, pl.marks["post_stem"], None, timer=self.timer)
+            # action read-out of the pooled action tokens + the reference's action loss (:676-678, :725-726)
+            SA = S + A
+            pooled = ws["x"].view(B * T, SA, 256)[:, S:].mean(dim=1)
+            W, bias = self.view(f"action_out_projectors.{domain}.weight"), self.view(f"action_out_projectors.{domain}.bias")
+            out = torch.addmm(bias, pooled, W.t())
+            labels_a = actions[:, :T].reshape(B * T, d_a).to(F32)
+            mfrac = m.mean()
+            self._act = dict(pooled=pooled, out=out, labels=labels_a, mfrac=mfrac, dom=domain,
+                             loss=((labels_a - out) ** 2).mean() * mfrac)
+        elif self.jpa:
+            raise NotImplementedError("jointly_predict_actions without action_ids (all action tokens masked, :663-666) is not built")
+        else:
+            pl.run(stream, timer=self.timer)
         self._last = (B, T, S, A, domain if A > 0 else None)
         self._last_fce = fce
         if labels is not None:
@@ -1156,9 +1188,33 @@ class STEngine:
         ws["dx"].zero_()
         if A > 0:
             ws["da_emb"].zero_()
+        jpa = self.jpa and A > 0 and self._act is not None
+        if jpa:
+            ws["da_tok"].zero_()
+            if self.act_scale != 0.0:
+                # backward of the action loss: the read-out's own gradients, and d loss / d (the action rows of the final x)
+                a = self._act
+                d_out = (a["out"] - a["labels"]) * (2.0 * self.act_scale / a["out"].numel()) * a["mfrac"]
+                W = self.view(f"action_out_projectors.{a['dom']}.weight")
+                self.view(f"action_out_projectors.{a['dom']}.weight", self.G).addmm_(d_out.t(), a["pooled"])
+                self.view(f"action_out_projectors.{a['dom']}.bias", self.G).add_(d_out.sum(dim=0))
+                ws["dx"].view(B * T, S + A, 256)[:, S:].add_((d_out @ W).div_(A)[:, None, :])
         pl = self._backward_plan(B, T, S, A, domain)
+
+        def tail(start):
+            if not jpa:
+                pl.run(stream, start, None, timer=self.timer)
+                return
+            # the embedding backward left the action rows' sums in da_tok: masked frames feed action_mask_tokens[t], the others the
+            # action stem (through da_emb, to which the adaLN stacks add afterwards)
+            pl.run(stream, start, pl.marks["post_embed"], timer=self.timer)
+            m = ws["amask"]
+            ws["da_emb"].add_(ws["da_tok"] * (1.0 - m))
+            self.view("action_mask_tokens", self.G).reshape(-1, 256)[:T].add_((ws["da_tok"] * m).view(B, T, 256).sum(dim=0))
+            pl.run(stream, pl.marks["post_embed"], None, timer=self.timer)
+
         if on_segment is None or segment_layers <= 0:
-            pl.run(stream, timer=self.timer)
+            tail(0)
             return
         L = self.cfg.num_layers
         start = 0
@@ -1168,7 +1224,7 @@ class STEngine:
                 pl.run(stream, start, stop, timer=self.timer)
                 start = stop
                 on_segment(f"layer{l}")
-        pl.run(stream, start, None, timer=self.timer)
+        tail(start)
         on_segment("end")
 
     def optimizer_step(self, lr: float, active_domains: Sequence[str], betas=(0.9, 0.95), eps: float = 1e-8,

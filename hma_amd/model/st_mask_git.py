@@ -156,6 +156,22 @@ class _EngineLoss(torch.autograd.Function):
         return None, None, None
 
 
+class _ActionLoss(torch.autograd.Function):
+    """The action loss of jointly_predict_actions as a second autograd leaf: its backward only records d total / d action_loss.  It
+    is created AFTER the video loss' node, so autograd runs it first and `_EngineLoss.backward` -- the one engine backward of the
+    step -- finds the scale (0 when the caller left the action loss out of the objective)."""
+
+    @staticmethod
+    def forward(ctx, anchor: torch.Tensor, owner, value: torch.Tensor) -> torch.Tensor:
+        ctx.owner = owner
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.owner._engine.act_scale = float(grad_out)
+        return None, None, None
+
+
 class STMaskGIT(nn.Module, PyTorchModelHubMixin):
     def __init__(self, config: GenieConfig):
         super().__init__()
@@ -295,7 +311,8 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         B, T = x_THW.shape[:2]
         ids = x_THW.reshape(B, T, -1).contiguous()
         dom = self._domain_key(domain) if action_ids is not None else None
-        ws = eng.forward(ids, labels, action_ids, dom, train, skip_normalization=bool(kwargs.get("skip_normalization", False)))
+        ws = eng.forward(ids, labels, action_ids, dom, train, skip_normalization=bool(kwargs.get("skip_normalization", False)),
+                         action_mask=kwargs.get("action_mask"))
         return eng, ws
 
     # ------------------------------------------------------------------ reference API
@@ -303,9 +320,10 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         """(B,T,H,W) ids -> (logits (B, C, T, H, W), None)  (st_mask_git.py:632-686)."""
         h, w = self._hw(kwargs)
         B, T = x_THW.shape[:2]
-        _, ws = self._run(x_THW, None, action_ids, domain, False, kwargs)
+        eng, ws = self._run(x_THW, None, action_ids, domain, False, kwargs)
         logits = ws["logits"].view(B, T, h, w, -1).clone().permute(0, 4, 1, 2, 3)  # (own storage: valid after the next forward)
-        return logits, None
+        actions = eng._act["out"].view(B, T, -1).clone() if eng._act is not None else None  # jointly_predict_actions (:676-678)
+        return logits, actions
 
     def forward(self, input_ids, labels, action_ids=None, domain="default", **kwargs):
         """input_ids / labels (B, T*H*W) int64; action_ids (B, T, Da) (st_mask_git.py:688-735)."""
@@ -314,6 +332,11 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         B = input_ids.shape[0]
         x_THW = input_ids.reshape(B, T, H, W)
         train = torch.is_grad_enabled() and self.training
+        if self.config.jointly_predict_actions and action_ids is not None and kwargs.get("action_mask") is None:
+            # between 0 (fully unmasked, as in video prediction) and 1 (fully masked, as in policies), drawn per sample (:704-710);
+            # pass `action_mask` (B, T) to fix it
+            drop_ratio = torch.rand(len(action_ids), 1, 1)
+            kwargs = dict(kwargs, action_mask=(torch.rand(len(action_ids), T, 1) < drop_ratio)[..., 0].to(input_ids.device))
         eng, ws = self._run(x_THW, labels, action_ids, domain, train, kwargs)
         stats = ws["stats"]
         loss_value = stats[0] / stats[2]
@@ -327,6 +350,10 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
             loss = _EngineLoss.apply(self._anchor, self, loss_value)
         else:
             loss = loss_value.clone()
+        if eng._act is not None:  # jointly_predict_actions: (:724-733)
+            a = eng._act
+            action_loss = _ActionLoss.apply(self._anchor, self, a["loss"]) if train else a["loss"].clone()
+            return ModelOutput(loss=loss, acc=acc.clone(), logits=logits, action_loss=action_loss, actions=a["out"].view(B, T, -1).clone())
         return ModelOutput(loss=loss, acc=acc.clone(), logits=logits)
 
     def compute_video_loss_and_acc(self, logits_CTHW, targets_THW, relevant_mask_THW):

@@ -107,6 +107,9 @@ class ParamLayout:
         for i in range(cfg.num_factored_vocabs):
             add(f"token_embed.factored_embeds.{i}.weight", (cfg.factored_vocab_size, d), "tail")
         add("pos_embed_TSC", (1, cfg.T, cfg.S + cfg.action_token_size, d), "tail")
+        jpa = bool(getattr(cfg, "jointly_predict_actions", False))
+        if jpa:  # trainable with action prediction (st_mask_git.py:656-660): lives with the embeddings
+            add("action_mask_tokens", (1, cfg.T, 1, d), "tail")
         end()
 
         modulate = "modulate" in cfg.action_network
@@ -128,13 +131,17 @@ class ParamLayout:
             add(f"action_mlp.{dom}.model.0.bias", (d,), f"dom:{dom}")
             add(f"action_mlp.{dom}.model.1.bias", (d,), f"dom:{dom}")
             add(f"action_mlp.{dom}.model.3.bias", (d,), f"dom:{dom}")
+            if jpa:  # the domain's action read-out (st_mask_git.py:676-678)
+                add(f"action_out_projectors.{dom}.weight", (da, d), f"dom:{dom}")
+                add(f"action_out_projectors.{dom}.bias", (da,), f"dom:{dom}")
             end()
 
-        begin("frozen")  # never receive a gradient on this path (jointly_predict_actions=False)
-        add("action_mask_tokens", (1, cfg.T, 1, d), "frozen")
-        for dom, da in zip(self.domains, self.d_actions):
-            add(f"action_out_projectors.{dom}.weight", (da, d), "frozen")
-            add(f"action_out_projectors.{dom}.bias", (da,), "frozen")
+        begin("frozen")  # never receive a gradient with jointly_predict_actions=False
+        if not jpa:
+            add("action_mask_tokens", (1, cfg.T, 1, d), "frozen")
+            for dom, da in zip(self.domains, self.d_actions):
+                add(f"action_out_projectors.{dom}.weight", (da, d), "frozen")
+                add(f"action_out_projectors.{dom}.bias", (da,), "frozen")
         end()
         self.total = _align(self._cur)
 

@@ -229,7 +229,7 @@ class Trainer:
         okf = ok.to(torch.float32)
         self.loss_info += torch.stack([torch.where(ok, loss, torch.zeros_like(loss)) * B, okf * B, 1.0 - okf, okf * 0.0])
 
-    def micro_step(self, input_ids, labels, action_ids=None, domain=None, step_domains=None) -> Dict[str, torch.Tensor]:
+    def micro_step(self, input_ids, labels, action_ids=None, domain=None, step_domains=None, action_mask=None) -> Dict[str, torch.Tensor]:
         """forward + backward of one micro-batch; gradients accumulate in the flat buffer.
 
         `step_domains`: every domain that any rank sees in any micro-batch of THIS optimizer step (only read on the first
@@ -243,12 +243,18 @@ class Trainer:
         T = self.model.config.T
         eng.grad_scale.value = 1.0 / (self.accum * red.world)
         eng.gscale.fill_(1.0)
-        if self.use_graphs and self.accum == 1 and eng.timer is None and eng.device.type == "cuda":
+        if self.use_graphs and self.accum == 1 and eng.timer is None and eng.device.type == "cuda" and not eng.jpa:
             ws = self._graphed_micro_step(input_ids.reshape(B, T, -1), labels, action_ids, dom)
             self._micro += 1
             return ws
-        ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True, need_logits=False)
+        if eng.jpa and action_ids is not None and action_mask is None:  # the reference draws it inside forward (st_mask_git.py:704-710)
+            drop_ratio = torch.rand(B, 1)
+            action_mask = (torch.rand(B, T) < drop_ratio).to(eng.device)
+        ws = eng.forward(input_ids.reshape(B, T, -1), labels, action_ids, dom, train=True, loss_grad=True, need_logits=False,
+                         action_mask=action_mask)
         self._book(ws, B)
+        if eng.jpa:  # loss += config.action_loss_weight * action_loss (train_multi.py:574-576)
+            eng.act_scale = float(getattr(self.model.config, "action_loss_weight", 0.5)) * eng.grad_scale.value
         if last and red.world > 1:
             red.begin()
             eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
@@ -358,9 +364,9 @@ class Trainer:
         """Whether the last optimizer step was skipped on every rank because some rank's loss was not finite (host read)."""
         return bool(self.last_loss_info[2].item() > 0) or not bool(torch.isfinite(self.engine.sqnorm).item())
 
-    def step(self, input_ids, labels, action_ids=None, domain=None, step_domains=None) -> Dict[str, torch.Tensor]:
+    def step(self, input_ids, labels, action_ids=None, domain=None, step_domains=None, action_mask=None) -> Dict[str, torch.Tensor]:
         """One full optimizer step on one micro-batch (grad_accum must be 1)."""
-        ws = self.micro_step(input_ids, labels, action_ids, domain, step_domains=step_domains)
+        ws = self.micro_step(input_ids, labels, action_ids, domain, step_domains=step_domains, action_mask=action_mask)
         self.optimizer_step()
         return ws
 
