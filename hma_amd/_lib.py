@@ -138,6 +138,7 @@ _PROTOS = {
     "hma_count_masked": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64],
     "hma_ce_fwd_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_i32, c_i64, c_f32],
     "hma_maskgit_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32],
+    "hma_maskgit_step_wide": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_i32],
     "hma_maskgit_step_sampled": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32,
                                  c_i32],
     "hma_attn_temporal_cached": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32],

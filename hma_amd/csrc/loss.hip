@@ -128,81 +128,55 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 }
 
 // --------------------------------------------------------------------------------- MaskGIT step
-__global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ logits, int64_t* __restrict__ prompt,
-                                                      uint8_t* __restrict__ unmasked, const float* __restrict__ conf_override,
-                                                      float* __restrict__ conf_out, int T, int S, int out_t, int n_mask, int last,
-                                                      int64_t mask_id, int logits_T, int logits_t,
-                                                      const float* __restrict__ sample_noise) {
-  extern __shared__ float sm[];              // conf[S] | sample[S] (as int)
-  float* conf = sm;
-  int* samp = reinterpret_cast<int*>(sm + S);
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const float* lg = logits + ((b * logits_T + logits_t) * (int64_t)S) * C;
-  // (a wave walks its tokens with the NEXT token's 4 KB of logits already in flight: one exposed HBM round trip per token made
-  // this kernel 170 us for 64 workgroups)
-  float xn[2][8];
-  if (w < S) {
-    load8(lg + (int64_t)w * C + V + lane * 8, xn[1]);
-    load8(lg + (int64_t)w * C + lane * 8, xn[0]);
-  }
-  for (int s = w; s < S; s += 4) {
-    int sample = 0;
-    float c = 1.f;
-    float xc[2][8];
+// one token's 2 x 512 logits (lane holds 8 per factor) -> (sampled id, confidence); every lane returns the same values
+__device__ __forceinline__ void maskgit_token(const float (&xc)[2][8], int lane, const float* __restrict__ noise_tok, int& sample,
+                                              float& c) {
+  sample = 0;
+  c = 1.f;
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+  for (int f = 1; f >= 0; --f) {  // flip(2): highest factor first (:408)
+    float x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xc[f][j] = xn[f][j];
-    {
-      const int sn = s + 4 < S ? s + 4 : s;
-      load8(lg + (int64_t)sn * C + V + lane * 8, xn[1]);
-      load8(lg + (int64_t)sn * C + lane * 8, xn[0]);
-    }
+    for (int j = 0; j < 8; ++j) x[j] = xc[f][j];
+    const FactorStats st = factor_stats(x, lane, -1);
+    if (!noise_tok) {  // greedy (temperature <= 1e-8, :409-410)
+      sample = sample * V + st.arg;
+      c *= 1.0f / st.sumexp;  // softmax prob of the arg-max = exp(0) / sum exp(x - max)
+    } else {
+      // Categorical(probs).sample() (:411-416; the temperature cancels in the normalisation): torch.multinomial draws ONE
+      // sample as argmax_k p_k / q_k with q ~ Exp(1) -- q is the injected draw, so a run is replayable bit for bit.
+      float q[8];
+      load8(noise_tok + f * V + lane * 8, q);
+      const float inv = 1.0f / st.sumexp;
+      float best = -1.f, pbest = 0.f;
+      int a = 0;
 #pragma unroll
-    for (int f = 1; f >= 0; --f) {  // flip(2): highest factor first (:408)
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = xc[f][j];
-      const FactorStats st = factor_stats(x, lane, -1);
-      if (!sample_noise) {  // greedy (temperature <= 1e-8, :409-410)
-        sample = sample * V + st.arg;
-        c *= 1.0f / st.sumexp;  // softmax prob of the arg-max = exp(0) / sum exp(x - max)
-      } else {
-        // Categorical(probs).sample() (:411-416; the temperature cancels in the normalisation): torch.multinomial draws ONE
-        // sample as argmax_k p_k / q_k with q ~ Exp(1) -- q is the injected draw, so a run is replayable bit for bit.
-        float q[8];
-        load8(sample_noise + ((b * (int64_t)S + s) * 2 + f) * V + lane * 8, q);
-        const float inv = 1.0f / st.sumexp;
-        float best = -1.f, pbest = 0.f;
-        int a = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pj = __expf(x[j] - st.m) * inv;
-          const float r = pj / q[j];
-          if (r > best) { best = r; a = j; pbest = pj; }
-        }
-        a += lane * 8;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ob = __shfl_xor(best, o, 64), op = __shfl_xor(pbest, o, 64);
-          const int oa = __shfl_xor(a, o, 64);
-          if (ob > best || (ob == best && oa < a)) { best = ob; a = oa; pbest = op; }
-        }
-        sample = sample * V + a;
-        c *= pbest;  // torch.gather(probs, 1, sample) (:420)
+      for (int j = 0; j < 8; ++j) {
+        const float pj = __expf(x[j] - st.m) * inv;
+        const float r = pj / q[j];
+        if (r > best) { best = r; a = j; pbest = pj; }
       }
-    }
-    if (lane == 0) {
-      conf[s] = c;
-      samp[s] = sample;
+      a += lane * 8;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64), op = __shfl_xor(pbest, o, 64);
+        const int oa = __shfl_xor(a, o, 64);
+        if (ob > best || (ob == best && oa < a)) { best = ob; a = oa; pbest = op; }
+      }
+      sample = sample * V + a;
+      c *= pbest;  // torch.gather(probs, 1, sample) (:420)
     }
   }
-  __syncthreads();
-  // S <= 256: thread s owns token s.  Rank = position in a STABLE ascending sort of the confidences
-  // (previously unmasked tokens pinned to +inf, :442-443); the n_mask lowest are re-masked (:446),
-  // the rest become unmasked (:445); previously unmasked tokens keep their prompt value (:449).
-  const int s = tid;
+}
+
+// S <= 256: thread s owns token s.  Rank = position in a STABLE ascending sort of the confidences (previously unmasked tokens
+// pinned to +inf, :442-443); the n_mask lowest are re-masked (:446), the rest become unmasked (:445); previously unmasked tokens
+// keep their prompt value (:449).  conf / samp: LDS, filled for every token; conf is overwritten with the ranking keys.
+__device__ __forceinline__ void maskgit_rank_update(float* conf, const int* samp, int64_t* __restrict__ prompt,
+                                                    uint8_t* __restrict__ unmasked, const float* __restrict__ conf_override,
+                                                    float* __restrict__ conf_out, int64_t b, int T, int S, int out_t, int n_mask,
+                                                    int last, int64_t mask_id) {
+  const int s = threadIdx.x;
   const bool active = s < S;
   bool prev_unm = false;
   int64_t out = 0;
@@ -238,6 +212,84 @@ __global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ 
   }
 }
 
+// One launch, one workgroup per sample (no scratch needed): a wave walks its tokens with the NEXT token's 4 KB of logits in flight.
+__global__ __launch_bounds__(256) void maskgit_kernel(const float* __restrict__ logits, int64_t* __restrict__ prompt,
+                                                      uint8_t* __restrict__ unmasked, const float* __restrict__ conf_override,
+                                                      float* __restrict__ conf_out, int T, int S, int out_t, int n_mask, int last,
+                                                      int64_t mask_id, int logits_T, int logits_t,
+                                                      const float* __restrict__ sample_noise) {
+  extern __shared__ float sm[];              // conf[S] | sample[S] (as int)
+  float* conf = sm;
+  int* samp = reinterpret_cast<int*>(sm + S);
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* lg = logits + ((b * logits_T + logits_t) * (int64_t)S) * C;
+  float xn[2][8];
+  if (w < S) {
+    load8(lg + (int64_t)w * C + V + lane * 8, xn[1]);
+    load8(lg + (int64_t)w * C + lane * 8, xn[0]);
+  }
+  for (int s = w; s < S; s += 4) {
+    float xc[2][8];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xc[f][j] = xn[f][j];
+    {
+      const int sn = s + 4 < S ? s + 4 : s;
+      load8(lg + (int64_t)sn * C + V + lane * 8, xn[1]);
+      load8(lg + (int64_t)sn * C + lane * 8, xn[0]);
+    }
+    int sample;
+    float c;
+    maskgit_token(xc, lane, sample_noise ? sample_noise + (b * (int64_t)S + s) * 2 * V : nullptr, sample, c);
+    if (lane == 0) {
+      conf[s] = c;
+      samp[s] = sample;
+    }
+  }
+  __syncthreads();
+  maskgit_rank_update(conf, samp, prompt, unmasked, conf_override, conf_out, b, T, S, out_t, n_mask, last, mask_id);
+}
+
+// Two launches when the caller provides scratch (conf_out [B, S] f32 + samp_scratch [B, S] i32): one wave per TOKEN over the whole
+// chip (a decode step has 64 samples -- 64 workgroups walking 256 tokens each left three quarters of the CUs idle: 126 us), then
+// the per-sample ranking.
+__global__ __launch_bounds__(256) void maskgit_sample_kernel(const float* __restrict__ logits, float* __restrict__ conf_out,
+                                                             int* __restrict__ samp_out, int64_t tokens, int S, int logits_T,
+                                                             int logits_t, const float* __restrict__ sample_noise) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const int64_t b = tok / S, s = tok - b * S;
+  const float* lg = logits + (((b * logits_T + logits_t) * (int64_t)S) + s) * C;
+  float xc[2][8];
+  load8(lg + V + lane * 8, xc[1]);
+  load8(lg + lane * 8, xc[0]);
+  int sample;
+  float c;
+  maskgit_token(xc, lane, sample_noise ? sample_noise + tok * 2 * V : nullptr, sample, c);
+  if (lane == 0) {
+    conf_out[tok] = c;
+    samp_out[tok] = sample;
+  }
+}
+__global__ __launch_bounds__(256) void maskgit_rank_kernel(int64_t* __restrict__ prompt, uint8_t* __restrict__ unmasked,
+                                                           const float* __restrict__ conf_override, const float* __restrict__ conf_in,
+                                                           const int* __restrict__ samp_in, int T, int S, int out_t, int n_mask,
+                                                           int last, int64_t mask_id) {
+  extern __shared__ float sm[];
+  float* conf = sm;
+  int* samp = reinterpret_cast<int*>(sm + S);
+  const int64_t b = blockIdx.x;
+  if ((int)threadIdx.x < S) {
+    conf[threadIdx.x] = conf_in[b * S + threadIdx.x];
+    samp[threadIdx.x] = samp_in[b * S + threadIdx.x];
+  }
+  __syncthreads();
+  maskgit_rank_update(conf, samp, prompt, unmasked, conf_override, nullptr, b, T, S, out_t, n_mask, last, mask_id);
+}
+
 }  // namespace
 
 extern "C" int hma_count_masked(void* stream, const int64_t* input_ids, float* stats, int64_t B, int32_t T, int32_t S,
@@ -269,13 +321,23 @@ extern "C" int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* 
 
 static int maskgit_launch(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked, const float* conf_override,
                           float* conf_out, int64_t B, int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last,
-                          int64_t mask_id, int32_t logits_T, int32_t logits_t, const float* sample_noise) {
+                          int64_t mask_id, int32_t logits_T, int32_t logits_t, const float* sample_noise, int32_t* samp_scratch = nullptr) {
   if (!logits || !prompt || !unmasked) return HMA_EINVAL;
   if (S > 256 || out_t < 0 || out_t >= T) return HMA_EINVAL;  // one pass of 256 threads covers the frame
   if (logits_T <= 0) { logits_T = T; logits_t = out_t; }
   if (logits_t < 0 || logits_t >= logits_T) return HMA_EINVAL;
   if (B <= 0) return 0;
   const size_t smem = (size_t)S * 8;
+  if (samp_scratch && conf_out) {
+    const int64_t tokens = B * S;
+    hipLaunchKernelGGL(maskgit_sample_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, conf_out,
+                       samp_scratch, tokens, (int)S, (int)logits_T, (int)logits_t, sample_noise);
+    HMA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(maskgit_rank_kernel, dim3((unsigned)B), dim3(256), smem, (hipStream_t)stream, prompt, unmasked, conf_override,
+                       (const float*)conf_out, (const int*)samp_scratch, (int)T, (int)S, (int)out_t, (int)n_mask, (int)last, mask_id);
+    HMA_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(maskgit_kernel, dim3((unsigned)B), dim3(256), smem, (hipStream_t)stream, logits, prompt, unmasked,
                      conf_override, conf_out, (int)T, (int)S, (int)out_t, (int)n_mask, (int)last, mask_id, (int)logits_T,
                      (int)logits_t, sample_noise);
@@ -298,4 +360,13 @@ extern "C" int hma_maskgit_step_sampled(void* stream, const float* logits, int64
   if (!sample_noise) return HMA_EINVAL;
   return maskgit_launch(stream, logits, prompt, unmasked, conf_override, conf_out, B, T, S, out_t, n_mask, last, mask_id, logits_T,
                         logits_t, sample_noise);
+}
+
+extern "C" int hma_maskgit_step_wide(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                                     const float* conf_override, float* conf_out, int32_t* samp_scratch, const float* sample_noise,
+                                     int64_t B, int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id,
+                                     int32_t logits_T, int32_t logits_t) {
+  if (!conf_out || !samp_scratch) return HMA_EINVAL;
+  return maskgit_launch(stream, logits, prompt, unmasked, conf_override, conf_out, B, T, S, out_t, n_mask, last, mask_id, logits_T,
+                        logits_t, sample_noise, samp_scratch);
 }

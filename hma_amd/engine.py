@@ -1002,6 +1002,19 @@ class STEngine:
         lg = self._ws["logits"] if logits is None else logits
         co = None if conf_override is None else conf_override.data_ptr()
         cout = None if conf_out is None else conf_out.data_ptr()
+        if sample_noise is not None:
+            assert sample_noise.is_contiguous() and sample_noise.dtype == F32 and sample_noise.numel() == B * S * 1024
+        if B * S <= 64 * 256:
+            # few samples (a decode step: 64): sampling as one wave per token over the whole chip, then the per-sample ranking
+            sc = getattr(self, "_mg_scratch", None)
+            if sc is None or sc[0].numel() < B * S or sc[0].device != prompt_BTS.device:
+                sc = self._mg_scratch = (torch.empty(B * S, dtype=F32, device=prompt_BTS.device),
+                                         torch.empty(B * S, dtype=torch.int32, device=prompt_BTS.device))
+            _lib.call("hma_maskgit_step_wide", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co,
+                      cout if cout is not None else sc[0].data_ptr(), sc[1].data_ptr(),
+                      None if sample_noise is None else sample_noise.data_ptr(), B, T, S, out_t, n_mask, int(last),
+                      self.cfg.image_vocab_size, logits_T, logits_t)
+            return
         if sample_noise is None:
             _lib.call("hma_maskgit_step", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co, cout,
                       B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
@@ -1053,8 +1066,11 @@ class STEngine:
         self._dws, self._dws_key = d, key
         return d
 
-    def _decode_plan(self, B: int, T_total: int, S: int, A: int, domain: Optional[str], t: int, readout: bool) -> Plan:
-        key = (B, T_total, S, A, domain, t, readout, self._skip_norm)
+    def _decode_plan(self, B: int, T_total: int, S: int, A: int, domain: Optional[str], t: int, readout: bool,
+                     same_actions: bool = False) -> Plan:
+        """`same_actions`: the frame's actions are those of the previous pass (the 2nd .. last MaskGIT iteration of a frame and its
+        K / V refresh): the action stem and the adaLN stacks -- a_emb and the per-layer shift / scale rows -- are reused, not re-run."""
+        key = (B, T_total, S, A, domain, t, readout, self._skip_norm, same_actions)
         if key in self._dplans:
             return self._dplans[key]
         cfg, d = self.cfg, self._dws
@@ -1062,7 +1078,7 @@ class STEngine:
         SA, M1 = S + A, B * (S + A)
         pl = Plan()
         use_mod = A > 0 and self.modulate
-        if A > 0:
+        if A > 0 and not same_actions:
             am = f"action_mlp.{domain}.model"
             pl.add("hma_action_stem_fwd", d["actions"].data_ptr(), self.buffers[domain][0].data_ptr(),
                    self.buffers[domain][1].data_ptr(), self.action_dims[domain], self._p(f"{am}.0.weight"), self._p(f"{am}.0.bias"),
@@ -1124,7 +1140,7 @@ class STEngine:
                            T_cache=T_total).run(stream)
 
     def decode_frame(self, ids_BS: torch.Tensor, actions_t: Optional[torch.Tensor], domain: Optional[str], t: int, T_total: int,
-                     readout: bool = True) -> torch.Tensor:
+                     readout: bool = True, same_actions: bool = False) -> torch.Tensor:
         """One pass of frame t (tokens ids_BS, possibly partly masked) against the cached frames < t; refreshes
         frame t's own cache rows.  Returns the (B*S, 1024) fp32 logits buffer of that frame."""
         B, S = ids_BS.shape
@@ -1132,15 +1148,16 @@ class STEngine:
         d = self.decode_begin(B, T_total, S, A)
         stream = torch.cuda.current_stream().cuda_stream
         d["ids"].view(B, S).copy_(ids_BS, non_blocking=True)
-        if actions_t is not None:
+        same_actions = same_actions and actions_t is not None
+        if actions_t is not None and not same_actions:
             d_a = self.d_actions[domain]
             d["actions"][: B * d_a].copy_(actions_t.reshape(-1), non_blocking=True)
-        pl = self._decode_plan(B, T_total, S, A, domain if A > 0 else None, t, readout)
+        pl = self._decode_plan(B, T_total, S, A, domain if A > 0 else None, t, readout, same_actions)
         if not self.decode_graphs:
             pl.run(stream)
             return d["logits"]
         # ~420 launches of M = B * 320 rows each: replayed as one hipGraph per (frame index, readout) after two eager runs
-        key = (B, T_total, S, A, domain if A > 0 else None, t, readout, self._skip_norm)
+        key = (B, T_total, S, A, domain if A > 0 else None, t, readout, self._skip_norm, same_actions)
         g = self._dgraphs.get(key)
         if g is None:
             pl.run(stream)

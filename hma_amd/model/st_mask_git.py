@@ -490,7 +490,8 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
             unmasked = torch.zeros(B, S, dtype=torch.uint8, device=dev)
             a_t = None if acts is None else acts[:, t]
             for step in range(maskgit_steps):
-                logits = eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total)
+                # (the frame's action embedding and adaLN rows are computed by its first pass and reused by the later ones)
+                logits = eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total, same_actions=step > 0)
                 if step_hook is not None:
                     win = out.clone()
                     win[:, t] = frame[:, 0]
@@ -514,7 +515,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
                 eng.maskgit_step(frame, unmasked, 0, n, last, override, logits_T=1, logits_t=0, logits=logits, sample_noise=noise)
             out[:, t] = frame[:, 0]
             if t + 1 < T_total:  # store the finished frame's K/V (its tokens changed after the last pass)
-                eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total, readout=False)
+                eng.decode_frame(frame.view(B, S), a_t, dom, t, T_total, readout=False, same_actions=True)
         return out.reshape(B, -1)
 
     @torch.no_grad()

@@ -205,6 +205,14 @@ int hma_maskgit_step_sampled(void* stream, const float* logits, int64_t* prompt,
                              const float* conf_override, float* conf_out, const float* sample_noise,
                              int64_t B, int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last,
                              int64_t mask_id, int32_t logits_T, int32_t logits_t);
+/* Either of the two steps above as TWO launches when the caller owns scratch: one wave per token over the whole chip writes the
+ * sampled ids (samp_scratch, int32 [B, S]) and confidences (conf_out, f32 [B, S], required), then one workgroup per sample ranks
+ * and updates.  Same results; for small B (a decode step has 64 samples) the one-launch form leaves most CUs idle.
+ * sample_noise NULL = greedy. */
+int hma_maskgit_step_wide(void* stream, const float* logits, int64_t* prompt, uint8_t* unmasked,
+                          const float* conf_override, float* conf_out, int32_t* samp_scratch, const float* sample_noise,
+                          int64_t B, int32_t T, int32_t S, int32_t out_t, int32_t n_mask, int32_t last, int64_t mask_id,
+                          int32_t logits_T, int32_t logits_t);
 
 /* sum of squares of g[0:n) accumulated into *out (fp32 atomic; zero it first) -- clip_grad_norm_,
  * train_multi.py:594 */
