@@ -20,8 +20,9 @@ def patchify(x, p):
     return torch.einsum("nthpwqc->nthwpqc", x).reshape(B, T, H // p, W // p, C * p * p)
 
 
-def compute_latents(sd, cfg, x_patches, action_ids, domain):
-    """x_patches (B, T, h, w, 16) -> z (B, T, h*w, d)."""
+def compute_latents(sd, cfg, x_patches, action_ids, domain, with_actions=False):
+    """x_patches (B, T, h, w, 16) -> z (B, T, h*w, d); `with_actions` (jointly_predict_actions, st_mar.py:187-189): also the mean of
+    every frame's action tokens (B, T, d) -- the action mask is NOT applied to the inputs here (:146-172 ignore it)."""
     B, T, h, w, _ = x_patches.shape
     x = F.linear(x_patches.reshape(B, T, h * w, -1).float(), sd["token_embed.weight"])
     a_emb = R.action_stem(sd, cfg, action_ids, domain[0])
@@ -30,10 +31,12 @@ def compute_latents(sd, cfg, x_patches, action_ids, domain):
     x = F.layer_norm(x, (cfg.d_model,), sd["z_proj_ln.weight"], sd["z_proj_ln.bias"], 1e-6)
     for l in range(cfg.num_layers):
         x = R.st_block(sd, cfg, l, x, a_emb, domain[0])
+    pooled = x[:, :, -cfg.action_token_size:].mean(dim=2)
     x = x[:, :, : h * w]
     y = F.linear(x, sd["out_x_proj.weight"], sd["out_x_proj.bias"])
     y = F.layer_norm(y, (cfg.d_model,), sd["decoder_norm.weight"], sd["decoder_norm.bias"], 1e-6)
-    return y + sd["diffusion_pos_embed_learned"].view(1, -1, h * w, cfg.d_model)[:, :T]
+    z = y + sd["diffusion_pos_embed_learned"].view(1, -1, h * w, cfg.d_model)[:, :T]
+    return (z, pooled) if with_actions else z
 
 
 def forward(sd, cfg, input_ids, labels, action_ids, domain, masked, t, noise, patch_size, H, W, diff_depth):
@@ -49,6 +52,28 @@ def forward(sd, cfg, input_ids, labels, action_ids, domain, masked, t, noise, pa
     P = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
     loss, _ = DR.diffloss_forward(P, target.reshape(n, -1).float(), z.reshape(n, -1), pmask.reshape(n).float(), t, noise, diff_depth)
     return loss, z
+
+
+def forward_with_actions(sd, cfg, input_ids, labels, action_ids, domain, masked, t, noise, patch_size, H, W, diff_depth, action_mask,
+                         t_act, noise_act):
+    """STMAR.forward with jointly_predict_actions (st_mar.py:231-273): the video loss as `forward`, plus the per-domain action
+    diffusion head (`action_diff_losses[domain]`, :119-129) on the pooled action tokens against the RAW action ids, masked-mean over
+    the (B, T) action mask (frames from a drawn timestep on, :234-240, given here)."""
+    B = input_ids.shape[0]
+    T = cfg.T
+    x = input_ids.reshape(B, T, H, W, -1).clone()
+    x[masked] = sd["mask_token"].reshape(-1)
+    z, pooled = compute_latents(sd, cfg, patchify(x, patch_size), action_ids, domain, with_actions=True)
+    target = patchify(labels.reshape(B, T, H, W, -1), patch_size)
+    pmask = patchify(masked[..., None].float(), patch_size).sum(-1) > 0
+    n = B * T * z.shape[2]
+    P = {k[len("diffloss."):]: v for k, v in sd.items() if k.startswith("diffloss.")}
+    loss, _ = DR.diffloss_forward(P, target.reshape(n, -1).float(), z.reshape(n, -1), pmask.reshape(n).float(), t, noise, diff_depth)
+    pre = f"action_diff_losses.{domain[0]}."
+    PA = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    aloss, _ = DR.diffloss_forward(PA, action_ids[:, :T].reshape(B * T, -1).float(), pooled.reshape(B * T, -1),
+                                   action_mask.reshape(B * T).float(), t_act, noise_act, diff_depth)
+    return loss, z, aloss, pooled
 
 
 def unpatchify(x, p, c):

@@ -56,3 +56,25 @@ def test_mar_decode_matches_reference():
                                      CFG["diffloss_d"], CFG["num_sampling_steps"])
     assert torch.allclose(orig.permute(0, 2, 1).reshape(2, 256, 16, 16), D["orig_latents"], rtol=1e-3, atol=2e-4)
     assert torch.allclose(frame, D["frame"], rtol=1e-3, atol=1e-3)
+
+
+def test_stmar_jointly_predict_actions_matches_reference():
+    """G17 (make_golden_stmar_jpa.py): the per-domain action diffusion head on the pooled action tokens (st_mar.py:119-129, 187-189,
+    231-273), gradients of loss + action_loss."""
+    G17 = load_file(os.path.join(HERE, "golden", "g17_stmar_jpa.safetensors"))
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not (k.endswith(".mean") or k.endswith(".std")) else v)
+          for k, v in seeded_state(template()).items()}
+    inp = inputs()
+    loss, z, aloss, pooled = M.forward_with_actions(sd, ref_cfg(), inp["latents"], inp["latents"], inp["actions_domA"], ["domA"] * 2,
+                                                    inp["masked"], inp["t"], inp["noise"], 2, 32, 32, CFG["diffloss_d"], G17["action_mask"],
+                                                    G17["t_act"], G17["noise_act"])
+    assert torch.allclose(z, G17["z"], rtol=1e-3, atol=2e-4)
+    assert torch.allclose(pooled, G17["actions"], rtol=1e-3, atol=2e-4)
+    assert abs(loss.item() - G17["loss"].item()) <= 1e-4 * abs(G17["loss"].item())
+    assert abs(aloss.item() - G17["action_loss"].item()) <= 1e-4 * abs(G17["action_loss"].item())
+    (loss + aloss).backward()
+    for k in G17:
+        if k.startswith("grad."):
+            want, got = G17[k], sd[k[5:]].grad
+            assert torch.allclose(got, want, rtol=5e-3, atol=2e-5 * want.abs().max().item() + 1e-9), k
+    assert G17["grad_is_none.domB_head"].item() == 1.0 and sd["action_diff_losses.domB.net.cond_embed.weight"].grad is None
