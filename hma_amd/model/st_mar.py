@@ -10,7 +10,8 @@ modules and their parameters are shared with an internal `STMaskGIT` whose flat 
 `hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
 `DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
 `maskgit_generate` / `generate` are the MAR decode (st_mar.py:277-452) with `DiffLoss.sample`.
-Not built: `jointly_predict_actions` and cfg != 1 in the MAR decode (the reference's own branch,
+`jointly_predict_actions` is built for training (the per-domain action diffusion heads, st_mar.py:119-129, 231-273), not for
+the MAR decode (:441-446).  Not built: cfg != 1 in the MAR decode (the reference's own branch,
 st_mar.py:417-418, indexes bs rows of latents with a 2 bs mask and cannot run; `DiffLoss.sample(cfg=...)` itself is built).
 """
 from __future__ import annotations
@@ -47,6 +48,21 @@ class _MarLoss(torch.autograd.Function):
         return None, None, None
 
 
+class _MarActionLoss(torch.autograd.Function):
+    """jointly_predict_actions: the action loss as a second autograd leaf whose backward only records d total / d action_loss; it is
+    created after `_MarLoss`' node, so autograd runs it first and the one `_backward` of the step finds the scale."""
+
+    @staticmethod
+    def forward(ctx, anchor, owner, value):
+        ctx.owner = owner
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.owner._act_scale = g.detach().clone()
+        return None, None, None
+
+
 class STMAR(nn.Module, PyTorchModelHubMixin):
     """Spatial-Time MAR with VisionTransformer backbone (st_mar.py:36-78)."""
 
@@ -54,8 +70,6 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         super().__init__()
         if isinstance(config, dict):
             config = DiffusionGenieConfig.from_dict(config)
-        if config.jointly_predict_actions:
-            raise NotImplementedError("jointly_predict_actions is not built")
         if config.diffusion_batch_mul < 1:
             raise ValueError("diffusion_batch_mul must be >= 1")
         self.config = config
@@ -185,6 +199,23 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                  Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))
         _lib.call("hma_mar_readout_fwd", stream, ptr(y), ptr(self.decoder_norm.weight), ptr(self.decoder_norm.bias), 1e-6,
                   ptr(self.diffusion_pos_embed_learned), ptr(z), ptr(yhat), ptr(rstd_r), Mi, T, S)
+        act = None
+        self._act_scale = None
+        if cfg.jointly_predict_actions:
+            # st_mar.py:231-240, 187-189, 266-273: the frames from a drawn timestep on are "masked" (the mask only weights the loss:
+            # compute_latents does not apply it), every frame's action tokens are mean-pooled after the trunk and the domain's action
+            # diffusion head is trained on them against the RAW action ids
+            amask = kwargs.get("action_mask")
+            if amask is None:
+                start = torch.randint(0, T, (B, 1), device=dev)
+                amask = (torch.arange(T, device=dev)[None, :] >= start).to(F32)
+            pooled = ws["x"].view(Fr, SA, d)[:, S:].mean(dim=1)
+            za = pooled.detach().requires_grad_(train)
+            mulA = self.diffusion_batch_mul
+            tgt_a = action_ids[:, :T].reshape(Fr, -1).to(dev, F32)
+            inner_a = self.action_diff_losses[dom](tgt_a.repeat(mulA, 1), za.repeat(mulA, 1), amask.reshape(Fr).to(dev, F32).repeat(mulA),
+                                                   t=kwargs.get("action_diffusion_t"), noise=kwargs.get("action_diffusion_noise"))
+            act = dict(inner=inner_a, za=za, actions=pooled.view(B, T, d).clone())
         zl = z.detach().requires_grad_(train)
         mul = self.diffusion_batch_mul
         if mul > 1:  # st_mar.py:133-140: every token is scored at `mul` independent (t, noise) draws; the rows are repeated whole
@@ -195,12 +226,18 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         logits = z.view(B, T, h_, w_, d).permute(0, 4, 1, 2, 3)
         acc = torch.zeros((), device=dev)
         if not train:
+            if act is not None:
+                return ModelOutput(loss=inner.detach(), acc=acc, logits=logits, action_loss=act["inner"].detach(), actions=act["actions"])
             return ModelOutput(loss=inner.detach(), acc=acc, logits=logits)
-        self._saved = dict(inner=inner, zl=zl, yhat=yhat, rstd_r=rstd_r, xhat_e=xhat_e, rstd_e=rstd_e, patches=patches, mk=mk, wtok_t=wtok_t,
+        self._saved = dict(act=act, inner=inner, zl=zl, yhat=yhat, rstd_r=rstd_r, xhat_e=xhat_e, rstd_e=rstd_e, patches=patches, mk=mk, wtok_t=wtok_t,
                            wout_t=wout_t, dims=(B, T, H, W, Cc, p, S, A, dom), pos_stride=pos_stride)
         if self._anchor is None or self._anchor.device != dev:
             self._anchor = torch.zeros((), device=dev, requires_grad=True)
-        return ModelOutput(loss=_MarLoss.apply(self._anchor, self, inner.detach()), acc=acc, logits=logits)
+        loss = _MarLoss.apply(self._anchor, self, inner.detach())
+        if act is not None:
+            return ModelOutput(loss=loss, acc=acc, logits=logits, action_loss=_MarActionLoss.apply(self._anchor, self, act["inner"].detach()),
+                               actions=act["actions"])
+        return ModelOutput(loss=loss, acc=acc, logits=logits)
 
     # ------------------------------------------------------------------------------------------ generation (MAR decode)
     @torch.no_grad()
@@ -332,6 +369,11 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         eng = self._core._engine
         z0 = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
         sv["inner"].backward(grad_out)                       # DiffLoss: parameter grads + d loss / d z
+        dza = None
+        if sv.get("act") is not None and self._act_scale is not None:
+            # the action diffusion head (its own parameter gradients) and d action_loss / d (pooled action tokens)
+            sv["act"]["inner"].backward(self._act_scale)
+            dza = sv["act"]["za"].grad
         hooks = self.__dict__.get("_bwd_hooks") or {}         # (a data-parallel driver: MarTrainer, last micro-batch of a step)
         if hooks.get("after_head"):
             hooks["after_head"]()                             # the head's gradients are final: their all-reduce can start now
@@ -348,6 +390,8 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                      dW=ptr(dWo), lddw=d, dBias=ptr(dBo))
             self._nt(stream, A=ptr(dy), lda=d, a_kind=A_F32, W=ptr(sv["wout_t"]), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
                      Cp=ws["dx"].data_ptr(), ldc=d, c_group=(S, SA))
+            if dza is not None:  # the mean over a frame's A action rows
+                ws["dx"].view(Fr, SA, d)[:, S:].add_((dza / A)[:, None, :])
 
         dxtok, dpos, dg_z, db_z = z0(Mi, d), z0(self.pos_embed_TSC.shape), z0(d), z0(d)
         dWt, dpatch, dmask_tok = z0(d, _PAD), z0(Mi, _PAD), z0(8)
@@ -399,16 +443,9 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         return [(n, p) for n, p in self.named_parameters()
                 if not n.startswith(("decoder.", "action_mlp.", "action_diff_losses.")) and n != "action_mask_tokens"]
 
-    def _own_flat(self, dev=None):
-        """A SECOND flat range next to the engine's: the own parameters become views into one fp32 buffer with mirrored gradient
-        and Adam-moment buffers, so they are all-reduced with ONE collective and stepped by ONE fused clip + AdamW launch
-        (hma_adamw_counted) instead of tensor by tensor.  Decay flags per 64 elements follow train_multi.py:907-918: only
-        names containing "bias" are un-decayed."""
-        named = self._own_named()
-        dev = torch.device(dev) if dev is not None else named[0][1].device
-        own = self.__dict__.get("_own")
-        if own is not None and own["P"].device == dev and all(p.data_ptr() == v.data_ptr() for (_, p), v in zip(named, own["pviews"])):
-            return own
+    def _make_flat(self, named, dev):
+        """One fp32 buffer holding `named` parameters (64-element aligned) as views, with mirrored gradient and Adam-moment buffers and
+        decay flags per 64 elements (train_multi.py:907-918: only names containing "bias" are exempt)."""
         A = self._OWN_ALIGN
         offs, total = [], 0
         for _, p in named:
@@ -426,10 +463,45 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                 pviews.append(v)
                 gviews.append(G[o:o + p.numel()].view(p.shape))
                 flags[o // A:(o + p.numel() + A - 1) // A] = 1 if "bias" in n else 2
-        own = dict(P=P, G=G, M=torch.zeros_like(P), V=torch.zeros_like(P), flags=flags.to(dev), pviews=pviews, gviews=gviews,
-                   names=[n for n, _ in named], steps=torch.zeros(2, dtype=torch.int32, device=dev), calls=0)
+        return dict(P=P, G=G, M=torch.zeros_like(P), V=torch.zeros_like(P), flags=flags.to(dev), pviews=pviews, gviews=gviews,
+                    names=[n for n, _ in named], steps=torch.zeros(2, dtype=torch.int32, device=dev), calls=0)
+
+    def _own_flat(self, dev=None):
+        """A SECOND flat range next to the engine's: the own parameters become views into one fp32 buffer with mirrored gradient
+        and Adam-moment buffers, so they are all-reduced with ONE collective and stepped by ONE fused clip + AdamW launch
+        (hma_adamw_counted) instead of tensor by tensor."""
+        named = self._own_named()
+        dev = torch.device(dev) if dev is not None else named[0][1].device
+        own = self.__dict__.get("_own")
+        if own is not None and own["P"].device == dev and all(p.data_ptr() == v.data_ptr() for (_, p), v in zip(named, own["pviews"])):
+            return own
+        own = self._make_flat(named, dev)
         self.__dict__["_own"] = own
         return own
+
+    def _act_named(self, dom: str):
+        return [(f"action_diff_losses.{dom}.{n}", p) for n, p in self.action_diff_losses[dom].named_parameters()]
+
+    def _act_flat(self, dom: str, dev=None):
+        """jointly_predict_actions: one more flat range PER DOMAIN for its action diffusion head -- stepped (and its update counted)
+        only when the domain is active, like the engine's per-domain blocks and like the reference's grad-None parameters."""
+        named = self._act_named(dom)
+        dev = torch.device(dev) if dev is not None else named[0][1].device
+        cache = self.__dict__.setdefault("_actf", {})
+        af = cache.get(dom)
+        if af is not None and af["P"].device == dev and all(p.data_ptr() == v.data_ptr() for (_, p), v in zip(named, af["pviews"])):
+            return af
+        af = cache[dom] = self._make_flat(named, dev)
+        return af
+
+    @staticmethod
+    def _gather(named, flat) -> None:
+        for (n, p), gv in zip(named, flat["gviews"]):
+            if p.grad is None:
+                gv.zero_()
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+            p.grad = gv
 
     def _own_head_range(self, own):
         """(start, stop) elements of the diffusion head's parameters inside the own flat range (they are consecutive in it)."""
@@ -461,12 +533,19 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         own = self._own_flat(eng.device)
         self._own_gather_grads(own)
         domains = [domain] if isinstance(domain, str) else list(domain)
-        eng.optimizer_step(lr, domains, betas, eps, weight_decay, max_norm, extra_grads=[own["G"]])
+        flats = [own]
+        if self.config.jointly_predict_actions:  # the active domains' action heads
+            for dom in domains:
+                af = self._act_flat(dom, eng.device)
+                self._gather(self._act_named(dom), af)
+                flats.append(af)
+        eng.optimizer_step(lr, domains, betas, eps, weight_decay, max_norm, extra_grads=[f["G"] for f in flats])
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.call("hma_adamw_counted", stream, ptr(own["P"]), ptr(own["G"]), ptr(own["M"]), ptr(own["V"]), None, own["P"].numel(), lr,
-                  betas[0], betas[1], eps, weight_decay, ptr(own["steps"]), own["calls"] & 1, eng.sqnorm.data_ptr(),
-                  float(max_norm or 0.0), ptr(own["flags"]))
-        own["calls"] += 1
+        for f in flats:
+            _lib.call("hma_adamw_counted", stream, ptr(f["P"]), ptr(f["G"]), ptr(f["M"]), ptr(f["V"]), None, f["P"].numel(), lr,
+                      betas[0], betas[1], eps, weight_decay, ptr(f["steps"]), f["calls"] & 1, eng.sqnorm.data_ptr(),
+                      float(max_norm or 0.0), ptr(f["flags"]))
+            f["calls"] += 1
 
     def zero_grad(self, set_to_none: bool = True):
         own = self.__dict__.get("_own")
@@ -475,6 +554,10 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         if own is not None:  # own gradients accumulate in place in the flat buffer
             own["G"].zero_()
             for (_, p), gv in zip(self._own_named(), own["gviews"]):
+                p.grad = gv
+        for dom, af in self.__dict__.get("_actf", {}).items():
+            af["G"].zero_()
+            for (_, p), gv in zip(self._act_named(dom), af["gviews"]):
                 p.grad = gv
         if self._core._engine is not None:
             self._core._engine.zero_grad()

@@ -524,6 +524,9 @@ class MarTrainer:
         B = batch["input_ids"].shape[0]
         self.loss_info += torch.stack([torch.where(ok, loss, torch.zeros_like(loss)) * B, okf * B, 1.0 - okf, okf * 0.0])
         scaled = out.loss * (1.0 / (self.accum * red.world))
+        jpa = getattr(out, "action_loss", None) is not None
+        if jpa:  # loss += config.action_loss_weight * action_loss (train_multi.py:574-576)
+            scaled = scaled + out.action_loss * (float(self.model.config.action_loss_weight) / (self.accum * red.world))
         self._micro += 1
         if self._micro == self.accum and (red.world > 1 or self.force_overlap):
             # Last micro-batch of the step: gradients become final in backward order -- the diffusion head first, then the trunk
@@ -549,7 +552,13 @@ class MarTrainer:
             finally:
                 m.__dict__["_bwd_hooks"] = None
             m._own_gather_grads(own, skip="diffloss.")
-            red.finish(self._active, extra=[own["G"][:ha], own["G"][hb:], self.loss_info])
+            extra = [own["G"][:ha], own["G"][hb:]]
+            if m.config.jointly_predict_actions:  # the active domains' action heads (their own flat ranges)
+                for d_ in self._active:
+                    af = m._act_flat(d_, self.engine.device)
+                    m._gather(m._act_named(d_), af)
+                    extra.append(af["G"])
+            red.finish(self._active, extra=extra + [self.loss_info])
         else:
             scaled.backward()
         return out
@@ -573,11 +582,15 @@ class MarTrainer:
     def _locate(self, name: str):
         """(moment buffers, offset, numel, shape, updates applied) of a named parameter, or None if it is never stepped."""
         eng, own = self.engine, self.own
-        if name in own["names"]:
-            i = own["names"].index(name)
-            pv = own["pviews"][i]
-            off = (pv.data_ptr() - own["P"].data_ptr()) // 4
-            return own["M"], own["V"], off, pv.numel(), tuple(pv.shape), int(own["steps"][own["calls"] & 1].item())
+        flats = [own]
+        if name.startswith("action_diff_losses.") and self.model.config.jointly_predict_actions:
+            flats = [self.model._act_flat(name.split(".")[1], eng.device)]
+        for fl in flats:
+            if name in fl["names"]:
+                i = fl["names"].index(name)
+                pv = fl["pviews"][i]
+                off = (pv.data_ptr() - fl["P"].data_ptr()) // 4
+                return fl["M"], fl["V"], off, pv.numel(), tuple(pv.shape), int(fl["steps"][fl["calls"] & 1].item())
         e = eng.layout.entries.get(name)
         if e is None or e.region == "frozen" or eng.M is None:
             return None
@@ -618,6 +631,10 @@ class MarTrainer:
             if name in own["names"]:
                 M, V, off, numel, _, _ = self._locate(name)
                 own_k = max(own_k, k)
+            elif name.startswith("action_diff_losses."):  # jointly_predict_actions: the domain's action head (its own flat range)
+                M, V, off, numel, _, _ = self._locate(name)
+                af = self.model._act_flat(name.split(".")[1], eng.device)
+                af["steps"][af["calls"] & 1] = max(int(af["steps"][af["calls"] & 1].item()), k)
             else:
                 e = eng.layout.entries[name]
                 M, V, off, numel = eng.M, eng.V, e.offset, e.numel
