@@ -506,7 +506,7 @@ def main():
             del trainer, eng, batches
             model = None
             torch.cuda.empty_cache()
-            out["decode"] = decode_bench(args, dev, steps=2, warmup=1, batch=64)
+            out["decode"] = decode_bench(args, dev, steps=3, warmup=2, batch=64)  # (two warm-up rollouts: a frame pass is captured on its second use)
             out["mar"] = mar_bench(args, dev, steps=5, warmup=2)
         print(json.dumps(out), flush=True)
     if world > 1:
