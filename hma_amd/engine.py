@@ -893,7 +893,7 @@ class STEngine:
             # action stem -> mix in the mask tokens -> everything else (the modulation keeps the embedded actions, :672)
             pl.run(stream, 0, pl.marks["post_stem"], timer=self.timer)
             m = ws["amask"]
-            m.zero_() if action_mask is None else m.copy_(action_mask.reshape(B * T, 1).to(F32))
+            m.zero_() if action_mask is None else m.copy_(action_mask.reshape(B * T, 1).to(self.device, F32))
             mt = self.view("action_mask_tokens").reshape(-1, 256)[:T]
             torch.where(m.bool(), mt.repeat(B, 1), ws["a_emb"], out=ws["a_tok"])
             pl.run(stream, pl.marks["post_stem"], None, timer=self.timer)
@@ -902,7 +902,7 @@ class STEngine:
             pooled = ws["x"].view(B * T, SA, 256)[:, S:].mean(dim=1)
             W, bias = self.view(f"action_out_projectors.{domain}.weight"), self.view(f"action_out_projectors.{domain}.bias")
             out = torch.addmm(bias, pooled, W.t())
-            labels_a = actions[:, :T].reshape(B * T, d_a).to(F32)
+            labels_a = actions[:, :T].reshape(B * T, d_a).to(self.device, F32)
             mfrac = m.mean()
             self._act = dict(pooled=pooled, out=out, labels=labels_a, mfrac=mfrac, dom=domain,
                              loss=((labels_a - out) ** 2).mean() * mfrac)
