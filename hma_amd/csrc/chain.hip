@@ -186,7 +186,9 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
   for (int s = 0; s < total; ++s) {
     CPROF_MARK(2);
     const int ahead = issued - 1 - s;  // bundles issued after bundle s (each 16 pieces; shift / scale pieces only make the wait stricter)
-    if (ahead >= 2)
+    if (ahead >= 3)  // (rings deeper than four slots; the counter has 6 bits, so more than three bundles behind s cannot be told apart)
+      asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (ahead == 2)
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else if (ahead == 1)
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
