@@ -194,3 +194,44 @@ def test_stmar_full_size_batch_and_dropout_properties():
     _note("dropout.train_loss", l1)
     _note("dropout.eval_loss", le1)
     _note("b16.loss", e0)
+
+
+@pytest.mark.timeout(900)
+def test_stmar_shipped_config_window_vs_oracle():
+    """The shipped MAR config's block shape (hma/configs/mar_n32_h8_d256_action.json: T = 12, use_mup false, qkv_bias true, mlp_bias
+    false; attn_drop is constructed but never applied by the reference's attention, attention.py:37-61 / :151; mlp_drop set to 0 for a
+    deterministic comparison) at 3 layers and the full-width head: loss, latents and gradients against the oracle on the host cores."""
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
+    over = dict(num_layers=3, T=12, use_mup=False, attn_drop=0.1)
+    m, sd = _model(**over)
+    B, T, H = 1, 12, 32
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(B, T * H * H, 4, generator=g) * 0.18215 * 4
+    masked = torch.rand(B, T, H, H, generator=g) < 0.55
+    masked[:, 0] = False
+    n = B * T * 256
+    inp = dict(lat=lat, masked=masked, act=torch.randn(B, T, 7, generator=g), t=torch.randint(0, 1000, (n,), generator=g),
+               noise=torch.randn(n, 16, generator=g))
+    rc = R.RefConfig(num_layers=3, num_heads=8, d_model=256, T=12, use_mup=False, qkv_bias=True, mlp_bias=False)
+    keep = lambda k: (".action_projectors." not in k and not k.startswith("action_")) or ".domA." in k
+    full = {k: v for k, v in sd.items() if keep(k)}
+    leaf = {k: v.clone().requires_grad_(True) for k, v in full.items()
+            if not (k.endswith(".mean") or k.endswith(".std")) and not k.startswith("action_diff_losses")}
+    full.update(leaf)
+    loss_ref, z_ref = MR.forward(full, rc, inp["lat"], inp["lat"], inp["act"], ["domA"], inp["masked"], inp["t"], inp["noise"], 2, 32, 32, 4)
+    loss_ref.backward()
+    out = m(**_kw(inp, 1))
+    z = out.logits.permute(0, 2, 3, 4, 1).reshape(1, T, 256, 256)
+    assert abs(out.loss.item() - loss_ref.item()) <= 1e-3 * abs(loss_ref.item()), (out.loss.item(), loss_ref.item())
+    assert rms_err(z, z_ref.detach()) <= 2e-2
+    out.loss.backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for name, p in leaf.items():
+        if p.grad is None or name not in named or named[name].grad is None or float(p.grad.abs().sum()) == 0.0:
+            continue
+        e = rms_err(named[name].grad, p.grad)
+        worst = max(worst, e)
+        assert e <= 3e-2, f"{name}: rms rel err {e:.3e}"
+    _note("shipped_T12.loss_abs_err", abs(out.loss.item() - loss_ref.item()))
+    _note("shipped_T12.worst_grad_rms", worst)

@@ -389,7 +389,7 @@ def test_attn_spatial(frames, n):
         close(dqkv[:, sl], qr.grad[:, sl], 4 * BF, f"spatial {name}")
 
 
-@pytest.mark.parametrize("B,T,n_s", [(2, 16, 5), (3, 3, 7), (1, 1, 4)])
+@pytest.mark.parametrize("B,T,n_s", [(2, 16, 5), (3, 3, 7), (1, 1, 4), (2, 12, 5)])
 def test_attn_temporal(B, T, n_s):
     scale = 0.25
     rows = B * T * n_s

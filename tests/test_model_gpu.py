@@ -492,3 +492,48 @@ def test_mlp_dropout_fused_path_equals_epilogue_path():
     m0 = build_model()
     l0 = m0(input_ids=inp["input_ids"], labels=inp["labels"], action_ids=inp["actions_domA"], domain=["domA"] * 2).loss.item()
     assert abs(la - l0) > 1e-4 * abs(l0)
+
+
+def test_shipped_config_window_against_oracle():
+    """The shipped discrete config (hma/configs/magvit_n32_h8_d256_action.json: T = 12, use_mup false -- the softmax scale is
+    head_dim ** -0.5, attention.py:27 -- qkv_bias false, mlp_bias true) at 3 layers instead of 32, init-scale weights: loss, logits and
+    every gradient against the oracle on the host cores.  (The golden fixtures use T = 3 and use_mup true; full depth uses T = 16.)"""
+    import math
+    from oracle.param_spec import seeded_state_dict, state_dict_spec
+    shipped = dict(num_layers=3, num_heads=8, use_actions=True, d_model=256, T=12, S=256, image_vocab_size=262144, use_mup=False,
+                   action_network="concat+modulate", num_factored_vocabs=2, qkv_bias=False, proj_bias=True, attn_drop=0.0, qk_norm=False,
+                   mlp_ratio=4.0, mlp_drop=0.0, mlp_bias=True)
+    doms, das, stats = ["domA"], [7], [TINY["action_stats"][0]]
+    rc = R.RefConfig(**{k: v for k, v in shipped.items() if k in R.RefConfig.__dataclass_fields__})
+    sd = seeded_state_dict(state_dict_spec(rc, doms, das, [7]), seed=31, std=0.02, embed_std=0.02)
+    sd["action_preprocessor.domA.mean"] = torch.tensor(stats[0][0])
+    sd["action_preprocessor.domA.std"] = torch.tensor(stats[0][1])
+    m = STMaskGIT(GenieConfig(**shipped))
+    m.init_action_projectors(doms, das, stats, shipped["action_network"])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    gq = torch.Generator().manual_seed(12)
+    B, T = 2, 12
+    labels = torch.randint(0, 262144, (B, T, 16, 16), generator=gq)
+    prob = torch.cos(torch.rand(B, T - 1, 1, 1, generator=gq) * math.pi / 2)
+    ids = labels.clone()
+    ids[:, 1:][torch.rand(B, T - 1, 16, 16, generator=gq) < prob] = 262144
+    act = torch.randn(B, T, 7, generator=gq)
+    out = m(input_ids=ids.reshape(B, -1).to(DEV), labels=labels.reshape(B, -1).to(DEV), action_ids=act.to(DEV), domain=["domA"] * B)
+    out.loss.backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(params)
+    loss, acc, logits = R.forward(full, rc, ids.reshape(B, -1), labels.reshape(B, -1), act, ["domA"] * B)
+    loss.backward()
+    assert abs(out.loss.item() - loss.item()) <= 1e-3, (out.loss.item(), loss.item())
+    assert rel_err(out.logits, logits.detach()) <= 2e-2
+    worst = 0.0
+    for name, p in m.named_parameters():
+        gr = params[name].grad
+        if gr is None or float(gr.abs().sum()) == 0.0:
+            continue
+        worst = max(worst, rms_err(p.grad, gr))
+    _note("shipped_T12.loss_abs_err", abs(out.loss.item() - loss.item()))
+    _note("shipped_T12.worst_grad_rms", worst)
+    assert worst <= 3e-2, worst
