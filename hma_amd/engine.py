@@ -619,7 +619,7 @@ class STEngine:
             return {"cache": kv_cache[l].data_ptr(), "row_off": 0, "c_group": (T * (S + A), T_cache * (S + A)), "t_query": -1,
                     "T_cache": T_cache}
 
-        if A > 0:
+        if A > 0 and domain is not None:  # (domain None with A > 0: jointly_predict_actions' policy mode -- mask tokens, no stem, no modulation)
             dom = domain
             am = f"action_mlp.{dom}.model"
             if embed:
@@ -649,7 +649,7 @@ class STEngine:
             s = sl(l)
             names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t", "xh2", "rstd2") + (() if fused else ("u", "hg"))
             bufs = {k: dp(ws[k], s, ws[k][0].numel()) for k in names}
-            if A > 0 and self.modulate:
+            if A > 0 and self.modulate and domain is not None:
                 bufs.update({k: dp(ws[k], s, ws[k][0].numel()) for k in ("xhm", "xm", "rstdm")})
                 bufs["ss"] = dp(ws["ss"], l, Fr * 512)
             ln_next = None
@@ -663,7 +663,7 @@ class STEngine:
                 s1 = sl(l + 1)
                 nxt = (dp(ws["qkv_s"], s1, ws["qkv_s"][0].numel()), dp(ws["xh1"], s1, ws["xh1"][0].numel()),
                        dp(ws["rstd1"], s1, ws["rstd1"][0].numel()))
-            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate, domain, kv=kv_for_layer(l), train=train,
+            self._emit_layer(pl, l, x, bufs, M, Fr, B, T, SA, A > 0 and self.modulate and domain is not None, domain, kv=kv_for_layer(l), train=train,
                              have_ln1=fused and l > l0, ln_next=ln_next, fused=fused, have_qkv_s=cb and l > l0, chain_b=cb,
                              next_qkv_s=nxt[0] if nxt else None, next_ln1=(nxt[1], nxt[2]) if nxt else None)
         # readout on the image tokens only                      st_mask_git.py:681-683
@@ -866,6 +866,12 @@ class STEngine:
         gradient): readout and cross-entropy run as one launch and ws["logits"] is NOT written."""
         B, T, S = ids_BTS.shape
         A = self.cfg.action_token_size if (actions is not None and "concat" in self.cfg.action_network) else 0
+        # jointly_predict_actions without input actions (st_mask_git.py:663-666, "as in policies"): every action token is a mask token,
+        # the decoder runs unconditioned, the domain only selects the action read-out.  Inference only (the reference's forward has no
+        # action labels in this case).
+        policy = self.jpa and actions is None and domain in self.d_actions and not train and "concat" in self.cfg.action_network
+        if policy:
+            A = self.cfg.action_token_size
         if actions is not None and A == 0:
             raise NotImplementedError("only the 'concat+modulate' action network is built")
         if actions is not None and domain not in self.d_actions:
@@ -887,9 +893,15 @@ class STEngine:
         if train:
             self.bump_dropout()
         fce = labels is not None and train and loss_grad and not need_logits and self._use_fused_ce(B, T, S)
-        pl = self._forward_plan(B, T, S, A, train, domain if A > 0 else None, readout=not fce)
+        pl = self._forward_plan(B, T, S, A, train, domain if (A > 0 and not policy) else None, readout=not fce)
         self._act, self.act_scale = None, 0.0
-        if self.jpa and A > 0:
+        if policy:
+            ws["a_tok"].copy_(self.view("action_mask_tokens").reshape(-1, 256)[:T].repeat(B, 1))
+            pl.run(stream, timer=self.timer)
+            pooled = ws["x"].view(B * T, S + A, 256)[:, S:].mean(dim=1)
+            W, bias = self.view(f"action_out_projectors.{domain}.weight"), self.view(f"action_out_projectors.{domain}.bias")
+            self._act = dict(out=torch.addmm(bias, pooled, W.t()), loss=None, dom=domain)
+        elif self.jpa and A > 0:
             # action stem -> mix in the mask tokens -> everything else (the modulation keeps the embedded actions, :672)
             pl.run(stream, 0, pl.marks["post_stem"], timer=self.timer)
             m = ws["amask"]
@@ -906,11 +918,9 @@ class STEngine:
             mfrac = m.mean()
             self._act = dict(pooled=pooled, out=out, labels=labels_a, mfrac=mfrac, dom=domain,
                              loss=((labels_a - out) ** 2).mean() * mfrac)
-        elif self.jpa:
-            raise NotImplementedError("jointly_predict_actions without action_ids (all action tokens masked, :663-666) is not built")
         else:
             pl.run(stream, timer=self.timer)
-        self._last = (B, T, S, A, domain if A > 0 else None)
+        self._last = (B, T, S, A, domain if (A > 0 and not policy) else None)
         self._last_fce = fce
         if labels is not None:
             ws["labels"].copy_(labels.reshape(B, T * S), non_blocking=True)

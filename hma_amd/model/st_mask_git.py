@@ -310,7 +310,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
             eng.weights_changed()
         B, T = x_THW.shape[:2]
         ids = x_THW.reshape(B, T, -1).contiguous()
-        dom = self._domain_key(domain) if action_ids is not None else None
+        dom = self._domain_key(domain) if (action_ids is not None or (self.config.jointly_predict_actions and not train)) else None
         ws = eng.forward(ids, labels, action_ids, dom, train, skip_normalization=bool(kwargs.get("skip_normalization", False)),
                          action_mask=kwargs.get("action_mask"))
         return eng, ws
@@ -350,6 +350,8 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
             loss = _EngineLoss.apply(self._anchor, self, loss_value)
         else:
             loss = loss_value.clone()
+        if eng._act is not None and eng._act["loss"] is None:  # policy mode (no action ids): predicted actions, no action loss
+            return ModelOutput(loss=loss, acc=acc.clone(), logits=logits, actions=eng._act["out"].view(B, T, -1).clone())
         if eng._act is not None:  # jointly_predict_actions: (:724-733)
             a = eng._act
             action_loss = _ActionLoss.apply(self._anchor, self, a["loss"]) if train else a["loss"].clone()

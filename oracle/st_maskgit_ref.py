@@ -229,10 +229,17 @@ def compute_logits_and_actions(sd: SD, cfg: RefConfig, x_THW: torch.Tensor, acti
     """compute_logits with jointly_predict_actions (hma/model/st_mask_git.py:656-660, 676-683): also the action read-out -- the
     mean of a frame's action tokens through `action_out_projectors[domain]` (a plain Linear at width_mult == 1) -> (B, T, d_action)."""
     B, T, H, W = x_THW.shape
-    x, a_emb = trunk_input(sd, cfg, x_THW, action_ids, domain, action_mask=action_mask)
+    if action_ids is None:
+        # policy mode (:663-666): every action token is action_mask_tokens[t]; the decoder gets no actions, hence no modulation
+        x = token_embed(sd, cfg, x_THW.reshape(B, T, -1))
+        cond = sd["action_mask_tokens"][:, :T].expand(B, T, cfg.action_token_size, cfg.d_model)
+        x = torch.cat([x, cond], dim=2) + sd["pos_embed_TSC"][:, :T, : H * W + cfg.action_token_size]
+        a_emb = None
+    else:
+        x, a_emb = trunk_input(sd, cfg, x_THW, action_ids, domain, action_mask=action_mask)
     dom = domain[0]
     for l in range(cfg.num_layers):
-        x = st_block(sd, cfg, l, x, a_emb, dom)
+        x = st_block(sd, cfg, l, x, a_emb, dom if a_emb is not None else None)
     pooled = x[:, :, -cfg.action_token_size:].mean(dim=2)
     actions = F.linear(pooled, sd[f"action_out_projectors.{dom}.weight"], sd[f"action_out_projectors.{dom}.bias"])
     logits = F.linear(x[:, :, : H * W], sd["out_x_proj.weight"], sd["out_x_proj.bias"])

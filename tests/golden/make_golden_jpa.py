@@ -49,6 +49,14 @@ def main():
         out[f"{tag}.logits_sub"] = o.logits.detach()[:, :, :, ::4, ::4]
         for k, v in MG.grad_digest(model.named_parameters()).items():
             out[f"{tag}.{k}"] = v
+    # policy mode: no action ids, every action token is a mask token, the decoder runs unconditioned (st_mask_git.py:663-666)
+    model.eval()
+    with torch.no_grad():
+        # (B = 1: the reference concatenates the un-expanded (1, T, A, D) mask tokens, :665-666, so this branch only runs for one sample)
+        x_THW = inp["input_ids"].reshape(2, cfg.T, 16, 16)[:1]
+        logits, actions = model.compute_logits(x_THW, action_ids=None, domain=["domB"], h=[16], w=[16])
+    out["policy.actions"] = actions.detach()
+    out["policy.logits_sub"] = logits.detach()[:, :, :, ::4, ::4]
     MG.save("g16_jpa", out)
 
 

@@ -93,3 +93,24 @@ def test_compute_logits_returns_actions_and_random_mask_is_drawn():
         torch.manual_seed(4)
         b = m(input_ids=inp["input_ids"], labels=inp["labels"], action_ids=inp["actions_domA"], domain=["domA"] * 2)
     assert a.action_loss.item() != b.action_loss.item() or a.loss.item() != b.loss.item()  # different masks were drawn
+
+
+def test_policy_mode_predicts_actions_without_action_ids():
+    """No action ids (st_mask_git.py:663-666, "as in policies"): every action token is a mask token, the decoder runs unconditioned,
+    the domain selects the action read-out.  G16's `policy.*` entries are the reference at B = 1 (its branch only runs for one
+    sample); here any batch works and the rows are independent."""
+    g = golden("g16_jpa")
+    m = build().eval()
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    T = m.config.T
+    x = inp["input_ids"].reshape(2, T, 16, 16)
+    with torch.no_grad():
+        logits1, actions1 = m.compute_logits(x[:1], action_ids=None, domain=["domB"])
+        assert rel_err(actions1, g["policy.actions"]) <= 2e-2
+        assert rel_err(logits1[:, :, :, ::4, ::4], g["policy.logits_sub"]) <= 2e-2
+        logits2, actions2 = m.compute_logits(x, action_ids=None, domain=["domB"] * 2)
+        assert actions2.shape == (2, T, 14)
+        assert rel_err(actions2[:1], actions1) <= 2e-3 and rel_err(logits2[:1], logits1) <= 2e-3
+        # and with action ids again afterwards (the plans of the two modes do not interfere)
+        _, actions3 = m.compute_logits(x, action_ids=inp["actions_domB"], domain=["domB"] * 2)
+        assert actions3.shape == (2, T, 14) and rel_err(actions3, actions2) > 1e-3

@@ -129,6 +129,18 @@ def test_g16_jointly_predict_actions(tag):
     assert {"action_mask_tokens", f"action_out_projectors.{tag}.weight", f"action_out_projectors.{tag}.bias"} <= seen
 
 
+def test_g16_policy_mode():
+    """jointly_predict_actions without action ids (st_mask_git.py:663-666): mask tokens in, predicted actions out."""
+    g = golden("g16_jpa")
+    cfg = tiny_ref_config()
+    sd = tiny_state_dict(cfg)
+    inp = tiny_inputs()
+    with torch.no_grad():
+        logits, actions = R.compute_logits_and_actions(sd, cfg, inp["input_ids"].reshape(2, cfg.T, 16, 16)[:1], None, ["domB"], None)
+    assert rel_err(actions, g["policy.actions"]) < TOL
+    assert rel_err(logits[:, :, :, ::4, ::4], g["policy.logits_sub"]) < TOL
+
+
 def test_g6b_initlike_forward_backward():
     g = golden("g6b_initlike")
     cfg = tiny_ref_config()
