@@ -15,7 +15,8 @@ import torch
 
 def state_dict_spec(cfg, domains: Sequence[str] = (), d_actions: Sequence[int] = (),
                     action_dims: Sequence[int] = ()) -> "OrderedDict[str, Tuple[int, ...]]":
-    """name -> shape, parameters and buffers, for the qk_norm=False MagVit configs."""
+    """name -> shape, parameters and buffers.  qk_norm=True (hma/model/st_transformer.py:55,62 and attention.py:31-35): norm1 / norm2 are
+    nn.Identity (no parameters) and each attention owns a LayerNorm(head_dim) shared by q and k."""
     d, L = cfg.d_model, cfg.num_layers
     hid = int(d * cfg.mlp_ratio)
     C = cfg.factored_vocab_size * cfg.num_factored_vocabs
@@ -24,8 +25,10 @@ def state_dict_spec(cfg, domains: Sequence[str] = (), d_actions: Sequence[int] =
     out["action_mask_tokens"] = (1, cfg.T, 1, d)
     for l in range(L):
         p = f"decoder.layers.{l}"
-        out[f"{p}.norm1.weight"] = (d,)
-        out[f"{p}.norm1.bias"] = (d,)
+        qkn = bool(getattr(cfg, "qk_norm", False))
+        if not qkn:
+            out[f"{p}.norm1.weight"] = (d,)
+            out[f"{p}.norm1.bias"] = (d,)
         for a in ("spatial_attn", "temporal_attn"):
             out[f"{p}.{a}.qkv.weight"] = (3 * d, d)
             if cfg.qkv_bias:
@@ -33,8 +36,12 @@ def state_dict_spec(cfg, domains: Sequence[str] = (), d_actions: Sequence[int] =
             out[f"{p}.{a}.proj.weight"] = (d, d)
             if cfg.proj_bias:
                 out[f"{p}.{a}.proj.bias"] = (d,)
-        out[f"{p}.norm2.weight"] = (d,)
-        out[f"{p}.norm2.bias"] = (d,)
+            if qkn:
+                out[f"{p}.{a}.norm.weight"] = (d // cfg.num_heads,)
+                out[f"{p}.{a}.norm.bias"] = (d // cfg.num_heads,)
+        if not qkn:
+            out[f"{p}.norm2.weight"] = (d,)
+            out[f"{p}.norm2.bias"] = (d,)
         out[f"{p}.mlp.fc1.weight"] = (hid, d)
         out[f"{p}.mlp.fc2.weight"] = (d, hid)
         if cfg.mlp_bias:
@@ -80,7 +87,7 @@ def seeded_state_dict(spec: "OrderedDict[str, Tuple[int, ...]]", seed: int = 0, 
     sd: Dict[str, torch.Tensor] = {}
     for name in sorted(spec):
         t = torch.randn(spec[name], generator=g, dtype=torch.float32) * std
-        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("model.1.weight"):
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("model.1.weight") or name.endswith("attn.norm.weight"):
             t = t + 1.0
         if name.endswith(".std"):
             t = t.abs() / std + 0.5

@@ -120,8 +120,10 @@ def action_stem(sd: SD, cfg: RefConfig, action_ids: torch.Tensor, domain: str,
 
 def self_attention(x: torch.Tensor, w_qkv: torch.Tensor, b_qkv: Optional[torch.Tensor],
                    w_proj: torch.Tensor, b_proj: Optional[torch.Tensor],
-                   num_heads: int, scale: float, causal: bool) -> torch.Tensor:
-    """BasicSelfAttention.forward, hma/model/attention.py:37-61 (qk_norm=False branch).
+                   num_heads: int, scale: float, causal: bool,
+                   qk_norm: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """BasicSelfAttention.forward, hma/model/attention.py:37-61.  `qk_norm` = (weight, bias) of the attention's LayerNorm(head_dim):
+    q and k are normalised per head with the SAME affine before the scale (:44-48).
 
     q is scaled before the product (`:49`); the causal fill is -finfo.max (`:52-56`);
     attn_drop is constructed but never applied.
@@ -129,9 +131,13 @@ def self_attention(x: torch.Tensor, w_qkv: torch.Tensor, b_qkv: Optional[torch.T
     Bn, N, C = x.shape
     hd = C // num_heads
     qkv = F.linear(x, w_qkv, b_qkv).reshape(Bn, N, 3, num_heads, hd)
-    q = qkv[:, :, 0].transpose(1, 2) * scale  # (Bn, h, N, hd)
+    q = qkv[:, :, 0].transpose(1, 2)  # (Bn, h, N, hd)
     k = qkv[:, :, 1].transpose(1, 2)
     v = qkv[:, :, 2].transpose(1, 2)
+    if qk_norm is not None:
+        q = F.layer_norm(q, (hd,), qk_norm[0], qk_norm[1], 1e-5)
+        k = F.layer_norm(k, (hd,), qk_norm[0], qk_norm[1], 1e-5)
+    q = q * scale
     att = q @ k.transpose(-1, -2)
     if causal:
         keep = torch.ones(N, N, dtype=torch.bool).tril()
@@ -172,7 +178,8 @@ def st_block(sd: SD, cfg: RefConfig, l: int, x_btsd: torch.Tensor,
     xn = xs if cfg.qk_norm else F.layer_norm(xs, (D,), g("norm1.weight"), g("norm1.bias"), 1e-5)
     xs = xs + self_attention(xn, g("spatial_attn.qkv.weight"), g("spatial_attn.qkv.bias"),
                              g("spatial_attn.proj.weight"), g("spatial_attn.proj.bias"),
-                             cfg.num_heads, cfg.attn_scale, causal=False)
+                             cfg.num_heads, cfg.attn_scale, causal=False,
+                             qk_norm=(g("spatial_attn.norm.weight"), g("spatial_attn.norm.bias")) if cfg.qk_norm else None)
     # (B S) T C view (:89)
     xt = xs.reshape(B, T, S, D).permute(0, 2, 1, 3)  # B S T D
     if a_emb is not None and domain is not None and "modulate" in cfg.action_network:
@@ -183,7 +190,8 @@ def st_block(sd: SD, cfg: RefConfig, l: int, x_btsd: torch.Tensor,
     # causal temporal attention on the UN-normed stream (:111)
     xt = xt + self_attention(xt, g("temporal_attn.qkv.weight"), g("temporal_attn.qkv.bias"),
                              g("temporal_attn.proj.weight"), g("temporal_attn.proj.bias"),
-                             cfg.num_heads, cfg.attn_scale, causal=True)
+                             cfg.num_heads, cfg.attn_scale, causal=True,
+                             qk_norm=(g("temporal_attn.norm.weight"), g("temporal_attn.norm.bias")) if cfg.qk_norm else None)
     xn2 = xt if cfg.qk_norm else F.layer_norm(xt, (D,), g("norm2.weight"), g("norm2.bias"), 1e-5)
     xt = xt + mlp(xn2, g("mlp.fc1.weight"), g("mlp.fc1.bias"), g("mlp.fc2.weight"), g("mlp.fc2.bias"))  # :112
     return xt.reshape(B, S, T, D).permute(0, 2, 1, 3).contiguous()

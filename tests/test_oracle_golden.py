@@ -3,6 +3,7 @@ import torch
 import pytest
 
 from oracle import st_maskgit_ref as R
+from tests.golden.golden_cfg import TINY  # noqa: E402
 from tests.helpers import golden, tiny_ref_config, tiny_state_dict, tiny_inputs, rel_err
 
 TOL = 2e-5  # fp32 restatement vs fp32 reference: summation-order noise only
@@ -139,6 +140,41 @@ def test_g16_policy_mode():
         logits, actions = R.compute_logits_and_actions(sd, cfg, inp["input_ids"].reshape(2, cfg.T, 16, 16)[:1], None, ["domB"], None)
     assert rel_err(actions, g["policy.actions"]) < TOL
     assert rel_err(logits[:, :, :, ::4, ::4], g["policy.logits_sub"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["domA", "noact"])
+def test_g18_qk_norm(tag):
+    """qk_norm=True (attention.py:31-35,44-48; st_transformer.py:55,62): per-head LayerNorm of q and k, identity norm1 / norm2."""
+    from oracle.param_spec import seeded_state_dict, state_dict_spec
+    g = golden("g18_qknorm")
+    cfg = tiny_ref_config(qk_norm=True)
+    sd = seeded_state_dict(state_dict_spec(cfg, TINY["domains"], TINY["d_actions"], [len(s[0]) for s in TINY["action_stats"]]),
+                           seed=TINY["seed"] + 2, std=0.02, embed_std=0.02)
+    for dom, st in zip(TINY["domains"], TINY["action_stats"]):
+        sd[f"action_preprocessor.{dom}.mean"] = torch.tensor(st[0], dtype=torch.float32)
+        sd[f"action_preprocessor.{dom}.std"] = torch.tensor(st[1], dtype=torch.float32)
+    inp = tiny_inputs()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(params)
+    act = None if tag == "noact" else inp[f"actions_{tag}"]
+    dom = None if tag == "noact" else [tag] * 2
+    loss, acc, logits = R.forward(full, cfg, inp["input_ids"], inp["labels"], act, dom)
+    loss.backward()
+    assert abs(loss.item() - g[f"{tag}.loss"].item()) < 1e-5
+    assert acc.item() == g[f"{tag}.acc"].item()
+    assert rel_err(logits.detach()[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) < TOL
+    seen = 0
+    for name, p in params.items():
+        key = f"{tag}.grad_samp.{name}"
+        if key not in g:
+            continue
+        seen += 1
+        gf = p.grad.reshape(-1)
+        idx = torch.linspace(0, gf.numel() - 1, 64).long()
+        scale = g[f"{tag}.grad_abs.{name}"].item() / gf.numel() + 1e-12
+        assert (gf[idx] - g[key]).abs().max().item() < 5e-4 * scale + 1e-9, name
+    assert seen > 20 and f"{tag}.grad_samp.decoder.layers.0.spatial_attn.norm.weight" in g
 
 
 def test_g6b_initlike_forward_backward():
