@@ -124,6 +124,8 @@ _PROTOS = {
     "hma_gemm_tn_pair": [c_vp, C.POINTER(GemmTN), C.POINTER(GemmTN)],
     "hma_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32],
     "hma_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hma_qknorm_fwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_i64, c_i64, c_i64],
+    "hma_qknorm_bwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64],
     "hma_modln_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32],
     "hma_modln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "hma_attn_spatial_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],

@@ -166,6 +166,108 @@ inline unsigned stream_grid(int64_t rows) {
   return (unsigned)b;
 }
 
+// ---------------------------------------------------------------------------------------------- q / k LayerNorm (qk_norm=True)
+// attention.py:31-35,44-48: q and k are normalised per head (32 values, eps 1e-5) with ONE affine shared by q, k and all heads, before
+// the softmax scale.  One wave per token row of the packed qkv buffer: lane l holds 8 consecutive values of the 512 q | k values
+// (4 lanes = one head), statistics by two shuffles.  In place; the pre-norm values are saved for the backward.
+__device__ __forceinline__ int64_t qkn_row(int64_t r, int64_t g_rows, int64_t g_stride) {
+  return g_rows > 0 ? (r / g_rows) * g_stride + r % g_rows : r;
+}
+__global__ __launch_bounds__(256) void qknorm_fwd_kernel(uint16_t* __restrict__ qkv, int64_t ld, uint16_t* __restrict__ raw,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         int64_t rows, int64_t g_rows, int64_t g_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const int j0 = 8 * (lane & 3);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gm[e] = gamma[j0 + e], bt[e] = beta[j0 + e];
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+    uint16_t* p = qkv + qkn_row(row, g_rows, g_stride) * ld + lane * 8;
+    const uint4 pk = *reinterpret_cast<const uint4*>(p);
+    if (raw) *reinterpret_cast<uint4*>(raw + row * 512 + lane * 8) = pk;
+    float v[8];
+    unpack8(pk, v);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s * (1.0f / 32.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q = __builtin_fmaf(v[e] - mean, v[e] - mean, q);
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    const float rstd = rsqrtf(q * (1.0f / 32.0f) + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+    *reinterpret_cast<uint4*>(p) = pack8(v);
+  }
+}
+// dqkv (bf16, in place on its q | k parts): gradient wrt the normalised q / k -> gradient wrt the raw ones; dgamma / dbeta += (fp32 atomics)
+__global__ __launch_bounds__(256) void qknorm_bwd_kernel(uint16_t* __restrict__ dqkv, int64_t ld, const uint16_t* __restrict__ raw,
+                                                         const float* __restrict__ gamma, float eps, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const int j0 = 8 * (lane & 3);
+  float gm[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gm[e] = gamma[j0 + e], dg[e] = 0.f, db[e] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+    uint16_t* p = dqkv + row * ld + lane * 8;
+    float g[8], v[8];
+    unpack8(*reinterpret_cast<const uint4*>(p), g);
+    unpack8(*reinterpret_cast<const uint4*>(raw + row * 512 + lane * 8), v);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s * (1.0f / 32.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q = __builtin_fmaf(v[e] - mean, v[e] - mean, q);
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    const float rstd = rsqrtf(q * (1.0f / 32.0f) + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (v[e] - mean) * rstd;        // xhat
+      dg[e] = __builtin_fmaf(g[e], v[e], dg[e]);
+      db[e] += g[e];
+      g[e] *= gm[e];                      // d xhat
+      s1 += g[e];
+      s2 = __builtin_fmaf(g[e], v[e], s2);
+    }
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    s1 *= 1.0f / 32.0f;
+    s2 *= 1.0f / 32.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = rstd * (g[e] - s1 - v[e] * s2);
+    *reinterpret_cast<uint4*>(p) = pack8(g);
+  }
+  // the affine's gradients: lanes with the same (lane & 3) hold the same 8 columns
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      dg[e] += __shfl_xor(dg[e], o, 64);
+      db[e] += __shfl_xor(db[e], o, 64);
+    }
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(dgamma + j0 + e, dg[e]);
+      atomicAdd(dbeta + j0 + e, db[e]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int hma_ln_fwd(void* stream, const float* x, void* xhat, float* rstd, int64_t rows, float eps) {
@@ -206,6 +308,30 @@ extern "C" int hma_modln_bwd(void* stream, const void* dxm, const void* xhat, co
   if (frames <= 0 || rows_per_frame <= 0) return 0;
   hipLaunchKernelGGL(modln_bwd_kernel, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)dxm, (const uint16_t*)xhat, rstd, ss, dx, dss, (uint16_t*)dx_bf16, rows_per_frame);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_qknorm_fwd(void* stream, void* qkv, int64_t ld, void* raw, const float* gamma, const float* beta, float eps, int64_t rows,
+                              int64_t g_rows, int64_t g_stride) {
+  if (!qkv || !gamma || !beta || ld < 512 || (ld & 7)) return HMA_EINVAL;
+  if (rows <= 0) return 0;
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(qknorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv, ld, (uint16_t*)raw, gamma,
+                     beta, eps, rows, g_rows, g_stride);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_qknorm_bwd(void* stream, void* dqkv, int64_t ld, const void* raw, const float* gamma, float eps, float* dgamma,
+                              float* dbeta, int64_t rows) {
+  if (!dqkv || !raw || !gamma || !dgamma || !dbeta || ld < 512 || (ld & 7)) return HMA_EINVAL;
+  if (rows <= 0) return 0;
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;  // bounds the dgamma / dbeta atomics
+  hipLaunchKernelGGL(qknorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dqkv, ld, (const uint16_t*)raw,
+                     gamma, eps, dgamma, dbeta, rows);
   HMA_CHECK_LAUNCH();
   return 0;
 }

@@ -173,14 +173,16 @@ class STEngine:
     def __init__(self, cfg, domains: Sequence[str], d_actions: Sequence[int], action_dims: Sequence[int], device):
         if cfg.d_model != 256 or cfg.num_heads != 8:
             raise NotImplementedError("the gfx950 kernels are specialised for d_model=256, 8 heads of 32 (HMA-base)")
-        if cfg.qk_norm:
-            raise NotImplementedError("qk_norm=True is not used by the shipped MagVit configs and is not built")
         if cfg.num_factored_vocabs != 2 or cfg.factored_vocab_size != 512:
             raise NotImplementedError("readout/loss kernels are built for the 2 x 512 factorised vocabulary")
         # jointly_predict_actions (st_mask_git.py:656-660, 676-678, 724-733): the action tokens of masked frames are
         # `action_mask_tokens[t]`, a frame's action tokens are mean-pooled after the trunk and read out per domain, and an action
         # loss trains that head.  The trunk kernels are unchanged; the three small per-frame pieces ([B*T, 256] mixes, a 256 x d_a
         # Linear, its MSE) are fp32 torch ops on the GPU between plan segments.
+        # qk_norm=True (the GenieConfig dataclass default; no shipped JSON uses it): norm1 / norm2 are identities and q, k get a per-head
+        # LayerNorm (attention.py:31-35,44-48; st_transformer.py:55,62).  Runs on the GEMM-per-Linear plans (the chain / fused-MLP
+        # kernels have the block's LayerNorms built in) with hma_qknorm_fwd / _bwd behind the qkv projections.
+        self.qkn = bool(cfg.qk_norm)
         self.jpa = bool(cfg.jointly_predict_actions)
         self._act: Optional[dict] = None
         self.act_scale = 0.0   # d total / d action_loss of the backward in flight (0: the action loss is not part of the objective)
@@ -255,6 +257,8 @@ class STEngine:
             for dom in self.domains:
                 self.CP[f"lin:{dom}"] = mk(L, 8 * BUN)
                 self.CP[f"lin_T:{dom}"] = mk(L, 8 * BUN)
+        if self.qkn:
+            self.use_chain = self.fused_mlp = self.fused_mlp_train = self.chain_b_ok = self.fused_ce = False
         self.buffers: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}  # domain -> (mean, std) of ActionStat
         self._seen_version = -1       # P._version at the last refresh (detects external in-place updates)
         self._wb_ok = False           # flat bf16 copy current
@@ -345,8 +349,8 @@ class STEngine:
                 _lib.call("hma_transpose_cast_bf16", stream, self._p(f"decoder.layers.{L - 1}.{suffix}"),
                           self.WT[key][L - 1].data_ptr(), rows, cols, L, ls, -rows * cols)
             _lib.call("hma_transpose_cast_bf16", stream, self._p("out_x_proj.weight"), self.WT["out"].data_ptr(), 1024, d, 1, 0, 0)
-            for key, lin, norm, rows, has_bias in (("qkv_s", "spatial_attn.qkv", "norm1", 3 * d, cfg.qkv_bias),
-                                                   ("fc1", "mlp.fc1", "norm2", hid, cfg.mlp_bias)):
+            for key, lin, norm, rows, has_bias in (() if self.qkn else (("qkv_s", "spatial_attn.qkv", "norm1", 3 * d, cfg.qkv_bias),
+                                                                        ("fc1", "mlp.fc1", "norm2", hid, cfg.mlp_bias))):
                 pre = f"decoder.layers.{L - 1}."
                 _lib.call("hma_fold_ln_bf16", stream, self._p(pre + lin + ".weight"), self._p(pre + norm + ".weight"),
                           self._p(pre + norm + ".bias"), self._p(pre + lin + ".bias") if has_bias else None,
@@ -441,6 +445,9 @@ class STEngine:
         buf("lse_s", (Ls, M, 8), F32)
         buf("rstd1", (Ls, M), F32)
         buf("rstd2", (Ls, M), F32)
+        if self.qkn and train:
+            buf("qraw_s", (Ls, M, 512), BF16)  # q | k in front of their LayerNorm, for its backward
+            buf("qraw_t", (Ls, M, 512), BF16)
         fused = self._use_fused(M, train, SA)
         if not fused:  # the fused MLP block never materialises the hidden activation
             buf("u", (Ls, M, 1024), BF16)
@@ -509,7 +516,15 @@ class STEngine:
         qb = lambda a: self._lw(l, f"{a}.qkv.bias", "p") if cfg.qkv_bias else None
         pb = lambda a: self._lw(l, f"{a}.proj.bias", "p") if cfg.proj_bias else None
         # spatial: x += proj(attn(qkv(LN1 x)))          st_transformer.py:85-86
-        if not have_qkv_s:  # (otherwise the previous block's chain B already wrote this block's spatial qkv)
+        qkn = self.qkn
+        qn = lambda a: (self._lw(l, f"{a}.norm.weight", "p"), self._lw(l, f"{a}.norm.bias", "p"))
+        if qkn:
+            # norm1 is the identity: the qkv Linear reads bf16(x); then the per-head LayerNorm of q and k, in place
+            pl.add("hma_cast_bf16", x, b["xh1"], M * 256)
+            pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self._lw(l, "spatial_attn.qkv.weight"), ldw=256, M=M, N=768, K=256,
+                       epi=EPI_BF16, Cp=b["qkv_s"], ldc=768, bias=qb("spatial_attn"))
+            pl.add("hma_qknorm_fwd", b["qkv_s"], 768, b.get("qraw_s"), *qn("spatial_attn"), 1e-5, M, 0, 0)
+        elif not have_qkv_s:  # (otherwise the previous block's chain B already wrote this block's spatial qkv)
             if not have_ln1:  # (otherwise the previous block's fused MLP already wrote this block's LN1 output)
                 pl.add("hma_ln_fwd", x, b["xh1"], b["rstd1"], M, 1e-5)
             pl.gemm_nt(A=b["xh1"], lda=256, a_kind=A_BF16, W=self.WF["qkv_s"][l].data_ptr(), ldw=256, M=M, N=768, K=256,
@@ -543,6 +558,8 @@ class STEngine:
             # temporal (causal, un-normed input)                st_transformer.py:111
             pl.gemm_nt(A=b["x2b"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.qkv.weight"), ldw=256, M=M, N=768,
                        K=256, epi=EPI_BF16, Cp=qkv_dst, ldc=768, c_group=qkv_grp, bias=qb("temporal_attn"))
+        if qkn:
+            pl.add("hma_qknorm_fwd", qkv_dst, 768, b.get("qraw_t"), *qn("temporal_attn"), 1e-5, M, qkv_grp[0], qkv_grp[1])
         if kv is None:
             pl.add("hma_attn_temporal_fwd", b["qkv_t"], b["o_t"], B, T, SA, self.scale, flops=4.0 * M * T * 256, nbytes=2048.0 * M)
         else:
@@ -563,16 +580,21 @@ class STEngine:
                            b_qkv=self.BF["qkv_s"][l + 1].data_ptr() if next_qkv_s is not None else None, qkv=next_qkv_s, **sv,
                            **self._drop_fused(train, l))
             return
-        pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
-                   epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
+        if qkn:  # norm2 is the identity: the MLP reads bf16 of the new x (the residual epilogue's second output)
+            pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), C2=b["xh2"], ldc2=256)
+        else:
+            pl.gemm_nt(A=b["o_t"], lda=256, a_kind=A_BF16, W=self._lw(l, "temporal_attn.proj.weight"), ldw=256, M=M, N=256, K=256,
+                       epi=EPI_RESID, Cp=x, ldc=256, bias=pb("temporal_attn"), ln_xhat=b["xh2"], ln_rstd=b["rstd2"], ln_eps=1e-5)
         # MLP (its LayerNorm: fused above)                   st_transformer.py:112
         if fused:
             pl.mlp_fwd(M, xhat=b["xh2"], x=x, w1p=self.MP["w1p"][l].data_ptr(), w2p=self.MP["w2p"][l].data_ptr(),
                        b1=self.BF["fc1"][l].data_ptr(), b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
                        ln_xhat=ln_next[0] if ln_next else None, ln_rstd=ln_next[1] if ln_next else None, ln_eps=1e-5)
             return
-        pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16, W=self.WF["fc1"][l].data_ptr(), ldw=256, M=M, N=1024, K=256,
-                   epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024, bias=self.BF["fc1"][l].data_ptr(),
+        pl.gemm_nt(A=b["xh2"], lda=256, a_kind=A_BF16, W=self._lw(l, "mlp.fc1.weight") if qkn else self.WF["fc1"][l].data_ptr(), ldw=256,
+                   M=M, N=1024, K=256, epi=EPI_GELU2, Cp=b["u"], ldc=1024, C2=b["hg"], ldc2=1024,
+                   bias=(self._lw(l, "mlp.fc1.bias", "p") if cfg.mlp_bias else None) if qkn else self.BF["fc1"][l].data_ptr(),
                    **self._drop(train, l, 0))  # norm2 folded into W / bias
         pl.gemm_nt(A=b["hg"], lda=1024, a_kind=A_BF16, W=self._lw(l, "mlp.fc2.weight"), ldw=1024, M=M, N=256, K=1024,
                    epi=EPI_RESID, Cp=x, ldc=256, bias=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None,
@@ -648,6 +670,8 @@ class STEngine:
         for l in range(l0, l1):
             s = sl(l)
             names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "qkv_t", "o_t", "xh2", "rstd2") + (() if fused else ("u", "hg"))
+            if self.qkn and train:
+                names = names + ("qraw_s", "qraw_t")
             bufs = {k: dp(ws[k], s, ws[k][0].numel()) for k in names}
             if A > 0 and self.modulate and domain is not None:
                 bufs.update({k: dp(ws[k], s, ws[k][0].numel()) for k in ("xhm", "xm", "rstdm")})
@@ -760,17 +784,25 @@ class STEngine:
                 pl.gemm_nt(A=dmlp, lda=256, a_kind=A_BF16, W=wt("fc2"), ldw=256, M=M, N=1024, K=256, epi=EPI_DGELU, Cp=u, ldc=1024,
                            U=u, ldu=1024, **self._drop(True, l, 0))  # dU overwrites u in place
                 # the two MLP weight gradients in one launch (dmlp / hg and dU / xhat2 are all live here)
+                aff2 = dict(a_kind=A_BF16) if self.qkn else dict(a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm2.weight", "p"),
+                                                                 beta=self._lw(l, "norm2.bias", "p"))
                 pl.gemm_tn_pair(dict(dY=dmlp, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16, M=M, N=256, K=1024,
                                      dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
-                                dict(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
-                                     gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
-                                     K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias)))
-                pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
-                pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
-                       dxb)
+                                dict(dY=u, ldy=1024, y_kind=A_BF16, A=xh2, lda=256, M=M, N=1024,
+                                     K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias), **aff2))
+                if self.qkn:  # norm2 is the identity: the fc1 input gradient goes straight into the residual gradient
+                    pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_RESID, Cp=dx, ldc=256,
+                               C2=dxb, ldc2=256)
+                else:
+                    pl.gemm_nt(A=u, lda=1024, a_kind=A_BF16, W=wt("fc1"), ldw=1024, M=M, N=256, K=1024, epi=EPI_BF16, Cp=t256, ldc=256)
+                    pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
+                           dxb)
             # ---- temporal attention
             pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256, nbytes=3584.0 * M)
+            if self.qkn:  # through the per-head LayerNorm of q and k (dqkv in place; the affine's gradients by atomics)
+                pl.add("hma_qknorm_bwd", dqkv, 768, dp(ws["qraw_t"], l, M * 512), self._lw(l, "temporal_attn.norm.weight", "p"), 1e-5,
+                       gw("temporal_attn.norm.weight"), gw("temporal_attn.norm.bias"), M)
             # projection and qkv weight gradients in one launch (dxb is not updated before the dqkv dgrad below)
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
@@ -810,14 +842,22 @@ class STEngine:
                    flops=10.0 * Fr * SA * SA * 256,  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
                    nbytes=(1536.0 + 512 + 512 + 32 + 1536) * Fr * SA)  # qkv, o, dO, lse read once; dqkv written
             # projection and qkv weight gradients in one launch (dxb is next updated by the LayerNorm backward below)
+            if self.qkn:
+                pl.add("hma_qknorm_bwd", dqkv, 768, dp(ws["qraw_s"], l, M * 512), self._lw(l, "spatial_attn.norm.weight", "p"), 1e-5,
+                       gw("spatial_attn.norm.weight"), gw("spatial_attn.norm.bias"), M)
+            aff1 = dict(a_kind=A_BF16) if self.qkn else dict(a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
+                                                             beta=self._lw(l, "norm1.bias", "p"))
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
-                            dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, a_kind=A_BF16_AFFINE,
-                                 gamma=self._lw(l, "norm1.weight", "p"), beta=self._lw(l, "norm1.bias", "p"), M=M, N=768, K=256,
-                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias)))
-            pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
-                   dxb)
+                            dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, M=M, N=768, K=256,
+                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
+            if self.qkn:  # norm1 is the identity
+                pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
+                           C2=dxb, ldc2=256)
+            else:
+                pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
+                pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
+                       dxb)
             pl.mark(f"layer{l}")
         # ---- embedding, adaLN stacks, action stem
         pl.mark("embed")

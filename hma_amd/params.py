@@ -75,19 +75,27 @@ class ParamLayout:
         add("out_x_proj.bias", (C,), "head")
         end()
 
+        qkn = bool(getattr(cfg, "qk_norm", False))  # norm1 / norm2 are nn.Identity; each attention owns a LayerNorm(head_dim) for q, k
+
         def layer_tensors():
-            t = [("norm1.weight", (d,))]
+            t = [] if qkn else [("norm1.weight", (d,))]
             for a in ("spatial_attn", "temporal_attn"):
                 t.append((f"{a}.qkv.weight", (3 * d, d)))
                 t.append((f"{a}.proj.weight", (d, d)))
-            t += [("norm2.weight", (d,)), ("mlp.fc1.weight", (hid, d)), ("mlp.fc2.weight", (d, hid))]
-            t.append(("norm1.bias", (d,)))
+                if qkn:
+                    t.append((f"{a}.norm.weight", (d // cfg.num_heads,)))
+            t += ([] if qkn else [("norm2.weight", (d,))]) + [("mlp.fc1.weight", (hid, d)), ("mlp.fc2.weight", (d, hid))]
+            if not qkn:
+                t.append(("norm1.bias", (d,)))
             for a in ("spatial_attn", "temporal_attn"):
                 if cfg.qkv_bias:
                     t.append((f"{a}.qkv.bias", (3 * d,)))
                 if cfg.proj_bias:
                     t.append((f"{a}.proj.bias", (d,)))
-            t.append(("norm2.bias", (d,)))
+                if qkn:
+                    t.append((f"{a}.norm.bias", (d // cfg.num_heads,)))
+            if not qkn:
+                t.append(("norm2.bias", (d,)))
             if cfg.mlp_bias:
                 t += [("mlp.fc1.bias", (hid,)), ("mlp.fc2.bias", (d,))]
             return t

@@ -120,6 +120,16 @@ int hma_ln_fwd(void* stream, const float* x, void* xhat, float* rstd, int64_t ro
  * the operand the next linear's backward GEMMs read (autocast hands them grad_output in bf16). */
 int hma_ln_bwd(void* stream, const void* dxn, const void* xhat, const float* rstd, const float* gamma,
                float* dx, float* dgamma, float* dbeta, int64_t rows, void* dx_bf16);
+/* qk_norm=True (attention.py:31-35,44-48): per-head LayerNorm (32 values, shared affine gamma / beta [32]) of the q and k parts of a
+ * packed qkv buffer [*, ld] (q | k | v), IN PLACE, one pass over `rows` token rows; raw (bf16 [rows, 512], may be NULL) receives the
+ * pre-norm q | k for the backward.  Row r sits at (r / g_rows) * g_stride + r % g_rows (g_rows <= 0: r) -- the decode cache's frames. */
+int hma_qknorm_fwd(void* stream, void* qkv, int64_t ld, void* raw, const float* gamma, const float* beta, float eps, int64_t rows,
+                   int64_t g_rows, int64_t g_stride);
+/* Backward: dqkv's q | k parts (gradient wrt the normalised values) become the gradient wrt the raw ones, in place; dgamma / dbeta [32]
+ * are ADDED (fp32 atomics). */
+int hma_qknorm_bwd(void* stream, void* dqkv, int64_t ld, const void* raw, const float* gamma, float eps, float* dgamma, float* dbeta,
+                   int64_t rows);
+
 /* ModulateLayer prologue, st_mask_git.py:71-74: xhat = LN(x, eps 1e-6, no affine);
  * xm = xhat * (1 + scale[bt]) + shift[bt], ss = [shift | scale] (fp32, 512 per (b,t)). */
 int hma_modln_fwd(void* stream, const float* x, const float* ss, void* xhat, void* xm, float* rstd,

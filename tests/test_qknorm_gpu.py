@@ -1,0 +1,113 @@
+"""qk_norm=True on the GPU (the GenieConfig dataclass default; hma/model/attention.py:31-35,44-48, st_transformer.py:55,62): the q / k
+LayerNorm kernels against fp32 PyTorch, and the whole model against G18 (the real reference, tests/golden/make_golden_qknorm.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hma_amd import _lib, ops
+from hma_amd.config import GenieConfig
+from hma_amd.model import STMaskGIT
+from hma_amd.train import Trainer
+from oracle.param_spec import seeded_state_dict, state_dict_spec
+from tests.helpers import TINY, golden, rel_err, tiny_inputs, tiny_ref_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+rb = lambda t: t.bfloat16().float()
+
+
+def test_qknorm_kernels():
+    g = torch.Generator().manual_seed(3)
+    M = 1000
+    qkv = rb(torch.randn(M, 768, generator=g) * 1.5 + 0.2)
+    gam, bet = 1 + 0.2 * torch.randn(32, generator=g), 0.1 * torch.randn(32, generator=g)
+    qk = qkv[:, :512].reshape(M, 16, 32).clone().requires_grad_(True)
+    gp, bp = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.layer_norm(qk, (32,), gp, bp, 1e-5)
+    dq = rb(torch.randn(M, 768, generator=g) * 0.1)
+    (y * dq[:, :512].reshape(M, 16, 32)).sum().backward()
+    d = lambda t: t.to(DEV).contiguous()
+    buf, raw = d(qkv).bfloat16(), torch.zeros(M, 512, dtype=torch.bfloat16, device=DEV)
+    gd, bd = d(gam), d(bet)
+    _lib.call("hma_qknorm_fwd", ops.stream_ptr(), ops.ptr(buf), 768, ops.ptr(raw), ops.ptr(gd), ops.ptr(bd), 1e-5, M, 0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(raw.float().cpu(), qkv[:, :512]) and torch.equal(buf[:, 512:].float().cpu(), qkv[:, 512:])
+    assert rel_err(buf[:, :512].float(), y.detach().reshape(M, 512)) <= 8e-3
+    db = d(dq).bfloat16()
+    dg, dbt = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    _lib.call("hma_qknorm_bwd", ops.stream_ptr(), ops.ptr(db), 768, ops.ptr(raw), ops.ptr(gd), 1e-5, ops.ptr(dg), ops.ptr(dbt), M)
+    torch.cuda.synchronize()
+    assert torch.equal(db[:, 512:].float().cpu(), dq[:, 512:])
+    assert rel_err(db[:, :512].float(), qk.grad.reshape(M, 512)) <= 1e-2
+    assert rel_err(dg, gp.grad) <= 2e-3 and rel_err(dbt, bp.grad) <= 2e-3
+    # rows kept apart (the decode cache's frames): 3 groups of 8 rows at a stride of 20
+    big = torch.zeros(60, 768, dtype=torch.bfloat16, device=DEV)
+    src = d(qkv[:24]).bfloat16()
+    idx = torch.tensor([(r // 8) * 20 + r % 8 for r in range(24)], device=DEV)
+    big[idx] = src
+    _lib.call("hma_qknorm_fwd", ops.stream_ptr(), ops.ptr(big), 768, None, ops.ptr(gd), ops.ptr(bd), 1e-5, 24, 8, 20)
+    torch.cuda.synchronize()
+    assert torch.equal(big[idx], buf[:24])
+
+
+def build():
+    cfg = GenieConfig(**dict(TINY["config"], qk_norm=True))
+    m = STMaskGIT(cfg)
+    m.init_action_projectors(TINY["domains"], TINY["d_actions"], TINY["action_stats"], cfg.action_network)
+    rc = tiny_ref_config(qk_norm=True)
+    sd = seeded_state_dict(state_dict_spec(rc, TINY["domains"], TINY["d_actions"], [len(s[0]) for s in TINY["action_stats"]]),
+                           seed=TINY["seed"] + 2, std=0.02, embed_std=0.02)
+    for dom, st in zip(TINY["domains"], TINY["action_stats"]):
+        sd[f"action_preprocessor.{dom}.mean"] = torch.tensor(st[0], dtype=torch.float32)
+        sd[f"action_preprocessor.{dom}.std"] = torch.tensor(st[1], dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).train(), sd
+
+
+@pytest.mark.parametrize("tag", ["domA", "noact"])
+def test_forward_backward_with_qk_norm_matches_reference(tag):
+    g = golden("g18_qknorm")
+    m, _ = build()
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    kw = dict(input_ids=inp["input_ids"], labels=inp["labels"])
+    kw.update(dict(action_ids=inp["actions_domA"], domain=["domA"] * 2) if tag == "domA" else dict(domain=None))
+    out = m(**kw)
+    assert abs(out.loss.item() - g[f"{tag}.loss"].item()) <= 1e-3
+    assert out.acc.item() == g[f"{tag}.acc"].item()
+    assert rel_err(out.logits[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) <= 2e-2
+    out.loss.backward()
+    checked = 0
+    for name, p in m.named_parameters():
+        key = f"{tag}.grad_samp.{name}"
+        if key not in g:
+            continue
+        assert p.grad is not None, name
+        gf = p.grad.reshape(-1).float().cpu()
+        idx = torch.linspace(0, gf.numel() - 1, 64).long()
+        ref = g[key]
+        err = (gf[idx] - ref).pow(2).mean().sqrt().item() / (ref.pow(2).mean().sqrt().item() + 1e-20)
+        assert err <= 6e-2, f"{name}: {err:.3e}"
+        checked += 1
+    assert checked > 20
+    names = dict(m.named_parameters())
+    assert "decoder.layers.0.spatial_attn.norm.weight" in names and "decoder.layers.0.norm1.weight" not in names
+
+
+def test_qk_norm_trainer_and_generate():
+    m, sd = build()
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    tr = Trainer(m, lr=1e-3, device=DEV)
+    losses = []
+    for _ in range(4):
+        ws = tr.step(inp["input_ids"], inp["labels"], inp["actions_domA"], ["domA"] * 2)
+        losses.append(tr.loss_and_acc(ws)[0].item())
+    assert losses[-1] < losses[0]
+    moved = {n for n, p in m.named_parameters() if not torch.equal(p.detach().cpu(), sd[n])}
+    assert {"decoder.layers.0.spatial_attn.norm.weight", "decoder.layers.1.temporal_attn.norm.bias"} <= moved
+    m.eval()
+    T = m.config.T
+    ids = inp["labels"].reshape(2, T, 256)[:, : T - 1].reshape(2, -1)
+    kw = dict(max_new_tokens=256, maskgit_steps=2, temperature=0.0, action_ids=inp["actions_domA"], domain=["domA"] * 2, unmask_mode="greedy")
+    a = m.generate(ids, None, use_cache=False, **kw)
+    b = m.generate(ids, None, use_cache=True, **kw)   # the K / V cache holds the NORMALISED keys
+    assert (a == b).float().mean().item() >= 0.99
