@@ -149,7 +149,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
     def _engine(self, dev):
         core = self._core
         eng = core._get_engine(dev)
-        ver = tuple(p._version for p in (self.decoder.layers[0].mlp.fc1.weight, self.decoder.layers[-1].norm1.weight))
+        ver = tuple(p._version for p in (self.decoder.layers[0].mlp.fc1.weight, self.decoder.layers[-1].mlp.fc2.weight))
         if ver != getattr(self, "_seen_versions", None):  # load_state_dict / an optimizer wrote through the named parameters
             self._seen_versions = ver
             eng.weights_changed()

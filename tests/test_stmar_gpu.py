@@ -325,3 +325,41 @@ def test_jointly_predict_actions_matches_reference():
     o2.loss.backward()
     g = dict(m.named_parameters())["action_diff_losses.domA.net.cond_embed.weight"].grad
     assert g is None or float(g.abs().sum()) == 0.0
+
+
+def test_stmar_with_qk_norm_against_oracle():
+    """STMAR on a qk_norm=True trunk (attention.py:31-35,44-48: per-head LayerNorm of q and k, identity norm1 / norm2), the tiny fixture's
+    shapes: loss, latents and gradients against oracle/st_mar_ref.py (whose trunk is pinned for qk_norm by G18) on the host."""
+    from oracle import st_mar_ref as MR
+    from oracle import st_maskgit_ref as R
+    m = STMAR(DiffusionGenieConfig(**dict(CFG, qk_norm=True)))
+    m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, CFG["action_network"])
+    sd = seeded_state(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    inp = inputs()
+    rc = R.RefConfig(num_layers=2, num_heads=8, d_model=256, T=3, S=1024, use_mup=True, qkv_bias=True, mlp_bias=False, qk_norm=True)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+            if v.is_floating_point() and not (k.endswith(".mean") or k.endswith(".std")) and not k.startswith("action_diff_losses")}
+    full = dict(sd)
+    full.update(leaf)
+    loss_ref, z_ref = MR.forward(full, rc, inp["latents"], inp["latents"], inp["actions_domA"], ["domA"] * 2, inp["masked"], inp["t"],
+                                 inp["noise"], 2, 32, 32, CFG["diffloss_d"])
+    loss_ref.backward()
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    out = m(input_ids=d["latents"].clone(), labels=d["latents"].clone(), action_ids=d["actions_domA"], domain=["domA"] * 2,
+            masked_tokens_indicator=d["masked"], h=[32, 32], w=[32, 32], diffusion_t=d["t"], diffusion_noise=d["noise"])
+    assert abs(out.loss.item() - loss_ref.item()) <= 2e-3 * abs(loss_ref.item())
+    z = out.logits.permute(0, 2, 3, 4, 1).reshape(2, 3, 256, 256)
+    assert rel(z, z_ref.detach()) < 1e-2
+    out.loss.backward()
+    named = dict(m.named_parameters())
+    assert "decoder.layers.0.temporal_attn.norm.weight" in named and "decoder.layers.0.norm2.weight" not in named
+    bad = {}
+    for k, p in leaf.items():
+        if p.grad is None or float(p.grad.abs().sum()) == 0.0 or named[k].grad is None:
+            continue
+        e = rel(named[k].grad, p.grad)
+        if e > 3e-2:
+            bad[k] = e
+    assert not bad, bad
