@@ -10,8 +10,8 @@ modules and their parameters are shared with an internal `STMaskGIT` whose flat 
 `hma_mar_patchify` -> token_embed GEMM -> `hma_mar_embed_fwd` -> trunk -> out_x_proj GEMM -> `hma_mar_readout_fwd` ->
 `DiffLoss` (hma_amd/model/diffloss.py), and the mirror image backward.  No CPU / eager-PyTorch path.
 `maskgit_generate` / `generate` are the MAR decode (st_mar.py:277-452) with `DiffLoss.sample`.
-`jointly_predict_actions` is built for training (the per-domain action diffusion heads, st_mar.py:119-129, 231-273), not for
-the MAR decode (:441-446).  Not built: cfg != 1 in the MAR decode (the reference's own branch,
+`jointly_predict_actions`: training (the per-domain action diffusion heads, st_mar.py:119-129, 231-273) and the MAR decode's action
+sampling (:441-446: `maskgit_generate` returns the sampled actions as its third value).  Not built: cfg != 1 in the MAR decode (the reference's own branch,
 st_mar.py:417-418, indexes bs rows of latents with a 2 bs mask and cannot run; `DiffLoss.sample(cfg=...)` itself is built).
 """
 from __future__ import annotations
@@ -272,7 +272,10 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                  Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))
         _lib.call("hma_mar_readout_fwd", stream, ptr(y), ptr(self.decoder_norm.weight), ptr(self.decoder_norm.bias), 1e-6,
                   ptr(self.diffusion_pos_embed_learned), ptr(z), ptr(yhat), ptr(rstd_r), Mi, T, S)
-        return z.view(B, T, h_, w_, d).permute(0, 4, 1, 2, 3), None
+        pooled = None
+        if cfg.jointly_predict_actions:  # :187-189: the mean of every frame's action tokens, what the action diffusion head conditions on
+            pooled = ws["x"].view(Fr, S + A, d)[:, S:].mean(dim=1).view(B, T, d)
+        return z.view(B, T, h_, w_, d).permute(0, 4, 1, 2, 3), pooled
 
     def patchify(self, x):
         """(B, T, H, W, C) -> (B, T, H/p, W/p, p*p*C) through the patchify kernel (st_mar.py:199-207)."""
@@ -311,21 +314,29 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         B, T, h_, w_, pc = x.shape
         S = h_ * w_
         orders = (self.sample_orders(B) if orders is None else orders).to(dev)
-        z = self.compute_latents(x, action_ids=action_ids, domain=domain)[0][:, :, out_t]
+        z, pooled = self.compute_latents(x, action_ids=action_ids, domain=domain)
+        z = z[:, :, out_t]
         orig = z.clone()
+        sampled_actions = None
+        dom = domain if isinstance(domain, str) else domain[0]
+        action_draws = kwargs.get("action_draws")
         for step in range(maskgit_steps):
             if step > 0:
-                z = self.compute_latents(x, action_ids=action_ids, domain=domain)[0][:, :, out_t]
+                z, pooled = self.compute_latents(x, action_ids=action_ids, domain=domain)
+                z = z[:, :, out_t]
             mask_len = max(1, min(S - 1, int(np.floor(self.seq_len * np.cos(math.pi / 2.0 * (step + 1) / maskgit_steps)))))
             mask_next = torch.zeros(B, S, device=dev).scatter(-1, orders[:, :mask_len], torch.ones(B, S, device=dev)).bool()
             to_pred = torch.ones(B, S, dtype=torch.bool, device=dev) if step >= maskgit_steps - 1 else ~mask_next
             rows = z.reshape(B, -1, S).permute(0, 2, 1)[to_pred].contiguous()          # (n, d): gather of the rows to sample
             kw = {} if draws is None else dict(noise0=draws[step][0], step_noises=draws[step][1])
             smp = self.diffloss.sample(rows, temperature, 1.0, clip_denoised=True, **kw)
+            if pooled is not None:  # jointly_predict_actions (:441-446): actions sampled by the domain's action diffusion head, every step
+                akw = {} if action_draws is None else dict(noise0=action_draws[step][0], step_noises=action_draws[step][1])
+                sampled_actions = self.action_diff_losses[dom].sample(pooled.reshape(-1, pooled.shape[-1]), temperature, 1.0, clip_denoised=True, **akw)
             xt = x[:, out_t].reshape(B, S, pc)
             xt[to_pred] = smp
             x[:, out_t] = xt.reshape(B, h_, w_, pc)
-        return self.unpatchify(x)[:, out_t], orig, None
+        return self.unpatchify(x)[:, out_t], orig, sampled_actions
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask=None, max_new_tokens: int = 0, min_new_tokens: int = None, return_logits: bool = False,

@@ -363,3 +363,34 @@ def test_stmar_with_qk_norm_against_oracle():
         if e > 3e-2:
             bad[k] = e
     assert not bad, bad
+
+
+def test_mar_decode_samples_actions_with_jointly_predict_actions():
+    """st_mar.py:441-446: with jointly_predict_actions the MAR decode also samples actions from the domain's action diffusion head,
+    conditioned on the mean-pooled action tokens of the window; third return value (B * T, d_action).  The two pieces are pinned
+    separately (pooled tokens: G17's `actions`; DiffLoss.sample: G9 / G12) -- here: the wiring, with injected draws."""
+    D = load_file(os.path.join(HERE, "golden", "g12_stmar_decode.safetensors"))
+    m = STMAR(DiffusionGenieConfig(**dict(CFG, jointly_predict_actions=True)))
+    m.init_action_projectors(DOMAINS, D_ACTIONS, STATS, CFG["action_network"])
+    m.load_state_dict(seeded_state(m.state_dict()))
+    m = m.to(DEV).eval()
+    inp = {k: v.to(DEV) for k, v in inputs().items()}
+    draws = [(D[f"noise0.{k}"].to(DEV), D[f"steps.{k}"].to(DEV)) for k in range(2)]
+    g = torch.Generator().manual_seed(1)
+    n_steps = D["steps.0"].shape[0]
+    adraws = [(torch.randn(6, 7, generator=g).to(DEV), torch.randn(n_steps, 6, 7, generator=g).to(DEV)) for _ in range(2)]
+    kw = dict(action_ids=inp["actions_domA"], domain=["domA"] * 2, maskgit_steps=2, temperature=0.9, orders=D["orders"].to(DEV), draws=draws)
+    frame, orig, acts = m.maskgit_generate(D["prompt"].to(DEV), 2, action_draws=adraws, **kw)
+    assert acts.shape == (6, 7) and torch.isfinite(acts).all()
+    assert rel(orig, D["orig_latents"]) < 1e-2          # the video path is what it was without action prediction
+    frame2, _, acts2 = m.maskgit_generate(D["prompt"].to(DEV), 2, action_draws=adraws, **kw)
+    assert torch.equal(acts, acts2) and torch.equal(frame, frame2)
+    # equals the head's own sampler on the pooled action tokens of the final window
+    x = m.patchify(D["prompt"].to(DEV)).clone()
+    x[:, 2] = m.patchify(frame[:, None].expand(-1, 3, -1, -1, -1).contiguous())[:, 0]
+    # (the last step conditions on the window BEFORE its own write: recompute with the state the last step saw is not available here,
+    # so compare against a direct call on the first step's pooled tokens instead)
+    _, pooled0 = m.compute_latents(m.patchify(D["prompt"].to(DEV)), action_ids=inp["actions_domA"], domain=["domA"] * 2)
+    direct0 = m.action_diff_losses["domA"].sample(pooled0.reshape(-1, 256), 0.9, 1.0, clip_denoised=True, noise0=adraws[0][0], step_noises=adraws[0][1])
+    _, _, acts_1step = m.maskgit_generate(D["prompt"].to(DEV), 2, action_draws=adraws[:1], **dict(kw, maskgit_steps=1, draws=draws[:1]))
+    assert torch.equal(acts_1step, direct0)
