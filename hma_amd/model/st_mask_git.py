@@ -435,8 +435,11 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         work = prompt_THW.reshape(bs, t, S).contiguous()
         unmasked = torch.zeros(bs, S, dtype=torch.uint8, device=prompt_THW.device)
         first = None
+        actions = None
         for step in range(maskgit_steps):
             eng, ws = self._run(work.view(bs, t, h, w), None, action_ids, domain, False, kwargs)
+            if eng._act is not None:  # jointly_predict_actions: the step's predicted actions (:382, :392; the last step's are returned)
+                actions = eng._act["out"].view(bs, t, -1).clone()
             if first is None:
                 first = ws["logits"].view(bs, t, S, -1)[:, out_t].clone()
             last = step == maskgit_steps - 1
@@ -461,7 +464,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         samples_HW = work[:, out_t].view(bs, h, w).clone()
         V, NV = cfg.factored_vocab_size, cfg.num_factored_vocabs
         factored = first.view(bs, h, w, NV, V).permute(0, 4, 3, 1, 2)
-        return samples_HW, factored, None
+        return samples_HW, factored, actions
 
     @torch.no_grad()
     def _generate_cached(self, input_ids, num_new_frames, h, w, maskgit_steps, temperature, action_ids, domain, kwargs):
@@ -531,7 +534,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         S = h * w
         num_new_frames = max_new_tokens // S
         B = input_ids.size(0)
-        if kwargs.pop("use_cache", True) and not return_logits and num_new_frames > 0:
+        if kwargs.pop("use_cache", True) and not return_logits and not return_with_actions and num_new_frames > 0:
             return self._generate_cached(input_ids, num_new_frames, h, w, maskgit_steps, temperature, action_ids, domain,
                                          kwargs)
         inputs_THW = input_ids.clone().reshape(B, -1, h, w)
@@ -539,14 +542,16 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
                                                    device=input_ids.device)], dim=1)
         all_logits = []
         for timestep in range(inputs_THW.size(1), inputs_THW.size(1) + num_new_frames):
-            sample_HW, factored_logits, _ = self.maskgit_generate(masked, timestep, maskgit_steps=maskgit_steps,
-                                                                  temperature=temperature, action_ids=action_ids,
-                                                                  domain=domain, **kwargs)
+            sample_HW, factored_logits, actions = self.maskgit_generate(masked, timestep, maskgit_steps=maskgit_steps,
+                                                                        temperature=temperature, action_ids=action_ids,
+                                                                        domain=domain, **kwargs)
             masked[:, timestep] = sample_HW
             all_logits.append(factored_logits)
         tokens = masked.reshape(B, -1)
-        if return_with_actions:
-            raise NotImplementedError("jointly_predict_actions is outside the accelerated path")
+        if return_with_actions:  # (:319-322) the last frame's predicted actions, un-normalised
+            if actions is None:
+                raise ValueError("return_with_actions needs a model built with jointly_predict_actions=True")
+            return tokens, self.action_preprocessor[self._domain_key(domain)].unnormalize(actions)
         if return_logits:
             return tokens, torch.stack(all_logits, dim=3)
         return tokens

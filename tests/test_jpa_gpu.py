@@ -114,3 +114,22 @@ def test_policy_mode_predicts_actions_without_action_ids():
         # and with action ids again afterwards (the plans of the two modes do not interfere)
         _, actions3 = m.compute_logits(x, action_ids=inp["actions_domB"], domain=["domB"] * 2)
         assert actions3.shape == (2, T, 14) and rel_err(actions3, actions2) > 1e-3
+
+
+def test_generate_returns_unnormalised_actions():
+    """generate(return_with_actions=True) (st_mask_git.py:304-322): the actions predicted during the LAST frame's MaskGIT steps, mapped
+    back through the domain's statistics; the window (non-cached) path, whose every step also yields the action read-out."""
+    m = build().eval()
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    T = m.config.T
+    ids = inp["labels"].reshape(2, T, 256)[:, : T - 1].reshape(2, -1)
+    kw = dict(max_new_tokens=256, maskgit_steps=2, temperature=0.0, action_ids=inp["actions_domA"], domain=["domA"] * 2, unmask_mode="greedy")
+    tokens, actions = m.generate(ids, None, return_with_actions=True, **kw)
+    plain = m.generate(ids, None, use_cache=False, **kw)
+    assert torch.equal(tokens, plain) and actions.shape == (2, T, 7) and torch.isfinite(actions).all()
+    prompt = tokens.reshape(2, T, 16, 16).clone()
+    prompt[:, T - 1] = m.mask_token_id
+    _, _, raw = m.maskgit_generate(prompt, T - 1, maskgit_steps=2, temperature=0.0, action_ids=inp["actions_domA"], domain=["domA"] * 2,
+                                   unmask_mode="greedy")
+    st = m.action_preprocessor["domA"]
+    assert torch.allclose(actions, raw * (st.std + 1e-10) + st.mean, rtol=1e-6, atol=1e-6)
