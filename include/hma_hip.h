@@ -144,7 +144,8 @@ int hma_modln_bwd(void* stream, const void* dxm, const void* xhat, const float* 
  * n <= 320. */
 int hma_attn_spatial_fwd(void* stream, const void* qkv, void* o, float* lse, int64_t frames, int32_t n,
                          float scale);
-/* dqkv (bf16, same layout as qkv) from do (bf16); delta is [frames*n, 8] fp32 scratch */
+/* dqkv (bf16, same layout as qkv) from do (bf16); delta ([frames*n, 8] fp32) receives rowsum(dO * O) per head.  n = 256 / 320: ONE
+ * kernel per launch (q / k / v / dO of a (frame, head) staged in LDS once, dS shared through LDS); n = 64: the dq + dkv pair. */
 int hma_attn_spatial_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
                          float* delta, void* dqkv, int64_t frames, int32_t n, float scale);
 /* Causal temporal self-attention over the T frames of each (b, s) column, attention.py:37-61 with
@@ -443,8 +444,8 @@ typedef struct {
 } hma_chain_a_bwd_t;
 int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p);
 
-/* Chain B forward, passes that save nothing (inference / decode): st_transformer.py:111 proj, :112 norm2 + Mlp (:24-27), and the
- * NEXT block's :85-86 norm1 + qkv (attention.py:39):
+/* Chain B forward (inference / decode passes, and training passes with the fields at the end of the struct): st_transformer.py:111
+ * proj, :112 norm2 + Mlp (:24-27), and the NEXT block's :85-86 norm1 + qkv (attention.py:39):
  *   x1 = x + o Wproj^T + b_proj;  x2 = x1 + fc2(gelu(fc1(LN(x1)))) ;  qkv = LN(x2) Wqkv'^T + b_qkv'
  * in: o [M,256] bf16 (temporal attention output), x [M,256] fp32 (updated in place to x2); out: qkv [M, ldq] bf16 of the next
  * block (NULL: last block, no qkv stage).  Both LayerNorms are affine-free here: their gamma / beta are folded into the
