@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -34,7 +35,12 @@ class Plan:
     tn_workspace: Optional[torch.Tensor] = None  # scratch for the two-stage weight-gradient reduction
     _tn_workspaces: Dict[int, torch.Tensor] = {}
 
+    side_stream: "Optional[torch.cuda.Stream]" = None   # launches tagged `side` run here, forked from / joined to the caller's stream
+    tn_workspace_side: Optional[torch.Tensor] = None     # (their weight-gradient partials: the main workspace may be in use)
+
     def __init__(self):
+        self.side: Dict[int, bool] = {}     # call index -> runs on the side stream
+        self.join: Dict[int, bool] = {}     # call index -> the caller's stream first waits for the side stream
         self.calls: List[Tuple[Callable, str, tuple]] = []
         self.flops: List[float] = []   # algorithmic FLOPs of each call (0 for non-GEMM launches)
         self.bytes: List[float] = []   # algorithmic HBM bytes of each call: every operand read once, every result written once
@@ -65,23 +71,32 @@ class Plan:
         self.keep.append(g)
         self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._nt_bytes(g))
 
-    def gemm_tn(self, **kw) -> None:
-        if Plan.tn_workspace is not None:
-            kw.setdefault("ws", Plan.tn_workspace.data_ptr())
-            kw.setdefault("ws_elems", Plan.tn_workspace.numel())
+    def gemm_tn(self, side: bool = False, **kw) -> None:
+        side = side and Plan.tn_workspace_side is not None
+        wsb = Plan.tn_workspace_side if side else Plan.tn_workspace
+        if wsb is not None:
+            kw.setdefault("ws", wsb.data_ptr())
+            kw.setdefault("ws_elems", wsb.numel())
         g = make_gemm_tn(**kw)
         self.keep.append(g)
+        if side:
+            self.side[len(self.calls)] = True
         self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._tn_bytes(g))
 
-    def gemm_tn_pair(self, kw0: dict, kw1: dict) -> None:
-        """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair)."""
+    def gemm_tn_pair(self, kw0: dict, kw1: dict, side: bool = False) -> None:
+        """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair).  `side`: on the side
+        stream (nothing on the caller's stream depends on it until the next `join_next()` call or the end of the run)."""
         gs = []
+        wsb = Plan.tn_workspace_side if (side and Plan.tn_workspace_side is not None) else Plan.tn_workspace
+        side = side and Plan.tn_workspace_side is not None
         for kw in (kw0, kw1):
-            if Plan.tn_workspace is not None:
-                kw.setdefault("ws", Plan.tn_workspace.data_ptr())
-                kw.setdefault("ws_elems", Plan.tn_workspace.numel())
+            if wsb is not None:
+                kw.setdefault("ws", wsb.data_ptr())
+                kw.setdefault("ws_elems", wsb.numel())
             gs.append(make_gemm_tn(**kw))
         self.keep.extend(gs)
+        if side:
+            self.side[len(self.calls)] = True
         self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
                  flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
 
@@ -129,12 +144,41 @@ class Plan:
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
 
+    def join_next(self) -> None:
+        """The next recorded call waits for everything launched on the side stream so far."""
+        self.join[len(self.calls)] = True
+
     def run(self, stream: int, start: int = 0, stop: Optional[int] = None, timer: "Optional[LaunchTimer]" = None) -> None:
-        if timer is None:
+        if timer is None and not self.side:
             for fn, name, args in self.calls[start:stop]:
                 rc = fn(stream, *args)
                 if rc != 0:
                     raise _lib.HmaKernelError(f"{name} failed with code {rc}")
+            return
+        if timer is None:
+            # fork / join: a `side` call starts when everything enqueued so far on the caller's stream is done and runs beside what
+            # follows; a `join` call (and the end of this run) waits for the side stream.  Under hipGraph capture these become edges.
+            main = torch.cuda.current_stream()
+            if Plan.side_stream is None:
+                Plan.side_stream = torch.cuda.Stream()
+            sd = Plan.side_stream
+            pending = False
+            stop_ = len(self.calls) if stop is None else stop
+            for i in range(start, stop_):
+                fn, name, args = self.calls[i]
+                if pending and self.join.get(i):
+                    main.wait_stream(sd)
+                    pending = False
+                if self.side.get(i):
+                    sd.wait_stream(main)
+                    rc = fn(sd.cuda_stream, *args)
+                    pending = True
+                else:
+                    rc = fn(stream, *args)
+                if rc != 0:
+                    raise _lib.HmaKernelError(f"{name} failed with code {rc}")
+            if pending:
+                main.wait_stream(sd)
             return
         stop = len(self.calls) if stop is None else stop
         for i in range(start, stop):
@@ -183,6 +227,13 @@ class STEngine:
         # LayerNorm (attention.py:31-35,44-48; st_transformer.py:55,62).  Runs on the GEMM-per-Linear plans (the chain / fused-MLP
         # kernels have the block's LayerNorms built in) with hma_qknorm_fwd / _bwd behind the qkv projections.
         self.qkn = bool(cfg.qk_norm)
+        # Weight gradients beside the backward's critical path: nothing downstream reads them, so the MLP pair and the spatial pair run on a
+        # side stream (a fork / join in the recorded plan; graph edges under hipGraph capture) while the main stream goes on with the
+        # temporal projection / attention and the qkv dgrad / LayerNorm backward.  Measured on one box (bench.py --mode train): 91.49 ms
+        # without, 90.18 (MLP pair), 89.92 (+ spatial pair), 92.37 with all four -- the temporal pair and linear_out would run beside
+        # chain A backward / the attention backward, whose 100-156 KB of LDS leave their workgroups no room on a CU.  Bits: 1 MLP pair,
+        # 2 temporal pair, 4 linear_out, 8 spatial pair.
+        self.fork_wgrad = 9
         self.jpa = bool(cfg.jointly_predict_actions)
         self._act: Optional[dict] = None
         self.act_scale = 0.0   # d total / d action_loss of the backward in flight (0: the action loss is not part of the objective)
@@ -286,6 +337,10 @@ class STEngine:
         if idx not in Plan._tn_workspaces:
             Plan._tn_workspaces[idx] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))  # 64 MB + bias partials
         Plan.tn_workspace = Plan._tn_workspaces[idx]
+        if self.fork_wgrad:
+            if ("side", idx) not in Plan._tn_workspaces:
+                Plan._tn_workspaces[("side", idx)] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))
+            Plan.tn_workspace_side = Plan._tn_workspaces[("side", idx)]
 
     # ------------------------------------------------------------------------------ Adam update counts (device-resident)
     def _steps_now(self) -> List[int]:
@@ -486,6 +541,12 @@ class STEngine:
             if self._use_chain(M, SA) and A > 0 and self.modulate:
                 buf("dx2b", (M, 256), BF16)  # bf16(dx) in front of the modulate block: dY of linear_out's weight gradient
             buf("dqkv", (M, 768), BF16)
+            if self.fork_wgrad and fused and self._use_chain(M, SA):
+                # forked weight gradients (a side stream beside the backward's critical path) read bf16(dx) / dqkv while the main stream
+                # goes on: every producer of bf16(dx) writes the next of four buffers, the spatial attention gets its own dqkv
+                buf("dqkv_s", (M, 768), BF16)
+                buf("dxb3", (M, 256), BF16)
+                buf("dxb4", (M, 256), BF16)
             buf("delta", (M, 8), F32)
             if A > 0:
                 buf("dss", (L, Fr, 512), F32)
@@ -732,6 +793,14 @@ class STEngine:
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
         dxb = ws["dxb"].data_ptr()
+        fork = bool(self.fork_wgrad) and "dqkv_s" in ws and self._use_fused(M, True, SA) and self._use_chain(M, SA)
+        fbit = lambda b: fork and bool(self.fork_wgrad & b)
+        ring = [ws[k].data_ptr() for k in ("dxb", "dxb2", "dxb3", "dxb4")] if fork else []
+
+        def rot(cur):  # the next bf16(dx) buffer (forked weight gradients may still read the current and the two before it)
+            return ring[(ring.index(cur) + 1) % 4]
+
+        dqkv_s = ws["dqkv_s"].data_ptr() if fork else dqkv
         # readout
         pl.gemm_tn(dY=ws["dlogits"].data_ptr(), ldy=1024, y_kind=A_BF16, A=x, lda=256, a_kind=A_F32, a_group=(S, SA), M=Mi,
                    N=1024, K=256, dW=self._g("out_x_proj.weight"), lddw=256, dBias=self._g("out_x_proj.bias"))
@@ -757,12 +826,13 @@ class STEngine:
                 # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
                 # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
                 # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
-                dxb_new = ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr()
+                dxb_new = rot(dxb) if fork else (ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr())
                 hg, du = ws["hg1"].data_ptr(), ws["du1"].data_ptr()
                 dkw = self._drop_fused(True, l)
                 dy2 = dxb  # dY of the fc2 weight gradient: behind the output Dropout when there is one (written by hma_mlp_bwd)
                 if dkw:
                     dy2 = dkw["dy_drop"] = ws["dxm"].data_ptr()
+                pl.join_next()  # (the previous layer's forked weight gradients still read hg / du / the old bf16 dx this kernel overwrites)
                 pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
                            w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
                            b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du, **dkw)
@@ -772,7 +842,7 @@ class STEngine:
                                      gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
                                      K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias),
                                      w_master=self._lw(l, "mlp.fc1.weight", "p"), dgamma=gw("norm2.weight"),
-                                     dbeta=gw("norm2.bias")))
+                                     dbeta=gw("norm2.bias")), side=fbit(1))
                 dxb = dxb_new
             else:
                 u, hg = dp(ws["u"], l, M * 1024), dp(ws["hg"], l, M * 1024)
@@ -807,7 +877,7 @@ class STEngine:
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
                             dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
-                                 dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)))
+                                 dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)), side=fbit(2))
             if self._use_chain(M, SA):
                 # ---- chain A backward (csrc/chain.hip): temporal qkv dgrad + residual -> linear_out dgrad -> modulate-LN backward
                 # -> spatial projection dgrad, one launch; dss accumulates by atomics (zeroed at the top of the plan)
@@ -820,10 +890,12 @@ class STEngine:
                     kwm = dict(xhat=xhm, rstd=rstdm, ss=dp(ws["ss"], l, Fr * 512), dx2_bf16=ws["dx2b"].data_ptr(),
                                dss=dp(ws["dss"], l, Fr * 512))
                 segs.append((self.CP["proj_s_T"][l].data_ptr(), 8))
+                if fork:
+                    dxb = rot(dxb)  # (the forked temporal weight gradients still read the previous buffer)
                 pl.chain_a_bwd(M, use_mod, segs=segs, dqkv=dqkv, dx=dx, dx1_bf16=dxb, d_o=t256, rows_per_frame=SA, **kwm)
                 if use_mod:
                     pl.gemm_tn(dY=ws["dx2b"].data_ptr(), ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
+                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"), side=fbit(4))
             else:
                 pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
@@ -838,24 +910,27 @@ class STEngine:
                     pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
                 # ---- spatial attention
                 pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv, Fr, SA, self.scale,
+            pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv_s, Fr, SA, self.scale,
                    flops=10.0 * Fr * SA * SA * 256,  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
                    nbytes=(1536.0 + 512 + 512 + 32 + 1536) * Fr * SA)  # qkv, o, dO, lse read once; dqkv written
             # projection and qkv weight gradients in one launch (dxb is next updated by the LayerNorm backward below)
             if self.qkn:
-                pl.add("hma_qknorm_bwd", dqkv, 768, dp(ws["qraw_s"], l, M * 512), self._lw(l, "spatial_attn.norm.weight", "p"), 1e-5,
+                pl.add("hma_qknorm_bwd", dqkv_s, 768, dp(ws["qraw_s"], l, M * 512), self._lw(l, "spatial_attn.norm.weight", "p"), 1e-5,
                        gw("spatial_attn.norm.weight"), gw("spatial_attn.norm.bias"), M)
             aff1 = dict(a_kind=A_BF16) if self.qkn else dict(a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
                                                              beta=self._lw(l, "norm1.bias", "p"))
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
-                            dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=xh1, lda=256, M=M, N=768, K=256,
-                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
+                            dict(dY=dqkv_s, ldy=768, y_kind=A_BF16, A=xh1, lda=256, M=M, N=768, K=256,
+                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1),
+                            side=fbit(8))
             if self.qkn:  # norm1 is the identity
-                pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
+                pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
             else:
-                pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
+                pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
+                if fork:
+                    dxb = rot(dxb)  # (the forked spatial weight gradients still read the previous buffer)
                 pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
                        dxb)
             pl.mark(f"layer{l}")
