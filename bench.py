@@ -2,6 +2,7 @@
 """Headline benchmark: video-tokens/s of one HMA-base optimizer step (fwd + bwd + all-reduce + clip + AdamW).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...            (no launcher around it: starts the N ranks itself, `launch_ranks`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -325,6 +326,43 @@ def decode_bench(args, dev, steps=None, warmup=None, batch=None):
     return res
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process, relay rank 0's JSON line, return the child's exit code.  Runs BEFORE anything initialises the
+    GPU in this process (counting devices does not), and the ranks are fresh processes, never an exec of this one."""
+    import socket
+    import subprocess
+
+    one_device = os.environ.get("HMA_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < (1 if one_device else n):
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit code {rc})", file=sys.stderr, flush=True)
+        return rc
+    if line is None or json.loads(line).get("n_gpus") != n:
+        print(f"bench.py: the ranks did not produce an n_gpus = {n} line", file=sys.stderr, flush=True)
+        return 3
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,10 +382,14 @@ def main():
                          "the fused block (hma_mlp_fwd / hma_mlp_bwd)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Launched bare with --gpus N: this process becomes the launcher -- it never touches a GPU -- and starts N fresh ranks
+        # (the reference: `torchrun --nproc_per_node=8`, experiments/scripts/run_30datasets_waction.sh:17-19).
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Debug only: HMA_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 with the gloo backend, so the N > 1 trainer path
     # (domain all-gather, bucketed all-reduce on the side stream between per-bucket hipGraphs) can be exercised on a
@@ -364,6 +406,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    backend = (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else "")) if world > 1 else None
 
     if args.mode == "decode":
         if rank == 0:
@@ -453,7 +498,7 @@ def main():
                                    f"({sum(p.numel() for p in model.parameters()) / 1e6:.1f}M params), synthetic VQ tokens "
                                    f"T={T} H=W=16 ids<8192 (+64 action tokens/frame), batch {B}/GPU",
                        "global_batch": B * world, "seq_len": T * 256, "parallelism": f"dp{world}"},
-            "per_gpu": value / world,
+            "per_gpu": value / world, "backend": backend,
             "mfma_roofline_frac_step": value / world * FLOP_PER_TOKEN_FWD_BWD / MFMA_PEAK,
             "final_loss": loss,
         }

@@ -1261,8 +1261,15 @@ class STEngine:
         if actions is not None:
             d_a = self.d_actions[domain]
             ws["actions"][: B * P * d_a].copy_(actions[:, :P].reshape(-1), non_blocking=True)
-        self._forward_plan(B, P, S, A, False, domain if A > 0 else None, readout=False, kv_cache=d["cache"],
-                           T_cache=T_total).run(stream)
+        pl = self._forward_plan(B, P, S, A, False, domain if A > 0 else None, readout=False, kv_cache=d["cache"], T_cache=T_total)
+        if self.jpa and A > 0:
+            # jointly_predict_actions: the plan's embedding reads `a_tok` (what the concatenated action tokens carry).  Prompt frames
+            # are never action-masked in a rollout (st_mask_git.py:656-660 with no relevant_action_mask): a_tok = the embedded actions.
+            pl.run(stream, 0, pl.marks["post_stem"])
+            ws["a_tok"].copy_(ws["a_emb"])
+            pl.run(stream, pl.marks["post_stem"], None)
+        else:
+            pl.run(stream)
 
     def decode_frame(self, ids_BS: torch.Tensor, actions_t: Optional[torch.Tensor], domain: Optional[str], t: int, T_total: int,
                      readout: bool = True, same_actions: bool = False) -> torch.Tensor:

@@ -534,7 +534,10 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         S = h * w
         num_new_frames = max_new_tokens // S
         B = input_ids.size(0)
-        if kwargs.pop("use_cache", True) and not return_logits and not return_with_actions and num_new_frames > 0:
+        # (jointly_predict_actions without input actions -- the policy mode, :663-666 -- appends mask tokens to every frame: only the
+        # window path builds that; the K/V-cached loop is for the conditioned / unconditioned rollouts)
+        policy = self.config.jointly_predict_actions and action_ids is None
+        if kwargs.pop("use_cache", True) and not return_logits and not return_with_actions and num_new_frames > 0 and not policy:
             return self._generate_cached(input_ids, num_new_frames, h, w, maskgit_steps, temperature, action_ids, domain,
                                          kwargs)
         inputs_THW = input_ids.clone().reshape(B, -1, h, w)

@@ -56,7 +56,8 @@ def _pack_t(w, c=0):  # input gradient: A[n][k] = W[256 c + k][n]
     return ops.chain_pack(wd[256 * c:], kind=0, rows=256, cols=256, row_stride=1, col_stride=256)
 
 
-@pytest.mark.parametrize("M,rpf,mod", [(112, 16, True), (1000 // 16 * 16, 16, True), (320 * 7, 320, True), (40960, 320, True),
+# (163 840 rows = the headline step's launch size, B = 32 x T = 16 frames of 320 rows: 5.7 tiles per workgroup)
+@pytest.mark.parametrize("M,rpf,mod", [(112, 16, True), (1000 // 16 * 16, 16, True), (320 * 7, 320, True), (40960, 320, True), (163840, 320, True),
                                        (1008, 0, False), (2560, 0, False)])
 def test_chain_a_fwd(M, rpf, mod):
     wp, wl, wq, bp, bl, bq = _weights(300)
@@ -106,7 +107,7 @@ def test_chain_a_fwd(M, rpf, mod):
     assert (qkv_o.float().cpu() - qkv).abs().max() < 0.2 * (qkv_o.float().cpu() - qkv.flip(1)).abs().max()
 
 
-@pytest.mark.parametrize("M,rpf,mod", [(112, 16, True), (320 * 7, 320, True), (40960, 320, True), (1008, 0, False)])
+@pytest.mark.parametrize("M,rpf,mod", [(112, 16, True), (320 * 7, 320, True), (40960, 320, True), (163840, 320, True), (1008, 0, False)])
 def test_chain_a_bwd(M, rpf, mod):
     wp, wl, wq, _, _, _ = _weights(400)
     dqkv = rb(torch.randn(M, 768, generator=g(11)) * 0.02)
@@ -159,7 +160,7 @@ def test_chain_a_bwd(M, rpf, mod):
     assert (do.float().cpu() - d_o).abs().max() < 0.2 * (do.float().cpu() - d_o.flip(1)).abs().max()
 
 
-@pytest.mark.parametrize("M,with_qkv,save", [(112, True, False), (1008, True, True), (20480, True, False), (40960, True, True),
+@pytest.mark.parametrize("M,with_qkv,save", [(112, True, False), (1008, True, True), (20480, True, False), (40960, True, True), (163840, True, True),
                                              (2560, False, False), (2560, False, True)])
 def test_chain_b_fwd(M, with_qkv, save):
     _chain_b_case(M, with_qkv, save, 0.0)

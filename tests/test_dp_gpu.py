@@ -158,3 +158,31 @@ def test_stmar_mixed_domains_under_accumulation_without_step_domains(tmp_path):
         assert moved > 0, name
         err = (w2 - one[name]).double().pow(2).mean().sqrt().item()
         assert err <= (0.15 if w2.numel() <= 1024 else 3e-2) * moved, (name, err, moved)
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two fresh ranks itself (torch.distributed.run as a child
+    process) and relays ONE line with n_gpus = 2; HMA_BENCH_ONE_DEVICE=1 puts both ranks on GPU 0 over gloo (a one-GPU box: the
+    numbers mean nothing, the path -- rendezvous, step-domain schedule, per-bucket graphs + side-stream all-reduces -- is the
+    N-rank one).  The reference launches the same way: experiments/scripts/run_30datasets_waction.sh:17-19."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HMA_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1",
+                        "--domains", "4", "--batch", "4", "--mode", "train", "--no-cpu-baseline", "--no-kernel-timing"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 8
+    assert line["backend"] == "gloo" and line["value"] > 0
+    # more ranks than visible devices (no one-device override): a loud failure, not a silent single-rank line
+    env.pop("HMA_BENCH_ONE_DEVICE")
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--layers", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,0 +1,313 @@
+"""Parity of the TIMED configuration: the shape bench.py's headline number is measured on -- B = 32, T = 16,
+16 x 16 tokens + 64 action tokens per frame (M = 163 840 token rows), 40 action domains -- through the path the timed region takes:
+`Trainer` with hipGraph replay and the weight gradients forked to the side stream (`fork_wgrad = 9`: the four-buffer bf16(dx) ring,
+the second dqkv).  The full-depth tests against the oracle run at B = 1 (tests/test_fulldepth_gpu.py); what can go wrong only at
+size (tiles per workgroup, M-slices per weight gradient, buffer lifetimes of the forked launches, graph edges) is pinned here by
+properties that do not need an oracle run of that size:
+
+  (a) gradient decomposition: the loss is a masked mean (hma/model/st_mask_git.py:620-627), so the flat gradient of one B = 32 step
+      equals the masked-token-weighted sum of the gradients of its four B = 8 chunks -- taken EAGERLY and UNFORKED;
+  (b) graph replay + forks against eager unforked launches on the same batches, over consecutive optimizer steps;
+  (c) the spatial attention backward at 512 frames against fp32 math (the other kernels' M = 163 840 cases are parametrisations of
+      tests/test_chain_gpu.py / tests/test_kernels_gpu.py);
+  (d) the same decomposition for `MarTrainer` at configs[3]'s per-GPU batch 16;
+  (e) configs[0] literally: `hma_amd.train_multi.main` on ONE dataset, batch 1, window 8.
+Reference lines: hma/train_multi.py:556-599 (the step), hma/model/st_transformer.py:79-114 (the block).
+"""
+import json
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402  (build_model / synthetic_batch: the bench's own model and batch constructors)
+from hma_amd.train import MarTrainer, Trainer  # noqa: E402
+
+DEV = "cuda"
+MASK = 262144
+REPORT = {}
+
+
+def _note(key, val):
+    REPORT[key] = val
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_report_headline.json", "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _rms(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
+
+
+def _region_errs(lay, G, Gref, dom):
+    """rms error of the flat gradient per region of the layout (head, every layer, tail, the active domain's block)."""
+    out = {}
+    for name, (a, b) in lay.regions.items():
+        if name == "frozen" or (name.startswith("dom:") and name != f"dom:{dom}"):
+            continue
+        out[name] = _rms(G[a:b], Gref[a:b])
+    return out
+
+
+def _trainer(layers, fork, graphs, seed_offset=0):
+    model, domains, d_actions = bench.build_model(40, 16, layers)
+    model = model.to(DEV).train()
+    tr = Trainer(model, lr=1e-4, warmup_steps=0, device=torch.device(DEV, torch.cuda.current_device()))
+    tr.engine.fork_wgrad = fork
+    tr.use_graphs = graphs
+    return tr, domains, d_actions
+
+
+def _grad_of(tr, ids, labels, act, dom):
+    """flat gradient + loss of one micro-batch (no optimizer step: the weights stay put)."""
+    B = ids.shape[0]
+    ws = tr.micro_step(ids, labels, act, [dom] * B, step_domains=[dom])
+    loss = float(tr.loss_and_acc(ws)[0].item())
+    G = tr.engine.G.clone()
+    tr._micro = 0
+    return G, loss
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("layers", [4, 32])
+def test_gradient_decomposition_at_headline_shape(layers):
+    di = 3
+    tr, domains, d_actions = _trainer(layers, fork=9, graphs=True)
+    eng = tr.engine
+    dom = domains[di]
+    ids, labels, act = bench.synthetic_batch(32, 16, 100 + di, d_actions[di], DEV)
+    # the timed path: eager, eager + capture, then replays (the third and fourth calls)
+    for _ in range(3):
+        G32, loss32 = _grad_of(tr, ids, labels, act, dom)
+    assert tr._graphs, "the step was not captured"
+    G32b, loss32b = _grad_of(tr, ids, labels, act, dom)
+    errs = _region_errs(eng.layout, G32b, G32, dom)
+    assert max(errs.values()) <= 1e-3, f"two replays of the same step differ: {errs}"
+    assert "dqkv_s" in eng._ws, "the forked plan's buffers are not in use"
+    # the four chunks, eagerly and unforked
+    tr.use_graphs = False
+    eng.fork_wgrad = 0
+    eng._plans = {}
+    Gsum = torch.zeros_like(G32)
+    num = den = 0.0
+    for c in range(0, 32, 8):
+        sl = slice(c, c + 8)
+        Gc, lc = _grad_of(tr, ids[sl], labels[sl], act[sl], dom)
+        assert "dqkv_s" not in eng._ws
+        n = float((ids[sl].reshape(8, 16, 256)[:, 1:] == MASK).sum())
+        Gsum += Gc * n
+        num += lc * n
+        den += n
+    Gsum /= den
+    assert abs(loss32 - num / den) <= 1e-3, (loss32, num / den)
+    errs = _region_errs(eng.layout, G32, Gsum, dom)
+    _note(f"decomposition.L{layers}.loss_err", abs(loss32 - num / den))
+    _note(f"decomposition.L{layers}.worst_region_rms", max(errs.values()))
+    _note(f"decomposition.L{layers}.regions", errs)
+    bad = {k: v for k, v in errs.items() if not v <= 1e-2}
+    assert not bad, f"gradient of the B = 32 graph-replayed forked step != weighted sum of its eager B = 8 chunks: {bad}"
+    # untouched domains received nothing
+    for d2 in (domains[0], domains[39]):
+        a, b = eng.layout.regions[f"dom:{d2}"]
+        assert float(G32[a:b].abs().max()) == 0.0
+
+
+@pytest.mark.timeout(1200)
+def test_graph_replay_with_forks_equals_eager_unforked_over_steps():
+    """Two trainers on identical models and batches: A replays hipGraphs with fork_wgrad = 9 (also 15: all four forks), B launches
+    eagerly with no fork.  Per step: the flat gradient (rms per region) and the loss; at the end the weights, against the distance
+    they moved."""
+    for fork in (9, 15):
+        trA, domains, d_actions = _trainer(4, fork=fork, graphs=True)
+        trB, _, _ = _trainer(4, fork=0, graphs=False)
+        assert torch.equal(trA.engine.P, trB.engine.P)
+        P0 = trA.engine.P.clone()
+        di = 5
+        dom = domains[di]
+        batches = [bench.synthetic_batch(32, 16, 300 + k, d_actions[di], DEV) for k in range(5)]
+        for k, (ids, labels, act) in enumerate(batches):
+            out = []
+            for tr in (trA, trB):
+                ws = tr.micro_step(ids, labels, act, [dom] * 32, step_domains=[dom])
+                out.append((tr.engine.G.clone(), float(tr.loss_and_acc(ws)[0].item())))
+                tr.optimizer_step()
+            (GA, lA), (GB, lB) = out
+            errs = _region_errs(trA.engine.layout, GA, GB, dom)
+            _note(f"replay_vs_eager.fork{fork}.step{k}.worst_region_rms", max(errs.values()))
+            assert abs(lA - lB) <= 1e-3, (k, lA, lB)
+            # (steps 0 / 1 run eagerly in A as well; from step 2 on A replays.  Later steps start from weights that differ by the
+            # earlier steps' rounding noise through Adam: the bound covers that)
+            assert max(errs.values()) <= 1e-2, (fork, k, errs)
+        assert trA._graphs and not trB._graphs
+        moved = (trB.engine.P - P0).double().pow(2).sum().sqrt().item()
+        diff = (trA.engine.P - trB.engine.P).double().pow(2).sum().sqrt().item()
+        _note(f"replay_vs_eager.fork{fork}.weights_diff_over_moved", diff / moved)
+        assert diff <= 2e-2 * moved, (diff, moved)
+        del trA, trB
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
+def test_segmented_graphs_with_forks_equal_one_graph():
+    """The data-parallel form of the replay (one graph per gradient bucket, `force_segments`) against the single graph, forks on."""
+    trA, domains, d_actions = _trainer(4, fork=9, graphs=True)
+    trB, _, _ = _trainer(4, fork=9, graphs=True)
+    trB.force_segments = True
+    trB.layers_per_bucket = 2
+    di = 7
+    dom = domains[di]
+    ids, labels, act = bench.synthetic_batch(32, 16, 400, d_actions[di], DEV)
+    for _ in range(3):
+        GA, lA = _grad_of(trA, ids, labels, act, dom)
+        GB, lB = _grad_of(trB, ids, labels, act, dom)
+    assert len(next(iter(trB._graphs.values()))) == 3 and len(next(iter(trA._graphs.values()))) == 1
+    errs = _region_errs(trA.engine.layout, GA, GB, dom)
+    assert abs(lA - lB) <= 1e-5 and max(errs.values()) <= 1e-3, (lA, lB, errs)
+
+
+@pytest.mark.timeout(900)
+def test_attn_spatial_bwd_at_512_frames():
+    """hma_attn_spatial_fwd / _bwd at the headline launch size (512 frames of 320 tokens: 4 096 (frame, head) items, 16 per
+    persistent workgroup) against fp32 math on the GPU, frame chunks of 32."""
+    from hma_amd import ops
+    frames, n, scale = 512, 320, 0.25
+    g = torch.Generator().manual_seed(40)
+    qkv = (torch.randn(frames * n, 768, generator=g)).bfloat16().to(DEV)
+    d_o = (torch.randn(frames * n, 256, generator=g)).bfloat16().to(DEV)
+    o, lse = ops.attn_spatial_fwd(qkv, frames, n, scale)
+    dqkv = ops.attn_spatial_bwd(qkv, o, d_o, lse, frames, n, scale)
+    torch.cuda.synchronize()
+    BFE = 2.0 ** -8
+    worst = {"o": 0.0, "dq": 0.0, "dk": 0.0, "dv": 0.0}
+    for f0 in range(0, frames, 32):
+        rows = slice(f0 * n, (f0 + 32) * n)
+        x = qkv[rows].float().requires_grad_(True)
+        q, k, v = x.reshape(32, n, 3, 8, 32).permute(2, 0, 3, 1, 4)
+        ref = (((q * scale) @ k.transpose(-1, -2)).softmax(-1) @ v).transpose(1, 2).reshape(32 * n, 256)
+        ref.backward(d_o[rows].float())
+        sc = ref.detach().abs().max().item()
+        worst["o"] = max(worst["o"], (o[rows].float() - ref.detach()).abs().max().item() / sc)
+        for name, sl in (("dq", slice(0, 256)), ("dk", slice(256, 512)), ("dv", slice(512, 768))):
+            gs = x.grad[:, sl].abs().max().item()
+            worst[name] = max(worst[name], (dqkv[rows][:, sl].float() - x.grad[:, sl]).abs().max().item() / gs)
+    _note("attn512.worst_rel", worst)
+    assert worst["o"] <= 2 * BFE and max(worst["dq"], worst["dk"], worst["dv"]) <= 4 * BFE, worst
+
+
+# ------------------------------------------------------------------------------------------------ (d) MarTrainer, B = 16
+def _mar_model(layers):
+    from hma_amd.config import DiffusionGenieConfig
+    from hma_amd.model.st_mar import STMAR
+
+    cfgd = dict(num_layers=layers, num_heads=8, d_model=256, T=16, S=1024, use_mup=True, action_network="concat+modulate",
+                num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.0, mlp_bias=False, patch_size=2,
+                vae_embed_dim=4, diffloss_w=1024, diffloss_d=4, num_sampling_steps="100", attn_drop=0.0)
+    torch.manual_seed(0)
+    m = STMAR(DiffusionGenieConfig(**cfgd))
+    doms = [f"dom{i}" for i in range(30)]
+    m.init_action_projectors(doms, [14] + [7 * min(max(1, f // 2), 9) for f in bench.FREQ[1:30]], [[[0.0] * 7, [1.0] * 7]] * 30,
+                             cfgd["action_network"])
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
+                p_.normal_(0, 0.02)
+    return m.to(DEV).train()
+
+
+@pytest.mark.timeout(1200)
+def test_mar_trainer_gradient_decomposition_at_batch_16():
+    """configs[3]'s per-GPU batch through `MarTrainer` (fixed diffusion draws; mlp_drop 0 so that the chunks see the batch's
+    arithmetic): the masked-mean loss and every gradient range -- trunk flat buffer, the model's own range (input / output stages +
+    diffusion head) -- of the B = 16 step equal the patch-mask-weighted sums over four B = 4 steps."""
+    from oracle import st_mar_ref as MR
+
+    m = _mar_model(4)
+    tr = MarTrainer(m, lr=1e-4, warmup_steps=0, device=torch.device(DEV, torch.cuda.current_device()))
+    B, T = 16, 16
+    g = torch.Generator(device=DEV).manual_seed(0)
+    lat = torch.randn(B, T * 1024, 4, device=DEV, generator=g) * 0.7
+    masked = torch.rand(B, T, 32, 32, device=DEV, generator=g) < 0.6
+    act = torch.randn(B, T, 14, device=DEV, generator=g)
+    n1 = T * 256
+    tt = torch.randint(0, 1000, (B * n1,), device=DEV, generator=g)
+    nz = torch.randn(B * n1, 16, device=DEV, generator=g)
+
+    def run(lo, hi):
+        b = hi - lo
+        kw = dict(input_ids=lat[lo:hi].clone(), labels=lat[lo:hi].clone(), action_ids=act[lo:hi], domain=["dom0"] * b,
+                  masked_tokens_indicator=masked[lo:hi], h=[32] * b, w=[32] * b, diffusion_t=tt[lo * n1:hi * n1],
+                  diffusion_noise=nz[lo * n1:hi * n1])
+        out = tr.micro_step(step_domains=["dom0"], **kw)
+        tr.model._own_gather_grads(tr.own)
+        Gt, Go = tr.engine.G.clone(), tr.own["G"].clone()
+        tr._micro = 0
+        return Gt, Go, float(out.loss.item())
+
+    Gt16, Go16, l16 = run(0, 16)
+    Gt, Go = torch.zeros_like(Gt16), torch.zeros_like(Go16)
+    num = den = 0.0
+    for c in range(0, B, 4):
+        gt, go, lc = run(c, c + 4)
+        pm = MR.patchify(masked[c:c + 4][..., None].float().cpu(), 2).sum(-1) > 0
+        n = float(pm.sum())
+        Gt += gt * n
+        Go += go * n
+        num += lc * n
+        den += n
+    Gt /= den
+    Go /= den
+    assert abs(l16 - num / den) <= 1e-3 * abs(l16), (l16, num / den)
+    errs = _region_errs(tr.engine.layout, Gt16, Gt, "dom0")
+    errs = {k: v for k, v in errs.items() if k != "head"}  # (the discrete readout: not part of the continuous model's step)
+    errs["own"] = _rms(Go16, Go)
+    _note("mar_decomposition.worst_region_rms", max(errs.values()))
+    _note("mar_decomposition.loss_err", abs(l16 - num / den))
+    bad = {k: v for k, v in errs.items() if not v <= 1e-2}
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------ (e) configs[0] literally
+@pytest.mark.timeout(900)
+def test_configs0_single_dataset_batch1_window8(tmp_path, capsys):
+    """BASELINE configs[0]: HMA-base-disc (the shipped 32-layer config), single-dataset `train_multi` on one dataset, batch 1,
+    T = 8 -- the reference's plumbing case (hma/train_multi.py:779-1030 with --per_device_train_batch_size 1 --window_size 8)."""
+    import numpy as np
+
+    from hma_amd import train_multi
+    from hma_amd.data import write_token_dataset
+
+    rng = np.random.default_rng(0)
+    name = "kaist_nonprehensile_converted_externally_to_rlds"   # 10 Hz in the reference's frequency table: stride 5, 35 action values per frame
+    root = tmp_path / name
+    n_frames = 120
+    tokens = rng.integers(0, 8192, size=(n_frames, 16, 16), dtype=np.uint32)
+    write_token_dataset(root, tokens, np.zeros(n_frames, dtype=np.int32), rng.standard_normal((n_frames, 7)).astype(np.float32), name=name,
+                        hz=10)
+    cfg = dict(num_layers=32, num_heads=8, d_model=256, T=8, S=256, image_vocab_size=262144, use_mup=True,
+               action_network="concat+modulate", num_factored_vocabs=2, qkv_bias=False, proj_bias=True, attn_drop=0.0, qk_norm=False,
+               mlp_ratio=4.0, mlp_drop=0.0, mlp_bias=True, use_actions=True)
+    cfg_path = tmp_path / "cfg.json"
+    cfg_path.write_text(json.dumps(cfg))
+    out_dir = tmp_path / "out"
+    argv = ["--train_data_dir", str(root), "--genie_config", str(cfg_path), "--output_dir", str(out_dir), "--window_size", "8",
+            "--per_device_train_batch_size", "1", "--max_train_steps", "3", "--learning_rate", "1e-4", "--seed", "0", "--log_every", "1"]
+    steps = train_multi.main(argv)
+    assert steps == 3
+    ckpt = out_dir / "step_3"
+    assert (ckpt / "config.json").exists() and (ckpt / "model.safetensors").exists() and (ckpt / "optimizer.bin").exists()
+    saved = json.load(open(ckpt / "config.json"))
+    assert saved["action_domains"] == [name] and saved["d_actions"] == [35] and saved["T"] == 8 and saved["num_layers"] == 32
+    line = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    assert line["step"] == 3 and math.isfinite(line["loss"]) and abs(line["loss"] - 2 * math.log(512)) < 1.0, line

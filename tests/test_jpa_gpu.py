@@ -133,3 +133,25 @@ def test_generate_returns_unnormalised_actions():
                                    unmask_mode="greedy")
     st = m.action_preprocessor["domA"]
     assert torch.allclose(actions, raw * (st.std + 1e-10) + st.mean, rtol=1e-6, atol=1e-6)
+
+
+def test_cached_generate_equals_window_generate_on_a_jpa_model():
+    """`generate()` defaults to the K/V-cached loop; on a jointly_predict_actions model its prefill must feed the
+    embedded actions as the prompt frames' action tokens (what the window path, st_mask_git.py:656-660 without an action mask, feeds),
+    and the policy mode (no action ids: mask tokens on every frame, :663-666) must take the window path."""
+    m = build().eval()
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    T = m.config.T
+    ids = inp["labels"].reshape(2, T, 256)[:, : T - 2].reshape(2, -1)
+    kw = dict(max_new_tokens=512, maskgit_steps=2, temperature=0.0, action_ids=inp["actions_domA"], domain=["domA"] * 2, unmask_mode="greedy")
+    with torch.no_grad():
+        eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+        window = m.generate(ids, None, use_cache=False, **kw)
+        eng._workspace(2, T - 2, 256, m.config.action_token_size, False)["a_tok"].fill_(float("nan"))  # stale content must not matter
+        cached = m.generate(ids, None, **kw)
+        assert (cached != m.mask_token_id).all()
+        agree = (cached == window).float().mean().item()
+        assert agree >= 0.97, agree   # (the two paths differ by bf16 noise: near-tie ids may flip, tests/test_fulldepth_gpu.py)
+        # policy mode: cached request == window path exactly (it is routed there)
+        kwp = dict(kw, action_ids=None, domain=["domB"] * 2)
+        assert torch.equal(m.generate(ids, None, **kwp), m.generate(ids, None, use_cache=False, **kwp))

@@ -254,7 +254,7 @@ def test_gemm_tn_ring(M, N, K):
     close(dW, 0.5 + refa, BF, "dW ring affine, no bias")
 
 
-@pytest.mark.parametrize("M", [4096, 32 * 130, 40])
+@pytest.mark.parametrize("M", [4096, 32 * 130, 40, 163840])   # (163 840: the headline step's rows -- every problem split over several M-slices)
 def test_gemm_tn_pair(M):
     """hma_gemm_tn_pair: two weight gradients in one launch (MLP pair, fc1 with the deferred LayerNorm affine, and a
     projection / qkv pair without a qkv bias) give what two hma_gemm_tn calls give; M = 40 is not eligible for the ring
@@ -704,7 +704,7 @@ def _from_frag32(t, M):
     return v.permute(0, 2, 5, 1, 4, 3, 6).reshape(Mt, ld)[:M]  # tile, group, row | block, c/16, c/8, c%8
 
 
-@pytest.mark.parametrize("M", [128, 1000, 40960])
+@pytest.mark.parametrize("M", [128, 1000, 40960, 163840])
 def test_mlp_bwd_fused(M):
     _mlp_bwd_case(M, 0.0)
 
