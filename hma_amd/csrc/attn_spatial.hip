@@ -231,7 +231,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
       l *= alpha;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] *= alpha;
-      typedef float f32x2_t __attribute__((ext_vector_type(2)));
       const f32x2_t c2 = {c_log2, c_log2}, nm2 = {-m_new, -m_new};
       f32x2_t la = {0.f, 0.f}, lb = {0.f, 0.f};
 #pragma unroll

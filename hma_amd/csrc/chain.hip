@@ -34,22 +34,58 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
-// (measurement builds: -DCH_NCW=3 -DCH_NS=3 makes 4-wave workgroups of 48-row tiles, two per CU -- tools/chain_variants.sh)
+// CH_ST = 1 (measurement builds, tools/chain_variants.sh "st:-DCH_ST=1"): STORER mode -- round 4's test of VERDICT item 6.  A chain's
+// stores and its other work ADD (chain A forward: default 250 us, without its global stores 91 us), so here compute waves never store:
+// they put every finished 16-row x 128-byte block into a small per-wave LDS ring (`stage_block`) and dedicated STORER waves drain the
+// rings into HBM.  s_barrier would tie the storers to the others (every live wave of a workgroup has to arrive), so the weight ring is
+// synchronised by LDS words instead: the loader publishes `ready` = bundles landed, each compute wave `done` = steps whose fragments
+// it has read; the staging rings carry a sequence number in each block's descriptor.  512 threads = 7 - CH_NSTW compute waves +
+// loader + CH_NSTW storers.  Parity-green (tests/test_chain_gpu.py) and SLOWER (profiles/chain_storer_r4.txt): a storer wave needs
+// ~650 cycles per 2 KB block whatever feeds it (two storers per CU: 3.2 TB/s at best), the 8 KB rings cannot take a tile's bursts,
+// and the flag hand-offs add ~500 cycles to a step -- chain A forward 343-400 us against 245, chain B forward 520 against 410.
+// CH_ST = 0 (default): 7 compute waves + loader, one s_barrier per CH_PB steps, stores from the compute waves.
+#ifndef CH_ST
+#define CH_ST 0
+#endif
+#ifndef CH_NSTW   // storer waves (one wave has at most 63 stores in flight: ~2.3 TB/s over the chip at the write latency under load)
+#define CH_NSTW 2
+#endif
 #ifndef CH_NCW
-#define CH_NCW 7
+#define CH_NCW (CH_ST ? 7 - CH_NSTW : 7)
+#endif
+#ifndef CH_PB   // CH_ST = 0 only: bundles per barrier (the ring is refilled, and the compute waves synchronise, every CH_PB steps)
+#define CH_PB (CH_ST ? 1 : 2)
 #endif
 #ifndef CH_NS
-#define CH_NS 4
+#define CH_NS (CH_PB == 1 ? 4 : 3 * CH_PB)
 #endif
-constexpr int NCW = CH_NCW;                  // compute waves; wave NCW is the loader
-constexpr int CH_THREADS = 64 * (NCW + 1);
+#ifndef CH_R    // CH_ST = 1: blocks per compute wave in its staging ring
+#define CH_R 4
+#endif
+constexpr bool ST = CH_ST != 0;
+constexpr int NCW = CH_NCW;                  // compute waves; wave NCW is the loader, wave NCW + 1 (storer mode) the storer
+constexpr int NSTW = ST ? CH_NSTW : 0;       // storer k takes the staging rings of the compute waves w with w % NSTW == k
+constexpr int CH_THREADS = 64 * (NCW + 1 + NSTW);
 constexpr int WGS_PER_CU = NCW <= 3 ? 2 : 1;
 constexpr int NS = CH_NS;                    // ring slots
+constexpr int PB = CH_PB;                    // steps per barrier (every chain has an even number of steps per tile)
+static_assert(NS % PB == 0 && NS >= 2 * PB, "the ring holds whole barrier groups");
+static_assert(!ST || PB == 1, "storer mode: per-step flags");
 constexpr int SLOT = 16384;                  // one bundle
-constexpr int TILE_ROWS = 16 * NCW;          // 112
-constexpr int L_BIAS = NS * SLOT;            // 2048 floats of bias vectors
-constexpr int L_SS = L_BIAS + 8192;          // 2 tiles x NCW waves x 2 KB: the frames' shift | scale rows
-constexpr int SMEM = L_SS + 2 * NCW * 2048;  // 102400 B
+constexpr int TILE_ROWS = 16 * NCW;
+constexpr int L_BIAS = NS * SLOT;            // up to 2304 floats of bias vectors (chain B)
+constexpr int L_SS = L_BIAS + (ST ? 9216 : 8192);  // 2 tiles x NCW waves x 2 KB: the frames' shift | scale rows (CH_ST = 0: chain B's biases run into it)
+constexpr int L_SYNC = L_SS + 2 * NCW * 2048;      // storer mode: [0] ready | [8 + w] done | [16 + w] freed (32-bit words)
+constexpr int RB = CH_R;                           // staging blocks per compute wave
+#ifndef CH_RG   // blocks reserved per wait: small groups let a wave refill its ring while the storer drains the rest of it
+#define CH_RG 2
+#endif
+constexpr int RG = CH_RG;
+static_assert(RG <= RB && (RG & (RG - 1)) == 0, "reserve groups divide the ring");
+static_assert((RB & (RB - 1)) == 0, "power of two");
+constexpr int L_DESC = L_SYNC + 256;               // NCW x RB descriptors of 16 bytes: {address lo, hi, row pitch, sequence number}
+constexpr int L_STG = L_DESC + NCW * RB * 16;      // NCW x RB blocks of 16 rows x 128 bytes
+constexpr int SMEM = ST ? L_STG + NCW * RB * 2048 : L_SYNC;
 
 __device__ __forceinline__ bf16x8_t lds_frag(HMA_LDS(char)* p) { return __builtin_bit_cast(bf16x8_t, *(HMA_LDS(u32x4_t)*)p); }
 __device__ __forceinline__ float4 lds_f4(HMA_LDS(char)* p) {
@@ -92,6 +128,163 @@ __device__ unsigned long long g_ch_prof[2][8][8];
     asm volatile("" ::: "memory");                        \
     CH_SCHED_FENCE                                        \
   } while (0)
+
+// ------------------------------------------------------------------------------------------------ storer mode: flags and staging
+__device__ __forceinline__ uint32_t lds_poll(HMA_LDS(char)* p) {
+  return __builtin_amdgcn_readfirstlane(*(volatile HMA_LDS(uint32_t)*)p);
+}
+// wait until the LDS word at p is >= need (`seen` caches the last value read: the producer usually runs ahead)
+__device__ __forceinline__ void wait_word(HMA_LDS(char)* p, uint32_t need, uint32_t& seen) {
+  while ((int32_t)(seen - need) < 0) {
+    seen = lds_poll(p);
+    if ((int32_t)(seen - need) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void post_word(HMA_LDS(char)* p, uint32_t v, int lane) {
+  asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order: everything it read or wrote before is done first)
+  if (lane == 0) *(volatile HMA_LDS(uint32_t)*)p = v;
+}
+// what a compute wave carries through a kernel in storer mode
+struct stage_t {
+  HMA_LDS(char)* stg;    // this wave's RB blocks
+  HMA_LDS(char)* desc;   // their descriptors
+  HMA_LDS(char)* freed;  // blocks of this wave the storer has taken out of LDS
+  HMA_LDS(char)* ready;  // bundles landed (loader)
+  HMA_LDS(char)* done;   // steps this wave is through with
+  uint32_t nb, freed_seen, ready_seen, sg;  // blocks staged; cached words; steps begun
+  int lane;
+};
+__device__ __forceinline__ stage_t make_stage(HMA_LDS(char)* lds, int wave, int lane) {
+  stage_t st;
+  st.stg = lds + L_STG + wave * RB * 2048;
+  st.desc = lds + L_DESC + wave * RB * 16;
+  st.freed = lds + L_SYNC + 64 + 4 * wave;
+  st.ready = lds + L_SYNC;
+  st.done = lds + L_SYNC + 32 + 4 * wave;
+  st.nb = st.freed_seen = st.ready_seen = st.sg = 0;
+  st.lane = lane;
+  return st;
+}
+// one 16-row x 128-byte block (rows `pitch` bytes apart from `base`): this lane's two 16-byte pieces go to LDS byte offsets s0 / s1
+// of the block (row tok, chunk c at c ^ (tok & 7): conflict-free here and for the storer's row-linear reads)
+// n <= RB blocks may be staged without further checks (one wait loop per burst instead of one per block)
+__device__ __forceinline__ void stage_reserve(stage_t& st, int n) {
+  if constexpr (ST) wait_word(st.freed, st.nb + (uint32_t)n - RB, st.freed_seen);
+}
+template <bool WAIT = true>
+__device__ __forceinline__ void stage_block(stage_t& st, const void* base, uint32_t pitch, int s0, int s1, const uint4& q0, const uint4& q1) {
+  if constexpr (WAIT) wait_word(st.freed, st.nb + 1 - RB, st.freed_seen);
+  HMA_LDS(char)* d = st.stg + (st.nb & (RB - 1)) * 2048;
+  *(HMA_LDS(u32x4_t)*)(d + s0) = __builtin_bit_cast(u32x4_t, q0);
+  *(HMA_LDS(u32x4_t)*)(d + s1) = __builtin_bit_cast(u32x4_t, q1);
+  asm volatile("" ::: "memory");
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  if (st.lane == 0)
+    *(volatile HMA_LDS(u32x4_t)*)(st.desc + (st.nb & (RB - 1)) * 16) = u32x4_t{(uint32_t)a, (uint32_t)(a >> 32), pitch, st.nb + 1};
+  ++st.nb;
+}
+// the step protocol of a compute wave: begin -> fragments of bundle sg may be read; end -> they have been
+__device__ __forceinline__ void step_begin(stage_t& st) {
+  if constexpr (ST) wait_word(st.ready, st.sg + 1, st.ready_seen);
+}
+__device__ __forceinline__ void step_end(stage_t& st) {
+  if constexpr (ST) {
+    ++st.sg;
+    post_word(st.done, st.sg, st.lane);
+  }
+}
+__device__ __forceinline__ void steps_skip(stage_t& st, int n) {  // a wave whose rows lie past the matrix
+  if constexpr (ST) {
+    st.sg += n;
+    post_word(st.done, st.sg, st.lane);
+  }
+}
+__device__ __forceinline__ void stage_finish(stage_t& st) {  // the wave's last block: tells the storer it is through
+  if constexpr (ST) stage_block(st, nullptr, 0xffffffffu, st.lane * 16, 1024 + st.lane * 16, make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0));
+}
+// The storer wave.  One round: lane l < NW x RB reads the descriptor of staging block l (wave l / RB, slot l % RB) -- one LDS
+// instruction sees every ring -- and a block is complete when its sequence number is the one its slot holds next.  A wave fills
+// its slots in order, so the complete blocks of a wave are a run behind the ones already taken.  They go to HBM in batches of up to
+// eight: all sixteen LDS reads first, then sixteen whole-line store instructions (8 rows x 128 bytes each) -- a block at a time
+// the loop was bound by the LDS round trip (~400 cycles per block against the ~230 the write bandwidth leaves).
+template <int NW>
+__device__ __forceinline__ void storer_run(HMA_LDS(char)* lds, int lane, int k) {
+  __builtin_amdgcn_s_setprio(3);
+  static_assert(NW * RB <= 64, "one lane per staging block");
+  const int w_ = lane < NW * RB ? lane / RB : 0, j_ = lane & (RB - 1);
+  const bool mine = lane < NW * RB && w_ % NSTW == k;
+  uint32_t all = 0;  // the compute waves this storer serves
+  for (int w = k; w < NW; w += NSTW) all |= 1u << w;
+  uint32_t sent = 0;  // blocks of wave w_ taken (the same value in the RB lanes of a wave)
+  uint32_t fin = 0;
+  const int r8 = lane >> 3, lc = (lane & 7) ^ (r8 & 7);
+  HMA_LDS(char)* blk = lds + L_STG + lane * 16;
+  CPROF_DECL;
+  while (true) {
+    const u32x4_t d = *(volatile HMA_LDS(u32x4_t)*)(lds + L_DESC + (mine ? lane : 0) * 16);
+    const uint32_t nxt = sent + ((uint32_t)(j_ - (int)sent) & (RB - 1));  // the block this slot holds next
+    uint64_t mask = __ballot(mine && d[3] == nxt + 1);
+    if (mask == 0) {
+      if (fin == all) break;
+      __builtin_amdgcn_s_sleep(1);
+      CPROF_MARK(0);
+      continue;
+    }
+    CPROF_MARK(1);
+#ifdef CH_PROF
+    pacc_[5] += 1;
+    pacc_[6] += __builtin_popcountll(mask);
+#endif
+    const uint32_t took = (uint32_t)__builtin_popcountll((mask >> (w_ * RB)) & ((1ull << RB) - 1));
+    while (mask) {
+      int idx[8];
+      u32x4_t v0[8], v1[8];
+      uint32_t lo[8], hi[8], pitch[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        idx[k] = -1;
+        if (mask) {
+          const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+          mask &= mask - 1;
+          lo[k] = __builtin_amdgcn_readlane(d[0], b);
+          hi[k] = __builtin_amdgcn_readlane(d[1], b);
+          pitch[k] = __builtin_amdgcn_readlane(d[2], b);
+          if (pitch[k] == 0xffffffffu) {
+            fin |= 1u << (b / RB);
+          } else {
+            idx[k] = b;
+            v0[k] = *(HMA_LDS(u32x4_t)*)(blk + b * 2048);
+            v1[k] = *(HMA_LDS(u32x4_t)*)(blk + b * 2048 + 1024);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (idx[k] >= 0 && !(CH_ABL & 1)) {
+          char* g = reinterpret_cast<char*>((uintptr_t)(((uint64_t)hi[k] << 32) | lo[k])) + (uint64_t)r8 * pitch[k] + lc * 16;
+          __builtin_nontemporal_store(v0[k], reinterpret_cast<u32x4_t*>(g));
+          __builtin_nontemporal_store(v1[k], reinterpret_cast<u32x4_t*>(g + 8 * (uint64_t)pitch[k]));
+        }
+      }
+    }
+    sent += took;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's reads of the blocks are done before they are handed back)
+    if (mine && j_ == 0) *(volatile HMA_LDS(uint32_t)*)(lds + L_SYNC + 64 + 4 * w_) = sent;
+    CPROF_MARK(2);
+#ifdef CH_ST_DEPTH  // (measurement builds: at most this many store instructions in flight)
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (CH_ST_DEPTH & 15) | ((CH_ST_DEPTH >> 4) << 14));
+#endif
+  }
+  CPROF_FLUSH(0, NCW + 1 + k);
+}
+// zero the flag words and descriptors (before the kernel's first __syncthreads)
+__device__ __forceinline__ void sync_init(HMA_LDS(char)* lds, int tid) {
+  if constexpr (ST) {
+    for (int i = tid; i < (L_STG - L_SYNC) / 4; i += CH_THREADS) ((HMA_LDS(uint32_t)*)(lds + L_SYNC))[i] = 0;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
@@ -139,7 +332,8 @@ struct ring_src {
 };
 template <int PROF_K, int NW = NCW>
 __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
-                                           int64_t M, int rows_per_frame) {
+                                           int64_t M, int rows_per_frame, HMA_LDS(char)* lds = nullptr) {
+  if constexpr (ST) __builtin_amdgcn_s_setprio(2);
   const int total = per_tile * nt;
   int issued = 0, seg = 0, left = ws.n0, tl_issue = 0, slot_issue = 0;
   const char* cur = ws.s0;
@@ -179,13 +373,15 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
       left = nn;
     }
   };
+  // With PB bundles per barrier the group [s, s + PB) is complete before barrier s / PB, and the PB slots the compute waves have
+  // left -- they are past group s / PB - 1 when they arrive -- are refilled behind it.
 #pragma unroll 1
-  for (int b = 0; b < NS - 1 && b < total; ++b) issue();
+  for (int b = 0; b < NS - PB && b < total; ++b) issue();
   CPROF_DECL;
 #pragma unroll 1
-  for (int s = 0; s < total; ++s) {
+  for (int s = 0; s < total; s += PB) {
     CPROF_MARK(2);
-    const int ahead = issued - 1 - s;  // bundles issued after bundle s (each 16 pieces; shift / scale pieces only make the wait stricter)
+    const int ahead = issued - PB - s;  // bundles issued after the group (each 16 pieces; shift / scale pieces only make the wait stricter)
     if (ahead >= 3)  // (rings deeper than four slots; the counter has 6 bits, so more than three bundles behind s cannot be told apart)
       asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
     else if (ahead == 2)
@@ -195,9 +391,27 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CPROF_MARK(0);
-    CH_BARRIER();
-    CPROF_MARK(1);
-    if (issued < total) issue();
+    if constexpr (ST) {
+      // bundle s has landed: publish it; the slot of bundle s - 1 is refilled once every compute wave is through with step s - 1
+      post_word(lds + L_SYNC, (uint32_t)(s + 1), lane);
+      if (issued < total) {
+        const uint32_t need = (uint32_t)(issued - NS + 1);
+        while (true) {
+          const uint32_t dv = *(volatile HMA_LDS(uint32_t)*)(lds + L_SYNC + 32 + 4 * (lane < NW ? lane : 0));
+          if (__ballot((int32_t)(dv - need) >= 0) == ~0ull) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        CPROF_MARK(1);
+        issue();
+      }
+    } else {
+      CH_BARRIER();
+      CPROF_MARK(1);
+#pragma unroll
+      for (int k = 0; k < PB; ++k)
+        if (issued < total) issue();
+    }
   }
   CPROF_MARK(2);
   CPROF_FLUSH(PROF_K, NCW);
@@ -251,6 +465,7 @@ __device__ __forceinline__ uint4 dpp_swap8(const uint4& v) {
 struct line_offs {
   int a, b;  // byte offsets from the tile's first row: this lane's piece in rows 0..7 (instruction A) / rows 8..15 (instruction B)
   bool lo;
+  int pitch, s0, s1;  // storer mode: the row pitch and the LDS byte offsets of q0 / q1 inside a staged block
 };
 // pitch = row pitch in bytes; g16 = byte offset of the lane group's q0 inside the 128-byte line; d = distance of q1 behind q0
 __device__ __forceinline__ line_offs make_lines(int pitch, int tok, int g16, int d) {
@@ -258,9 +473,19 @@ __device__ __forceinline__ line_offs make_lines(int pitch, int tok, int g16, int
   L.lo = tok < 8;
   L.a = (tok & 7) * pitch + g16 + (L.lo ? 0 : d);
   L.b = ((tok & 7) + 8) * pitch + g16 + (L.lo ? d : 0);
+  L.pitch = pitch;
+  L.s0 = tok * 128 + ((((g16 >> 4)) ^ (tok & 7)) << 4);
+  L.s1 = tok * 128 + (((((g16 + d) >> 4)) ^ (tok & 7)) << 4);
   return L;
 }
-__device__ __forceinline__ void store_lines(void* tile_base, const line_offs& L, int off, const uint4& q0, const uint4& q1) {
+// a 16-row x 128-byte block of an output array: rows from tile_base + off, the lane's pieces q0 | q1.  Storer mode: into the wave's
+// staging ring; otherwise straight to HBM as two whole-line instructions.
+template <bool WAIT = true>
+__device__ __forceinline__ void store_lines(stage_t& st, void* tile_base, const line_offs& L, int off, const uint4& q0, const uint4& q1) {
+  if constexpr (ST) {
+    stage_block<WAIT>(st, reinterpret_cast<char*>(tile_base) + off, (uint32_t)L.pitch, L.s0, L.s1, q0, q1);
+    return;
+  }
   if (CH_ABL & 1) return;
   const uint4 r = dpp_swap8(q1);
   uint4 da, db;
@@ -326,17 +551,23 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
       bl[i] = v;
     }
   }
+  sync_init(lds, tid);
   __syncthreads();
   constexpr int S3 = MOD ? 16 : 8;       // first qkv step
   constexpr int PER_TILE = S3 + 24;
+  if (ST && wave > NCW) {
+    storer_run<NW>(lds, lane, wave - NCW - 1);
+    return;
+  }
   if (wave >= NW && wave != NCW) return;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame, lds);
     return;
   }
+  stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
     return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
@@ -389,19 +620,29 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
     auto burst_ln = [&]() __attribute__((always_inline)) {
       if constexpr (MOD && SAVE) {
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) store_lines(xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
+        for (int pp = 0; pp < (ST ? 0 : 4); ++pp) {
+          if (pp % RG == 0) stage_reserve(stg_, RG);
+          store_lines<false>(stg_, xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
+        }
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp)
-          store_lines(xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+        for (int pp = 0; pp < 4; ++pp) {
+          if (pp % RG == 0) stage_reserve(stg_, RG);
+          store_lines<false>(stg_, xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+        }
       }
     };
     auto burst_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+      for (int pr = 0; pr < 8; ++pr) {
+        if (pr % RG == 0) stage_reserve(stg_, RG);
+        store_lines<false>(stg_, xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+      }
       if constexpr (SAVE) {
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp)
-          store_lines(xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
+        for (int pp = 0; pp < 4; ++pp) {
+          if (pp % RG == 0) stage_reserve(stg_, RG);
+          store_lines<false>(stg_, xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
+        }
       }
     };
     // qkv blocks first .. first + 2 * npairs - 1 (block pq lives in qb[pq & 7])
@@ -409,7 +650,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
       constexpr int first = decltype(first_)::value, npairs = decltype(npairs_)::value;
       static_for<npairs>([&](auto k_) __attribute__((always_inline)) {
         constexpr int b = first + 2 * decltype(k_)::value;
-        store_lines(qt, Lq, 64 * b, qb[b & 7], qb[(b + 1) & 7]);
+        store_lines(stg_, qt, Lq, 64 * b, qb[b & 7], qb[(b + 1) & 7]);
       });
     };
 #pragma unroll
@@ -417,13 +658,14 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
     static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
       constexpr int s = decltype(sc_)::value;
       CPROF_MARK(3);
-      CH_BARRIER();
+      if constexpr (ST) step_begin(stg_); else if constexpr (s % PB == 0) CH_BARRIER();
       CPROF_MARK(0);
       HMA_LDS(char)* wb = ring + slot * SLOT;
       slot = slot + 1 == NS ? 0 : slot + 1;
       if constexpr (s < 8) {
         // ---- x1 = x + o Wproj^T + b
         nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
+        step_end(stg_);
         add4(acc[2 * s], lds_f4(bias + 128 * s));
         add4(acc[2 * s + 1], lds_f4(bias + 128 * s + 16));
         if constexpr (s == 7 && !MOD) {
@@ -452,6 +694,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
           const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
           const float nb = -mean * rstd;
           HMA_LDS(char)* ssl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 32 * g;
+          static_assert(!ST || RB >= 4, "the four xhat blocks of a tile are staged without a wait in between");
+          if constexpr (SAVE && ST) stage_reserve(stg_, 4);  // (in front of the loop: no control flow between its loads and their uses)
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr) {
             float h[8], mm[8];
@@ -465,7 +709,15 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
 #pragma unroll
             for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(h[e], 1.0f + sc[e], sh[e]);
             a1[pr] = as_frag(pack8(mm));
-            if (SAVE) hqs[pr] = hq;
+            if constexpr (SAVE && ST) {  // (staged pair by pair: the packed xhat of the tile is not kept)
+              if ((pr & 1) == 0) {
+                hqs[0] = hq;
+              } else {
+                store_lines<false>(stg_, xh, Lb, 64 * (pr - 1), hqs[0], hq);
+              }
+            } else if (SAVE) {
+              hqs[pr] = hq;
+            }
           }
           if (SAVE && !(CH_ABL & 1)) p.rstd[r0 + tok] = rstd;  // (the row's four lanes write the same value)
         }
@@ -473,6 +725,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
         // ---- x2 = x1 + xm Wlin^T + b: the new residual row; its bf16 copy is the qkv GEMM's operand
         constexpr int pr = s - 8;
         nb_mma(wb, a1, acc[2 * pr], acc[2 * pr + 1]);
+        step_end(stg_);
         add4(acc[2 * pr], lds_f4(bias + 1024 + 128 * pr));
         add4(acc[2 * pr + 1], lds_f4(bias + 1024 + 128 * pr + 16));
         a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
@@ -481,13 +734,27 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
         constexpr int pq = s - S3;
         f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * pq), c1 = lds_f4v(bias + 2048 + 128 * pq + 16);
         nb_mma(wb, a0, c0, c1);
+        step_end(stg_);
         qb[pq & 7] = pack_pair(c0, c1);
       }
       CPROF_MARK(2);
       using I4 = std::integral_constant<int, 4>;
-      if constexpr (MOD && s == 7) burst_ln();
-      if constexpr (s == S3 - 1) burst_x();
-      if constexpr (s >= S3 && ((s - S3) & 7) == 7) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{});
+      if constexpr (ST) {
+        // Storer mode: a wave's blocks leave EVENLY over the tile's steps (at most two per step), so that the staging ring --
+        // four blocks -- never has to take a burst: xhat pairs inside the LayerNorm (step 7), xm over the linear_out steps, the
+        // fp32 rows over the first eight qkv steps (the next tile's rows are requested into those registers right behind),
+        // their bf16 copy over the rest, a qkv block as soon as its two 64-byte halves exist.
+        if constexpr (MOD && SAVE && s >= 8 && s < 16 && (s & 1) == 0)
+          store_lines(stg_, xm, Lb, 64 * (s - 8), __builtin_bit_cast(uint4, a1[s - 8]), __builtin_bit_cast(uint4, a1[s - 7]));
+        if constexpr (s >= S3 && s < S3 + 8) store_lines(stg_, xt, Lf, 128 * (s - S3), as_u4(acc[2 * (s - S3)]), as_u4(acc[2 * (s - S3) + 1]));
+        if constexpr (SAVE && s >= S3 + 8 && ((s - S3) & 3) == 0)
+          store_lines(stg_, xb, Lb, 32 * (s - S3 - 8), __builtin_bit_cast(uint4, a0[(s - S3 - 8) / 2]), __builtin_bit_cast(uint4, a0[(s - S3 - 8) / 2 + 1]));
+        if constexpr (s >= S3 && ((s - S3) & 1) == 1) burst_q(std::integral_constant<int, s - S3 - 1>{}, std::integral_constant<int, 1>{});
+      } else {
+        if constexpr (MOD && s == 7) burst_ln();
+        if constexpr (s == S3 - 1) burst_x();
+        if constexpr (s >= S3 && ((s - S3) & 7) == 7) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{});
+      }
       CPROF_MARK(1);
       if constexpr (s == S3 + 8) prefetch(tl + 1 < nt ? tl + 1 : tl);  // the next tile's rows, sixteen steps before they are used
     });
@@ -501,12 +768,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
     if (r0 >= p.M) {  // (whole wave past the matrix: possible in a workgroup's last tile only)
+      if constexpr (ST) {
+        steps_skip(stg_, PER_TILE);
+        slot = (slot + PER_TILE) % NS;
+      } else {
 #pragma unroll 1
-      for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
+        for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
+      }
       continue;
     }
     tile(tl, r0);
   }
+  stage_finish(stg_);
   CPROF_FLUSH(0, wave);
 }
 
@@ -542,13 +815,22 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   constexpr int S3 = MOD ? 32 : 24;      // first d_o step
   constexpr int PER_TILE = S3 + 8;
+  if constexpr (ST) {
+    sync_init(lds, tid);
+    __syncthreads();
+    if (wave > NCW) {
+      storer_run<NCW>(lds, lane, wave - NCW - 1);
+      return;
+    }
+  }
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame);
+    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame, lds);
     return;
   }
+  stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
     return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
@@ -587,27 +869,34 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
     uint16_t* ot = reinterpret_cast<uint16_t*>(p.d_o) + r0 * 256;
     auto burst_d2 = [&]() __attribute__((always_inline)) {  // bf16(dx2), the dY of linear_out's weight gradient
 #pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
-        store_lines(d2, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+      for (int pp = 0; pp < 4; ++pp) {
+        if (pp % RG == 0) stage_reserve(stg_, RG);
+        store_lines<false>(stg_, d2, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+      }
     };
     auto burst_dx = [&]() __attribute__((always_inline)) {  // dx1, the new residual gradient, and its bf16 copy
 #pragma unroll
-      for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+      for (int pr = 0; pr < 8; ++pr) {
+        if (pr % RG == 0) stage_reserve(stg_, RG);
+        store_lines<false>(stg_, xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+      }
 #pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
-        store_lines(d1, Lb, 128 * pp, __builtin_bit_cast(uint4, a2[2 * pp]), __builtin_bit_cast(uint4, a2[2 * pp + 1]));
+      for (int pp = 0; pp < 4; ++pp) {
+        if (pp % RG == 0) stage_reserve(stg_, RG);
+        store_lines<false>(stg_, d1, Lb, 128 * pp, __builtin_bit_cast(uint4, a2[2 * pp]), __builtin_bit_cast(uint4, a2[2 * pp + 1]));
+      }
     };
     auto burst_o = [&](auto first_) __attribute__((always_inline)) {  // d_o blocks first .. first + 3
       constexpr int first = decltype(first_)::value;
-      store_lines(ot, Lb, 64 * first, qb[first], qb[first + 1]);
-      store_lines(ot, Lb, 64 * first + 128, qb[first + 2], qb[first + 3]);
+      store_lines(stg_, ot, Lb, 64 * first, qb[first], qb[first + 1]);
+      store_lines(stg_, ot, Lb, 64 * first + 128, qb[first + 2], qb[first + 3]);
     };
     load_chunk(m, 1, dq[1]);  // this tile's second k-chunk of dqkv
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
     static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
       constexpr int s = decltype(sc_)::value;
-      CH_BARRIER();
+      if constexpr (ST) step_begin(stg_); else if constexpr (s % PB == 0) CH_BARRIER();
       HMA_LDS(char)* wb = ring + slot * SLOT;
       slot = slot + 1 == NS ? 0 : slot + 1;
       if constexpr (s < 24) {
@@ -628,6 +917,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
           }
         }
         nb_mma(wb, dq[c], acc[2 * pr], acc[2 * pr + 1]);
+        step_end(stg_);
         if constexpr (s == 23) {
 #pragma unroll
           for (int t = 0; t < 16; ++t) acc[t] += dxr[t];
@@ -655,6 +945,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
           for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
         }
         nb_mma(wb, a1, dm[2 * pr], dm[2 * pr + 1]);
+        step_end(stg_);
         if constexpr (s == 31) {
           // ---- modulate + LayerNorm backward
           HMA_LDS(char)* scl = lds + L_SS + ((tl & 1) * NCW + wave) * 2048 + 1024 + 32 * g;
@@ -726,11 +1017,14 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
         if constexpr (s == S3) prefetch(tl + 1 < nt ? tl + 1 : tl);
         f32x4v_t c0 = f32x4v_t{0.f, 0.f, 0.f, 0.f}, c1 = f32x4v_t{0.f, 0.f, 0.f, 0.f};
         nb_mma(wb, a2, c0, c1);
+        step_end(stg_);
         qb[pr] = pack_pair(c0, c1);
       }
       if constexpr (MOD && s == 23) burst_d2();
       if constexpr (s == S3 - 1) burst_dx();
-      if constexpr (s == S3 + 7) {
+      if constexpr (ST) {
+        if constexpr (s >= S3 && ((s - S3) & 1) == 1) store_lines(stg_, ot, Lb, 64 * (s - S3 - 1), qb[s - S3 - 1], qb[s - S3]);
+      } else if constexpr (s == S3 + 7) {
         burst_o(std::integral_constant<int, 0>{});
         burst_o(std::integral_constant<int, 4>{});
       }
@@ -742,12 +1036,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
     if (r0 >= p.M) {
+      if constexpr (ST) {
+        steps_skip(stg_, PER_TILE);
+        slot = (slot + PER_TILE) % NS;
+      } else {
 #pragma unroll 1
-      for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
+        for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
+      }
       continue;
     }
     tile(tl, r0);
   }
+  stage_finish(stg_);
 }
 
 // ------------------------------------------------------------------------------------------------ chain B, forward (inference)
@@ -794,17 +1094,23 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
       bl[i] = v;
     }
   }
+  sync_init(lds, tid);
   __syncthreads();
   constexpr int SM = 8, SQ = 8 + 64;           // first MLP step, first qkv step
   constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
+  if (ST && wave > NCW) {
+    storer_run<NW>(lds, lane, wave - NCW - 1);
+    return;
+  }
   if (wave >= NW && wave != NCW) return;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1, lds);
     return;
   }
+  stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
     return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
@@ -813,6 +1119,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   f32x4v_t acc[16];
   uint4 qb[8];
   auto prefetch = [&](int tl) __attribute__((always_inline)) {
+    if (CH_ABL & 2) return;
     int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
@@ -825,6 +1132,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
       acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
     }
   };
+  if (CH_ABL & 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = as_frag(make_uint4(lane, j, lane, j));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
+  }
   prefetch(0);
   CH_TOUCH_A(a1);
   CH_TOUCH_ACC(acc);
@@ -874,8 +1187,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     if constexpr (SAVE) {
       uint16_t* xo = reinterpret_cast<uint16_t*>(xhat_out) + r0 * 256;
 #pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
-        store_lines(xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
+      for (int pp = 0; pp < 4; ++pp) {
+        if (pp % RG == 0) stage_reserve(stg_, RG);
+        store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
+      }
       if (!(CH_ABL & 1)) rstd_out[r0 + tok] = rstd;
     }
   };
@@ -883,8 +1198,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
     if (r0 >= p.M) {
+      if constexpr (ST) {
+        steps_skip(stg_, PER_TILE);
+        slot = (slot + PER_TILE) % NS;
+      } else {
 #pragma unroll 1
-      for (int s = 0; s < PER_TILE; ++s) CH_BARRIER();
+        for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
+      }
       continue;
     }
     float* xt = p.x + r0 * 256;
@@ -894,12 +1214,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     bf16x8_t hf;
     static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
       constexpr int s = decltype(sc_)::value;
-      CH_BARRIER();
-      HMA_LDS(char)* wb = ring + slot * SLOT;
-      slot = slot + 1 == NS ? 0 : slot + 1;
+      if constexpr (ST) step_begin(stg_); else if constexpr (s % PB == 0) CH_BARRIER();
+      HMA_LDS(char)* wb;
+      if constexpr (PER_TILE % NS == 0) {  // (every tile starts at slot 0: the slot of a step is a constant)
+        wb = ring + (s % NS) * SLOT;
+      } else {
+        wb = ring + slot * SLOT;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+      }
       if constexpr (s < SM) {
         // ---- x1 = x + o Wproj^T + b
         nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
+        step_end(stg_);
         add4(acc[2 * s], lds_f4(bias + 128 * s));
         add4(acc[2 * s + 1], lds_f4(bias + 128 * s + 16));
         if constexpr (s == SM - 1) {
@@ -923,12 +1249,21 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
           // ---- u = W1f[hidden block h] xhat2 + b1f; gelu; the lane's 8 hidden units are the next step's B operand
           f32x4v_t c0 = lds_f4v(bias + 2048 + 128 * h), c1 = lds_f4v(bias + 2048 + 128 * h + 16);
           nb_mma(wb, a1, c0, c1);
-          float hv[8];
+          step_end(stg_);
+          // (the staged one-transcendental GELU of the fused MLP kernels, hma_common.h: ~10 VALU operations per value against the
+          // ~19 of the rcp + exp form -- an fc1 step is VALU-bound: 16 MFMAs against 8 GELUs per lane)
+          float uv[8], hv[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            hv[e] = gelu_f(c0[e]);
-            hv[4 + e] = gelu_f(c1[e]);
+            uv[e] = c0[e];
+            uv[4 + e] = c1[e];
           }
+#ifdef CH_OLD_GELU  // (measurement builds: the rcp + exp form)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[e] = gelu_f(uv[e]);
+#else
+          gelu_n<8>(uv, hv);
+#endif
           if constexpr (DROP) {
             const int64_t e0 = (r0 + tok) * 1024 + 32 * h + 8 * g;
 #pragma unroll
@@ -943,6 +1278,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
         } else {
           // ---- x2 += W2[:, hidden block h] gelu(u)
           ks_mma(wb, hf, acc);
+          step_end(stg_);
           if constexpr (s == SQ - 1) {
             if constexpr (DROP) {
               const int64_t e0 = (r0 + tok) * 256 + 8 * g;
@@ -958,7 +1294,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
               }
             }
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) store_lines(xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+            for (int pr = 0; pr < 8; ++pr) {
+              if (pr % RG == 0) stage_reserve(stg_, RG);
+              store_lines<false>(stg_, xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+            }
             if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, r0);  // the next block's norm1 (affine folded into its qkv weights / bias)
             prefetch(tl + 1 < nt ? tl + 1 : tl);
           }
@@ -968,16 +1307,20 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
         constexpr int pq = s - SQ;
         f32x4v_t c0 = lds_f4v(bias + 6144 + 128 * pq), c1 = lds_f4v(bias + 6144 + 128 * pq + 16);
         nb_mma(wb, a0, c0, c1);
+        step_end(stg_);
         qb[pq & 7] = pack_pair(c0, c1);
-        if constexpr ((pq & 7) == 7) {
+        if constexpr (ST) {
+          if constexpr ((pq & 1) == 1) store_lines(stg_, qt, Lq, 64 * (pq - 1), qb[(pq - 1) & 7], qb[pq & 7]);
+        } else if constexpr ((pq & 7) == 7) {
 #pragma unroll
-          for (int pp = 0; pp < 4; ++pp) store_lines(qt, Lq, 64 * (pq - 7) + 128 * pp, qb[2 * pp], qb[2 * pp + 1]);
+          for (int pp = 0; pp < 4; ++pp) store_lines(stg_, qt, Lq, 64 * (pq - 7) + 128 * pp, qb[2 * pp], qb[2 * pp + 1]);
         }
       }
     });
     CH_TOUCH_A(a1);
     CH_TOUCH_ACC(acc);
   }
+  stage_finish(stg_);
 }
 
 // ------------------------------------------------------------------------------------------------ readout + cross-entropy
@@ -998,15 +1341,21 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);
     for (int i = tid; i < 1024; i += CH_THREADS) bl[i] = p.bias ? p.bias[i] : 0.f;
   }
+  sync_init(lds, tid);
   __syncthreads();
+  if (ST && wave > NCW) {
+    storer_run<NW>(lds, lane, wave - NCW - 1);
+    return;
+  }
   if (wave >= NW && wave != NCW) return;
   if (wave == NCW) {
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0, NW>(ws, 32, nt, lds_b, lane, nullptr, p.rows, 1);
+    loader_run<0, NW>(ws, 32, nt, lds_b, lane, nullptr, p.rows, 1, lds);
     return;
   }
+  stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   constexpr int V = 512;
   const float wgt = p.grad_scale * (p.grad_scale_dev ? *p.grad_scale_dev : 1.0f) / p.stats[2];
@@ -1022,8 +1371,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
     if (r0 >= p.rows) {
+      if constexpr (ST) {
+        steps_skip(stg_, 32);
+        slot = (slot + 32) % NS;
+      } else {
 #pragma unroll 1
-      for (int s = 0; s < 32; ++s) CH_BARRIER();
+        for (int s = 0; s < 32; s += PB) CH_BARRIER();
+      }
       continue;
     }
     const int64_t i = r0 + tok, frame = i / p.S;
@@ -1042,11 +1396,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
     static_for<32>([&](auto sc_) __attribute__((always_inline)) {
       constexpr int s = decltype(sc_)::value;
       constexpr int f = s >> 4, j = s & 15;
-      CH_BARRIER();
+      if constexpr (ST) step_begin(stg_); else if constexpr (s % PB == 0) CH_BARRIER();
       HMA_LDS(char)* wb = ring + slot * SLOT;
       slot = slot + 1 == NS ? 0 : slot + 1;
       f32x4v_t c0 = lds_f4v(bias + 128 * s), c1 = lds_f4v(bias + 128 * s + 16);
       nb_mma(wb, a, c0, c1);
+      step_end(stg_);
       lg[2 * j] = c0;
       lg[2 * j + 1] = c1;
       if constexpr (j == 15) {
@@ -1096,7 +1451,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
                 lg[t][r] = __builtin_fmaf(w, __expf(lg[t][r] - lse), base + (colg == tg2 ? hit : 0.f));
               }
             }
-            store_lines(dl, Ld, 1024 * f + 128 * jp, pack_pair(lg[4 * jp], lg[4 * jp + 1]), pack_pair(lg[4 * jp + 2], lg[4 * jp + 3]));
+            store_lines(stg_, dl, Ld, 1024 * f + 128 * jp, pack_pair(lg[4 * jp], lg[4 * jp + 1]), pack_pair(lg[4 * jp + 2], lg[4 * jp + 3]));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -1107,6 +1462,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
       acc_acc += ok ? 1.f : 0.f;
     }
   }
+  stage_finish(stg_);
   // one atomic pair per wave
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1155,9 +1511,9 @@ bool weights_ok(const hma_chain_weights_t& w, int expect) {
 
 // compute waves for a pass of M rows: 5 when 7-wave tiles would leave CUs without a tile and 5-wave tiles fill more of them
 int chain_waves(int64_t M) {
-  if (NCW != 7) return NCW;
-  const int64_t t7 = (M + 111) / 112, t5 = (M + 79) / 80;
-  return (t7 < num_cus() && t5 > t7) ? 5 : 7;
+  if (NCW < 6) return NCW;
+  const int64_t tn = (M + 16 * NCW - 1) / (16 * NCW), t5 = (M + 79) / 80;
+  return (tn < num_cus() && t5 > tn) ? 5 : NCW;
 }
 
 int chain_grid(int64_t M, int nw = NCW) {

@@ -87,6 +87,84 @@ __device__ __forceinline__ float dgelu_f(float u) {
   gelu_parts(u, cdf, gauss);
   return cdf + u * 0.3989422804014327f * gauss;
 }
+// ---- GELU (exact-erf, nn.GELU() of st_transformer.py:20) for 8 accumulator values at a time ---------------------------
+// gelu(u) = max(u, 0) - |u| h(|u|), h(a) = Phi(-a) = exp2(q(a)) with q a degree-6 polynomial fit of log2(Phi(-a)) on [0, 6]
+// (|error of h| <= 2e-5, |error of gelu| <= 7e-6: 1/500 of a bf16 ulp of the values it produces) and a clamped to 6
+// (a h(a) < 6e-9 beyond).  Per element: 1 v_med3, 6 FMAs (in pairs: v_pk_fma_f32), ONE transcendental, 1 max, 1 FMA.
+// The A&S 7.1.26 form used by the unfused epilogues costs a v_rcp and a v_exp (quarter rate) plus 11 plain operations,
+// and on gfx950 a wave64 VALU instruction is 4 cycles (packed: 8): the GELU is the VALU budget of these kernels.
+// Written stage by stage over all values, with an empty asm that takes and returns a stage's values as a join point:
+// left alone, the compiler serialises element pairs with dependency nops.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define HMA_PIN4(a, o) asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]))
+#define HMA_PIN8(a, o)                                                                                                   \
+  asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), \
+               "+v"(a[o + 7]))
+#define HMA_PIN16(a) do { HMA_PIN8(a, 0); HMA_PIN8(a, 8); } while (0)
+constexpr float GQ6 = 2.2999249267741106e-05f, GQ5 = -0.0006114901625551283f, GQ4 = 0.007200188934803009f,
+                GQ3 = -0.05120821297168732f, GQ2 = -0.46122226119041443f, GQ1 = -1.150214433670044f, GQ0 = -1.000058889389038f;
+
+// ph[e] = Phi(-|u[e]|), N values (N = 8 or 16)
+template <int N>
+__device__ __forceinline__ void gelu_phi_neg(const float (&u)[N], float (&ph)[N]) {
+  f32x2_t a2[N / 2], q2[N / 2];
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i)
+    a2[i] = f32x2_t{__builtin_amdgcn_fmed3f(fabsf(u[2 * i]), 0.f, 6.0f), __builtin_amdgcn_fmed3f(fabsf(u[2 * i + 1]), 0.f, 6.0f)};
+  if constexpr (N == 8) HMA_PIN4(a2, 0); else HMA_PIN8(a2, 0);
+#define HMA_HORNER(c)                                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < N / 2; ++i) q2[i] = __builtin_elementwise_fma(q2[i], a2[i], (f32x2_t{c, c})); \
+  if constexpr (N == 8) HMA_PIN4(q2, 0); else HMA_PIN8(q2, 0);
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) q2[i] = __builtin_elementwise_fma(f32x2_t{GQ6, GQ6}, a2[i], f32x2_t{GQ5, GQ5});
+  if constexpr (N == 8) HMA_PIN4(q2, 0); else HMA_PIN8(q2, 0);
+  HMA_HORNER(GQ4) HMA_HORNER(GQ3) HMA_HORNER(GQ2) HMA_HORNER(GQ1) HMA_HORNER(GQ0)
+#undef HMA_HORNER
+#pragma unroll
+  for (int e = 0; e < N; ++e) ph[e] = __builtin_amdgcn_exp2f(q2[e >> 1][e & 1]);
+  if constexpr (N == 8) HMA_PIN8(ph, 0); else HMA_PIN16(ph);
+}
+// h[e] = gelu(u[e])
+template <int N>
+__device__ __forceinline__ void gelu_n(const float (&u)[N], float (&h)[N]) {
+  float ph[N], r[N];
+  gelu_phi_neg<N>(u, ph);
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = fmaxf(u[e], 0.f);
+  if constexpr (N == 8) HMA_PIN8(r, 0); else HMA_PIN16(r);
+#pragma unroll
+  for (int e = 0; e < N; ++e) h[e] = __builtin_fmaf(-fabsf(u[e]), ph[e], r[e]);
+  if constexpr (N == 8) HMA_PIN8(h, 0); else HMA_PIN16(h);
+}
+// hg[e] = gelu(u[e]) (the forward's values, bit for bit) and du[e] = d[e] * gelu'(u[e]), gelu'(u) = Phi(u) + u phi(u)
+template <int N>
+__device__ __forceinline__ void gelu_bwd_n(const float (&u)[N], const float (&d)[N], float (&hg)[N], float (&du)[N]) {
+  float ph[N], gs[N], r[N];
+  gelu_phi_neg<N>(u, ph);
+#pragma unroll
+  for (int e = 0; e < N; ++e) gs[e] = -0.72134752044448170f * u[e] * u[e];
+  if constexpr (N == 8) HMA_PIN8(gs, 0); else HMA_PIN16(gs);
+#pragma unroll
+  for (int e = 0; e < N; ++e) gs[e] = __builtin_amdgcn_exp2f(gs[e]);
+  if constexpr (N == 8) HMA_PIN8(gs, 0); else HMA_PIN16(gs);
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = fmaxf(u[e], 0.f);
+  if constexpr (N == 8) HMA_PIN8(r, 0); else HMA_PIN16(r);
+#pragma unroll
+  for (int e = 0; e < N; ++e) hg[e] = __builtin_fmaf(-fabsf(u[e]), ph[e], r[e]);
+  if constexpr (N == 8) HMA_PIN8(hg, 0); else HMA_PIN16(hg);
+  // Phi(u) = 0.5 + copysign(0.5 - h, u)
+#pragma unroll
+  for (int e = 0; e < N; ++e) ph[e] = 0.5f + __builtin_copysignf(0.5f - ph[e], u[e]);
+  if constexpr (N == 8) HMA_PIN8(ph, 0); else HMA_PIN16(ph);
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] = __builtin_fmaf(u[e] * 0.3989422804014327f, gs[e], ph[e]);
+  if constexpr (N == 8) HMA_PIN8(r, 0); else HMA_PIN16(r);
+#pragma unroll
+  for (int e = 0; e < N; ++e) du[e] = d[e] * r[e];
+  if constexpr (N == 8) HMA_PIN8(du, 0); else HMA_PIN16(du);
+}
+
 __device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
 __device__ __forceinline__ float dsilu_f(float u) {
   const float s = 1.0f / (1.0f + __expf(-u));

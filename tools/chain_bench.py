@@ -102,7 +102,7 @@ if os.environ.get("CH_PROF"):
     print("fwd, workgroup 0, cycles.  compute waves: [barrier wait, stores, compute, loop/prefetch, end-of-tile wait]; loader (wave 7): [vmcnt wait, barrier wait, issue]")
     for w in range(8):
         v = [buf[w * 8 + i] for i in range(8)]
-        print(f"  wave {w}: " + " ".join(f"{x:9d}" for x in v[:5]) + f"   sum {sum(v)}")
+        print(f"  wave {w}: " + " ".join(f"{x:9d}" for x in v[:7]) + f"   sum {sum(v[:5])}")
 
 # ---- chain B forward (training form: the two LayerNorm outputs saved) beside proj_t + LN GEMM, hma_mlp_fwd, qkv_s GEMM
 w1, w2 = mk(1024, 256) * 0.05, mk(256, 1024) * 0.05
