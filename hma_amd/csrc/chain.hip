@@ -279,6 +279,14 @@ __device__ __forceinline__ void storer_run(HMA_LDS(char)* lds, int lane, int k) 
   }
   CPROF_FLUSH(0, NCW + 1 + k);
 }
+// Measurement builds (-DCH_STAGGER=n): workgroups start up to n x 3.7 us apart, so that the CUs are not all in the same step of
+// their tiles (every CU storing at once, then none)
+__device__ __forceinline__ void start_stagger() {
+#ifdef CH_STAGGER
+  const int nsl = (((int)blockIdx.x * 37) & 255) * CH_STAGGER / 256;
+  for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+}
 // zero the flag words and descriptors (before the kernel's first __syncthreads)
 __device__ __forceinline__ void sync_init(HMA_LDS(char)* lds, int tid) {
   if constexpr (ST) {
@@ -552,6 +560,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
     }
   }
   sync_init(lds, tid);
+  start_stagger();
   __syncthreads();
   constexpr int S3 = MOD ? 16 : 8;       // first qkv step
   constexpr int PER_TILE = S3 + 24;
@@ -815,6 +824,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   constexpr int S3 = MOD ? 32 : 24;      // first d_o step
   constexpr int PER_TILE = S3 + 8;
+  start_stagger();
   if constexpr (ST) {
     sync_init(lds, tid);
     __syncthreads();
@@ -1095,6 +1105,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     }
   }
   sync_init(lds, tid);
+  start_stagger();
   __syncthreads();
   constexpr int SM = 8, SQ = 8 + 64;           // first MLP step, first qkv step
   constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
@@ -1342,6 +1353,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
     for (int i = tid; i < 1024; i += CH_THREADS) bl[i] = p.bias ? p.bias[i] : 0.f;
   }
   sync_init(lds, tid);
+  start_stagger();
   __syncthreads();
   if (ST && wave > NCW) {
     storer_run<NW>(lds, lane, wave - NCW - 1);

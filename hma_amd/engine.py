@@ -1044,11 +1044,23 @@ class STEngine:
         return ws
 
     # ------------------------------------------------------------------------------ trunk-only training (STMAR)
-    def trunk_train_forward(self, B: int, T: int, S: int, actions: torch.Tensor, domain: str, build_x: Callable[[dict], None],
-                            train: bool = True) -> dict:
+    def trunk_train_forward(self, B: int, T: int, S: int, actions: Optional[torch.Tensor], domain: Optional[str],
+                            build_x: Callable[[dict], None], train: bool = True) -> dict:
         """Action stem -> `build_x(ws)` writes the residual stream ws["x"] ([B*T*(S+A), 256] fp32, may read ws["a_emb"])
         -> the L ST-blocks with every activation saved.  No token embedding, readout or loss: the caller owns those
-        (hma/model/st_mar.py keeps the trunk of st_mask_git.py and replaces what is around it)."""
+        (hma/model/st_mar.py keeps the trunk of st_mask_git.py and replaces what is around it).  `actions` None (st_mar.py:154,
+        the unconditioned model): no action tokens (A = 0), no modulation -- the blocks alone."""
+        if actions is None:
+            ws = self._workspace(B, T, S, 0, train)
+            stream = torch.cuda.current_stream().cuda_stream
+            self.refresh_weights(None, stream)
+            build_x(ws)
+            if train:
+                self.bump_dropout()
+            self._forward_plan(B, T, S, 0, train, None, embed=False, readout=False).run(stream, timer=self.timer)
+            if train:
+                self._last = (B, T, S, 0, None)
+            return ws
         A = self.cfg.action_token_size
         d_a = self.d_actions[domain]
         if actions.shape[-1] != d_a:
@@ -1080,7 +1092,8 @@ class STEngine:
         ws = self._ws
         stream = torch.cuda.current_stream().cuda_stream
         ws["dx"].zero_()
-        ws["da_emb"].zero_()
+        if A > 0:
+            ws["da_emb"].zero_()
         fill_dx(ws)
         pl = self._backward_plan(B, T, S, A, domain)
         start = pl.marks["post_readout"]

@@ -29,8 +29,8 @@ class SelfAttention(nn.Module):
         """x (Bn, N, 256): spatial (causal=False, N in {64, 256, 320}) or temporal (causal=True, N <= 16).  With autograd on and
         anything that requires a gradient in reach, the same kernels run as `torch.ops.hma.*` custom ops with their backward
         formulas (hma_amd/torch_ops.py), so a caller that trains through the module gets gradients for x, qkv and proj."""
-        if self.qk_norm or self.num_heads != 8 or self.head_dim != 32:
-            raise NotImplementedError("kernels are built for 8 heads of 32 without qk_norm")
+        if self.num_heads != 8 or self.head_dim != 32:
+            raise NotImplementedError("kernels are built for 8 heads of 32")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self._forward_autograd(x, causal)
         with torch.no_grad():
@@ -42,6 +42,8 @@ class SelfAttention(nn.Module):
         bf = torch.bfloat16
         xb = x.reshape(Bn * N, Cd).to(bf)
         qkv = torch.ops.hma.linear(xb, self.qkv.weight.to(bf), self.qkv.bias)
+        if self.qk_norm:  # q, k = norm(q), norm(k) per head (attention.py:44-48)
+            qkv, _ = torch.ops.hma.qknorm(qkv, self.norm.weight, self.norm.bias, float(self.norm.eps))
         if causal:  # rows (t, column): one sample of N frames with Bn positions
             o = torch.ops.hma.attn_temporal(qkv.view(Bn, N, 768).transpose(0, 1).reshape(-1, 768), 1, N, Bn, self.scale)
             o = o.view(N, Bn, Cd).transpose(0, 1).reshape(Bn * N, Cd)
@@ -54,6 +56,8 @@ class SelfAttention(nn.Module):
         Bn, N, Cd = x.shape
         xf = x.reshape(Bn * N, Cd).contiguous().float()
         qkv = ops.linear(xf, self.qkv.weight.detach().to(torch.bfloat16), self.qkv.bias, epi=EPI_BF16)
+        if self.qk_norm:
+            qkv, _ = ops.qknorm_fwd(qkv, self.norm.weight.detach().float(), self.norm.bias.detach().float(), float(self.norm.eps), save_raw=False)
         if causal:
             o = ops.attn_temporal_fwd(qkv.view(Bn, N, 768).transpose(0, 1).contiguous().view(-1, 768), 1, N, Bn, self.scale)
             o = o.view(N, Bn, Cd).transpose(0, 1).contiguous().view(Bn * N, Cd)

@@ -158,9 +158,9 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, input_ids, labels, action_ids=None, domain="default", **kwargs):
         assert "masked_tokens_indicator" in kwargs
-        if action_ids is None:
-            raise NotImplementedError("STMAR without action conditioning is not built")
         cfg = self.config
+        if action_ids is None and cfg.jointly_predict_actions:
+            raise NotImplementedError("jointly_predict_actions without input actions (mask tokens on every frame) is built for the discrete model only")
         masked = kwargs["masked_tokens_indicator"]
         T, H, W = cfg.T, self.h, self.w
         if "h" in kwargs:
@@ -168,11 +168,11 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         dev = input_ids.device
         B, Cc, p = input_ids.shape[0], cfg.vae_embed_dim, cfg.patch_size
         h_, w_ = H // p, W // p
-        S, A, d = h_ * w_, cfg.action_token_size, cfg.d_model
+        S, A, d = h_ * w_, (cfg.action_token_size if action_ids is not None else 0), cfg.d_model  # (no actions: st_mar.py:154, no action tokens)
         if S != self.seq_len:
             raise ValueError(f"{H}x{W} latents give {S} patch tokens per frame, the model was built for {self.seq_len}")
         SA, Fr, Mi, M, pc = S + A, B * T, B * T * S, B * T * (S + A), Cc * p * p
-        dom = domain if isinstance(domain, str) else domain[0]
+        dom = None if action_ids is None else (domain if isinstance(domain, str) else domain[0])
         train = torch.is_grad_enabled() and self.training
         stream = torch.cuda.current_stream(dev).cuda_stream
         e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
@@ -190,10 +190,10 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
 
         def build_x(ws):
             self._nt(stream, A=ptr(patches), lda=_PAD, a_kind=A_BF16, W=ptr(wtok), ldw=_PAD, M=Mi, N=d, K=_PAD, epi=EPI_F32, Cp=ptr(xtok), ldc=d)
-            _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr(), ptr(self.pos_embed_TSC), pos_stride,
+            _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr() if A > 0 else None, ptr(self.pos_embed_TSC), pos_stride,
                       ptr(self.z_proj_ln.weight), ptr(self.z_proj_ln.bias), 1e-6, ws["x"].data_ptr(), ptr(xhat_e), ptr(rstd_e), Fr, T, S, A)
 
-        ws = eng.trunk_train_forward(B, T, S, action_ids.to(dev, F32), dom, build_x, train=train)
+        ws = eng.trunk_train_forward(B, T, S, None if action_ids is None else action_ids.to(dev, F32), dom, build_x, train=train)
         y, z, yhat, rstd_r = e(Mi, d), e(Mi, d), e(Mi, d, dt=BF16), e(Mi)
         self._nt(stream, A=ws["x"].data_ptr(), lda=d, a_kind=A_F32, a_group=(S, SA), W=ptr(wout), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
                  Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))
@@ -243,14 +243,14 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
     @torch.no_grad()
     def compute_latents(self, x_patches: torch.Tensor, action_ids: torch.Tensor = None, domain=None, **kwargs):
         """st_mar.py:146-197 on already patchified latents (B, T, h, w, p*p*c) -> (decoded_states (B, d, T, h, w), None)."""
-        if action_ids is None:
-            raise NotImplementedError("STMAR without action conditioning is not built")
         cfg = self.config
+        if action_ids is None and cfg.jointly_predict_actions:
+            raise NotImplementedError("jointly_predict_actions without input actions (mask tokens on every frame) is built for the discrete model only")
         B, T, h_, w_, pc = x_patches.shape
         dev = x_patches.device
-        S, A, d = h_ * w_, cfg.action_token_size, cfg.d_model
+        S, A, d = h_ * w_, (cfg.action_token_size if action_ids is not None else 0), cfg.d_model
         Fr, Mi, M = B * T, B * T * S, B * T * (S + A)
-        dom = domain if isinstance(domain, str) else domain[0]
+        dom = None if action_ids is None else (domain if isinstance(domain, str) else domain[0])
         stream = torch.cuda.current_stream(dev).cuda_stream
         e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         patches = torch.zeros(Mi, _PAD, dtype=BF16, device=dev)
@@ -263,10 +263,10 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
 
         def build_x(ws):
             self._nt(stream, A=ptr(patches), lda=_PAD, a_kind=A_BF16, W=ptr(wtok), ldw=_PAD, M=Mi, N=d, K=_PAD, epi=EPI_F32, Cp=ptr(xtok), ldc=d)
-            _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr(), ptr(self.pos_embed_TSC), pos_stride,
+            _lib.call("hma_mar_embed_fwd", stream, ptr(xtok), ws["a_emb"].data_ptr() if A > 0 else None, ptr(self.pos_embed_TSC), pos_stride,
                       ptr(self.z_proj_ln.weight), ptr(self.z_proj_ln.bias), 1e-6, ws["x"].data_ptr(), ptr(xhat_e), ptr(rstd_e), Fr, T, S, A)
 
-        ws = eng.trunk_train_forward(B, T, S, action_ids.to(dev, F32), dom, build_x, train=False)
+        ws = eng.trunk_train_forward(B, T, S, None if action_ids is None else action_ids.to(dev, F32), dom, build_x, train=False)
         y, z, yhat, rstd_r = e(Mi, d), e(Mi, d), e(Mi, d, dt=BF16), e(Mi)
         self._nt(stream, A=ws["x"].data_ptr(), lda=d, a_kind=A_F32, a_group=(S, S + A), W=ptr(wout), ldw=d, M=Mi, N=d, K=d, epi=EPI_F32,
                  Cp=ptr(y), ldc=d, bias=ptr(self.out_x_proj.bias))
@@ -409,7 +409,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
 
         def embed_bwd(ws):
             _lib.call("hma_mar_embed_bwd", stream, ws["dx"].data_ptr(), ptr(sv["xhat_e"]), ptr(sv["rstd_e"]), ptr(self.z_proj_ln.weight), ptr(dxtok),
-                      ws["da_emb"].data_ptr(), ptr(dpos), sv["pos_stride"], ptr(dg_z), ptr(db_z), Fr, T, S, A)
+                      ws["da_emb"].data_ptr() if A > 0 else None, ptr(dpos), sv["pos_stride"], ptr(dg_z), ptr(db_z), Fr, T, S, A)
             self._tn(stream, dY=ptr(dxtok), ldy=d, y_kind=A_F32, A=ptr(sv["patches"]), lda=_PAD, a_kind=A_BF16, M=Mi, N=d, K=_PAD, dW=ptr(dWt),
                      lddw=_PAD)
             self._nt(stream, A=ptr(dxtok), lda=d, a_kind=A_F32, W=ptr(sv["wtok_t"]), ldw=d, M=Mi, N=_PAD, K=d, epi=EPI_F32, Cp=ptr(dpatch), ldc=_PAD)

@@ -214,6 +214,24 @@ def ln_fwd(x: torch.Tensor, eps: float):
     return xhat, rstd
 
 
+def qknorm_fwd(qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, save_raw: bool = True):
+    """qk_norm=True (hma/model/attention.py:31-35,44-48): per-head LayerNorm of the q | k parts of a packed (rows, 768) bf16 qkv.
+    Returns (normalised copy, pre-norm q | k (rows, 512) for the backward or None)."""
+    out = qkv.clone()
+    raw = torch.empty(qkv.shape[0], 512, dtype=BF16, device=qkv.device) if save_raw else None
+    _lib.call("hma_qknorm_fwd", stream_ptr(), ptr(out), 768, ptr(raw), ptr(gamma), ptr(beta), eps, qkv.shape[0], 0, 0)
+    return out, raw
+
+
+def qknorm_bwd(dqkv: torch.Tensor, raw: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5):
+    """(gradient wrt the raw qkv, dgamma [32], dbeta [32]) from the gradient wrt the normalised one."""
+    out = dqkv.clone()
+    dg = torch.zeros(32, dtype=F32, device=dqkv.device)
+    db = torch.zeros(32, dtype=F32, device=dqkv.device)
+    _lib.call("hma_qknorm_bwd", stream_ptr(), ptr(out), 768, ptr(raw), ptr(gamma), eps, ptr(dg), ptr(db), dqkv.shape[0])
+    return out, dg, db
+
+
 def attn_spatial_fwd(qkv: torch.Tensor, frames: int, n: int, scale: float):
     o = torch.empty(frames * n, 256, dtype=BF16, device=qkv.device)
     lse = torch.empty(frames * n, 8, dtype=F32, device=qkv.device)

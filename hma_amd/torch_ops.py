@@ -168,6 +168,46 @@ attn_temporal.register_autograd(_at_backward, setup_context=_at_setup)
 
 
 
+# ------------------------------------------------------------------------------------------------ qk_norm (attention.py:31-35,44-48)
+@torch.library.custom_op("hma::qknorm", mutates_args=(), device_types="cuda")
+def qknorm(qkv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(qkv with its q | k parts LayerNorm-ed per head (32 values, shared affine), the raw q | k (rows, 512) for the backward)
+    -- hma_qknorm_fwd on a copy of the packed (rows, 768) bf16 buffer"""
+    _cuda(qkv, gamma, beta)
+    return ops.qknorm_fwd(qkv.contiguous(), gamma.float().contiguous(), beta.float().contiguous(), eps)
+
+
+@qknorm.register_fake
+def _(qkv, gamma, beta, eps):
+    return torch.empty_like(qkv), qkv.new_empty(qkv.shape[0], 512)
+
+
+@torch.library.custom_op("hma::qknorm_bwd", mutates_args=(), device_types="cuda")
+def qknorm_bwd(dqkv: torch.Tensor, raw: torch.Tensor, gamma: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    _cuda(dqkv, raw, gamma)
+    return ops.qknorm_bwd(dqkv.contiguous(), raw, gamma.float().contiguous(), eps)
+
+
+@qknorm_bwd.register_fake
+def _(dqkv, raw, gamma, eps):
+    return torch.empty_like(dqkv), gamma.new_empty(32, dtype=F32), gamma.new_empty(32, dtype=F32)
+
+
+def _qkn_setup(ctx, inputs, output):
+    qkv, gamma, beta, eps = inputs
+    ctx.save_for_backward(output[1], gamma)
+    ctx.eps = eps
+
+
+def _qkn_backward(ctx, dqkv, draw_unused):
+    raw, gamma = ctx.saved_tensors
+    d, dg, db = torch.ops.hma.qknorm_bwd(dqkv.to(BF16).contiguous(), raw, gamma, ctx.eps)
+    return d, dg.to(gamma.dtype), db.to(gamma.dtype), None
+
+
+qknorm.register_autograd(_qkn_backward, setup_context=_qkn_setup)
+
+
 # ------------------------------------------------------------------------------------------------ Mlp (fc1 -> GELU -> fc2)
 @torch.library.custom_op("hma::mlp", mutates_args=(), device_types="cuda")
 def mlp(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor,
@@ -226,5 +266,110 @@ def _mlp_backward(ctx, dy, du_unused, dh_unused):
 
 mlp.register_autograd(_mlp_backward, setup_context=_mlp_setup)
 
+# ------------------------------------------------------------------------------------------------ embedding, modulation, loss, decode, update
+from . import _lib  # noqa: E402
+from .ops import ptr, stream_ptr  # noqa: E402
+
+
+@torch.library.custom_op("hma::embed", mutates_args=(), device_types="cuda")
+def embed(ids: torch.Tensor, e0: torch.Tensor, e1: torch.Tensor, mask_embed: torch.Tensor, pos: torch.Tensor,
+          a_emb: Optional[torch.Tensor], action_tokens: int, mask_id: int) -> torch.Tensor:
+    """x (B, T, S + A, 256) fp32 = FactorizedEmbedding(ids) (+ the frame's embedded actions on A appended tokens) + pos_embed_TSC
+    -- hma_embed_fwd (factorization_utils.py:31-54, st_mask_git.py:640-672).  ids int64 (B, T, S); pos (1, T', S', 256)."""
+    _cuda(ids, e0, e1, mask_embed, pos, a_emb)
+    B, T, S = ids.shape
+    A = action_tokens if a_emb is not None else 0
+    x = torch.empty(B, T, S + A, 256, dtype=F32, device=ids.device)
+    _lib.call("hma_embed_fwd", stream_ptr(), ptr(ids.contiguous()), ptr(e0.float().contiguous()), ptr(e1.float().contiguous()),
+              ptr(mask_embed.float().contiguous()), ptr(pos.float().contiguous()), ptr(None if a_emb is None else a_emb.float().contiguous()),
+              ptr(x), B, T, S, A, pos.shape[-2], e0.shape[0], mask_id)
+    return x
+
+
+@embed.register_fake
+def _(ids, e0, e1, mask_embed, pos, a_emb, action_tokens, mask_id):
+    B, T, S = ids.shape
+    return e0.new_empty(B, T, S + (action_tokens if a_emb is not None else 0), 256, dtype=F32)
+
+
+@torch.library.custom_op("hma::modulate", mutates_args=(), device_types="cuda")
+def modulate(x: torch.Tensor, ss: torch.Tensor, rows_per_frame: int, eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """ModulateLayer's prologue (st_mask_git.py:71-74) on fp32 rows x (frames * rows_per_frame, 256): (xhat = LN(x) without affine,
+    xm = xhat (1 + scale) + shift, 1 / sigma) with ss (frames, 512) = [shift | scale] per frame -- hma_modln_fwd"""
+    _cuda(x, ss)
+    rows = x.numel() // 256
+    frames = rows // rows_per_frame
+    xhat = torch.empty(rows, 256, dtype=BF16, device=x.device)
+    xm = torch.empty_like(xhat)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    _lib.call("hma_modln_fwd", stream_ptr(), ptr(x.contiguous()), ptr(ss.float().contiguous()), ptr(xhat), ptr(xm), ptr(rstd), frames,
+              rows_per_frame, eps)
+    return xhat, xm, rstd
+
+
+@modulate.register_fake
+def _(x, ss, rows_per_frame, eps):
+    rows = x.numel() // 256
+    return x.new_empty(rows, 256, dtype=BF16), x.new_empty(rows, 256, dtype=BF16), x.new_empty(rows, dtype=F32)
+
+
+@torch.library.custom_op("hma::readout_ce", mutates_args=(), device_types="cuda")
+def readout_ce(logits: torch.Tensor, input_ids: torch.Tensor, labels: torch.Tensor, mask_id: int, label_smoothing: float,
+               grad_scale: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(stats [sum loss, sum correct, masked rows, -] fp32, dlogits bf16) of the factorised cross-entropy over the masked tokens of
+    frames >= 1 (st_mask_git.py:603-630): hma_count_masked + hma_ce_fwd_bwd on fp32 logits (B * T * S, 1024); ids / labels (B, T, S)"""
+    _cuda(logits, input_ids, labels)
+    B, T, S = input_ids.shape
+    stats = torch.zeros(4, dtype=F32, device=logits.device)
+    dlogits = torch.empty(logits.shape, dtype=BF16, device=logits.device)
+    ids = input_ids.contiguous()
+    _lib.call("hma_count_masked", stream_ptr(), ptr(ids), ptr(stats), B, T, S, mask_id)
+    _lib.call("hma_ce_fwd_bwd", stream_ptr(), ptr(logits.contiguous()), ptr(ids), ptr(labels.contiguous()), ptr(stats), ptr(dlogits), None,
+              grad_scale, B, T, S, mask_id, label_smoothing)
+    return stats, dlogits
+
+
+@readout_ce.register_fake
+def _(logits, input_ids, labels, mask_id, label_smoothing, grad_scale):
+    return logits.new_empty(4, dtype=F32), logits.new_empty(logits.shape, dtype=BF16)
+
+
+@torch.library.custom_op("hma::maskgit_step", mutates_args=("prompt", "unmasked"), device_types="cuda")
+def maskgit_step(logits: torch.Tensor, prompt: torch.Tensor, unmasked: torch.Tensor, out_t: int, n_mask: int, last: bool,
+                 mask_id: int) -> torch.Tensor:
+    """One greedy MaskGIT step (st_mask_git.py:397-453) on fp32 logits (B, T, S, 1024): writes the sampled ids into prompt[:, out_t]
+    (int64 (B, T, S)), updates `unmasked` (uint8 (B, S)); returns the model confidences (B, S) -- hma_maskgit_step"""
+    _cuda(logits, prompt, unmasked)
+    B, T, S = prompt.shape
+    conf = torch.empty(B, S, dtype=F32, device=logits.device)
+    _lib.call("hma_maskgit_step", stream_ptr(), ptr(logits), ptr(prompt), ptr(unmasked), None, ptr(conf), B, T, S, out_t, n_mask, int(last),
+              mask_id, 0, 0)
+    return conf
+
+
+@maskgit_step.register_fake
+def _(logits, prompt, unmasked, out_t, n_mask, last, mask_id):
+    return logits.new_empty(prompt.shape[0], prompt.shape[2], dtype=F32)
+
+
+@torch.library.custom_op("hma::adamw", mutates_args=("p", "m", "v"), device_types="cuda")
+def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+          weight_decay: float, step: int, max_norm: float) -> torch.Tensor:
+    """Global-norm clip + AdamW on one flat fp32 range (train_multi.py:593-598, 900-922): hma_sqnorm + hma_adamw; returns the bf16 copy
+    of the new weights.  `step` = the number of this update (1, 2, ...); max_norm <= 0: no clip."""
+    _cuda(p, g, m, v)
+    sq = torch.zeros(1, dtype=F32, device=p.device)
+    _lib.call("hma_sqnorm", stream_ptr(), ptr(g), g.numel(), ptr(sq))
+    pb = torch.empty(p.shape, dtype=BF16, device=p.device)
+    _lib.call("hma_adamw", stream_ptr(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(pb), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+              ptr(sq), max_norm, None)
+    return pb
+
+
+@adamw.register_fake
+def _(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, max_norm):
+    return p.new_empty(p.shape, dtype=BF16)
+
+
 OPS = ("linear", "linear_wgrad", "layer_norm", "attn_spatial", "attn_spatial_bwd", "attn_temporal", "attn_temporal_bwd", "mlp",
-       "mlp_bwd")
+       "mlp_bwd", "qknorm", "qknorm_bwd", "embed", "modulate", "readout_ce", "maskgit_step", "adamw")

@@ -25,12 +25,14 @@ def compute_latents(sd, cfg, x_patches, action_ids, domain, with_actions=False):
     every frame's action tokens (B, T, d) -- the action mask is NOT applied to the inputs here (:146-172 ignore it)."""
     B, T, h, w, _ = x_patches.shape
     x = F.linear(x_patches.reshape(B, T, h * w, -1).float(), sd["token_embed.weight"])
-    a_emb = R.action_stem(sd, cfg, action_ids, domain[0])
-    x = torch.cat([x, a_emb[:, :T, None].expand(B, T, cfg.action_token_size, cfg.d_model)], dim=2)
+    a_emb = None
+    if action_ids is not None:  # (st_mar.py:154-172; without actions: no action tokens, the decoder runs unconditioned)
+        a_emb = R.action_stem(sd, cfg, action_ids, domain[0])
+        x = torch.cat([x, a_emb[:, :T, None].expand(B, T, cfg.action_token_size, cfg.d_model)], dim=2)
     x = x + sd["pos_embed_TSC"][:, :T, : x.shape[2]]
     x = F.layer_norm(x, (cfg.d_model,), sd["z_proj_ln.weight"], sd["z_proj_ln.bias"], 1e-6)
     for l in range(cfg.num_layers):
-        x = R.st_block(sd, cfg, l, x, a_emb, domain[0])
+        x = R.st_block(sd, cfg, l, x, a_emb, domain[0] if action_ids is not None else None)
     pooled = x[:, :, -cfg.action_token_size:].mean(dim=2)
     x = x[:, :, : h * w]
     y = F.linear(x, sd["out_x_proj.weight"], sd["out_x_proj.bias"])

@@ -35,6 +35,24 @@ def test_g3_attention(tag, scale):
         assert rel_err(y, g[f"{tag}.y_{kind}"]) < TOL
 
 
+@pytest.mark.parametrize("tag,scale", [("mup", 8 / 32), ("std", 32 ** -0.5)])
+def test_g3_attention_qknorm(tag, scale):
+    """The oracle's qk_norm branch against the stand-alone reference module with qk_norm=True (forward and, through autograd, the
+    gradients of x, the qkv / proj weights and the per-head LayerNorm's affine)."""
+    g = golden("g3_attention_qknorm")
+    for kind, causal in (("spatial", False), ("temporal", True)):
+        leaf = {k: g[k].clone().requires_grad_(True) for k in ("qkv", "proj_w", "proj_b", "norm_w", "norm_b")}
+        x = g[f"{tag}.x_{kind}"].clone().requires_grad_(True)
+        y = R.self_attention(x, leaf["qkv"], None, leaf["proj_w"], leaf["proj_b"], 8, scale, causal, qk_norm=(leaf["norm_w"], leaf["norm_b"]))
+        assert rel_err(y, g[f"{tag}.y_{kind}"]) < TOL
+        y.backward(g[f"{tag}.dy_{kind}"])
+        assert rel_err(x.grad, g[f"{tag}.dx_{kind}"]) < TOL
+        assert rel_err(leaf["qkv"].grad[::8], g[f"{tag}.dqkv_w_{kind}"]) < TOL
+        assert rel_err(leaf["proj_w"].grad[::4], g[f"{tag}.dproj_w_{kind}"]) < TOL
+        assert rel_err(leaf["norm_w"].grad, g[f"{tag}.dnorm_w_{kind}"]) < 5 * TOL
+        assert rel_err(leaf["norm_b"].grad, g[f"{tag}.dnorm_b_{kind}"]) < 5 * TOL
+
+
 def test_g4_blocks():
     g = golden("g4_blocks")
     y = R.mlp(g["mlp.x"], g["mlp.fc1_w"], g["mlp.fc1_b"], g["mlp.fc2_w"], g["mlp.fc2_b"])

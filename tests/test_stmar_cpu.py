@@ -78,3 +78,31 @@ def test_stmar_jointly_predict_actions_matches_reference():
             want, got = G17[k], sd[k[5:]].grad
             assert torch.allclose(got, want, rtol=5e-3, atol=2e-5 * want.abs().max().item() + 1e-9), k
     assert G17["grad_is_none.domB_head"].item() == 1.0 and sd["action_diff_losses.domB.net.cond_embed.weight"].grad is None
+
+
+def _sub(name, g):
+    """the row subsets tests/golden/make_golden_stmar_noact.py keeps"""
+    if name == "pos_embed_TSC.image_rows":
+        return None
+    return g[::4] if g.dim() == 2 and g.shape[0] >= 256 else g[:, ::4] if g.dim() == 3 else g
+
+
+def test_stmar_without_actions_matches_reference():
+    """`action_ids=None` (hma/model/st_mar.py:146-197: no action tokens, no modulation): the oracle against G11b from the real reference."""
+    from safetensors.torch import load_file
+    Gn = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11b_stmar_noact.safetensors"))
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not (k.endswith(".mean") or k.endswith(".std")) else v)
+          for k, v in seeded_state(template()).items()}
+    inp = inputs()
+    loss, z = M.forward(sd, ref_cfg(), inp["latents"], inp["latents"], None, None, inp["masked"], inp["t"], inp["noise"], 2, 32, 32,
+                        CFG["diffloss_d"])
+    assert torch.allclose(z[:, :, ::4], Gn["z"], rtol=1e-3, atol=2e-4)
+    assert abs(loss.item() - Gn["loss"].item()) <= 1e-4 * abs(Gn["loss"].item())
+    loss.backward()
+    for k, want in Gn.items():
+        if not k.startswith("grad."):
+            continue
+        name = k[5:]
+        got = sd["pos_embed_TSC"].grad[:, :, :256:4] if name == "pos_embed_TSC.image_rows" else _sub(name, sd[name].grad)
+        assert torch.allclose(got, want, rtol=5e-3, atol=2e-5 * want.abs().max().item() + 1e-9), k
+    assert sd["action_mlp.domA.model.0.weight"].grad is None

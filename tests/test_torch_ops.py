@@ -186,3 +186,69 @@ def test_engine_backed_blocks_refuse_autograd():
         m.decoder.layers[0](x, action_ids=a, domain="domA")
     with torch.no_grad():
         assert m.decoder(x, action_ids=a, domain="domB").shape == x.shape
+
+
+@pytest.mark.gpu
+def test_embed_modulate_readout_ce_maskgit_step_adamw_ops():
+    """The operator-level entry points SURVEY section 8(b) lists beside the GEMM / attention ops, as `torch.ops.hma.*`: values against
+    plain PyTorch fp32 math (factorization_utils.py:31-54, st_mask_git.py:66-76, :603-630, :397-453, train_multi.py:593-598)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    V, MASK = 512, 262144
+    # ---- embed
+    B, T, S, A = 2, 3, 64, 16
+    ids = torch.randint(0, V * V, (B, T, S), generator=g)
+    ids[torch.rand(B, T, S, generator=g) < 0.3] = MASK
+    e0, e1 = torch.randn(V, 256, generator=g), torch.randn(V, 256, generator=g)
+    me, pos = torch.randn(1, 256, generator=g), torch.randn(1, T, S + A, 256, generator=g)
+    a_emb = torch.randn(B, T, 256, generator=g)
+    x = torch.ops.hma.embed(ids.to(dev), e0.to(dev), e1.to(dev), me.to(dev), pos.to(dev), a_emb.to(dev), A, MASK)
+    tok = torch.where((ids == MASK)[..., None], me.expand(B, T, S, 256), e0[ids.clamp(max=V * V - 1) % V] + e1[ids.clamp(max=V * V - 1) // V])
+    ref = torch.cat([tok, a_emb[:, :, None].expand(B, T, A, 256)], dim=2) + pos
+    assert torch.allclose(x.cpu(), ref, atol=1e-6)
+    # ---- modulate
+    rows_pf, frames = 80, 6
+    xr = torch.randn(frames * rows_pf, 256, generator=g) * 1.3 + 0.2
+    ss = torch.randn(frames, 512, generator=g) * 0.3
+    xhat, xm, rstd = torch.ops.hma.modulate(xr.to(dev), ss.to(dev), rows_pf, 1e-6)
+    xh = F.layer_norm(xr, (256,), eps=1e-6)
+    f = torch.arange(frames * rows_pf) // rows_pf
+    _close(xhat, xh, 2 * BF, "modulate xhat")
+    _close(xm, xh * (1 + ss[f, 256:]) + ss[f, :256], 3 * BF, "modulate xm")
+    _close(rstd, torch.rsqrt(xr.var(1, unbiased=False) + 1e-6), 1e-4, "modulate rstd")
+    # ---- readout_ce
+    B, T, S = 2, 3, 16
+    logits = torch.randn(B * T * S, 1024, generator=g) * 2
+    labels = torch.randint(0, V * V, (B, T, S), generator=g)
+    inp = labels.clone()
+    inp[:, 1:][torch.rand(B, T - 1, S, generator=g) < 0.5] = MASK
+    stats, dlog = torch.ops.hma.readout_ce(logits.to(dev), inp.to(dev), labels.to(dev), MASK, 0.01, 1.0)
+    lr_ = logits.clone().requires_grad_(True)
+    m = (inp == MASK).reshape(-1).float()
+    lab = labels.reshape(-1)
+    ce = sum(F.cross_entropy(lr_[:, k * V:(k + 1) * V], (lab // V ** k) % V, reduction="none", label_smoothing=0.01) for k in range(2))
+    loss = (ce * m).sum() / m.sum()
+    loss.backward()
+    assert abs(stats[0].item() / stats[2].item() - loss.item()) <= 1e-4 * abs(loss.item()) and stats[2].item() == m.sum().item()
+    _close(dlog, lr_.grad, 3 * BF, "dlogits")
+    # ---- maskgit_step (last step: every token of the frame is written with the factor-wise arg-max)
+    B, T, S = 3, 2, 32
+    lg = torch.randn(B, T, S, 1024, generator=g)
+    prompt = torch.full((B, T, S), MASK, dtype=torch.long)
+    prompt[:, 0] = torch.randint(0, V * V, (B, S), generator=g)
+    pd, um = prompt.to(dev), torch.zeros(B, S, dtype=torch.uint8, device=dev)
+    conf = torch.ops.hma.maskgit_step(lg.to(dev), pd, um, 1, 0, True, MASK)
+    want = lg[:, 1, :, :V].argmax(-1) + V * lg[:, 1, :, V:].argmax(-1)
+    assert torch.equal(pd[:, 1].cpu(), want) and torch.equal(pd[:, 0].cpu(), prompt[:, 0]) and conf.shape == (B, S)
+    # ---- adamw: one clipped step against torch.optim.AdamW
+    n = 64 * 40
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    pt.grad = gr.clone()
+    torch.nn.utils.clip_grad_norm_([pt], 1.0)
+    opt.step()
+    pdv, mdv, vdv = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.ops.hma.adamw(pdv, gr.to(dev), mdv, vdv, 1e-2, 0.9, 0.95, 1e-8, 0.05, 1, 1.0)
+    assert torch.allclose(pdv.cpu(), pt.detach(), atol=2e-6, rtol=1e-5) and torch.equal(pb.cpu(), pdv.cpu().bfloat16())
