@@ -234,6 +234,9 @@ class STEngine:
         # chain A backward / the attention backward, whose 100-156 KB of LDS leave their workgroups no room on a CU.  Bits: 1 MLP pair,
         # 2 temporal pair, 4 linear_out, 8 spatial pair.
         self.fork_wgrad = 9
+        # the per-domain adaLN stacks' backward runs per group of this many layers (a data-parallel driver sets it to its layers per
+        # gradient bucket, so that a domain's slice of a bucket is final when the bucket is)
+        self.ada_group = 8
         self.jpa = bool(cfg.jointly_predict_actions)
         self._act: Optional[dict] = None
         self.act_scale = 0.0   # d total / d action_loss of the backward in flight (0: the action loss is not part of the objective)
@@ -442,16 +445,17 @@ class STEngine:
             self._wt_ok = True
         if domain is not None and self.modulate and domain not in self._dom_fresh:
             pre = f"decoder.layers.0.action_projectors.{domain}"
+            ds = lay.dom_layer_stride  # (a domain's block is layer-major: the batch stride of every per-layer stack in it)
             _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.linear_out.weight"), self.WT[f"lin:{domain}"].data_ptr(),
-                      d, d, L, d * d, d * d)
+                      d, d, L, ds, d * d)
             _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.0.weight"),
-                      self.WT[f"ada0:{domain}"].data_ptr(), d, d, L, d * d, d * d)
+                      self.WT[f"ada0:{domain}"].data_ptr(), d, d, L, ds, d * d)
             _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.2.weight"),
-                      self.WT[f"ada2:{domain}"].data_ptr(), 2 * d, d, L, 2 * d * d, 2 * d * d)
+                      self.WT[f"ada2:{domain}"].data_ptr(), 2 * d, d, L, ds, 2 * d * d)
             if self.use_chain:
                 wl = self._p(f"{pre}.linear_out.weight")
-                _lib.call("hma_chain_pack", stream, wl, d, 1, None, None, self.CP[f"lin:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192, 1)
-                _lib.call("hma_chain_pack", stream, wl, 1, d, None, None, self.CP[f"lin_T:{domain}"].data_ptr(), 0, d, d, L, d * d, 8 * 8192, 1)
+                _lib.call("hma_chain_pack", stream, wl, d, 1, None, None, self.CP[f"lin:{domain}"].data_ptr(), 0, d, d, L, ds, 8 * 8192, 1)
+                _lib.call("hma_chain_pack", stream, wl, 1, d, None, None, self.CP[f"lin_T:{domain}"].data_ptr(), 0, d, d, L, ds, 8 * 8192, 1)
             self._dom_fresh.add(domain)
 
     def weights_changed(self) -> None:
@@ -717,11 +721,11 @@ class STEngine:
                 pl.gemm_nt(A=ws["a_emb"].data_ptr(), lda=256, a_kind=A_F32, W=self._wb(f"{ap}.adaLN_modulation.0.weight"),
                            ldw=256, M=Fr, N=256, K=256, epi=EPI_SILU2, Cp=ws["ada_pre"].data_ptr(), ldc=256,
                            bias=self._p(f"{ap}.adaLN_modulation.0.bias"), C2=ws["ada_act"].data_ptr(), ldc2=256, batch=L,
-                           sA=0, sW=256 * 256, sBias=256, sC=Fr * 256, sC2=Fr * 256)
+                           sA=0, sW=self.layout.dom_layer_stride, sBias=self.layout.dom_layer_stride, sC=Fr * 256, sC2=Fr * 256)
                 pl.gemm_nt(A=ws["ada_act"].data_ptr(), lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.adaLN_modulation.2.weight"),
                            ldw=256, M=Fr, N=512, K=256, epi=EPI_F32, Cp=ws["ss"].data_ptr(), ldc=512,
-                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=Fr * 256, sW=512 * 256, sBias=512,
-                           sC=Fr * 512)
+                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=Fr * 256, sW=self.layout.dom_layer_stride,
+                           sBias=self.layout.dom_layer_stride, sC=Fr * 512)
         if embed:
             pl.add("hma_embed_fwd", ws["ids"].data_ptr(), self._p("token_embed.factored_embeds.0.weight"),
                    self._p("token_embed.factored_embeds.1.weight"), self._p("token_embed.mask_token_embed"),
@@ -783,7 +787,7 @@ class STEngine:
         return pl
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
-        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A))
+        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -813,6 +817,7 @@ class STEngine:
         use_mod = A > 0 and self.modulate
         if use_mod and self._use_chain(M, SA):
             pl.add("hma_zero_f32", ws["dss"].data_ptr(), ws["dss"].numel())  # the backward chains add the frames' sums with atomics
+        ada_g, ada_hi = max(1, min(int(self.ada_group), L)), L
         for l in reversed(range(L)):
             xh1, rstd1 = dp(ws["xh1"], l, M * 256), dp(ws["rstd1"], l, M)
             qkv_s, o_s, lse_s = dp(ws["qkv_s"], l, M * 768), dp(ws["o_s"], l, M * 256), dp(ws["lse_s"], l, M * 8)
@@ -933,8 +938,28 @@ class STEngine:
                     dxb = rot(dxb)  # (the forked spatial weight gradients still read the previous buffer)
                 pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
                        dxb)
+            # ---- the adaLN stacks of a finished group of layers (batched over the group): their weight gradients are final with the
+            # group, so a domain's slice of a gradient bucket can be all-reduced with it; d a_emb accumulates (atomics) for the stem
+            if use_mod and ((L - l) % ada_g == 0 or l == 0):
+                n = ada_hi - l
+                ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                dsl = self.layout.dom_layer_stride
+                o = lambda name, per: dp(ws[name], l, per)
+                pl.gemm_tn(dY=o("dss", Fr * 512), ldy=512, y_kind=A_F32, A=o("ada_act", Fr * 256), lda=256, a_kind=A_BF16,
+                           M=Fr, N=512, K=256, dW=self._g(f"{ap}.adaLN_modulation.2.weight"), lddw=256,
+                           dBias=self._g(f"{ap}.adaLN_modulation.2.bias"), batch=n, sY=Fr * 512, sA=Fr * 256, sdW=dsl, sdBias=dsl)
+                pl.gemm_nt(A=o("dss", Fr * 512), lda=512, a_kind=A_F32, W=dp(self.WT[f"ada2:{domain}"], l, 256 * 512), ldw=512, M=Fr,
+                           N=256, K=512, epi=EPI_DSILU, Cp=o("dpre", Fr * 256), ldc=256, U=o("ada_pre", Fr * 256), ldu=256,
+                           batch=n, sA=Fr * 512, sW=256 * 512, sC=Fr * 256, sU=Fr * 256)
+                pl.gemm_tn(dY=o("dpre", Fr * 256), ldy=256, y_kind=A_BF16, A=ws["a_emb"].data_ptr(), lda=256, a_kind=A_F32,
+                           M=Fr, N=256, K=256, dW=self._g(f"{ap}.adaLN_modulation.0.weight"), lddw=256,
+                           dBias=self._g(f"{ap}.adaLN_modulation.0.bias"), batch=n, sY=Fr * 256, sA=0, sdW=dsl, sdBias=dsl)
+                pl.gemm_nt(A=o("dpre", Fr * 256), lda=256, a_kind=A_BF16, W=dp(self.WT[f"ada0:{domain}"], l, 256 * 256), ldw=256, M=Fr,
+                           N=256, K=256, epi=EPI_ATOMIC_F32, Cp=ws["da_emb"].data_ptr(), ldc=256, batch=n, sA=Fr * 256,
+                           sW=256 * 256, sC=0)
+                ada_hi = l
             pl.mark(f"layer{l}")
-        # ---- embedding, adaLN stacks, action stem
+        # ---- embedding, action stem
         pl.mark("embed")
         pl.add("hma_embed_bwd", ws["ids"].data_ptr(), dx, self._g("token_embed.factored_embeds.0.weight"),
                self._g("token_embed.factored_embeds.1.weight"), self._g("token_embed.mask_token_embed"), self._g("pos_embed_TSC"),
@@ -943,21 +968,6 @@ class STEngine:
         pl.mark("post_embed")
         if A > 0:
             dom = domain
-            if self.modulate:
-                ap = f"decoder.layers.0.action_projectors.{dom}"
-                pl.gemm_tn(dY=ws["dss"].data_ptr(), ldy=512, y_kind=A_F32, A=ws["ada_act"].data_ptr(), lda=256, a_kind=A_BF16,
-                           M=Fr, N=512, K=256, dW=self._g(f"{ap}.adaLN_modulation.2.weight"), lddw=256,
-                           dBias=self._g(f"{ap}.adaLN_modulation.2.bias"), batch=L, sY=Fr * 512, sA=Fr * 256, sdW=512 * 256,
-                           sdBias=512)
-                pl.gemm_nt(A=ws["dss"].data_ptr(), lda=512, a_kind=A_F32, W=self.WT[f"ada2:{dom}"].data_ptr(), ldw=512, M=Fr,
-                           N=256, K=512, epi=EPI_DSILU, Cp=ws["dpre"].data_ptr(), ldc=256, U=ws["ada_pre"].data_ptr(), ldu=256,
-                           batch=L, sA=Fr * 512, sW=256 * 512, sC=Fr * 256, sU=Fr * 256)
-                pl.gemm_tn(dY=ws["dpre"].data_ptr(), ldy=256, y_kind=A_BF16, A=ws["a_emb"].data_ptr(), lda=256, a_kind=A_F32,
-                           M=Fr, N=256, K=256, dW=self._g(f"{ap}.adaLN_modulation.0.weight"), lddw=256,
-                           dBias=self._g(f"{ap}.adaLN_modulation.0.bias"), batch=L, sY=Fr * 256, sA=0, sdW=256 * 256, sdBias=256)
-                pl.gemm_nt(A=ws["dpre"].data_ptr(), lda=256, a_kind=A_BF16, W=self.WT[f"ada0:{dom}"].data_ptr(), ldw=256, M=Fr,
-                           N=256, K=256, epi=EPI_ATOMIC_F32, Cp=ws["da_emb"].data_ptr(), ldc=256, batch=L, sA=Fr * 256,
-                           sW=256 * 256, sC=0)
             am = f"action_mlp.{dom}.model"
             pl.add("hma_action_stem_bwd", ws["da_emb"].data_ptr(), ws["an"].data_ptr(), ws["sxhat"].data_ptr(),
                    ws["srstd"].data_ptr(), ws["sh"].data_ptr(), self._p(f"{am}.1.weight"), self._p(f"{am}.3.weight"),
@@ -1228,10 +1238,11 @@ class STEngine:
                 pl.gemm_nt(A=d["a_emb"].data_ptr(), lda=256, a_kind=A_F32, W=self._wb(f"{ap}.adaLN_modulation.0.weight"), ldw=256,
                            M=B, N=256, K=256, epi=EPI_SILU2, Cp=d["ada_pre"].data_ptr(), ldc=256,
                            bias=self._p(f"{ap}.adaLN_modulation.0.bias"), C2=d["ada_act"].data_ptr(), ldc2=256, batch=L, sA=0,
-                           sW=256 * 256, sBias=256, sC=B * 256, sC2=B * 256)
+                           sW=self.layout.dom_layer_stride, sBias=self.layout.dom_layer_stride, sC=B * 256, sC2=B * 256)
                 pl.gemm_nt(A=d["ada_act"].data_ptr(), lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.adaLN_modulation.2.weight"),
                            ldw=256, M=B, N=512, K=256, epi=EPI_F32, Cp=d["ss"].data_ptr(), ldc=512,
-                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=B * 256, sW=512 * 256, sBias=512, sC=B * 512)
+                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=B * 256, sW=self.layout.dom_layer_stride,
+                           sBias=self.layout.dom_layer_stride, sC=B * 512)
         pfr = cfg.S + cfg.action_token_size
         pl.add("hma_embed_fwd", d["ids"].data_ptr(), self._p("token_embed.factored_embeds.0.weight"),
                self._p("token_embed.factored_embeds.1.weight"), self._p("token_embed.mask_token_embed"),

@@ -9,7 +9,8 @@ the adaLN GEMMs of all layers run as one batched launch.  Names, shapes and dtyp
 exactly the reference state-dict (hma/model/st_mask_git.py:152-251).
 
 Flat order:  head (out_x_proj) | trunk layers L-1 .. 0 | tail (embeddings, pos) | one block per
-action domain (type-major layer stacks) | never-trained tensors.
+action domain (layer-major: a layer's six modulation tensors together, constant layer stride; then the action stem) |
+never-trained tensors.
 """
 from __future__ import annotations
 
@@ -120,22 +121,27 @@ class ParamLayout:
             add("action_mask_tokens", (1, cfg.T, 1, d), "tail")
         end()
 
+        # A domain's block is LAYER-major: the six modulation tensors of layer 0, of layer 1, ... at a constant stride (the 32 layers'
+        # adaLN GEMMs still run as batched launches -- `dom_layer_stride` is their batch stride), then the action stem.  So the part
+        # of a domain's block that belongs to a gradient bucket (a run of consecutive layers) is ONE contiguous slice, and it is final
+        # when that bucket's backward is: it rides with the bucket's all-reduce instead of waiting for the end of the step.
         modulate = "modulate" in cfg.action_network
+        self.dom_layer_stride = 0
+        self.dom_layer_start: Dict[str, int] = {}
         for dom, da in zip(self.domains, self.d_actions):
             begin(f"dom:{dom}")
+            self.dom_layer_start[dom] = self._cur
             if modulate:
-                for key, shape in (("adaLN_modulation.0.weight", (d, d)), ("adaLN_modulation.2.weight", (2 * d, d)),
-                                   ("linear_out.weight", (d, d))):
-                    for l in range(L):
+                for l in range(L):
+                    l0 = self._cur
+                    for key, shape in (("adaLN_modulation.0.weight", (d, d)), ("adaLN_modulation.2.weight", (2 * d, d)),
+                                       ("linear_out.weight", (d, d)), ("adaLN_modulation.0.bias", (d,)),
+                                       ("adaLN_modulation.2.bias", (2 * d,)), ("linear_out.bias", (d,))):
                         add(f"decoder.layers.{l}.action_projectors.{dom}.{key}", shape, f"dom:{dom}")
+                    self.dom_layer_stride = self._cur - l0
             add(f"action_mlp.{dom}.model.0.weight", (d, da), f"dom:{dom}")
             add(f"action_mlp.{dom}.model.1.weight", (d,), f"dom:{dom}")
             add(f"action_mlp.{dom}.model.3.weight", (d, d), f"dom:{dom}")
-            if modulate:
-                for key, shape in (("adaLN_modulation.0.bias", (d,)), ("adaLN_modulation.2.bias", (2 * d,)),
-                                   ("linear_out.bias", (d,))):
-                    for l in range(L):
-                        add(f"decoder.layers.{l}.action_projectors.{dom}.{key}", shape, f"dom:{dom}")
             add(f"action_mlp.{dom}.model.0.bias", (d,), f"dom:{dom}")
             add(f"action_mlp.{dom}.model.1.bias", (d,), f"dom:{dom}")
             add(f"action_mlp.{dom}.model.3.bias", (d,), f"dom:{dom}")
@@ -179,6 +185,22 @@ class ParamLayout:
             end = self.regions[f"layer{last}"][1]
             out.append((start, end))
             start = end
+        return out
+
+    def dom_buckets(self, dom: str, layers_per_bucket: int) -> List[Tuple[int, int]]:
+        """The slices of a domain's block that become final with each dense bucket (same order and count as `buckets`), then the
+        rest of the block (the action stem, final at the end of the backward) as one more slice."""
+        L = self.cfg.num_layers
+        a0, a1 = self.regions[f"dom:{dom}"]
+        if self.dom_layer_stride == 0:
+            return [(a0, a0)] * ((L + layers_per_bucket - 1) // layers_per_bucket) + [(a0, a1)]
+        base, st = self.dom_layer_start[dom], self.dom_layer_stride
+        out = []
+        order = list(reversed(range(L)))
+        for i in range(0, L, layers_per_bucket):
+            hi, lo = order[i], order[min(i + layers_per_bucket, L) - 1]
+            out.append((base + lo * st, base + (hi + 1) * st))
+        out.append((base + L * st, a1))
         return out
 
     def decay_flags(self) -> torch.Tensor:

@@ -47,6 +47,9 @@ class GradReducer:
         self._next = 0
         self.side = torch.cuda.Stream() if G.is_cuda else None
         self._dom_index = {d: i for i, d in enumerate(layout.domains)}
+        # a domain's block is layer-major (params.py): its slice for the layers of dense bucket i is contiguous and final with the bucket
+        self._dom_buckets = {d: layout.dom_buckets(d, layers_per_bucket) for d in layout.domains}
+        self._active: List[str] = []
 
     def active_domains(self, local_domain: Optional[str]) -> List[str]:
         """Union over ranks of this micro-batch's domains, in layout order (same list on every rank).  FALLBACK for callers
@@ -81,13 +84,21 @@ class GradReducer:
         else:
             self._pending.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def begin(self) -> None:
+    def begin(self, active: Sequence[str] = ()) -> None:
+        """`active`: the step's domains (known before its last backward starts): their slices ride with the dense buckets."""
         self._pending, self._next = [], 0
+        self._active = list(active)
+
+    def _launch_bucket(self, i: int) -> None:
+        self._launch(*self.dense_buckets[i])
+        for dom in self._active:
+            self._launch(*self._dom_buckets[dom][i])
 
     def on_segment(self, label: str) -> None:
-        """Called by STEngine.backward after each enqueued segment; reduces every bucket that is final."""
+        """Called by STEngine.backward after each enqueued segment; reduces every bucket that is final: the dense range of its
+        layers and, for every active domain, the modulation tensors of the same layers."""
         while self._next < len(self.dense_buckets) and label == self.bucket_label[self._next]:
-            self._launch(*self.dense_buckets[self._next])
+            self._launch_bucket(self._next)
             self._next += 1
 
     def _launch_tensor(self, t: torch.Tensor) -> None:
@@ -105,12 +116,16 @@ class GradReducer:
     def finish(self, active: Sequence[str], extra: Sequence[torch.Tensor] = ()) -> None:
         """Reduce what is left (unlaunched dense buckets, embeddings, active domain blocks, `extra` flat tensors such as the
         loss bookkeeping or STMAR's own gradient range) and wait."""
+        early = set(self._active)
         while self._next < len(self.dense_buckets):
-            self._launch(*self.dense_buckets[self._next])
+            self._launch_bucket(self._next)
             self._next += 1
         self._launch(*self.tail)
         for dom in active:
-            self._launch(*self.layout.regions[f"dom:{dom}"])
+            if dom in early:   # (its per-bucket slices went with the buckets: the action stem is what is left)
+                self._launch(*self._dom_buckets[dom][-1])
+            else:
+                self._launch(*self.layout.regions[f"dom:{dom}"])
         for t in extra:
             self._launch_tensor(t)
         for w in self._pending:
@@ -185,6 +200,7 @@ class Trainer:
         self.accum = grad_accum
         self.reducer = GradReducer(self.engine.layout, self.engine.G, layers_per_bucket)
         self.layers_per_bucket = layers_per_bucket
+        self.engine.ada_group = layers_per_bucket  # (the adaLN stacks' backward per bucket: a domain's slice of a bucket is final with it)
         self.completed = 0
         self._micro = 0
         self._active: List[str] = []
@@ -256,7 +272,7 @@ class Trainer:
         if eng.jpa:  # loss += config.action_loss_weight * action_loss (train_multi.py:574-576)
             eng.act_scale = float(getattr(self.model.config, "action_loss_weight", 0.5)) * eng.grad_scale.value
         if last and red.world > 1:
-            red.begin()
+            red.begin(self._active)
             eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
             red.finish(self._active, extra=[self.loss_info])
         else:
@@ -298,12 +314,15 @@ class Trainer:
             ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True, need_logits=False)
             self._book(ws, B)
             if red.world > 1:
-                red.begin()
+                red.begin(self._active)
                 eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
                 red.finish(self._active, extra=[self.loss_info])
             else:
                 eng.backward(eng.grad_scale.value)
-            if n >= 2:  # buffers, plans and lazily-initialised kernel attributes exist now: capture for next time
+            # the first (shape, domain) of a trainer is captured on its SECOND use (buffers, plans and lazily-initialised kernel
+            # attributes exist then); every further domain on its first: the kernels are the same, only pointers into the flat
+            # buffers differ (with 40 domains: ~40 eager steps until a rank replays graphs only, instead of ~80)
+            if n >= (1 if self._graphs else 2):
                 torch.cuda.synchronize()
                 Bq, Tq, Sq, A, domq = eng._last
                 bwd = eng._backward_plan(Bq, Tq, Sq, A, domq)
@@ -337,7 +356,7 @@ class Trainer:
             ws["actions"][: B * T * d_a].copy_(action_ids[:, :T].reshape(-1), non_blocking=True)
         eng._last = (B, T, S, A, dom if A > 0 else None)
         if red.world > 1:
-            red.begin()
+            red.begin(self._active)
         for i, (g, label) in enumerate(graphs):
             g.replay()
             if i == 0:
@@ -488,6 +507,7 @@ class MarTrainer:
         self.max_grad_norm, self.warmup, self.accum = max_grad_norm, warmup_steps, grad_accum
         self.reducer = GradReducer(self.engine.layout, self.engine.G, layers_per_bucket)
         self.layers_per_bucket = layers_per_bucket
+        self.engine.ada_group = layers_per_bucket
         self.completed, self._micro = 0, 0
         self._active: List[str] = []
         self._known = False
@@ -534,7 +554,7 @@ class MarTrainer:
             # while the backward goes on (the reference: DDP's bucketed reduction, train_multi.py:779, 990).
             own, m = self.own, self.model
             ha, hb = m._own_head_range(own)
-            red.begin()
+            red.begin(self._active)
 
             def after_head():
                 m._own_gather_grads(own, prefix="diffloss.")

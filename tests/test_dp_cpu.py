@@ -36,10 +36,31 @@ def test_layout_matches_reference_state_dict_and_is_aligned():
     assert spans[-1][1] <= lay.total
     # constant per-layer stride, layers stored L-1 .. 0 (backward-completion order)
     assert lay.off("decoder.layers.0.mlp.fc1.weight") - lay.off("decoder.layers.1.mlp.fc1.weight") == lay.layer_stride > 0
-    # per-domain adaLN stacks are type-major with a constant layer stride (batched GEMMs)
-    a = lay.off("decoder.layers.0.action_projectors.domA.adaLN_modulation.2.weight")
-    b = lay.off("decoder.layers.1.action_projectors.domA.adaLN_modulation.2.weight")
-    assert b - a == 512 * 256
+    # a domain's block is layer-major with a constant layer stride (the batch stride of the adaLN GEMMs), so the modulation tensors of
+    # a run of layers -- a gradient bucket -- are one contiguous slice
+    for key in ("adaLN_modulation.0.weight", "adaLN_modulation.2.weight", "linear_out.weight", "adaLN_modulation.2.bias", "linear_out.bias"):
+        a = lay.off(f"decoder.layers.0.action_projectors.domA.{key}")
+        b = lay.off(f"decoder.layers.1.action_projectors.domA.{key}")
+        assert b - a == lay.dom_layer_stride == 256 * 256 * 4 + 256 * 4, key
+
+
+def test_domain_slices_of_the_buckets_tile_the_domain_block():
+    _, lay = make_layout(4)
+    for lpb in (1, 3, 8):
+        dense = lay.buckets(lpb)
+        for dom in lay.domains:
+            sl = lay.dom_buckets(dom, lpb)
+            assert len(sl) == len(dense) + 1
+            a0, a1 = lay.regions[f"dom:{dom}"]
+            cover = sorted(sl)
+            assert cover[0][0] == a0 and cover[-1][1] == a1
+            for (x0, x1), (y0, y1) in zip(cover, cover[1:]):
+                assert x1 == y0 and x0 < x1
+        # bucket 0 holds the LAST layers (backward order): the slice contains layer L - 1's tensors and not layer 0's
+        s0 = lay.dom_buckets("domA", 1)[0]
+        assert s0[0] <= lay.off("decoder.layers.3.action_projectors.domA.linear_out.bias") < s0[1]
+        assert not (s0[0] <= lay.off("decoder.layers.0.action_projectors.domA.linear_out.weight") < s0[1])
+        assert s0[0] <= lay.off("decoder.layers.3.action_projectors.domA.adaLN_modulation.0.weight") < s0[1]
 
 
 def test_decay_flags_follow_the_reference_grouping():
@@ -76,7 +97,7 @@ def test_lr_schedule_constant_with_warmup():
     assert lr_at(3, 2e-4, 0) == 2e-4
 
 
-def _worker(rank, world, port, lpb, out):
+def _worker(rank, world, port, lpb, early, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -95,13 +116,16 @@ def _worker(rank, world, port, lpb, out):
         G[dense[0]:dense[1]] = torch.arange(dense[1] - dense[0], dtype=torch.float32) * (rank + 1) * 1e-3
         a, b = lay.regions[f"dom:{local}"]
         G[a:b] = float(rank + 1)
-        red.begin()
+        red.begin(active if early else ())   # (early: the domains' per-bucket slices ride with the dense buckets)
         L = cfg.num_layers
         for l in reversed(range(L)):           # the labels STEngine.backward emits with segment_layers = lpb
             if (L - l) % lpb == 0 or l == 0:
                 red.on_segment(f"layer{l}")
         red.on_segment("end")
+        n_early = len(red._pending)
         red.finish(active, extra=[loss_info])
+        # dense buckets (+ two domain slices each when early) were launched from inside the "backward"
+        assert n_early == len(red.dense_buckets) * (3 if early else 1), n_early
         assert loss_info.tolist() == [7.5, 4.0, 1.0, 0.0]  # rides along with the gradients (train_multi.py:599)
         exp = torch.zeros(lay.total)
         exp[dense[0]:dense[1]] = torch.arange(dense[1] - dense[0], dtype=torch.float32) * 3e-3  # ranks 1x + 2x
@@ -119,13 +143,13 @@ def _worker(rank, world, port, lpb, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lpb", [1, 3])
-def test_sparse_by_domain_allreduce_world2_gloo(lpb):
+@pytest.mark.parametrize("lpb,early", [(1, True), (3, True), (3, False)])
+def test_sparse_by_domain_allreduce_world2_gloo(lpb, early):
     world = 2
-    port = 29500 + (os.getpid() % 2000) + lpb
+    port = 29500 + (os.getpid() % 2000) + lpb + (7 if early else 0)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, lpb, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, lpb, early, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
 
 
