@@ -101,6 +101,37 @@ def pmc_traffic_per_launch(kernel_substr="gemm_nt"):
         return None
 
 
+def pmc_traffic_per_call(kernels, count_kernel):
+    """HBM bytes per C-ABI call of a kernel family from the newest committed PMC passes: the FETCH_SIZE (x 2, see above) and WRITE_SIZE
+    sums of EVERY kernel the call launches (`kernels`: name substrings, e.g. the weight-gradient ring kernel AND its reduction) over the
+    number of calls (= launches of `count_kernel`).  Comparable with `bytes_per_launch` (algorithmic bytes per call)."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), "")
+    try:
+        d = json.load(open(path))
+        tot, calls = 0.0, 0
+        for name, v in d["fetch"].items():
+            if any(k in name for k in kernels):
+                tot += 2.0 * v["counter_sum_kb"] * 1024.0
+            if count_kernel in name:
+                calls += v["launches"]
+        for name, v in d["write"].items():
+            if any(k in name for k in kernels):
+                tot += v["counter_sum_kb"] * 1024.0
+        return (tot / calls if calls else None), os.path.basename(path)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def pmc_traffic_total(mode):
+    """Whole-workload HBM bytes of the `decode` / `mar` legs from their committed PMC passes (profiles/pmc_hbm_<mode>_r4.json: FETCH_SIZE
+    and WRITE_SIZE summed over every kernel of the measured unit, written by tools/prof_bench.sh MODE=<mode>)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_hbm_{mode}_r4.json")
+    try:
+        return json.load(open(path))["summary"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _cpu_train_steps(sd, rc, names, domain, d_a, T, B, warm, timed):
     """`warm` untimed + `timed` timed optimizer steps of the CPU oracle at batch B; returns the step times."""
     from oracle import st_maskgit_ref as R
@@ -224,7 +255,11 @@ def mar_bench(args, dev, steps=None, warmup=None):
         "roofline": {"bound": "mfma", "kernel": "whole step (algorithmic FLOPs: trunk 3 x 1.04e8 + diffusion head 3 x 4.94e7 per patch token)",
                      "achieved": tokens / dt * MAR_FLOP_PER_TOKEN / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": tokens / dt * MAR_FLOP_PER_TOKEN / MFMA_PEAK, "traffic": None},
-        "final_loss": float(out.loss)}
+        "final_loss": float(out.loss.detach())}
+    traffic = pmc_traffic_total("mar")
+    if traffic:
+        res["roofline"]["traffic"] = traffic["bytes_per_step"]
+        res["roofline"]["traffic_note"] = traffic["note"]
     if not args.no_cpu_baseline:
         from oracle import st_maskgit_ref as R
         from oracle import st_mar_ref as MR
@@ -307,6 +342,23 @@ def decode_bench(args, dev, steps=None, warmup=None, batch=None):
                      "achieved": flops_min / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops_min / dt / 2.5e15,
                      "traffic": None, "reference_equivalent_tflops": flops_ref / dt / 1e12},
     }
+    # the interactive caller (sim/simulator.py:286-293: one environment, one frame at a time): B = 1 latency of the same rollout
+    p1, a1 = prompt[:1].contiguous(), acts[:1].contiguous()
+    kw1 = dict(kw, action_ids=a1, domain=[domains[0]])
+    for _ in range(2):
+        model.generate(p1, None, **kw1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        model.generate(p1, None, **kw1)
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t0) / 3
+    res["latency_b1"] = {"ms_per_frame": 1e3 * dt1 / (T - P), "frames_per_s": (T - P) / dt1,
+                         "sample": f"batch 1, {T - P} generated frames x {iters} MaskGIT iterations, 2 warm-up + mean of 3 rollouts"}
+    traffic = pmc_traffic_total("decode")
+    if traffic:
+        res["roofline"]["traffic"] = traffic["bytes_per_rollout"]
+        res["roofline"]["traffic_note"] = traffic["note"]
     if not args.no_cpu_baseline:
         from oracle import st_maskgit_ref as R
         rc = R.RefConfig(num_layers=args.layers, num_heads=8, d_model=256, T=T, use_mup=True)
@@ -523,9 +575,15 @@ def main():
             dom_name = max(fams, key=lambda k: fams[k]["share_of_step_time"]) if fams else None
             if dom_name:
                 d0 = fams[dom_name]
-                traffic = pmc_traffic_per_launch({"hma_gemm_nt": "gemm_nt", "hma_mlp_bwd": "mlp_bwd", "hma_mlp_fwd": "mlp_fwd",
-                                                  "hma_gemm_tn_pair": "gemm_tn", "hma_chain_a_fwd": "chain_a_fwd",
-                                                  "hma_chain_a_bwd": "chain_a_bwd", "hma_chain_b_fwd": "chain_b_fwd"}.get(dom_name, dom_name))
+                # (every kernel the C-ABI call launches, per CALL: the weight-gradient entry points launch the ring kernel and its reduction)
+                fam_kernels = {"hma_gemm_nt": (("gemm_nt",), "gemm_nt"), "hma_mlp_bwd": (("mlp_bwd",), "mlp_bwd"), "hma_mlp_fwd": (("mlp_fwd",), "mlp_fwd"),
+                               "hma_gemm_tn_pair": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_a_fwd": (("chain_a_fwd",), "chain_a_fwd"),
+                               "hma_chain_a_bwd": (("chain_a_bwd",), "chain_a_bwd"), "hma_chain_b_fwd": (("chain_b_fwd",), "chain_b_fwd"),
+                               "hma_attn_spatial_bwd": (("attn_bwd_fused",), "attn_bwd_fused")}.get(dom_name, ((dom_name,), dom_name))
+                traffic, pmc_file = pmc_traffic_per_call(*fam_kernels)
+                same_scope = d0["bytes_per_launch"]
+                if dom_name == "hma_gemm_tn_pair":  # (three pairs + linear_out's single call per layer share the ring kernel)
+                    same_scope = (3.0 * d0["bytes_per_launch"] + (B * T * 320 * 1024.0 + 4.0 * 65536)) / 4.0
                 mfma = {"achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s", "frac": d0["frac"]}
                 hbm = {"achieved": d0["hbm_achieved_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": d0["hbm_frac"]}
                 # headline = the MFMA roof (SURVEY.md 8d / north_star: dense contraction => MFMA); the HBM view of the same
@@ -534,14 +592,18 @@ def main():
                                    "unit": mfma["unit"], "frac": mfma["frac"], "traffic": traffic,
                                    "flop_per_byte": d0["flop_per_byte"], "mfma": mfma, "hbm": hbm,
                                    "bound_by_intensity": d0["bound"],
-                                   "bytes_per_launch": d0["bytes_per_launch"],
-                                   "traffic_note": "traffic = measured HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
-                                                   "(profiles/pmc_hbm_*.json); achieved = ALGORITHMIC bytes (every operand once, every result once) / "
+                                   "bytes_per_launch": d0["bytes_per_launch"], "algorithmic_bytes_in_traffic_scope": same_scope,
+                                   "traffic_note": f"traffic = measured HBM bytes per C-ABI call (every kernel the call launches: for the weight gradients the "
+                                                   f"ring kernel + its reduction; the ring kernel also serves linear_out's single hma_gemm_tn call, so it is the "
+                                                   f"average over the layer's four weight-gradient calls), FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
+                                                   f"(profiles/{pmc_file}); achieved = ALGORITHMIC bytes (every operand once, every result once) / "
                                                    "launch time; bound = hbm when FLOP per algorithmic byte < 2500e12 / 8e12",
                                    "launches": d0["launches"], "avg_launch_us": d0["avg_launch_us"], "flops_per_launch": d0["flops_per_launch"],
                                    "share_of_step_time": d0["share_of_step_time"],
                                    "measured": f"HIP events around every launch of the MFMA kernel families in {inst_steps} eager steps run "
-                                               "right after the timed region (algorithmic FLOPs: recomputation is not counted)",
+                                               "right after the timed region on ONE stream (the timed region replays hipGraphs in which two "
+                                               "weight-gradient pairs per layer are forked to a side stream: the shares are of the un-forked sum; "
+                                               "algorithmic FLOPs: recomputation is not counted)",
                                    "families": fams}
             out["config"]["prepare_steps"] = prepare_steps
         if world == 1 and not args.no_cpu_baseline:

@@ -63,6 +63,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #define CH_R 4
 #endif
 constexpr bool ST = CH_ST != 0;
+#ifndef CH_SPREAD   // measurement builds: CH_ST = 0 with the storer mode's even store schedule (chain A forward)
+#define CH_SPREAD 0
+#endif
+constexpr bool SPREAD = ST || CH_SPREAD != 0;
 constexpr int NCW = CH_NCW;                  // compute waves; wave NCW is the loader, wave NCW + 1 (storer mode) the storer
 constexpr int NSTW = ST ? CH_NSTW : 0;       // storer k takes the staging rings of the compute waves w with w % NSTW == k
 constexpr int CH_THREADS = 64 * (NCW + 1 + NSTW);
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
 #pragma unroll
             for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(h[e], 1.0f + sc[e], sh[e]);
             a1[pr] = as_frag(pack8(mm));
-            if constexpr (SAVE && ST) {  // (staged pair by pair: the packed xhat of the tile is not kept)
+            if constexpr (SAVE && SPREAD) {  // (staged pair by pair: the packed xhat of the tile is not kept)
               if ((pr & 1) == 0) {
                 hqs[0] = hq;
               } else {
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
       }
       CPROF_MARK(2);
       using I4 = std::integral_constant<int, 4>;
-      if constexpr (ST) {
+      if constexpr (SPREAD) {
         // Storer mode: a wave's blocks leave EVENLY over the tile's steps (at most two per step), so that the staging ring --
         // four blocks -- never has to take a burst: xhat pairs inside the LayerNorm (step 7), xm over the linear_out steps, the
         // fp32 rows over the first eight qkv steps (the next tile's rows are requested into those registers right behind),
@@ -1165,7 +1169,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   if constexpr (DROP) {
     dseed = *p.drop_seed;
     dth = drop_thresh(p.drop_p);
-    dsc = 1.0f / (1.0f - p.drop_p);
+    dsc = drop_scale(p.drop_p);
   }
   // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand (training: also saved, with 1 / sigma, for the backward)
   auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t r0) __attribute__((always_inline)) {

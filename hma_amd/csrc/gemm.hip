@@ -303,7 +303,7 @@ __device__ __forceinline__ void epilogue_oct(const hma_gemm_nt_t& p, int64_t bz,
     float* C = reinterpret_cast<float*>(p.C) + bz * p.sC + crow * p.ldc + nq + 8 * g2 + 4 * hi;
     if (p.drop_p > 0.f) {  // Dropout on the branch output before the residual add (st_transformer.py:26)
       const uint32_t seed = *p.drop_seed, th = drop_thresh(p.drop_p);
-      const float sc = 1.0f / (1.0f - p.drop_p);
+      const float sc = drop_scale(p.drop_p);
       const int64_t e0 = crow * p.ldc + nq + 8 * g2 + 4 * hi;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
           for (int e = 0; e < 8; ++e) v[e] *= gt_lookup(gtl, (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
           if (p.drop_p > 0.f) {  // the forward's mask on gelu(u): same seed, salt and element index
             const uint32_t seed = *p.drop_seed, th = drop_thresh(p.drop_p);
-            const float sc = 1.0f / (1.0f - p.drop_p);
+            const float sc = drop_scale(p.drop_p);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = drop_keep(seed, p.drop_salt, crow * p.ldc + bn + nl + e, th) ? v[e] * sc : 0.f;
           }
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 4) void gemm_nt_sw_kernel(hma
           }
           if (p.drop_p > 0.f) {  // Dropout on the activation (st_transformer.py:25); u itself is saved undropped
             const uint32_t seed = *p.drop_seed, th = drop_thresh(p.drop_p);
-            const float sc = 1.0f / (1.0f - p.drop_p);
+            const float sc = drop_scale(p.drop_p);
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = drop_keep(seed, p.drop_salt, crow * p.ldc2 + bn + nl + e, th) ? h[e] * sc : 0.f;
           }
@@ -2031,7 +2031,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(hma_gemm_nt_t p, i
         float* Cb = reinterpret_cast<float*>(p.C);
         const uint32_t seed = p.drop_p > 0.f ? *p.drop_seed : 0u;
         const uint32_t th = drop_thresh(p.drop_p);
-        const float sc = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+        const float sc = p.drop_p > 0.f ? drop_scale(p.drop_p) : 1.0f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           float4 x[2][2][2][2];

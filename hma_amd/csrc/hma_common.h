@@ -192,6 +192,9 @@ __device__ __forceinline__ void drop_keep2(uint32_t seed, int salt, int64_t idx,
   k1 = (x >> 16) >= (thresh >> 16);
 }
 __device__ __forceinline__ uint32_t drop_thresh(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
+// the rescale that goes with the mask: 1 / (1 - the probability the 16-bit compare actually drops with) -- p rounded down to a multiple
+// of 2^-16 (for p < 2^-16 nothing is dropped and nothing is scaled)
+__device__ __forceinline__ float drop_scale(float p) { return 1.0f / (1.0f - (float)(drop_thresh(p) >> 16) * (1.0f / 65536.0f)); }
 
 __device__ __forceinline__ f32x16_t mfma32(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

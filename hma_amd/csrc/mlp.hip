@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(hma_mlp_bwd_t p) {
     if constexpr (DROP) {
       dseed = *p.drop_seed;
       dth = drop_thresh(p.drop_p);
-      dsc = 1.0f / (1.0f - p.drop_p);
+      dsc = drop_scale(p.drop_p);
     }
     MPROF_DECL;
     for (int g = 0; g <= nsteps; ++g) {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dropout_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n,
                                                            float p, const uint32_t* __restrict__ seed_dev, int salt) {
   const uint32_t seed = *seed_dev, th = drop_thresh(p);
-  const float sc = 1.0f / (1.0f - p);
+  const float sc = drop_scale(p);
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
     dst[i] = to_bf16(drop_keep(seed, salt, i, th) ? src[i] * sc : 0.f);

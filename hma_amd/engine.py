@@ -32,13 +32,22 @@ BF16, F32 = torch.bfloat16, torch.float32
 class Plan:
     """A recorded sequence of C-ABI launches with fixed arguments; `run` replays it on a stream."""
 
-    tn_workspace: Optional[torch.Tensor] = None  # scratch for the two-stage weight-gradient reduction
-    _tn_workspaces: Dict[int, torch.Tensor] = {}
+    # Per GPU, for the life of the process (recorded plans and captured graphs hold the raw pointers): the scratch of the two-stage
+    # weight-gradient reduction, a second one for launches forked to the side stream, and that stream.  Keyed by device index, so
+    # that engines on different devices of one process do not share a workspace or launch on a stream of the wrong device.
+    _tn_workspaces: Dict[object, torch.Tensor] = {}
+    _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
-    side_stream: "Optional[torch.cuda.Stream]" = None   # launches tagged `side` run here, forked from / joined to the caller's stream
-    tn_workspace_side: Optional[torch.Tensor] = None     # (their weight-gradient partials: the main workspace may be in use)
+    @property
+    def tn_workspace(self) -> Optional[torch.Tensor]:
+        return Plan._tn_workspaces.get(self.dev)
 
-    def __init__(self):
+    @property
+    def tn_workspace_side(self) -> Optional[torch.Tensor]:
+        return Plan._tn_workspaces.get(("side", self.dev))
+
+    def __init__(self, dev: Optional[int] = None):
+        self.dev = torch.cuda.current_device() if (dev is None and torch.cuda.is_available()) else dev
         self.side: Dict[int, bool] = {}     # call index -> runs on the side stream
         self.join: Dict[int, bool] = {}     # call index -> the caller's stream first waits for the side stream
         self.calls: List[Tuple[Callable, str, tuple]] = []
@@ -72,8 +81,8 @@ class Plan:
         self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._nt_bytes(g))
 
     def gemm_tn(self, side: bool = False, **kw) -> None:
-        side = side and Plan.tn_workspace_side is not None
-        wsb = Plan.tn_workspace_side if side else Plan.tn_workspace
+        side = side and self.tn_workspace_side is not None
+        wsb = self.tn_workspace_side if side else self.tn_workspace
         if wsb is not None:
             kw.setdefault("ws", wsb.data_ptr())
             kw.setdefault("ws_elems", wsb.numel())
@@ -87,8 +96,8 @@ class Plan:
         """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair).  `side`: on the side
         stream (nothing on the caller's stream depends on it until the next `join_next()` call or the end of the run)."""
         gs = []
-        wsb = Plan.tn_workspace_side if (side and Plan.tn_workspace_side is not None) else Plan.tn_workspace
-        side = side and Plan.tn_workspace_side is not None
+        wsb = self.tn_workspace_side if (side and self.tn_workspace_side is not None) else self.tn_workspace
+        side = side and self.tn_workspace_side is not None
         for kw in (kw0, kw1):
             if wsb is not None:
                 kw.setdefault("ws", wsb.data_ptr())
@@ -158,10 +167,10 @@ class Plan:
         if timer is None:
             # fork / join: a `side` call starts when everything enqueued so far on the caller's stream is done and runs beside what
             # follows; a `join` call (and the end of this run) waits for the side stream.  Under hipGraph capture these become edges.
-            main = torch.cuda.current_stream()
-            if Plan.side_stream is None:
-                Plan.side_stream = torch.cuda.Stream()
-            sd = Plan.side_stream
+            main = torch.cuda.current_stream(self.dev)
+            if self.dev not in Plan._side_streams:
+                Plan._side_streams[self.dev] = torch.cuda.Stream(device=self.dev)
+            sd = Plan._side_streams[self.dev]
             pending = False
             stop_ = len(self.calls) if stop is None else stop
             for i in range(start, stop_):
@@ -337,13 +346,11 @@ class STEngine:
         # torch.device("cuda") != tensor.device -- and a second engine's creation then freed the block under the first
         # engine's plans, whose wgrad partials landed in whatever the allocator put there next.)
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dev_index = idx
         if idx not in Plan._tn_workspaces:
             Plan._tn_workspaces[idx] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))  # 64 MB + bias partials
-        Plan.tn_workspace = Plan._tn_workspaces[idx]
-        if self.fork_wgrad:
-            if ("side", idx) not in Plan._tn_workspaces:
-                Plan._tn_workspaces[("side", idx)] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))
-            Plan.tn_workspace_side = Plan._tn_workspaces[("side", idx)]
+        if self.fork_wgrad and ("side", idx) not in Plan._tn_workspaces:
+            Plan._tn_workspaces[("side", idx)] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))
 
     # ------------------------------------------------------------------------------ Adam update counts (device-resident)
     def _steps_now(self) -> List[int]:
@@ -696,7 +703,7 @@ class STEngine:
         L = cfg.num_layers
         SA, M, Mi, Fr = S + A, B * T * (S + A), B * T * S, B * T
         fused = self._use_fused(M, train, SA)
-        pl = Plan()
+        pl = Plan(self._dev_index)
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         sl = (lambda l: l) if train else (lambda l: 0)
 
@@ -772,7 +779,7 @@ class STEngine:
         if key in self._plans:
             return self._plans[key]
         ws, cfg = self._ws, self.cfg
-        pl = Plan()
+        pl = Plan(self._dev_index)
         pl.add("hma_count_masked", ws["ids"].data_ptr(), ws["stats"].data_ptr(), B, T, S, cfg.image_vocab_size)
         if fused:
             pl.readout_ce(B * T * S, segs=[(self.CP["out"].data_ptr(), 32)], x=ws["x"].data_ptr(), bias=self._p("out_x_proj.bias"),
@@ -793,7 +800,7 @@ class STEngine:
         cfg, ws = self.cfg, self._ws
         L = cfg.num_layers
         SA, M, Mi, Fr = S + A, B * T * (S + A), B * T * S, B * T
-        pl = Plan()
+        pl = Plan(self._dev_index)
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
         dxb = ws["dxb"].data_ptr()
@@ -1224,7 +1231,7 @@ class STEngine:
         cfg, d = self.cfg, self._dws
         L = cfg.num_layers
         SA, M1 = S + A, B * (S + A)
-        pl = Plan()
+        pl = Plan(self._dev_index)
         use_mod = A > 0 and self.modulate
         if A > 0 and not same_actions:
             am = f"action_mlp.{domain}.model"

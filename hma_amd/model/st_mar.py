@@ -44,6 +44,7 @@ class _MarLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        ctx.owner.__dict__["_bwd_ran"] = True
         ctx.owner._backward(g)
         return None, None, None
 
@@ -59,7 +60,16 @@ class _MarActionLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.owner._act_scale = g.detach().clone()
+        owner = ctx.owner
+        owner._act_scale = g.detach().clone()
+        owner.__dict__["_bwd_ran"] = False
+
+        def after_pass():  # (an objective without the video loss: the one backward of the step still has to run, with a zero video scale)
+            if not owner.__dict__.get("_bwd_ran", False):
+                owner.__dict__["_bwd_ran"] = True
+                owner._backward(torch.zeros_like(g))
+
+        torch.autograd.Variable._execution_engine.queue_callback(after_pass)
         return None, None, None
 
 

@@ -152,6 +152,7 @@ class _EngineLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        ctx.owner.__dict__["_bwd_ran"] = True
         ctx.owner._engine_backward(grad_out)
         return None, None, None
 
@@ -159,7 +160,9 @@ class _EngineLoss(torch.autograd.Function):
 class _ActionLoss(torch.autograd.Function):
     """The action loss of jointly_predict_actions as a second autograd leaf: its backward only records d total / d action_loss.  It
     is created AFTER the video loss' node, so autograd runs it first and `_EngineLoss.backward` -- the one engine backward of the
-    step -- finds the scale (0 when the caller left the action loss out of the objective)."""
+    step -- finds the scale (0 when the caller left the action loss out of the objective).  An objective WITHOUT the video loss
+    (`out.action_loss.backward()` alone) never reaches that node: a callback at the end of the autograd pass then runs the engine
+    backward with a zero video-loss scale, so the action loss' gradients exist either way."""
 
     @staticmethod
     def forward(ctx, anchor: torch.Tensor, owner, value: torch.Tensor) -> torch.Tensor:
@@ -168,7 +171,16 @@ class _ActionLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.owner._engine.act_scale = float(grad_out)
+        owner = ctx.owner
+        owner._engine.act_scale = float(grad_out)
+        owner.__dict__["_bwd_ran"] = False
+
+        def after_pass():
+            if not owner.__dict__.get("_bwd_ran", False):
+                owner.__dict__["_bwd_ran"] = True
+                owner._engine_backward(torch.zeros((), device=grad_out.device))
+
+        torch.autograd.Variable._execution_engine.queue_callback(after_pass)
         return None, None, None
 
 

@@ -155,3 +155,27 @@ def test_cached_generate_equals_window_generate_on_a_jpa_model():
         # policy mode: cached request == window path exactly (it is routed there)
         kwp = dict(kw, action_ids=None, domain=["domB"] * 2)
         assert torch.equal(m.generate(ids, None, **kwp), m.generate(ids, None, use_cache=False, **kwp))
+
+
+def test_action_loss_alone_trains_the_action_head():
+    """`out.action_loss.backward()` with no video loss in the objective used to record a scale and compute nothing.
+    It now runs the engine backward at the end of the autograd pass: the gradients equal those of (0 * loss + action_loss)."""
+    inp = {k: v.to(DEV) for k, v in tiny_inputs().items()}
+    T = TINY["config"]["T"]
+    amask = (torch.arange(T)[None, :] >= torch.tensor([[1], [2]])).to(DEV)
+    kw = dict(input_ids=inp["input_ids"], labels=inp["labels"], action_ids=inp["actions_domA"], domain=["domA"] * 2, action_mask=amask)
+    grads = []
+    for alone in (True, False):
+        m = build().train()
+        out = m(**kw)
+        if alone:
+            out.action_loss.backward()
+        else:
+            (0.0 * out.loss + out.action_loss).backward()
+        g = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        assert "action_out_projectors.domA.weight" in g and float(g["action_out_projectors.domA.weight"].abs().max()) > 0
+        grads.append(g)
+    for n in ("action_out_projectors.domA.weight", "decoder.layers.0.mlp.fc1.weight", "decoder.layers.1.spatial_attn.qkv.weight",
+              "action_mask_tokens"):
+        a, b = grads[0][n], grads[1][n]
+        assert (a - b).norm() <= 2e-2 * (b.norm() + 1e-12), n

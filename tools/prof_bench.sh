@@ -1,18 +1,27 @@
 #!/bin/bash
-# rocprofv3 kernel-trace stats + two PMC passes (HBM read / write bytes) of the bench; every step time-bounded.
+# rocprofv3 kernel-trace stats + two PMC passes (HBM read / write bytes) of one bench leg; every step time-bounded.
+#   ROUND=r4 MODE=train|decode|mar  gpurun -- bash tools/prof_bench.sh
+# Writes gpurun_out/prof_<round>_<mode>/{kernel_stats_<round>.csv, pmc_<round>.json}; the PMC passes run in their own processes with
+# --pmc only (no trace domains).  train: 8-layer model (bytes per launch do not depend on the depth); decode / mar: the full depth,
+# one rollout / one step after the warm-up, and a `summary` with the bytes of the whole measured unit.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 R=${ROUND:-r1}
-OUT=gpurun_out/prof_$R
+MODE=${MODE:-train}
+OUT=gpurun_out/prof_${R}_$MODE
 rm -rf $OUT; mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $R -- python3 bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline --no-kernel-timing > $OUT/bench_trace.log 2>&1 < /dev/null
+case $MODE in
+  train)  TR="--steps 3 --warmup 1 --mode train --no-cpu-baseline --no-kernel-timing"; PM="--steps 1 --warmup 1 --layers 8 --mode train --no-cpu-baseline --no-kernel-timing";;
+  decode) TR="--steps 2 --warmup 2 --mode decode --no-cpu-baseline"; PM="--steps 1 --warmup 2 --mode decode --no-cpu-baseline";;
+  mar)    TR="--steps 3 --warmup 2 --mode mar --no-cpu-baseline"; PM="--steps 1 --warmup 2 --mode mar --no-cpu-baseline";;
+esac
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $R -- python3 bench.py $TR > $OUT/bench_trace.log 2>&1 < /dev/null
 echo "trace rc=$?"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $R -- python3 bench.py --steps 1 --warmup 1 --layers 8 --mode train --no-cpu-baseline --no-kernel-timing > $OUT/bench_pmc_fetch.log 2>&1 < /dev/null
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $R -- python3 bench.py $PM > $OUT/bench_pmc_fetch.log 2>&1 < /dev/null
 echo "pmc fetch rc=$?"
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $R -- python3 bench.py --steps 1 --warmup 1 --layers 8 --mode train --no-cpu-baseline --no-kernel-timing > $OUT/bench_pmc_write.log 2>&1 < /dev/null
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $R -- python3 bench.py $PM > $OUT/bench_pmc_write.log 2>&1 < /dev/null
 echo "pmc write rc=$?"
-find $OUT -name "*.csv" -size +0 | head -20
-timeout 120 python3 tools/prof_summary.py $OUT $R < /dev/null
+timeout 120 python3 tools/prof_summary.py $OUT $R $MODE < /dev/null
 # raw per-dispatch CSVs are large: keep only the summaries + stats
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
