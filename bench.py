@@ -343,18 +343,19 @@ def decode_bench(args, dev, steps=None, warmup=None, batch=None):
                      "traffic": None, "reference_equivalent_tflops": flops_ref / dt / 1e12},
     }
     # the interactive caller (sim/simulator.py:286-293: one environment, one frame at a time): B = 1 latency of the same rollout
-    p1, a1 = prompt[:1].contiguous(), acts[:1].contiguous()
-    kw1 = dict(kw, action_ids=a1, domain=[domains[0]])
-    for _ in range(2):
-        model.generate(p1, None, **kw1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        model.generate(p1, None, **kw1)
-    torch.cuda.synchronize()
-    dt1 = (time.perf_counter() - t0) / 3
-    res["latency_b1"] = {"ms_per_frame": 1e3 * dt1 / (T - P), "frames_per_s": (T - P) / dt1,
-                         "sample": f"batch 1, {T - P} generated frames x {iters} MaskGIT iterations, 2 warm-up + mean of 3 rollouts"}
+    if not getattr(args, "no_latency", False):
+        p1, a1 = prompt[:1].contiguous(), acts[:1].contiguous()
+        kw1 = dict(kw, action_ids=a1, domain=[domains[0]])
+        for _ in range(2):
+            model.generate(p1, None, **kw1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.generate(p1, None, **kw1)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / 3
+        res["latency_b1"] = {"ms_per_frame": 1e3 * dt1 / (T - P), "frames_per_s": (T - P) / dt1,
+                             "sample": f"batch 1, {T - P} generated frames x {iters} MaskGIT iterations, 2 warm-up + mean of 3 rollouts"}
     traffic = pmc_traffic_total("decode")
     if traffic:
         res["roofline"]["traffic"] = traffic["bytes_per_rollout"]
@@ -428,6 +429,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--mode", choices=["all", "train", "decode", "mar"], default="all",
                     help="all (default): the train line, plus the decode and mar sub-objects when --gpus 1")
+    ap.add_argument("--no-latency", action="store_true", help="decode: skip the batch-1 latency leg (profiling passes)")
     ap.add_argument("--quick-cpu", action="store_true", help="one warm-up + one timed CPU-oracle step instead of the BASELINE.md protocol")
     ap.add_argument("--unfused-mlp", action="store_true",
                     help="measurement only: train with the unfused MLP GEMMs (fc1 / fc2 / dfc2 / dfc1 + LayerNorm kernels) instead of "

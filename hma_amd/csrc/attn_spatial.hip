@@ -458,15 +458,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 // (ds_read_b64_tr_b16, like K^T) and forms dQ of that query tile (2 NT MFMAs) while the tile waves go on with the next query tile
 // (two dS buffers).  delta = rowsum(dO * O) is formed while the item is staged; the
 // NEXT item's rows are fetched into registers during the compute (one workgroup per CU: nothing else would hide the staging).
-#ifndef ATTN_ABL  // debug builds (timing only, results wrong): 1 no lse / delta reads, 2 no dQ job, 4 no exponentials, 8 no dS tile writes, 32 no compute at all (staging + stores)
+#ifndef ATTN_ABL  // debug builds (timing only, results wrong): 1 no lse / delta reads, 2 no dQ job, 4 no exponentials, 8 no dS tile writes, 32 no compute at all (staging + stores), 64 no row loads after the first item, 128 no dqkv stores
 #define ATTN_ABL 0
 #endif
 // LDS-only barrier: waits for this wave's LDS operations, not for its global loads (the next item's rows stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NT>
+template <int NT, int KT = 1>
 struct FusedStage {
-  static constexpr int N = NT * 32, ITEMS = N * 4, THREADS = (NT + 2) * 64, R = (ITEMS + THREADS - 1) / THREADS;
+  static constexpr int N = NT * 32, ITEMS = N * 4, THREADS = (NT / KT + 2) * 64, R = (ITEMS + THREADS - 1) / THREADS;
   // (vectors, not arrays: carried around the item loop as arrays, hipcc leaves three of them in scratch)
   typedef uint32_t vec_t __attribute__((ext_vector_type(4 * R)));
   vec_t rq, rk, rv, rg, ro;
@@ -526,11 +526,17 @@ struct FusedStage {
   }
 };
 
-template <int NT>
-__global__ __launch_bounds__((NT + 2) * 64, 1) void attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+// KT = key tiles per tile wave.  KT = 2 (round 4, n = 256 / 320): NT / 2 tile waves + 2 dQ waves = 7 waves at n = 320 -- two per SIMD
+// instead of three, 256 registers each.  A tile wave forms the scores of TWO independent key tiles per step: the second tile's
+// MFMAs run under the first tile's soft-max arithmetic (a wave issues in order, the matrix pipe works behind it), and what the two
+// tiles share -- the query tile's Q / dO fragments (row-major and transposed), lse, delta -- is read from LDS once instead of twice.
+template <int NT, int KT>
+__global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                                     const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                     float* __restrict__ delta, uint16_t* __restrict__ dqkv,
                                                                     int64_t frames, float c_log2, float scale) {
+  static_assert(NT % KT == 0, "whole key tiles per wave");
+  constexpr int TW = NT / KT;   // tile waves; waves TW, TW + 1 are the dQ waves
   constexpr int N = NT * 32;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Qs = smem;                 // [N][LDR]
@@ -544,9 +550,8 @@ __global__ __launch_bounds__((NT + 2) * 64, 1) void attn_bwd_fused_kernel(const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
   const int64_t nitems = frames * NH;
-  const int kt = wave;
 
-  FusedStage<NT> st;
+  FusedStage<NT, KT> st;
   int64_t item = blockIdx.x;
   if (item < nitems) st.fetch(qkv, o, d_o, lse, item, frames, tid);
 #pragma unroll 1
@@ -554,16 +559,16 @@ __global__ __launch_bounds__((NT + 2) * 64, 1) void attn_bwd_fused_kernel(const 
     st.stage(Qs, Ks, Vs, Gs, L2s, Dls, delta, item, frames, tid);
     lds_barrier();  // (LDS-only barriers throughout: a __syncthreads would also drain the previous item's dqkv stores)
     const int64_t nxt = item + gridDim.x;
-    if (nxt < nitems) st.fetch(qkv, o, d_o, lse, nxt, frames, tid);
+    if (nxt < nitems && !(ATTN_ABL & 64)) st.fetch(qkv, o, d_o, lse, nxt, frames, tid);  // (64: measurement only -- the rows of item 0 again)
     int64_t frame; int head;
     decode_block(item, frames, frame, head);
-    if (wave >= NT) {
-      // ---- the two dQ waves: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], wave NT + (qt & 1), while the
+    if (wave >= TW) {
+      // ---- the two dQ waves: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], wave TW + (qt & 1), while the
       // tile waves work on query tile qt + 1 (which goes to the other dS buffer)
 #pragma unroll 1
       for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
         lds_barrier();
-        if ((qt & 1) == wave - NT && !(ATTN_ABL & 2)) {
+        if ((qt & 1) == wave - TW && !(ATTN_ABL & 2)) {
           const uint16_t* Tq = Ts + (qt & 1) * N * LDR;
           f32x16_t a0 = zero16(), a1 = zero16();
           // 2 NT k-steps of 16 keys in groups of 4, the next group's transposing reads in flight behind this group's MFMAs (one read
@@ -591,23 +596,42 @@ __global__ __launch_bounds__((NT + 2) * 64, 1) void attn_bwd_fused_kernel(const 
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) a0[e] += a1[e];
-          store_dt(dqkv + (frame * N + qt * 32) * QKV_LD + head * HD, QKV_LD, a0, scale, lane);
+          if (!(ATTN_ABL & 128)) store_dt(dqkv + (frame * N + qt * 32) * QKV_LD + head * HD, QKV_LD, a0, scale, lane);
         }
       }
     } else {
-      const bf16x8_t k0 = frag_rows(Ks, kt * 32, 0, lane), k1 = frag_rows(Ks, kt * 32, 1, lane);
-      const bf16x8_t v0 = frag_rows(Vs, kt * 32, 0, lane), v1 = frag_rows(Vs, kt * 32, 1, lane);
-      f32x16_t dk = zero16(), dv = zero16();
+      bf16x8_t kf[KT][2], vf[KT][2];
+      f32x16_t dk[KT], dv[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int kt = wave * KT + t;
+        kf[t][0] = frag_rows(Ks, kt * 32, 0, lane); kf[t][1] = frag_rows(Ks, kt * 32, 1, lane);
+        vf[t][0] = frag_rows(Vs, kt * 32, 0, lane); vf[t][1] = frag_rows(Vs, kt * 32, 1, lane);
+        dk[t] = zero16(); dv[t] = zero16();
+      }
 #pragma unroll 1
       for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
-        // S[q][key], dP[q][key]: lane = key, rows = q
-        f32x16_t sc = mfma32(frag_rows(Qs, qt * 32, 0, lane), k0, zero16());
-        sc = mfma32(frag_rows(Qs, qt * 32, 1, lane), k1, sc);
-        f32x16_t dp = mfma32(frag_rows(Gs, qt * 32, 0, lane), v0, zero16());
-        dp = mfma32(frag_rows(Gs, qt * 32, 1, lane), v1, dp);
-        uint16_t* T = Ts + (qt & 1) * N * LDR + (kt * 32 + (lane & 31)) * LDR;
+        // S[q][key], dP[q][key]: lane = key, rows = q.  The query tile's fragments serve every key tile of the wave.
+        const bf16x8_t aq0 = frag_rows(Qs, qt * 32, 0, lane), aq1 = frag_rows(Qs, qt * 32, 1, lane);
+        const bf16x8_t ag0 = frag_rows(Gs, qt * 32, 0, lane), ag1 = frag_rows(Gs, qt * 32, 1, lane);
+        f32x16_t sc[KT], dp[KT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // rows 8 g + 4 hi + {0..3}: one 16-byte LDS read each for lse and delta
+        for (int t = 0; t < KT; ++t) {
+#ifdef ATTN_KV_LDS  // (measurement builds: the K / V fragments re-read from LDS every step instead of 16 registers per key tile)
+          const int kt = wave * KT + t;
+          sc[t] = mfma32(aq0, frag_rows(Ks, kt * 32, 0, lane), zero16());
+          sc[t] = mfma32(aq1, frag_rows(Ks, kt * 32, 1, lane), sc[t]);
+          dp[t] = mfma32(ag0, frag_rows(Vs, kt * 32, 0, lane), zero16());
+          dp[t] = mfma32(ag1, frag_rows(Vs, kt * 32, 1, lane), dp[t]);
+#else
+          sc[t] = mfma32(aq0, kf[t][0], zero16());
+          sc[t] = mfma32(aq1, kf[t][1], sc[t]);
+          dp[t] = mfma32(ag0, vf[t][0], zero16());
+          dp[t] = mfma32(ag1, vf[t][1], dp[t]);
+#endif
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // rows 8 g + 4 hi + {0..3}: one 16-byte LDS read each for lse and delta, shared by the key tiles
           float4 l4 = make_float4(c_log2, scale, c_log2, scale), d4 = l4;
           if (!(ATTN_ABL & 1)) {
             l4 = *reinterpret_cast<const float4*>(&L2s[qt * 32 + 8 * g + 4 * hi]);
@@ -615,29 +639,43 @@ __global__ __launch_bounds__((NT + 2) * 64, 1) void attn_bwd_fused_kernel(const 
           }
           const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float arg = sc[4 * g + e] * c_log2 - lq[e];
-            const float pr = (ATTN_ABL & 4) ? arg : fast_exp2(arg);
-            sc[4 * g + e] = pr;
-            dp[4 * g + e] = pr * (dp[4 * g + e] - dq4[e]);
+          for (int t = 0; t < KT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float arg = sc[t][4 * g + e] * c_log2 - lq[e];
+              const float pr = (ATTN_ABL & 4) ? arg : fast_exp2(arg);
+              sc[t][4 * g + e] = pr;
+              dp[t][4 * g + e] = pr * (dp[t][4 * g + e] - dq4[e]);
+            }
+            // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
+            if (!(ATTN_ABL & 8)) {
+              uint16_t* T = Ts + (qt & 1) * N * LDR + ((wave * KT + t) * 32 + (lane & 31)) * LDR;
+              *reinterpret_cast<uint2*>(T + 8 * g + 4 * hi) =
+                  make_uint2(pack_bf16(dp[t][4 * g], dp[t][4 * g + 1]), pack_bf16(dp[t][4 * g + 2], dp[t][4 * g + 3]));
+            }
           }
-          // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
-          if (!(ATTN_ABL & 8))
-            *reinterpret_cast<uint2*>(T + 8 * g + 4 * hi) =
-                make_uint2(pack_bf16(dp[4 * g], dp[4 * g + 1]), pack_bf16(dp[4 * g + 2], dp[4 * g + 3]));
         }
         // (dS tile of query tile qt complete after this barrier; the buffer's previous reader -- the dQ job of qt - 2 -- is past its
         // reads: it arrived at the barrier of qt - 1 only after them)
         lds_barrier();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          dv = mfma32(frag_tr(Gs, LDR, qt * 32 + 16 * s2, lane), pack_acc_half(sc, s2), dv);
-          dk = mfma32(frag_tr(Qs, LDR, qt * 32 + 16 * s2, lane), pack_acc_half(dp, s2), dk);
+          const bf16x8_t gt = frag_tr(Gs, LDR, qt * 32 + 16 * s2, lane), qtr = frag_tr(Qs, LDR, qt * 32 + 16 * s2, lane);
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            dv[t] = mfma32(gt, pack_acc_half(sc[t], s2), dv[t]);
+            dk[t] = mfma32(qtr, pack_acc_half(dp[t], s2), dk[t]);
+          }
         }
       }
-      const int64_t row0 = frame * N + kt * 32;
-      store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk, scale, lane);
-      store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv, 1.0f, lane);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int64_t row0 = frame * N + (wave * KT + t) * 32;
+        if (!(ATTN_ABL & 128)) {
+          store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[t], scale, lane);
+          store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv[t], 1.0f, lane);
+        }
+      }
     }
     lds_barrier();  // every wave is done with this item's LDS before the next one is staged
   }
@@ -679,16 +717,20 @@ int cu_count() {
   return n;
 }
 
+#ifndef ATTN_KT  // key tiles per tile wave of the fused backward (measurement builds: -DATTN_KT=1, the round-3 form)
+#define ATTN_KT 2
+#endif
 template <int NT>
 int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                      int64_t frames, float scale) {
   constexpr int N = NT * 32;
+  constexpr int KT = (NT >= 8 && NT % ATTN_KT == 0) ? ATTN_KT : 1;
   constexpr int bytes = 6 * N * LDR * 2 + 2 * N * 4;
-  int rc = set_lds<attn_bwd_fused_kernel<NT>>(bytes);
+  int rc = set_lds<attn_bwd_fused_kernel<NT, KT>>(bytes);
   if (rc) return rc;
   const int64_t items = frames * NH;
   const int grid = (int)(items < cu_count() ? items : cu_count());
-  hipLaunchKernelGGL(attn_bwd_fused_kernel<NT>, dim3((unsigned)grid), dim3((NT + 2) * 64), bytes, s, (const uint16_t*)qkv, (const uint16_t*)o,
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, KT>), dim3((unsigned)grid), dim3((NT / KT + 2) * 64), bytes, s, (const uint16_t*)qkv, (const uint16_t*)o,
                      (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale);
   HMA_CHECK_LAUNCH();
   return 0;

@@ -4,12 +4,15 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from hma_amd import _lib
+if os.environ.get("HMA_LIB"):  # a variant build (tools/chain_variants.sh)
+    _lib.LIB_PATH = os.environ["HMA_LIB"]
 from hma_amd.config import DiffusionGenieConfig
 from hma_amd.model.st_mar import STMAR
 
 B = int(os.environ.get("BATCH", 16)); T = 16; L = int(os.environ.get("LAYERS", 32))
 cfg = DiffusionGenieConfig(num_layers=L, num_heads=8, d_model=256, T=T, S=1024, use_mup=True, action_network="concat+modulate",
-                           num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=0.0, mlp_bias=False, patch_size=2,
+                           num_factored_vocabs=2, qkv_bias=True, proj_bias=True, qk_norm=False, mlp_drop=float(os.environ.get("MLP_DROP", 0.0)), mlp_bias=False, patch_size=2,
                            vae_embed_dim=4, diffloss_w=1024, diffloss_d=4, num_sampling_steps="100", attn_drop=0.0)
 m = STMAR(cfg)
 doms = ["d0", "d1"]

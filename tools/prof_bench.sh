@@ -2,8 +2,9 @@
 # rocprofv3 kernel-trace stats + two PMC passes (HBM read / write bytes) of one bench leg; every step time-bounded.
 #   ROUND=r4 MODE=train|decode|mar  gpurun -- bash tools/prof_bench.sh
 # Writes gpurun_out/prof_<round>_<mode>/{kernel_stats_<round>.csv, pmc_<round>.json}; the PMC passes run in their own processes with
-# --pmc only (no trace domains).  train: 8-layer model (bytes per launch do not depend on the depth); decode / mar: the full depth,
-# one rollout / one step after the warm-up, and a `summary` with the bytes of the whole measured unit.
+# --pmc only (no trace domains).  train: 8-layer model (bytes per launch do not depend on the depth); mar: the full depth, three steps;
+# decode: a 4-layer model, two rollouts (a full-depth rollout is ~14 000 launches: too slow under --pmc), scaled by 32 / 4 -- the
+# embedding / readout / sampling kernels outside the layers are < 2 % of a rollout's bytes.  `summary` = bytes of the measured unit.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 R=${ROUND:-r1}
@@ -12,7 +13,7 @@ OUT=gpurun_out/prof_${R}_$MODE
 rm -rf $OUT; mkdir -p $OUT
 case $MODE in
   train)  TR="--steps 3 --warmup 1 --mode train --no-cpu-baseline --no-kernel-timing"; PM="--steps 1 --warmup 1 --layers 8 --mode train --no-cpu-baseline --no-kernel-timing";;
-  decode) TR="--steps 2 --warmup 2 --mode decode --no-cpu-baseline"; PM="--steps 1 --warmup 2 --mode decode --no-cpu-baseline";;
+  decode) TR="--steps 2 --warmup 2 --mode decode --no-cpu-baseline --no-latency"; PM="--steps 1 --warmup 1 --layers 4 --mode decode --no-cpu-baseline --no-latency";;
   mar)    TR="--steps 3 --warmup 2 --mode mar --no-cpu-baseline"; PM="--steps 1 --warmup 2 --mode mar --no-cpu-baseline";;
 esac
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $R -- python3 bench.py $TR > $OUT/bench_trace.log 2>&1 < /dev/null
