@@ -430,6 +430,7 @@ def main():
     ap.add_argument("--mode", choices=["all", "train", "decode", "mar"], default="all",
                     help="all (default): the train line, plus the decode and mar sub-objects when --gpus 1")
     ap.add_argument("--no-latency", action="store_true", help="decode: skip the batch-1 latency leg (profiling passes)")
+    ap.add_argument("--lib", type=str, default=None, help="measurement only: another build of libhma_hip.so (same-box A / B of a kernel change)")
     ap.add_argument("--quick-cpu", action="store_true", help="one warm-up + one timed CPU-oracle step instead of the BASELINE.md protocol")
     ap.add_argument("--unfused-mlp", action="store_true",
                     help="measurement only: train with the unfused MLP GEMMs (fc1 / fc2 / dfc2 / dfc1 + LayerNorm kernels) instead of "
@@ -440,6 +441,9 @@ def main():
         # Launched bare with --gpus N: this process becomes the launcher -- it never touches a GPU -- and starts N fresh ranks
         # (the reference: `torchrun --nproc_per_node=8`, experiments/scripts/run_30datasets_waction.sh:17-19).
         raise SystemExit(launch_ranks(args.gpus))
+    if args.lib:
+        from hma_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

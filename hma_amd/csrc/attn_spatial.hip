@@ -475,8 +475,11 @@ struct FusedStage {
     v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
   }
   static __device__ __forceinline__ uint4 get(const vec_t& v, int i) { return make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]); }
+  // part i of R (i = -1: all of them): a wave blocks at the issue of a load while the memory pipeline is full, and R x 5 loads per
+  // thread issued at once by every wave of every CU are such a burst (~9 600 cycles per item, tools/attn_variants.sh -DATTN_ABL=64);
+  // the kernel therefore issues one part per step of the item in flight
   __device__ __forceinline__ void fetch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, int64_t item,
-                                        int64_t frames, int tid) {
+                                        int64_t frames, int tid, int part = -1) {
     int64_t frame; int head;
     decode_block(item, frames, frame, head);
     const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
@@ -484,6 +487,7 @@ struct FusedStage {
     const uint16_t* ob = o + frame * N * DM + head * HD;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
+      if (part >= 0 && part != i) continue;
       const int c = min(tid + i * THREADS, ITEMS - 1);
       const int64_t row = c >> 2;
       const int ch = (c & 3) * 8;
@@ -493,7 +497,7 @@ struct FusedStage {
       put(rg, i, *reinterpret_cast<const uint4*>(gb + row * DM + ch));
       put(ro, i, *reinterpret_cast<const uint4*>(ob + row * DM + ch));
     }
-    rl = lse[(frame * N + min(tid, N - 1)) * NH + head];
+    if (part <= 0) rl = lse[(frame * N + min(tid, N - 1)) * NH + head];
   }
   __device__ __forceinline__ void stage(uint16_t* Qs, uint16_t* Ks, uint16_t* Vs, uint16_t* Gs, float* L2s, float* Dls, float* delta,
                                         int64_t item, int64_t frames, int tid) const {
@@ -559,14 +563,24 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
     st.stage(Qs, Ks, Vs, Gs, L2s, Dls, delta, item, frames, tid);
     lds_barrier();  // (LDS-only barriers throughout: a __syncthreads would also drain the previous item's dqkv stores)
     const int64_t nxt = item + gridDim.x;
-    if (nxt < nitems && !(ATTN_ABL & 64)) st.fetch(qkv, o, d_o, lse, nxt, frames, tid);  // (64: measurement only -- the rows of item 0 again)
+    const bool do_fetch = nxt < nitems && !(ATTN_ABL & 64);  // (64: measurement only -- the rows of item 0 again)
+#ifndef ATTN_FETCH_SPREAD
+    if (do_fetch) st.fetch(qkv, o, d_o, lse, nxt, frames, tid);
+#endif
     int64_t frame; int head;
     decode_block(item, frames, frame, head);
     if (wave >= TW) {
       // ---- the two dQ waves: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], wave TW + (qt & 1), while the
       // tile waves work on query tile qt + 1 (which goes to the other dS buffer)
+#ifdef ATTN_FETCH_SPREAD
+#pragma unroll   // (static steps: a load that is pending at a loop head makes hipcc drain the memory queue there)
+#else
 #pragma unroll 1
+#endif
       for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+#ifdef ATTN_FETCH_SPREAD
+        if (do_fetch && qt % ATTN_FETCH_SPREAD == 0 && qt / ATTN_FETCH_SPREAD < FusedStage<NT, KT>::R) st.fetch(qkv, o, d_o, lse, nxt, frames, tid, qt / ATTN_FETCH_SPREAD);
+#endif
         lds_barrier();
         if ((qt & 1) == wave - TW && !(ATTN_ABL & 2)) {
           const uint16_t* Tq = Ts + (qt & 1) * N * LDR;
@@ -609,15 +623,22 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
         vf[t][0] = frag_rows(Vs, kt * 32, 0, lane); vf[t][1] = frag_rows(Vs, kt * 32, 1, lane);
         dk[t] = zero16(); dv[t] = zero16();
       }
+#ifdef ATTN_FETCH_SPREAD
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
       for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
         // S[q][key], dP[q][key]: lane = key, rows = q.  The query tile's fragments serve every key tile of the wave.
+#ifdef ATTN_FETCH_SPREAD
+        if (do_fetch && qt % ATTN_FETCH_SPREAD == 0 && qt / ATTN_FETCH_SPREAD < FusedStage<NT, KT>::R) st.fetch(qkv, o, d_o, lse, nxt, frames, tid, qt / ATTN_FETCH_SPREAD);
+#endif
         const bf16x8_t aq0 = frag_rows(Qs, qt * 32, 0, lane), aq1 = frag_rows(Qs, qt * 32, 1, lane);
         const bf16x8_t ag0 = frag_rows(Gs, qt * 32, 0, lane), ag1 = frag_rows(Gs, qt * 32, 1, lane);
         f32x16_t sc[KT], dp[KT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-#ifdef ATTN_KV_LDS  // (measurement builds: the K / V fragments re-read from LDS every step instead of 16 registers per key tile)
+#ifndef ATTN_KV_REGS  // (the K / V fragments are re-read from LDS every step: 16 registers per key tile would spill -- 376 us against 345)
           const int kt = wave * KT + t;
           sc[t] = mfma32(aq0, frag_rows(Ks, kt * 32, 0, lane), zero16());
           sc[t] = mfma32(aq1, frag_rows(Ks, kt * 32, 1, lane), sc[t]);

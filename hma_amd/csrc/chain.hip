@@ -63,6 +63,16 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #define CH_R 4
 #endif
 constexpr bool ST = CH_ST != 0;
+// A wave BLOCKS at the issue of a vector-memory instruction while the CU's memory pipeline is full, so a burst of row loads (24 per
+// lane for a tile's o and x rows) costs about its whole transfer time in issue stalls -- the loads are asynchronous only up to the
+// queue.  CH_PF_SPREAD = 1 (default, round 4): a tile's row loads are issued a pair per step over the steps in front of their use
+// instead of all at once: chain A forward 256 -> 229 us (tools/chain_variants.sh "pf0:-DCH_PF_SPREAD=0" is the burst form).
+#ifndef CH_PF_SPREAD
+#define CH_PF_SPREAD 1
+#endif
+#ifndef CH_PF_FIRST   // chain A forward: the qkv step the spread prefetch starts at (the stores of x / bf16(x) go out at the last step before)
+#define CH_PF_FIRST 0
+#endif
 #ifndef CH_SPREAD   // measurement builds: CH_ST = 0 with the storer mode's even store schedule (chain A forward)
 #define CH_SPREAD 0
 #endif
@@ -218,9 +228,9 @@ __device__ __forceinline__ void storer_run(HMA_LDS(char)* lds, int lane, int k) 
   __builtin_amdgcn_s_setprio(3);
   static_assert(NW * RB <= 64, "one lane per staging block");
   const int w_ = lane < NW * RB ? lane / RB : 0, j_ = lane & (RB - 1);
-  const bool mine = lane < NW * RB && w_ % NSTW == k;
+  const bool mine = lane < NW * RB && w_ % (NSTW > 0 ? NSTW : 1) == k;
   uint32_t all = 0;  // the compute waves this storer serves
-  for (int w = k; w < NW; w += NSTW) all |= 1u << w;
+  for (int w = k; w < NW; w += (NSTW > 0 ? NSTW : 1)) all |= 1u << w;
   uint32_t sent = 0;  // blocks of wave w_ taken (the same value in the RB lanes of a wave)
   uint32_t fin = 0;
   const int r8 = lane >> 3, lc = (lane & 7) ^ (r8 & 7);
@@ -589,18 +599,24 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
   f32x4v_t acc[16];
   uint4 hqs[8];   // packed xhat of the tile in flight
   uint4 qb[8];    // qkv blocks waiting for their burst (block pq in qb[pq & 7])
-  auto prefetch = [&](int tl) __attribute__((always_inline)) {
+  // the next tile's rows: o (8 loads) and x (16 loads).  `part` < 0: all of them; 0..11: loads 2 part, 2 part + 1 -- measurement builds
+  // (-DCH_PF_SPREAD) issue a pair per step instead of 24 at once
+  auto prefetch = [&](int tl, auto part_) __attribute__((always_inline)) {
+    constexpr int part = decltype(part_)::value;
     if (CH_ABL & 2) return;
     int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
+    for (int j = 0; j < 8; ++j)
+      if (part < 0 || j / 2 == part) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
     const float* xrow = p.x + m * 256 + 8 * g;
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
-      acc[2 * pr] = ld4(xrow + 32 * pr);
-      acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+      if (part < 0 || pr + 4 == part) {
+        acc[2 * pr] = ld4(xrow + 32 * pr);
+        acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+      }
     }
   };
   if (CH_ABL & 2) {
@@ -609,7 +625,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
   }
-  prefetch(0);
+  prefetch(0, std::integral_constant<int, -1>{});
   CH_TOUCH_A(a1);     // (waited for HERE: a load still pending at the loop head would make hipcc drain the stores of every tile there)
   CH_TOUCH_ACC(acc);
   HMA_LDS(char)* ring = lds + lane * 16;
@@ -769,7 +785,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
         if constexpr (s >= S3 && ((s - S3) & 7) == 7) burst_q(std::integral_constant<int, s - S3 - 7>{}, I4{});
       }
       CPROF_MARK(1);
-      if constexpr (s == S3 + 8) prefetch(tl + 1 < nt ? tl + 1 : tl);  // the next tile's rows, sixteen steps before they are used
+      // the next tile's rows (their registers are free from the first qkv step on: x and xm have been stored), a pair of loads per step
+      if constexpr (CH_PF_SPREAD && !SPREAD) {
+        if constexpr (s >= S3 + CH_PF_FIRST && s < S3 + CH_PF_FIRST + 12) prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, s - S3 - CH_PF_FIRST>{});
+      } else if constexpr (s == S3 + 8) {
+        prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, -1>{});
+      }
     });
     CPROF_MARK(3);
     CH_TOUCH_A(a1);
@@ -863,11 +884,33 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
 #pragma unroll
     for (int j = 0; j < 8; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
   };
+  // loads j0 .. j0 + n - 1 of a k-chunk (CH_PF_SPREAD: a row's loads are issued one or two per step in front of their use)
+  auto load_part = [&](int64_t mc, int c, bf16x8_t (&d)[8], auto j0_, auto n_) __attribute__((always_inline)) {
+    constexpr int j0 = decltype(j0_)::value, n = decltype(n_)::value;
+    if (CH_ABL & 2) return;
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(p.dqkv) + mc * p.ldq + 256 * c + 8 * g;
+#pragma unroll
+    for (int j = j0; j < j0 + n; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
+  };
+  auto next_row = [&](int tl) __attribute__((always_inline)) {
+    int64_t m = row0_of(tl + 1 < nt ? tl + 1 : tl) + tok;
+    return m < p.M ? m : p.M - 1;
+  };
   auto prefetch = [&](int tl) __attribute__((always_inline)) {  // the first k-chunk of the next tile's dqkv rows
     int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     load_chunk(m, 0, dq[0]);
   };
+  if ((CH_PF_SPREAD != 0) & ((CH_ABL & 2) != 0)) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dq[c][j] = as_frag(make_uint4(lane, j, c, j));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dxr[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
+  }
   prefetch(0);
   CH_TOUCH_A(dq[0]);
   int slot = 0;
@@ -905,7 +948,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
       store_lines(stg_, ot, Lb, 64 * first, qb[first], qb[first + 1]);
       store_lines(stg_, ot, Lb, 64 * first + 128, qb[first + 2], qb[first + 3]);
     };
-    load_chunk(m, 1, dq[1]);  // this tile's second k-chunk of dqkv
+    if constexpr (!CH_PF_SPREAD) load_chunk(m, 1, dq[1]);  // this tile's second k-chunk of dqkv
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
     static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
@@ -916,8 +959,30 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
       if constexpr (s < 24) {
         // ---- dx2 = dx + dqkv Wqkv (k = 768 in three chunks; chunk c + 1 is requested while chunk c is multiplied)
         constexpr int c = s >> 3, pr = s & 7;
-        if constexpr (s == 8) load_chunk(m, 2, dq[2]);
-        if constexpr (s == 16) {  // the residual gradient itself, added behind the product (eight steps from here)
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if constexpr (CH_PF_SPREAD) {
+          // this tile's k-chunks 1 (used from step 8) and 2 (from 16), the residual gradient's row (step 23) and -- MOD -- the saved
+          // xhat row (step 31): one or two loads per step
+          if constexpr (s < 4) load_part(m, 1, dq[1], std::integral_constant<int, 2 * s>{}, I2{});
+          if constexpr (s >= 4 && s < 12) load_part(m, 2, dq[2], std::integral_constant<int, s - 4>{}, I1{});
+          if constexpr (s >= 8 && s < 16) {
+            if (!(CH_ABL & 2)) {
+              const float* xrow = p.dx + m * 256 + 8 * g;
+              dxr[2 * (s - 8)] = ld4(xrow + 32 * (s - 8));
+              dxr[2 * (s - 8) + 1] = ld4(xrow + 32 * (s - 8) + 4);
+            }
+          }
+          if constexpr (MOD && s >= 16) {
+            if (!(CH_ABL & 2)) {
+              const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
+              xr[s - 16] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * (s - 16)));
+              if constexpr (s == 16) rs = p.rstd[m];
+            }
+          }
+        }
+        if constexpr (s == 8 && !CH_PF_SPREAD) load_chunk(m, 2, dq[2]);
+        if constexpr (s == 16 && !CH_PF_SPREAD) {  // the residual gradient itself, added behind the product (eight steps from here)
           if (!(CH_ABL & 2)) {
             const float* xrow = p.dx + m * 256 + 8 * g;
 #pragma unroll
@@ -946,14 +1011,16 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
         // ---- dxm = bf16(dx2) Wlin (the saved xhat row and 1 / sigma are requested at its first step, eight steps before use)
         constexpr int pr = s - 24;
         if constexpr (s == 24) {
-          if (!(CH_ABL & 2)) {
-            const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
+          if constexpr (!CH_PF_SPREAD) {
+            if (!(CH_ABL & 2)) {
+              const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
-            rs = p.rstd[m];
-          } else {
+              for (int j = 0; j < 8; ++j) xr[j] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * j));
+              rs = p.rstd[m];
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
+              for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
+            }
           }
 #pragma unroll
           for (int t = 0; t < 16; ++t) dm[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
@@ -1028,7 +1095,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
       } else {
         // ---- d_o = bf16(dx1) Wproj
         constexpr int pr = s - S3;
-        if constexpr (s == S3) prefetch(tl + 1 < nt ? tl + 1 : tl);
+        if constexpr (CH_PF_SPREAD) {  // the next tile's first k-chunk, a load per step
+          load_part(next_row(tl), 0, dq[0], std::integral_constant<int, pr>{}, std::integral_constant<int, 1>{});
+        } else if constexpr (s == S3) {
+          prefetch(tl + 1 < nt ? tl + 1 : tl);
+        }
         f32x4v_t c0 = f32x4v_t{0.f, 0.f, 0.f, 0.f}, c1 = f32x4v_t{0.f, 0.f, 0.f, 0.f};
         nb_mma(wb, a2, c0, c1);
         step_end(stg_);
@@ -1133,18 +1204,22 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
   uint4 qb[8];
-  auto prefetch = [&](int tl) __attribute__((always_inline)) {
+  auto prefetch = [&](int tl, auto part_) __attribute__((always_inline)) {  // (part < 0: all 24 loads; 0..11: a pair)
+    constexpr int part = decltype(part_)::value;
     if (CH_ABL & 2) return;
     int64_t m = row0_of(tl) + tok;
     m = m < p.M ? m : p.M - 1;
     const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
+    for (int j = 0; j < 8; ++j)
+      if (part < 0 || j / 2 == part) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
     const float* xrow = p.x + m * 256 + 8 * g;
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
-      acc[2 * pr] = ld4(xrow + 32 * pr);
-      acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+      if (part < 0 || pr + 4 == part) {
+        acc[2 * pr] = ld4(xrow + 32 * pr);
+        acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+      }
     }
   };
   if (CH_ABL & 2) {
@@ -1153,7 +1228,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
   }
-  prefetch(0);
+  prefetch(0, std::integral_constant<int, -1>{});
   CH_TOUCH_A(a1);
   CH_TOUCH_ACC(acc);
   HMA_LDS(char)* ring = lds + lane * 16;
@@ -1314,12 +1389,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
               store_lines<false>(stg_, xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
             }
             if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, r0);  // the next block's norm1 (affine folded into its qkv weights / bias)
-            prefetch(tl + 1 < nt ? tl + 1 : tl);
+            if constexpr (!(QKV && CH_PF_SPREAD)) prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, -1>{});
           }
         }
       } else {
-        // ---- the next block's spatial qkv
+        // ---- the next block's spatial qkv (the next tile's rows are requested a pair per step beside it)
         constexpr int pq = s - SQ;
+        if constexpr (CH_PF_SPREAD && pq >= 2 && pq < 14) prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, pq - 2>{});
         f32x4v_t c0 = lds_f4v(bias + 6144 + 128 * pq), c1 = lds_f4v(bias + 6144 + 128 * pq + 16);
         nb_mma(wb, a0, c0, c1);
         step_end(stg_);
