@@ -573,7 +573,7 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
       // ---- the two dQ waves: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], wave TW + (qt & 1), while the
       // tile waves work on query tile qt + 1 (which goes to the other dS buffer)
 #ifdef ATTN_FETCH_SPREAD
-#pragma unroll   // (static steps: a load that is pending at a loop head makes hipcc drain the memory queue there)
+#pragma unroll 1
 #else
 #pragma unroll 1
 #endif
@@ -623,11 +623,7 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
         vf[t][0] = frag_rows(Vs, kt * 32, 0, lane); vf[t][1] = frag_rows(Vs, kt * 32, 1, lane);
         dk[t] = zero16(); dv[t] = zero16();
       }
-#ifdef ATTN_FETCH_SPREAD
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
       for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
         // S[q][key], dP[q][key]: lane = key, rows = q.  The query tile's fragments serve every key tile of the wave.
 #ifdef ATTN_FETCH_SPREAD

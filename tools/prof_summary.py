@@ -44,6 +44,8 @@ if summary and mode in ("decode", "mar") and "fetch" in summary and "write" in s
 if summary:
     json.dump(summary, open(os.path.join(out, f"pmc_{tag}.json"), "w"), indent=1)
     for kind, d in summary.items():
+        if kind == "summary":
+            continue
         top = sorted(d.items(), key=lambda kv: -kv[1]["counter_sum_kb"])[:8]
         for k, v in top:
             print(f"{kind:6s} {v['counter_sum_kb']/max(v['launches'],1)/1024:10.1f} MB/launch (raw counter, KB units) x {v['launches']:5d}  {k[:80]}")
