@@ -1494,6 +1494,12 @@ constexpr int DM_STAGE_BYTES = 2 * DM_TILE_BYTES;
 #ifndef DM_STAGES_N
 #define DM_STAGES_N 4
 #endif
+#ifndef TN_PHASE
+#define TN_PHASE 1
+#endif
+#ifndef TN_INTERLEAVE
+#define TN_INTERLEAVE 0
+#endif
 constexpr int DM_STAGES = DM_STAGES_N;  // 4 x 32 KB (5 slots, the whole LDS, measured the same)
 constexpr int DM_SMEM_BYTES = DM_STAGES * DM_STAGE_BYTES;
 
@@ -1552,7 +1558,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
   int64_t m_end = m_begin + per * 64;
   if (m_end > p.M) m_end = p.M;
   if (m_begin >= m_end) return;
+#if TN_INTERLEAVE
+  // split s takes the 32-row stages s, s + splits, s + 2 splits, ...: at any moment the workgroups of a problem read ONE
+  // moving window of splits x 32 consecutive rows (whole DRAM pages, every channel) instead of `splits` streams that sit
+  // a fixed power-of-two-ish distance apart (163 840 rows / 32 splits = 10 MB of a 1024-wide operand)
+  const int64_t nstages = p.M / DM_ROWS;
+  const int nst = (int)((nstages - split + p.splits - 1) / p.splits);
+  const int64_t st_row0 = (int64_t)split * DM_ROWS, st_pitch = (int64_t)p.splits * DM_ROWS;
+#else
   const int nst = (int)((m_end - m_begin) / DM_ROWS);  // host guarantees M % 32 == 0
+  const int64_t st_row0 = m_begin, st_pitch = DM_ROWS;
+#endif
 
   const uint16_t* Yb = reinterpret_cast<const uint16_t*>(p.dY) + bz * p.sY + n0;
   const uint16_t* Ab = reinterpret_cast<const uint16_t*>(p.A) + bz * p.sA + k0;
@@ -1570,7 +1586,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
   // wave w fills rows 4 w .. 4 w + 3 of both tiles of a stage: two 1 KB pieces (two rows each) per tile
   auto issue = [&](int st, int slot) __attribute__((always_inline)) {
     if (ablate & 1) return;
-    const int64_t m0 = m_begin + (int64_t)st * DM_ROWS;
+    const int64_t m0 = st_row0 + (int64_t)st * st_pitch;
     const uint32_t slot_b = lds_b + slot * DM_STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1625,23 +1641,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     HMA_LDS(char)* Ys = lds + slot * DM_STAGE_BYTES;
     HMA_LDS(char)* As = Ys + DM_TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.y[i] = frag(Ys, wn2 * 128 + i * 32, kk);
+    for (int i = 0; i < 4; ++i) f.y[i] = frag(Ys, wn2 * 128 + ((i + wk4) & 3) * 32, kk);  // y[i] = n-block (i + wk4) & 3
 #pragma unroll
     for (int j = 0; j < 2; ++j) f.a[j] = frag(As, wk4 * 64 + j * 32, kk);
   };
   auto mma = [&](const Frags& f) __attribute__((always_inline)) {
     if (COLSUM) {
-      // the four waves of a wn2 half hold the same dY fragments: wave wk4 sums fragment wk4 (columns 32 wk4 + r)
-      uint4 ys = __builtin_bit_cast(uint4, f.y[0]);
-#pragma unroll
-      for (int i = 1; i < 4; ++i) {
-        const uint4 yi = __builtin_bit_cast(uint4, f.y[i]);
-        ys.x = wk4 == i ? yi.x : ys.x; ys.y = wk4 == i ? yi.y : ys.y;
-        ys.z = wk4 == i ? yi.z : ys.z; ys.w = wk4 == i ? yi.w : ys.w;
-      }
-      float v[8];
-      unpack8(ys, v);
-      colsum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      // the four waves of a wn2 half hold the same dY fragments: wave wk4 sums the n-block wk4, which the rotated fragment
+      // order (read_frags) puts in y[0] -- four v_dot2_f32_bf16 against (1, 1) per fragment (the select + unpack + add
+      // version was 28 VALU operations per eight MFMAs: 10 % of the MLP pair's time)
+      const uint4 ys = __builtin_bit_cast(uint4, f.y[0]);
+      const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.x), ones, colsum, false);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.y), ones, colsum, false);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.z), ones, colsum, false);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.w), ones, colsum, false);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1675,6 +1689,50 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     if (st < nst) issue(st, st);
   Frags f0, f1;
   int slot = 0;
+#if TN_PHASE
+  // The two waves of a SIMD (w and w + 4: the two wn2 halves) run a stage in opposite order: the first reads its fragments and
+  // then multiplies; the second multiplies the PREVIOUS stage's fragments (still in its registers) and then reads this
+  // stage's -- so one wave's LDS reads sit under the other's MFMAs instead of all eight waves reading, then all eight
+  // multiplying.  The lagging half finishes its reads before the next barrier (the slot is refilled behind it).
+  if (wn2 == 0) {
+    for (int st = 0; st < nst; ++st) {
+      wait_stage(st, DM_STAGES - 2);
+      if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
+#if TN_PHASE == 2
+      if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
+#endif
+      read_frags(f0, slot, 0);
+      read_frags(f1, slot, 1);
+      mma(f0);
+#if TN_PHASE != 2
+      if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
+#endif
+      mma(f1);
+      slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
+    }
+  } else {
+    wait_stage(0, DM_STAGES - 2);
+    if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
+    if (DM_STAGES - 1 < nst) issue(DM_STAGES - 1, DM_STAGES - 1);
+    read_frags(f0, 0, 0);
+    read_frags(f1, 0, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot = 1;
+    for (int st = 1; st < nst; ++st) {
+      wait_stage(st, DM_STAGES - 2);
+      if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
+      mma(f0);
+      mma(f1);
+      if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
+      read_frags(f0, slot, 0);
+      read_frags(f1, slot, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
+    }
+    mma(f0);
+    mma(f1);
+  }
+#else
   for (int st = 0; st < nst; ++st) {
     wait_stage(st, DM_STAGES - 2);
     // every wave's pieces of stage st are in LDS, and every wave is done reading stage st - 1 (its slot is refilled next)
@@ -1687,6 +1745,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     mma(f1);
     slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
   }
+#endif
   // bf16 partial of this workgroup's 256 x 256 block, in the order the accumulators sit in the waves: piece
   // ((wave * 8 + i * 2 + j) * 2 + h) * 64 + lane is the lane's 8 values e = 8 h .. 8 h + 7 of acc[i][j], i.e. row
   // n = 128 wn2 + 32 i + r, columns k = 64 wk4 + 32 j + 16 h + 4 hi + {0..3} and the same + 8 (tn_reduce_native_kernel
@@ -1703,7 +1762,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
           const f32x16_t& v = acc[i][j];
           const uint4 o = make_uint4(pack_bf16(v[8 * h], v[8 * h + 1]), pack_bf16(v[8 * h + 2], v[8 * h + 3]),
                                      pack_bf16(v[8 * h + 4], v[8 * h + 5]), pack_bf16(v[8 * h + 6], v[8 * h + 7]));
-          *reinterpret_cast<uint4*>(part + ((((wave * 8 + i * 2 + j) * 2 + h) * 64 + lane) << 3)) = o;
+          *reinterpret_cast<uint4*>(part + ((((wave * 8 + ((i + wk4) & 3) * 2 + j) * 2 + h) * 64 + lane) << 3)) = o;
         }
   if (COLSUM && k0 == 0 && p.colsum) {
     colsum += __shfl_xor(colsum, 32);

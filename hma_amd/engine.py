@@ -794,7 +794,8 @@ class STEngine:
         return pl
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
-        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group)
+        key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group,
+               int(self.fork_wgrad))
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -825,7 +826,9 @@ class STEngine:
         if use_mod and self._use_chain(M, SA):
             pl.add("hma_zero_f32", ws["dss"].data_ptr(), ws["dss"].numel())  # the backward chains add the frames' sums with atomics
         ada_g, ada_hi = max(1, min(int(self.ada_group), L)), L
+        pl.dxb_in = {}  # layer -> the bf16(dx) buffer its backward reads first (an entry into the middle of the plan must fill it)
         for l in reversed(range(L)):
+            pl.dxb_in[l] = dxb
             xh1, rstd1 = dp(ws["xh1"], l, M * 256), dp(ws["rstd1"], l, M)
             qkv_s, o_s, lse_s = dp(ws["qkv_s"], l, M * 768), dp(ws["o_s"], l, M * 256), dp(ws["lse_s"], l, M * 8)
             x2b = dp(ws["x2b"], l, M * 256)
@@ -1127,6 +1130,70 @@ class STEngine:
         pl.run(stream, pl.marks["post_embed"], None, timer=self.timer)
         if on_segment is not None and segment_layers > 0:
             on_segment("end")
+
+    # ------------------------------------------------------------------------------ blocks under autograd (STBlock / STTransformerDecoder)
+    def trunk_autograd_forward(self, x_BTSD: torch.Tensor, a_emb: Optional[torch.Tensor], domain: Optional[str], l0: int = 0,
+                               l1: Optional[int] = None) -> Tuple[torch.Tensor, tuple]:
+        """Layers [l0, l1) on a given residual stream with every activation saved (st_transformer.py:79-114, 172-177 as autograd
+        modules).  Returns the new stream and a stamp `trunk_autograd_backward` checks: the saved activations of a layer belong to
+        its LAST forward."""
+        B, T, SA, D = x_BTSD.shape
+        L = self.cfg.num_layers
+        l1 = L if l1 is None else l1
+        A = self.cfg.action_token_size if a_emb is not None else 0
+        S = SA - A
+        if a_emb is not None and not self.modulate:
+            raise NotImplementedError("only the 'modulate' action projector is built")
+        if T > 16:
+            raise NotImplementedError("temporal attention kernel handles T <= 16 frames")
+        dom = domain if A > 0 else None
+        ws = self._workspace(B, T, S, A, True)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh_weights(dom, stream)
+        ws["x"].view(B, T, SA, D).copy_(x_BTSD, non_blocking=True)
+        if A > 0:
+            ws["a_emb"].view(B, T, D).copy_(a_emb[:, :T], non_blocking=True)
+        self.bump_dropout()
+        self._forward_plan(B, T, S, A, True, dom, embed=False, l0=l0, l1=l1, readout=False).run(stream, timer=self.timer)
+        self._last = (B, T, S, A, dom)
+        stamps = getattr(self, "_trunk_stamps", None)
+        if stamps is None or len(stamps) != L:
+            stamps = self._trunk_stamps = [0] * L
+        self._trunk_counter = getattr(self, "_trunk_counter", 0) + 1
+        for l in range(l0, l1):
+            stamps[l] = self._trunk_counter
+        return ws["x"].view(B, T, SA, D).clone(), (B, T, S, A, dom, l0, l1, self.ws_generation, self._trunk_counter)
+
+    def trunk_autograd_backward(self, dy_BTSD: torch.Tensor, stamp: tuple) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """d loss / d (stream out) -> (d loss / d (stream in), d loss / d a_emb); the layers' weight gradients are ADDED into the flat
+        gradient buffer.  Runs the layers' part of the recorded backward plan (no forked weight gradients, one adaLN group per layer:
+        a range of layers is then a contiguous run of the plan)."""
+        B, T, S, A, dom, l0, l1, gen, count = stamp
+        L = self.cfg.num_layers
+        if gen != self.ws_generation or any(self._trunk_stamps[l] != count for l in range(l0, l1)):
+            raise RuntimeError("the saved activations of these layers were overwritten by a later forward (the engine keeps ONE set "
+                               "per layer): run backward before the next forward through the same layers")
+        ws = self._ws
+        SA, M, Fr = S + A, B * T * (S + A), B * T
+        stream = torch.cuda.current_stream().cuda_stream
+        saved = (self.fork_wgrad, self.ada_group)
+        self.fork_wgrad, self.ada_group = 0, 1
+        try:
+            pl = self._backward_plan(B, T, S, A, dom)
+        finally:
+            self.fork_wgrad, self.ada_group = saved
+        ws["dx"].view(B, T, SA, 256).copy_(dy_BTSD, non_blocking=True)
+        if A > 0:
+            ws["da_emb"].zero_()
+        if l1 == L:
+            start = pl.marks["post_readout"]
+        else:
+            start = pl.marks[f"layer{l1}"]
+            _lib.call("hma_cast_bf16", stream, ws["dx"].data_ptr(), pl.dxb_in[l1 - 1], M * 256)
+            if "dss" in ws:
+                ws["dss"].zero_()
+        pl.run(stream, start, pl.marks[f"layer{l0}"], timer=self.timer)
+        return ws["dx"].view(B, T, SA, 256).clone(), (ws["da_emb"].view(B, T, 256).clone() if A > 0 else None)
 
     def run_trunk(self, x_BTSD: torch.Tensor, a_emb: Optional[torch.Tensor], domain: Optional[str], l0: int = 0,
                   l1: Optional[int] = None) -> torch.Tensor:

@@ -403,6 +403,26 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
                 if eng.layout.entries[name].region in active:
                     p.grad = eng.view(name, eng.G)
 
+    def _trunk_grads_begin(self) -> None:
+        """Before a block-level autograd backward (st_transformer._TrunkFn): the flat gradient buffer starts from zero unless this
+        model's `.grad`s are already live views of it (gradient accumulation, or an earlier block of the same autograd pass)."""
+        if not self._grads_live or all(p.grad is None for p in self.parameters()):
+            self._engine.zero_grad()
+            self._grads_live = True
+
+    def _trunk_grads_publish(self, stamp) -> None:
+        """Point `.grad` of the parameters of layers [l0, l1) (the action projectors of the step's domain only) at their views of
+        the gradient buffer."""
+        eng = self._engine
+        dom, l0, l1 = stamp[4], stamp[5], stamp[6]
+        with torch.no_grad():
+            for l in range(l0, l1):
+                pre = f"decoder.layers.{l}."
+                for name, p in self.decoder.layers[l].named_parameters():
+                    if ".action_projectors." in "." + name and (dom is None or f"action_projectors.{dom}." not in name):
+                        continue
+                    p.grad = eng.view(pre + name, eng.G)
+
     def _save_pretrained(self, save_directory) -> None:
         """model.safetensors with the reference's tensor names (the views share one flat storage, which
         safetensors' save_model would treat as aliased tensors, so they are cloned out first)."""

@@ -1,6 +1,6 @@
 """ST-transformer trunk modules with the reference's names, constructor arguments and state-dict
 (hma/model/st_transformer.py:9-177).  They hold parameters; arithmetic runs in the HIP kernels.
-`STTransformerDecoder.forward` / `STBlock.forward` execute through the owning STMaskGIT's engine."""
+`STTransformerDecoder.forward` / `STBlock.forward` execute through the owning STMaskGIT's engine, with or without autograd."""
 from __future__ import annotations
 
 import weakref
@@ -50,15 +50,47 @@ class Mlp(nn.Module):
 
 
 
-def _refuse_autograd(what: str, x: torch.Tensor, module: nn.Module) -> None:
-    """The blocks run through the owning model's engine (recorded launch plans, no autograd graph).  A caller that would get no
-    gradients is told so instead of training on zeros."""
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
-        raise RuntimeError(
-            f"{what}.forward carries no autograd graph: train through STMaskGIT / STMAR.forward with hma_amd.train.Trainer / "
-            "MarTrainer (the engine's own backward), or call it under torch.no_grad() for inference.  SelfAttention and Mlp "
-            "do run under autograd (torch.ops.hma.*).")
+def _wants_grad(x: torch.Tensor, a: Optional[torch.Tensor], module: nn.Module) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or (a is not None and a.requires_grad) or
+                                        any(p.requires_grad for p in module.parameters()))
 
+
+class _TrunkFn(torch.autograd.Function):
+    """Layers [l0, l1) of the decoder as ONE autograd node over the engine's recorded forward / backward plans
+    (st_transformer.py:79-114, 172-177 are ordinary autograd modules).  Inputs: the residual stream, the embedded actions
+    (or None) and the owner's anchor (so the node runs when only parameters require a gradient).  The layers' weight gradients
+    do not travel through autograd: the backward ADDS them into the engine's flat gradient buffer and points the parameters'
+    `.grad` at their views of it, as `loss.backward()` of STMaskGIT.forward does."""
+
+    @staticmethod
+    def forward(ctx, x, a_emb, anchor, owner, domain, l0, l1):
+        eng = owner._get_engine(x.device)
+        y, stamp = eng.trunk_autograd_forward(x.detach().float(), None if a_emb is None else a_emb.detach().float(), domain, l0, l1)
+        ctx.owner, ctx.stamp = owner, stamp
+        ctx.x_dtype, ctx.a_dtype = x.dtype, (None if a_emb is None else a_emb.dtype)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        owner = ctx.owner
+        eng = owner._engine
+        if eng is None:
+            raise RuntimeError("the model's engine was rebuilt between forward and backward")
+        owner._trunk_grads_begin()
+        dx, da = eng.trunk_autograd_backward(dy.detach().float().contiguous(), ctx.stamp)
+        owner._trunk_grads_publish(ctx.stamp)
+        return (dx.to(ctx.x_dtype) if ctx.needs_input_grad[0] else None,
+                da.to(ctx.a_dtype) if (da is not None and ctx.needs_input_grad[1]) else None, None, None, None, None, None)
+
+
+def _trunk_autograd(owner, module: nn.Module, x: torch.Tensor, a_emb: Optional[torch.Tensor], domain, l0: int, l1: int):
+    cfg = owner.config
+    if (not module.training) and float(getattr(cfg, "mlp_drop", 0.0) or 0.0) > 0.0:
+        raise NotImplementedError("gradients through the blocks in eval() mode with mlp_drop > 0 (the saved-activation plans apply the "
+                                  "Dropout): call .train(), or run under torch.no_grad()")
+    if owner._anchor is None or owner._anchor.device != x.device:
+        owner._get_engine(x.device)
+    return _TrunkFn.apply(x, a_emb, owner._anchor, owner, domain, l0, l1)
 
 class STBlock(nn.Module):
     def __init__(self, num_heads: int, d_model: int, qkv_bias: bool = False, proj_bias: bool = True, qk_norm: bool = True,
@@ -80,8 +112,15 @@ class STBlock(nn.Module):
         self._index = -1
 
     def forward(self, x_TSC: torch.Tensor, action_ids: Optional[torch.Tensor] = None, domain=None) -> torch.Tensor:
-        """(B, T, S, C) -> same (st_transformer.py:79-114).  `action_ids` is the (B, T, C) action embedding.  Inference only."""
-        _refuse_autograd("STBlock", x_TSC, self)
+        """(B, T, S, C) -> same (st_transformer.py:79-114).  `action_ids` is the (B, T, C) action embedding.  With autograd on and
+        anything that requires a gradient in reach, the block runs as one autograd node (`_TrunkFn`): x and action_ids get their
+        gradients through autograd, the block's parameters through `.grad` views of the engine's gradient buffer."""
+        use = action_ids is not None and domain is not None and self.action_projectors is not None
+        if _wants_grad(x_TSC, action_ids if use else None, self):
+            owner = self._owner() if self._owner is not None else None
+            if owner is None:
+                raise RuntimeError("STBlock runs through its STMaskGIT's engine; construct it via STMaskGIT")
+            return _trunk_autograd(owner, self, x_TSC, action_ids if use else None, domain if use else None, self._index, self._index + 1)
         with torch.no_grad():
             return self._forward_inference(x_TSC, action_ids, domain)
 
@@ -126,8 +165,13 @@ class STTransformerDecoder(nn.Module):
             layer._index = i
 
     def forward(self, tgt: torch.Tensor, action_ids: Optional[torch.Tensor] = None, domain="") -> torch.Tensor:
-        """N x STBlock (st_transformer.py:172-177).  Inference only: see `_refuse_autograd`."""
-        _refuse_autograd("STTransformerDecoder", tgt, self)
+        """N x STBlock (st_transformer.py:172-177); under autograd the whole stack is one node (see STBlock.forward)."""
+        use = action_ids is not None and bool(domain) and self.layers[0].action_projectors is not None
+        if _wants_grad(tgt, action_ids if use else None, self):
+            owner = self._owner() if self._owner is not None else None
+            if owner is None:
+                raise RuntimeError("STTransformerDecoder runs through its STMaskGIT's engine; construct it via STMaskGIT")
+            return _trunk_autograd(owner, self, tgt, action_ids if use else None, domain if use else None, 0, len(self.layers))
         with torch.no_grad():
             return self._forward_inference(tgt, action_ids, domain)
 

@@ -141,7 +141,7 @@ def test_stblock_and_decoder_forward():
     g = golden("g5_stblock")
     m = build_model(train=False)
     x, a = g["x"].to(DEV), g["a_emb"].to(DEV)
-    with torch.no_grad():  # (engine-backed blocks are inference-only: with autograd on they raise, tests/test_torch_ops.py)
+    with torch.no_grad():  # (the same modules under autograd: tests/test_torch_ops.py::test_blocks_train_under_autograd)
         y = m.decoder.layers[0](x, action_ids=a, domain="domA")
         assert rel_err(y[:, :, ::8], g["y_layer0_domA"]) <= 1e-2
         y = m.decoder.layers[0](x[:, :, :256].contiguous(), action_ids=None, domain=None)

@@ -26,8 +26,9 @@ def run(name, N, K, bias, affine):
         ops.linear_wgrad(dys[i % NB], xs[i % NB], dW, db, gamma=g, beta=b, ws=WS)
     for i in range(3): fn(i)
     torch.cuda.synchronize()
-    reps = 18
+    reps = int(os.environ.get("TN_REPS", 18))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if reps > 1000: print('START', flush=True)
     e0.record()
     for i in range(reps): fn(i)
     e1.record(); torch.cuda.synchronize()
