@@ -461,6 +461,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #ifndef ATTN_ABL  // debug builds (timing only, results wrong): 1 no lse / delta reads, 2 no dQ job, 4 no exponentials, 8 no dS tile writes, 32 no compute at all (staging + stores), 64 no row loads after the first item, 128 no dqkv stores
 #define ATTN_ABL 0
 #endif
+// ---- LDS image of the fused backward's tiles (ATTN_SWZ, default): UNPADDED 64-byte rows, the 16-byte chunk c of row r stored at
+// chunk c ^ ((r >> 2) & 3).  With the padded rows of the other kernels (LDR = 40: 20 dwords) the transposing reads of a 32-lane pass
+// -- four consecutive rows, all 64 bytes of each -- wrap around the 64 banks (rows r and r + 3 share 12 of them: 2-way conflicts,
+// 34 % of this kernel's LDS cycles in profiles/pmc_sq_r4.txt); with 16-dword rows the four rows of a pass tile the banks exactly, and
+// the XOR keeps the row-major 16-byte reads of a 16-lane pass (16 consecutive rows, one chunk) and the staging writes (4 rows x 4
+// chunks) conflict-free as well.
+#ifndef ATTN_SWZ
+#define ATTN_SWZ 0
+#endif
+constexpr int LDF = ATTN_SWZ ? 32 : LDR;
+__device__ __forceinline__ int foff(int row, int chunk) {  // element offset of the 16-byte chunk `chunk` of row `row`
+  return ATTN_SWZ ? row * LDF + ((chunk ^ ((row >> 2) & 3)) << 3) : row * LDF + (chunk << 3);
+}
+__device__ __forceinline__ bf16x8_t frag_rows_f(const uint16_t* tile, int row0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(&tile[foff(row0 + (lane & 31), 2 * s + (lane >> 5))]);
+}
+__device__ __forceinline__ bf16x8_t frag_tr_f(const uint16_t* tile, int row0, int lane) {
+  const int i16 = lane & 15, g16 = lane >> 4;
+  const int row = row0 + 4 * (g16 >> 1) + (i16 >> 2);
+  const int chunk = 2 * (g16 & 1) + ((i16 & 3) >> 1), inner = 4 * (i16 & 1);
+  const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + foff(row, chunk) + inner));
+  const v4s16_t hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + foff(row + 8, chunk) + inner));
+  typedef short v8s16_t __attribute__((ext_vector_type(8)));
+  const v8s16_t v = __builtin_shufflevector(lo, hv, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // LDS-only barrier: waits for this wave's LDS operations, not for its global loads (the next item's rows stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -506,7 +533,7 @@ struct FusedStage {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int c = min(tid + i * THREADS, ITEMS - 1);
-      const int off = (c >> 2) * LDR + (c & 3) * 8;
+      const int off = foff(c >> 2, c & 3);
       *reinterpret_cast<uint4*>(&Qs[off]) = get(rq, i);
       *reinterpret_cast<uint4*>(&Ks[off]) = get(rk, i);
       *reinterpret_cast<uint4*>(&Vs[off]) = get(rv, i);
@@ -543,12 +570,12 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
   constexpr int TW = NT / KT;   // tile waves; waves TW, TW + 1 are the dQ waves
   constexpr int N = NT * 32;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  uint16_t* Qs = smem;                 // [N][LDR]
-  uint16_t* Ks = Qs + N * LDR;
-  uint16_t* Vs = Ks + N * LDR;
-  uint16_t* Gs = Vs + N * LDR;         // dO
-  uint16_t* Ts = Gs + N * LDR;         // 2 x [N keys][LDR]: dS of one query tile, [key][query]
-  float* L2s = reinterpret_cast<float*>(Ts + 2 * N * LDR);  // [N]
+  uint16_t* Qs = smem;                 // [N][LDF]
+  uint16_t* Ks = Qs + N * LDF;
+  uint16_t* Vs = Ks + N * LDF;
+  uint16_t* Gs = Vs + N * LDF;         // dO
+  uint16_t* Ts = Gs + N * LDF;         // 2 x [N keys][LDR]: dS of one query tile, [key][query]
+  float* L2s = reinterpret_cast<float*>(Ts + 2 * N * LDF);  // [N]
   float* Dls = L2s + N;                                      // [N]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -583,21 +610,21 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
 #endif
         lds_barrier();
         if ((qt & 1) == wave - TW && !(ATTN_ABL & 2)) {
-          const uint16_t* Tq = Ts + (qt & 1) * N * LDR;
+          const uint16_t* Tq = Ts + (qt & 1) * N * LDF;
           f32x16_t a0 = zero16(), a1 = zero16();
           // 2 NT k-steps of 16 keys in groups of 4, the next group's transposing reads in flight behind this group's MFMAs (one read
           // -> MFMA round trip per k-step made the job longer than the tile waves' step, and they wait for it at the next barrier)
           static_assert((2 * NT) % 4 == 0, "groups of four k-steps");
           bf16x8_t fa[4], fb[4], na[4], nb[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { fa[i] = frag_tr(Ks, LDR, 16 * i, lane); fb[i] = frag_tr(Tq, LDR, 16 * i, lane); }
+          for (int i = 0; i < 4; ++i) { fa[i] = frag_tr_f(Ks, 16 * i, lane); fb[i] = frag_tr_f(Tq, 16 * i, lane); }
 #pragma unroll
           for (int grp = 0; grp < NT / 2; ++grp) {
             if (grp + 1 < NT / 2) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                na[i] = frag_tr(Ks, LDR, 16 * (4 * grp + 4 + i), lane);
-                nb[i] = frag_tr(Tq, LDR, 16 * (4 * grp + 4 + i), lane);
+                na[i] = frag_tr_f(Ks, 16 * (4 * grp + 4 + i), lane);
+                nb[i] = frag_tr_f(Tq, 16 * (4 * grp + 4 + i), lane);
               }
             }
             a0 = mfma32(fa[0], fb[0], a0);
@@ -619,8 +646,8 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         const int kt = wave * KT + t;
-        kf[t][0] = frag_rows(Ks, kt * 32, 0, lane); kf[t][1] = frag_rows(Ks, kt * 32, 1, lane);
-        vf[t][0] = frag_rows(Vs, kt * 32, 0, lane); vf[t][1] = frag_rows(Vs, kt * 32, 1, lane);
+        kf[t][0] = frag_rows_f(Ks, kt * 32, 0, lane); kf[t][1] = frag_rows_f(Ks, kt * 32, 1, lane);
+        vf[t][0] = frag_rows_f(Vs, kt * 32, 0, lane); vf[t][1] = frag_rows_f(Vs, kt * 32, 1, lane);
         dk[t] = zero16(); dv[t] = zero16();
       }
 #pragma unroll 1
@@ -629,17 +656,17 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
 #ifdef ATTN_FETCH_SPREAD
         if (do_fetch && qt % ATTN_FETCH_SPREAD == 0 && qt / ATTN_FETCH_SPREAD < FusedStage<NT, KT>::R) st.fetch(qkv, o, d_o, lse, nxt, frames, tid, qt / ATTN_FETCH_SPREAD);
 #endif
-        const bf16x8_t aq0 = frag_rows(Qs, qt * 32, 0, lane), aq1 = frag_rows(Qs, qt * 32, 1, lane);
-        const bf16x8_t ag0 = frag_rows(Gs, qt * 32, 0, lane), ag1 = frag_rows(Gs, qt * 32, 1, lane);
+        const bf16x8_t aq0 = frag_rows_f(Qs, qt * 32, 0, lane), aq1 = frag_rows_f(Qs, qt * 32, 1, lane);
+        const bf16x8_t ag0 = frag_rows_f(Gs, qt * 32, 0, lane), ag1 = frag_rows_f(Gs, qt * 32, 1, lane);
         f32x16_t sc[KT], dp[KT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
 #ifndef ATTN_KV_REGS  // (the K / V fragments are re-read from LDS every step: 16 registers per key tile would spill -- 376 us against 345)
           const int kt = wave * KT + t;
-          sc[t] = mfma32(aq0, frag_rows(Ks, kt * 32, 0, lane), zero16());
-          sc[t] = mfma32(aq1, frag_rows(Ks, kt * 32, 1, lane), sc[t]);
-          dp[t] = mfma32(ag0, frag_rows(Vs, kt * 32, 0, lane), zero16());
-          dp[t] = mfma32(ag1, frag_rows(Vs, kt * 32, 1, lane), dp[t]);
+          sc[t] = mfma32(aq0, frag_rows_f(Ks, kt * 32, 0, lane), zero16());
+          sc[t] = mfma32(aq1, frag_rows_f(Ks, kt * 32, 1, lane), sc[t]);
+          dp[t] = mfma32(ag0, frag_rows_f(Vs, kt * 32, 0, lane), zero16());
+          dp[t] = mfma32(ag1, frag_rows_f(Vs, kt * 32, 1, lane), dp[t]);
 #else
           sc[t] = mfma32(aq0, kf[t][0], zero16());
           sc[t] = mfma32(aq1, kf[t][1], sc[t]);
@@ -666,8 +693,8 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
             }
             // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
             if (!(ATTN_ABL & 8)) {
-              uint16_t* T = Ts + (qt & 1) * N * LDR + ((wave * KT + t) * 32 + (lane & 31)) * LDR;
-              *reinterpret_cast<uint2*>(T + 8 * g + 4 * hi) =
+              uint16_t* T = Ts + (qt & 1) * N * LDF + foff((wave * KT + t) * 32 + (lane & 31), g);
+              *reinterpret_cast<uint2*>(T + 4 * hi) =
                   make_uint2(pack_bf16(dp[t][4 * g], dp[t][4 * g + 1]), pack_bf16(dp[t][4 * g + 2], dp[t][4 * g + 3]));
             }
           }
@@ -677,7 +704,7 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
         lds_barrier();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8_t gt = frag_tr(Gs, LDR, qt * 32 + 16 * s2, lane), qtr = frag_tr(Qs, LDR, qt * 32 + 16 * s2, lane);
+          const bf16x8_t gt = frag_tr_f(Gs, qt * 32 + 16 * s2, lane), qtr = frag_tr_f(Qs, qt * 32 + 16 * s2, lane);
 #pragma unroll
           for (int t = 0; t < KT; ++t) {
             dv[t] = mfma32(gt, pack_acc_half(sc[t], s2), dv[t]);
@@ -742,7 +769,7 @@ int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* 
                      int64_t frames, float scale) {
   constexpr int N = NT * 32;
   constexpr int KT = (NT >= 8 && NT % ATTN_KT == 0) ? ATTN_KT : 1;
-  constexpr int bytes = 6 * N * LDR * 2 + 2 * N * 4;
+  constexpr int bytes = 6 * N * LDF * 2 + 2 * N * 4;
   int rc = set_lds<attn_bwd_fused_kernel<NT, KT>>(bytes);
   if (rc) return rc;
   const int64_t items = frames * NH;

@@ -92,9 +92,15 @@ class Plan:
             self.side[len(self.calls)] = True
         self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._tn_bytes(g))
 
+    unpair_mlp = bool(os.environ.get("HMA_UNPAIR_MLP"))  # measurement switch: the MLP's two weight gradients as two launches
+
     def gemm_tn_pair(self, kw0: dict, kw1: dict, side: bool = False) -> None:
         """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair).  `side`: on the side
         stream (nothing on the caller's stream depends on it until the next `join_next()` call or the end of the run)."""
+        if Plan.unpair_mlp and 1024 in (kw0.get("K"), kw1.get("N")):
+            self.gemm_tn(side=side, **kw0)
+            self.gemm_tn(side=side, **kw1)
+            return
         gs = []
         wsb = self.tn_workspace_side if (side and self.tn_workspace_side is not None) else self.tn_workspace
         side = side and self.tn_workspace_side is not None

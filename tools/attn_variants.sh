@@ -6,7 +6,7 @@ mode=$1; shift
 if [ "$mode" = build ]; then
   mkdir -p variants
   rm -f variants/libhma_at_*.so
-  OBJS=$(ls hma_amd/build/*.o | grep -v -E "/attn_spatial.o")
+  OBJS=$(ls hma_amd/build/*.o | grep -v -E "/attn_spatial.o|/gemm_[a-z0-9_]+.o")
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment $flags -c hma_amd/csrc/attn_spatial.hip -o variants/attn_$name.o 2>&1 | grep -E "error" ;
