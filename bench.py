@@ -458,23 +458,35 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # HMA_FORCE_COLLECTIVES=1 (debug): a process group -- and with it the reducer's RCCL all-reduces on the side stream between the
+    # per-bucket graphs -- also at one rank, so a one-GPU box executes the N > 1 code path with the real backend
+    force = os.environ.get("HMA_FORCE_COLLECTIVES") == "1"
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if one_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
-    backend = (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else "")) if world > 1 else None
+    backend = (dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else "")) if (world > 1 or force) else None
 
+    if args.mode in ("decode", "mar") and world > 1:
+        raise SystemExit(f"--mode {args.mode} is a one-GPU leg (BASELINE configs[3] / configs[4]); run it with --gpus 1")
     if args.mode == "decode":
         if rank == 0:
             print(json.dumps(decode_bench(args, dev, batch=64 if args.batch == 32 else args.batch)), flush=True)
+        if force:
+            dist.destroy_process_group()
         return
     if args.mode == "mar":
         if rank == 0:
             print(json.dumps(mar_bench(args, dev)), flush=True)
+        if force:
+            dist.destroy_process_group()
         return
 
     from hma_amd.engine import LaunchTimer
@@ -515,14 +527,14 @@ def main():
     for k in range(args.warmup):
         ws = one(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
         ws = one(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -537,7 +549,7 @@ def main():
         timer, eng.timer = eng.timer, None
         timed_ms = sum(p[2].elapsed_time(p[3]) for p in timer.pairs)
         inst_steps = min(total, args.warmup + 3) - args.warmup
-    if world > 1:
+    if world > 1 or force:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -622,7 +634,7 @@ def main():
             out["decode"] = decode_bench(args, dev, steps=3, warmup=2, batch=64)  # (two warm-up rollouts: a frame pass is captured on its second use)
             out["mar"] = mar_bench(args, dev, steps=5, warmup=2)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

@@ -19,6 +19,7 @@ The per-micro-step barrier of the reference (train_multi.py:568) is dropped on p
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -37,6 +38,10 @@ class GradReducer:
         self.layout, self.G, self.group = layout, G, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # whether the collectives run: always with more than one rank; HMA_FORCE_COLLECTIVES=1 also runs them in a ONE-rank process
+        # group (an all-reduce over one rank is the identity, but it is RCCL that executes it, on the side stream, between the
+        # per-bucket graphs: the N > 1 code path end to end on a one-GPU box -- tests/test_dp_gpu.py)
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get("HMA_FORCE_COLLECTIVES") == "1")
         self.dense_buckets = layout.buckets(layers_per_bucket)
         L = layout.cfg.num_layers
         order = list(reversed(range(L)))
@@ -54,7 +59,7 @@ class GradReducer:
     def active_domains(self, local_domain: Optional[str]) -> List[str]:
         """Union over ranks of this micro-batch's domains, in layout order (same list on every rank).  FALLBACK for callers
         that do not pass `step_domains` to `Trainer.micro_step`: a blocking all-gather + host read per call."""
-        if self.world == 1:
+        if not self.collective:
             return [local_domain] if local_domain is not None else []
         idx = -1 if local_domain is None else self._dom_index[local_domain]
         mine = torch.tensor([idx], dtype=torch.int64, device=self.G.device)
@@ -72,7 +77,7 @@ class GradReducer:
         return [d for d in self.layout.domains if d in want]
 
     def _launch(self, a: int, b: int) -> None:
-        if self.world == 1 or b <= a:
+        if not self.collective or b <= a:
             return
         sl = self.G[a:b]
         if self.side is not None:
@@ -102,7 +107,7 @@ class GradReducer:
             self._next += 1
 
     def _launch_tensor(self, t: torch.Tensor) -> None:
-        if self.world == 1 or t.numel() == 0:
+        if not self.collective or t.numel() == 0:
             return
         if self.side is not None:
             ev = torch.cuda.Event()
@@ -130,7 +135,7 @@ class GradReducer:
             self._launch_tensor(t)
         for w in self._pending:
             w.wait()
-        if self.side is not None and self.world > 1:
+        if self.side is not None and self.collective:
             torch.cuda.current_stream().wait_stream(self.side)
         self._pending = []
 
@@ -271,7 +276,7 @@ class Trainer:
         self._book(ws, B)
         if eng.jpa:  # loss += config.action_loss_weight * action_loss (train_multi.py:574-576)
             eng.act_scale = float(getattr(self.model.config, "action_loss_weight", 0.5)) * eng.grad_scale.value
-        if last and red.world > 1:
+        if last and red.collective:
             red.begin(self._active)
             eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
             red.finish(self._active, extra=[self.loss_info])
@@ -283,7 +288,7 @@ class Trainer:
     def _segments(self, pl) -> List[Tuple[int, Optional[int], Optional[str]]]:
         """(start, stop, label) slices of the backward plan: one per gradient bucket when data-parallel."""
         L = self.model.config.num_layers
-        if self.reducer.world == 1 and not getattr(self, "force_segments", False):
+        if not self.reducer.collective and not getattr(self, "force_segments", False):
             return [(0, None, None)]
         out, start = [], 0
         for l in reversed(range(L)):
@@ -313,7 +318,7 @@ class Trainer:
             self._seen[key] = n
             ws = eng.forward(ids_BTS, labels, action_ids, dom, train=True, loss_grad=True, need_logits=False)
             self._book(ws, B)
-            if red.world > 1:
+            if red.collective:
                 red.begin(self._active)
                 eng.backward(eng.grad_scale.value, on_segment=red.on_segment, segment_layers=self.layers_per_bucket)
                 red.finish(self._active, extra=[self.loss_info])
@@ -355,7 +360,7 @@ class Trainer:
             d_a = eng.d_actions[dom]
             ws["actions"][: B * T * d_a].copy_(action_ids[:, :T].reshape(-1), non_blocking=True)
         eng._last = (B, T, S, A, dom if A > 0 else None)
-        if red.world > 1:
+        if red.collective:
             red.begin(self._active)
         for i, (g, label) in enumerate(graphs):
             g.replay()
@@ -363,7 +368,7 @@ class Trainer:
                 self._book(ws, B)  # (the first graph holds forward + loss: `stats` is final behind it)
             if label is not None:
                 red.on_segment(label)
-        if red.world > 1:
+        if red.collective:
             red.finish(self._active, extra=[self.loss_info])
         return ws
 
@@ -548,7 +553,7 @@ class MarTrainer:
         if jpa:  # loss += config.action_loss_weight * action_loss (train_multi.py:574-576)
             scaled = scaled + out.action_loss * (float(self.model.config.action_loss_weight) / (self.accum * red.world))
         self._micro += 1
-        if self._micro == self.accum and (red.world > 1 or self.force_overlap):
+        if self._micro == self.accum and (red.collective or self.force_overlap):
             # Last micro-batch of the step: gradients become final in backward order -- the diffusion head first, then the trunk
             # bucket by bucket, then the input / output stages -- and every finished range is all-reduced on the side stream
             # while the backward goes on (the reference: DDP's bucketed reduction, train_multi.py:779, 990).

@@ -186,3 +186,31 @@ def test_bench_gpus_2_spawns_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--layers", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(900)
+def test_rccl_all_reduces_run_in_a_one_rank_group():
+    """HMA_FORCE_COLLECTIVES=1: a ONE-rank `nccl` process group, so that a one-GPU box executes what an N-GPU job executes -- RCCL
+    initialised by this code, the bucketed all-reduces issued on the side stream between the per-bucket hipGraphs, the timing
+    barriers and the max-over-ranks of bench.py -- except the transport.  An all-reduce over one rank is the identity: the step's
+    loss must equal the plain one-process run's on the same seeds."""
+    import json
+
+    root = os.path.dirname(HERE)
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                              "HMA_BENCH_ONE_DEVICE", "HMA_FORCE_COLLECTIVES")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--layers", "4", "--steps", "3", "--warmup", "2", "--domains", "4",
+           "--batch", "4", "--mode", "train", "--no-cpu-baseline", "--no-kernel-timing"]
+
+    def run(env):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    plain = run(base)
+    forced = run(dict(base, HMA_FORCE_COLLECTIVES="1", MASTER_PORT=str(29500 + os.getpid() % 400)))
+    assert plain["backend"] is None and forced["backend"].startswith("nccl")
+    assert forced["n_gpus"] == 1 and forced["value"] > 0
+    assert abs(forced["final_loss"] - plain["final_loss"]) <= 1e-4 * max(1.0, abs(plain["final_loss"])), (forced["final_loss"], plain["final_loss"])
