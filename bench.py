@@ -444,6 +444,7 @@ def main():
     if args.lib:
         from hma_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this driver)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
