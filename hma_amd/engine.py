@@ -342,7 +342,7 @@ class STEngine:
         self._dplans: Dict[tuple, Plan] = {}
         self._dgraphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._dseen: Dict[tuple, int] = {}
-        self.decode_graphs = True
+        self.decode_graphs = os.environ.get("HMA_DECODE_GRAPHS", "1") != "0"  # (0: measurement -- eager launches)
         self._plans: Dict[tuple, Plan] = {}
         self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
         self.grad_scale = C.c_float(1.0)
