@@ -300,6 +300,15 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         self._grads_live = False
         return eng
 
+    def _check_versions(self, eng) -> None:
+        """In-place writes through the named parameters (load_state_dict, a torch optimizer) bump the parameters' own version
+        counters, not the flat buffer's: watch a few sentinels and re-derive the bf16 / packed weight copies when they move."""
+        ver = (self.out_x_proj.weight._version, self.pos_embed_TSC._version, self.decoder.layers[0].mlp.fc1.weight._version,
+               self.decoder.layers[-1].mlp.fc2.weight._version)
+        if ver != getattr(self, "_seen_versions", None):
+            self._seen_versions = ver
+            eng.weights_changed()
+
     def _domain_key(self, domain) -> Optional[str]:
         if domain is None:
             return None
@@ -314,12 +323,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
 
     def _run(self, x_THW: torch.Tensor, labels, action_ids, domain, train: bool, kwargs):
         eng = self._get_engine(x_THW.device)
-        # in-place writes through the named parameters (load_state_dict, a torch optimizer) bump the
-        # parameters' own version counters, not the flat buffer's: watch a few sentinels
-        ver = (self.out_x_proj.weight._version, self.pos_embed_TSC._version, self.decoder.layers[0].mlp.fc1.weight._version)
-        if ver != getattr(self, "_seen_versions", None):
-            self._seen_versions = ver
-            eng.weights_changed()
+        self._check_versions(eng)
         B, T = x_THW.shape[:2]
         ids = x_THW.reshape(B, T, -1).contiguous()
         dom = self._domain_key(domain) if (action_ids is not None or (self.config.jointly_predict_actions and not train)) else None

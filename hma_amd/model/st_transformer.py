@@ -65,16 +65,16 @@ class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, a_emb, anchor, owner, domain, l0, l1):
         eng = owner._get_engine(x.device)
+        owner._check_versions(eng)  # (an optimizer that wrote through the named parameters since the last pass)
         y, stamp = eng.trunk_autograd_forward(x.detach().float(), None if a_emb is None else a_emb.detach().float(), domain, l0, l1)
-        ctx.owner, ctx.stamp = owner, stamp
+        ctx.owner, ctx.stamp, ctx.eng = owner, stamp, eng
         ctx.x_dtype, ctx.a_dtype = x.dtype, (None if a_emb is None else a_emb.dtype)
         return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        owner = ctx.owner
-        eng = owner._engine
-        if eng is None:
+        owner, eng = ctx.owner, ctx.eng
+        if owner._engine is not eng:
             raise RuntimeError("the model's engine was rebuilt between forward and backward")
         owner._trunk_grads_begin()
         dx, da = eng.trunk_autograd_backward(dy.detach().float().contiguous(), ctx.stamp)
@@ -130,6 +130,7 @@ class STBlock(nn.Module):
             raise RuntimeError("STBlock runs through its STMaskGIT's engine; construct it via STMaskGIT")
         use = action_ids is not None and domain is not None and self.action_projectors is not None
         eng = owner._get_engine(x_TSC.device)
+        owner._check_versions(eng)
         return eng.run_trunk(x_TSC.float(), action_ids.float() if use else None, domain if use else None, self._index,
                              self._index + 1).to(x_TSC.dtype)
 
@@ -181,4 +182,5 @@ class STTransformerDecoder(nn.Module):
             raise RuntimeError("STTransformerDecoder runs through its STMaskGIT's engine; construct it via STMaskGIT")
         use = action_ids is not None and domain and self.layers[0].action_projectors is not None
         eng = owner._get_engine(tgt.device)
+        owner._check_versions(eng)
         return eng.run_trunk(tgt.float(), action_ids.float() if use else None, domain if use else None).to(tgt.dtype)

@@ -251,6 +251,25 @@ def test_blocks_train_under_autograd():
     _, _, _, pg = _oracle_blocks([0], x, a, "domA", r)
     w = m.decoder.layers[0].mlp.fc1.weight
     assert rms_err(w.grad, 2 * pg["decoder.layers.0.mlp.fc1.weight"]) <= 3e-2
+    # an external torch optimizer writes through the named parameters: the next forward runs on the new weights (the engine's bf16 /
+    # packed copies are re-derived when the parameters' version counters move)
+    from oracle import st_maskgit_ref as R
+    from tests.helpers import tiny_ref_config, tiny_state_dict
+    m.zero_grad()
+    blk = m.decoder.layers[0]
+    lr = 0.02 / max(float(v.abs().max()) for v in pg.values())
+    opt = torch.optim.SGD([p for p in blk.parameters()], lr=lr)
+    y0 = blk(x.cuda(), action_ids=a.cuda(), domain="domA")
+    (y0 * r.cuda()).sum().backward()
+    opt.step()
+    with torch.no_grad():
+        y1 = blk(x.cuda(), action_ids=a.cuda(), domain="domA")
+    cfg_r = tiny_ref_config()
+    sd2 = {k: (v - lr * pg[k] if k in pg else v) for k, v in tiny_state_dict(cfg_r).items()}
+    y1_ref = R.st_block(sd2, cfg_r, 0, x, a, "domA")
+    assert rel_err(y0.detach(), y1_ref) > 3e-2, "the update must move the output for this check to mean anything"
+    assert rel_err(y1, y1_ref) <= 1e-2
+    m.load_state_dict(tiny_state_dict(), strict=True)
     # one set of saved activations per layer: a backward after another forward through the same layer is refused
     m.zero_grad()
     xd = x.cuda().requires_grad_(True)

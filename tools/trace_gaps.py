@@ -5,7 +5,14 @@ kernel and the start of the next while nothing else runs, by size."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
+if len(sys.argv) > 2:  # trace_gaps.py trace.csv N: the last N dispatches instead of an optimizer step (decode: no adamw)
+    n_last = int(sys.argv[2])
+    ev = ev[-n_last:]
+    ev.append((ev[-1][1], ev[-1][1], "adamw_kernel end marker"))
+    ev.insert(0, (ev[0][0], ev[0][0], "adamw_kernel begin marker"))
 marks = [i for i, e in enumerate(ev) if "adamw_kernel" in e[2]]
+if len(sys.argv) > 2:
+    marks = [marks[0], marks[0], marks[-1], marks[-1]]
 # two adamw launches per step (dense + domain ranges): step boundaries = every second mark
 ends = marks[1::2] if len(marks) >= 4 else marks
 if len(ends) < 2:
