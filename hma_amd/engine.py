@@ -1168,14 +1168,17 @@ class STEngine:
         self._trunk_counter = getattr(self, "_trunk_counter", 0) + 1
         for l in range(l0, l1):
             stamps[l] = self._trunk_counter
-        return ws["x"].view(B, T, SA, D).clone(), (B, T, S, A, dom, l0, l1, self.ws_generation, self._trunk_counter)
+        return ws["x"].view(B, T, SA, D).clone(), (B, T, S, A, dom, l0, l1, self.ws_generation, self._trunk_counter, self._drop_counter)
 
     def trunk_autograd_backward(self, dy_BTSD: torch.Tensor, stamp: tuple) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """d loss / d (stream out) -> (d loss / d (stream in), d loss / d a_emb); the layers' weight gradients are ADDED into the flat
         gradient buffer.  Runs the layers' part of the recorded backward plan (no forked weight gradients, one adaLN group per layer:
         a range of layers is then a contiguous run of the plan)."""
-        B, T, S, A, dom, l0, l1, gen, count = stamp
+        B, T, S, A, dom, l0, l1, gen, count, drops = stamp
         L = self.cfg.num_layers
+        if self.mlp_drop > 0.0 and drops != self._drop_counter:
+            raise RuntimeError("another training forward drew new Dropout masks since this forward (one device seed per engine): run "
+                               "backward before the next forward when mlp_drop > 0")
         if gen != self.ws_generation or any(self._trunk_stamps[l] != count for l in range(l0, l1)):
             raise RuntimeError("the saved activations of these layers were overwritten by a later forward (the engine keeps ONE set "
                                "per layer): run backward before the next forward through the same layers")

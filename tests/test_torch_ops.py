@@ -345,3 +345,36 @@ def test_embed_modulate_readout_ce_maskgit_step_adamw_ops():
     pdv, mdv, vdv = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     pb = torch.ops.hma.adamw(pdv, gr.to(dev), mdv, vdv, 1e-2, 0.9, 0.95, 1e-8, 0.05, 1, 1.0)
     assert torch.allclose(pdv.cpu(), pt.detach(), atol=2e-6, rtol=1e-5) and torch.equal(pb.cpu(), pdv.cpu().bfloat16())
+
+
+@pytest.mark.gpu
+def test_blocks_under_autograd_with_dropout():
+    """mlp_drop > 0 in train() mode: the block's forward draws new masks per call (two calls differ), its backward runs on the masks of
+    ITS forward (finite, and dominated by the residual path's identity: d sum(y r) / d x stays close to r), a backward after another
+    training forward -- new masks on the device -- is refused, and eval() with gradients is refused (the saved-activation plans
+    apply the Dropout).  (The masks' arithmetic itself is pinned at model level: tests/test_dropout_gpu.py.)"""
+    from tests.test_model_gpu import build_model
+    from tests.helpers import golden
+    g = golden("g5_stblock")
+    m = build_model(train=True, mlp_drop=0.1)
+    blk = m.decoder.layers[0]
+    x, a = g["x"].cuda(), g["a_emb"].cuda()
+    gen = torch.Generator().manual_seed(3)
+    r = torch.randn(x.shape, generator=gen).cuda()
+    xd = x.clone().requires_grad_(True)
+    y1 = blk(xd, action_ids=a, domain="domA")
+    (y1 * r).sum().backward()
+    assert torch.isfinite(xd.grad).all() and float(xd.grad.abs().max()) > 0
+    y2 = blk(x, action_ids=a, domain="domA")
+    assert float((y1.detach() - y2.detach()).abs().max()) > 1e-3, "two training forwards must draw different masks"
+    # the residual path alone gives d (sum y r) / d x = r: the block's branches change it, Dropout must not break the identity part
+    cos = torch.nn.functional.cosine_similarity(xd.grad.flatten(), r.flatten(), dim=0)
+    assert float(cos) > 0.5
+    xd2 = x.clone().requires_grad_(True)
+    y3 = blk(xd2, action_ids=a, domain="domA")
+    m.decoder.layers[1](x, action_ids=a, domain="domA")  # (another training forward: new masks)
+    with pytest.raises(RuntimeError, match="Dropout masks"):
+        y3.sum().backward()
+    m.eval()
+    with pytest.raises(NotImplementedError, match="eval"):
+        blk(xd2, action_ids=a, domain="domA")
