@@ -352,7 +352,7 @@ def test_blocks_under_autograd_with_dropout():
     """mlp_drop > 0 in train() mode: the block's forward draws new masks per call (two calls differ), its backward runs on the masks of
     ITS forward (finite, and dominated by the residual path's identity: d sum(y r) / d x stays close to r), a backward after another
     training forward -- new masks on the device -- is refused, and eval() with gradients is refused (the saved-activation plans
-    apply the Dropout).  (The masks' arithmetic itself is pinned at model level: tests/test_dropout_gpu.py.)"""
+    apply the Dropout).  (The masks and their backward are pinned at model / kernel level: the mlp_drop tests of tests/test_model_gpu.py and tests/test_chain_gpu.py.)"""
     from tests.test_model_gpu import build_model
     from tests.helpers import golden
     g = golden("g5_stblock")
