@@ -153,7 +153,7 @@ def test_full_depth_forward_backward_vs_oracle(dom):
         e = rms_err(g_hip, g_ref)
         worst = max(worst, e)
         _note(f"{dom}.grad_rms.{name}", e)
-        assert e <= 3e-2, f"{name}: rms rel err {e:.3e}"
+        assert e <= 1.5e-2, f"{name}: rms rel err {e:.3e}"
     _note(f"{dom}.worst_grad_rms", worst)
 
 

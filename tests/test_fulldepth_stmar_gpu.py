@@ -147,7 +147,7 @@ def test_stmar_full_depth_forward_backward_vs_oracle():
         e = rms_err(g_hip, g_ref)
         worst = max(worst, e)
         _note(f"grad_rms.{name}", e)
-        assert e <= 3e-2, f"{name}: rms rel err {e:.3e}"
+        assert e <= 2e-2, f"{name}: rms rel err {e:.3e}"
     _note("worst_grad_rms", worst)
 
 

@@ -4,8 +4,9 @@ Tolerances (bf16 MFMA compute, fp32 accumulation / residual stream / loss):
   * loss: |hip - reference| <= 1e-3 (the north-star bound) on the init-scale fixture (weights N(0, 0.02), what a
     training run starts from); on the adversarial fixture (weights N(0, 0.05), unit-scale embeddings, logits of
     magnitude ~4, loss ~15.7) the bound is 3e-4 RELATIVE (5e-3 absolute); accuracy identical on the fixtures;
-  * logits: max error <= 2 % of the logits' range; parameter gradients: rms error <= 3 % per tensor
-    (<= 6 % for the tiny-magnitude tensors dominated by bf16 rounding of activations);
+  * logits: max error <= 1.2 % of the logits' range (measured 0.66 %); parameter gradients: rms error <= 2 % per tensor on the
+    adversarial fixture (measured worst 1.0 %, the factored embedding tables; tightened in round 4 once the headline-shape gradient
+    decomposition of tests/test_headline_gpu.py existed), <= 3 % on 64 sampled elements per tensor of the init-scale fixture;
   * token ids from MaskGIT decode: bit-exact given the same logits (kernel-level test); end to end in bf16 an id can flip
     only where the reference's top-2 logit margin is below the logits tolerance -- asserted step by step in
     tests/test_decode_rule_gpu.py (the agreement percentages here are logged, not asserted).
@@ -92,8 +93,8 @@ def test_forward_backward_matches_reference(tag):
     nt = tag + ("+fused_mlp" if fused else "+unfused_mlp" if unfused else "")
     _note(f"{nt}.loss_abs_err", abs(out.loss.item() - loss_ref.item()))
     _note(f"{nt}.logits_rel_err", e)
-    assert e <= 2e-2
-    assert rel_err(out.logits[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) <= 2e-2
+    assert e <= 1.2e-2  # (measured 6.6e-3)
+    assert rel_err(out.logits[:, :, :, ::4, ::4], g[f"{tag}.logits_sub"]) <= 1.2e-2
     out.loss.backward()
     worst = 0.0
     for name, p in m.named_parameters():
@@ -105,7 +106,7 @@ def test_forward_backward_matches_reference(tag):
         err = rms_err(p.grad, gr)
         worst = max(worst, err)
         _note(f"{nt}.grad_rms.{name}", err)
-        assert err <= 6e-2, f"{name}: rms rel err {err:.3e}"
+        assert err <= 2e-2, f"{name}: rms rel err {err:.3e}"  # (measured worst 1.0e-2: the factored embedding tables)
     _note(f"{nt}.worst_grad_rms", worst)
 
 
@@ -133,7 +134,7 @@ def test_loss_within_1e3_on_init_scale_weights():
         ref = g[key]
         err = (gf[idx] - ref).pow(2).mean().sqrt().item() / (ref.pow(2).mean().sqrt().item() + 1e-20)
         worst = max(worst, err)
-        assert err <= 8e-2, f"{name}: {err:.3e}"
+        assert err <= 3e-2, f"{name}: {err:.3e}"  # (64 sampled elements per tensor; measured worst 8.6e-3)
     _note("initlike.worst_grad_sample_rms", worst)
 
 
