@@ -164,15 +164,16 @@ def test_stmar_mixed_domains_under_accumulation_without_step_domains(tmp_path):
 def test_bench_gpus_2_spawns_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two fresh ranks itself (torch.distributed.run as a child
     process) and relays ONE line with n_gpus = 2; HMA_BENCH_ONE_DEVICE=1 puts both ranks on GPU 0 over gloo (a one-GPU box: the
-    numbers mean nothing, the path -- rendezvous, step-domain schedule, per-bucket graphs + side-stream all-reduces -- is the
-    N-rank one).  The reference launches the same way: experiments/scripts/run_30datasets_waction.sh:17-19."""
+    numbers mean nothing, the path -- rendezvous, the 40-domain layout of configs[2] with each rank drawing its own domain per step
+    from the shared sequence, per-bucket graphs + side-stream all-reduces of the dense slices and the active domains' slices -- is
+    the N-rank one).  The reference launches the same way: experiments/scripts/run_30datasets_waction.sh:17-19."""
     import json
 
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HMA_BENCH_ONE_DEVICE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1",
-                        "--domains", "4", "--batch", "4", "--mode", "train", "--no-cpu-baseline", "--no-kernel-timing"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "3", "--warmup", "1",
+                        "--domains", "40", "--batch", "4", "--mode", "train", "--no-cpu-baseline", "--no-kernel-timing"],
                        env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
