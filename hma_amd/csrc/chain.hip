@@ -73,6 +73,9 @@ constexpr bool ST = CH_ST != 0;
 #ifndef CH_PF_FIRST   // chain A forward: the qkv step the spread prefetch starts at (the stores of x / bf16(x) go out at the last step before)
 #define CH_PF_FIRST 0
 #endif
+#ifndef CH_BSPREAD  // chain B forward: the tile's x / next-LN1 / qkv stores dealt over the 24 qkv steps instead of one 1.5 KB-per-row burst + three
+#define CH_BSPREAD 0
+#endif
 #ifndef CH_SPREAD   // measurement builds: CH_ST = 0 with the storer mode's even store schedule (chain A forward)
 #define CH_SPREAD 0
 #endif
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     dsc = drop_scale(p.drop_p);
   }
   // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand (training: also saved, with 1 / sigma, for the backward)
-  auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t r0) __attribute__((always_inline)) {
+  auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t r0, bool defer = false) __attribute__((always_inline)) {
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
@@ -1276,14 +1279,17 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     }
     if constexpr (SAVE) {
       uint16_t* xo = reinterpret_cast<uint16_t*>(xhat_out) + r0 * 256;
+      if (!defer) {
 #pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        if (pp % RG == 0) stage_reserve(stg_, RG);
-        store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
+        for (int pp = 0; pp < 4; ++pp) {
+          if (pp % RG == 0) stage_reserve(stg_, RG);
+          store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
+        }
       }
       if (!(CH_ABL & 1)) rstd_out[r0 + tok] = rstd;
     }
   };
+  constexpr bool BSP = CH_BSPREAD && !ST && QKV;
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
@@ -1383,12 +1389,14 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
                 }
               }
             }
+            if constexpr (!BSP) {
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {
-              if (pr % RG == 0) stage_reserve(stg_, RG);
-              store_lines<false>(stg_, xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+              for (int pr = 0; pr < 8; ++pr) {
+                if (pr % RG == 0) stage_reserve(stg_, RG);
+                store_lines<false>(stg_, xt, Lf, 128 * pr, as_u4(acc[2 * pr]), as_u4(acc[2 * pr + 1]));
+              }
             }
-            if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, r0);  // the next block's norm1 (affine folded into its qkv weights / bias)
+            if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, r0, BSP);  // the next block's norm1 (affine folded into its qkv weights / bias)
             if constexpr (!(QKV && CH_PF_SPREAD)) prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, -1>{});
           }
         }
@@ -1400,7 +1408,15 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
         nb_mma(wb, a0, c0, c1);
         step_end(stg_);
         qb[pq & 7] = pack_pair(c0, c1);
-        if constexpr (ST) {
+        if constexpr (BSP) {
+          // x of this tile one 128-row-byte piece per step (its registers are re-loaded with the next tile's rows from step pq + 6 on),
+          // then the next block's xhat1, the qkv columns as they are finished
+          if constexpr (pq < 8) store_lines<false>(stg_, xt, Lf, 128 * pq, as_u4(acc[2 * pq]), as_u4(acc[2 * pq + 1]));
+          if constexpr (SAVE && pq >= 8 && pq < 12)
+            store_lines<false>(stg_, reinterpret_cast<uint16_t*>(p.xhat1n) + r0 * 256, Lb, 128 * (pq - 8), __builtin_bit_cast(uint4, a0[2 * (pq - 8)]),
+                               __builtin_bit_cast(uint4, a0[2 * (pq - 8) + 1]));
+          if constexpr ((pq & 1) == 1) store_lines(stg_, qt, Lq, 64 * (pq - 1), qb[(pq - 1) & 7], qb[pq & 7]);
+        } else if constexpr (ST) {
           if constexpr ((pq & 1) == 1) store_lines(stg_, qt, Lq, 64 * (pq - 1), qb[(pq - 1) & 7], qb[pq & 7]);
         } else if constexpr ((pq & 7) == 7) {
 #pragma unroll

@@ -7,7 +7,7 @@ mode=$1; shift
 if [ "$mode" = build ]; then
   mkdir -p variants
   rm -f variants/libhma_ch_*.so
-  OBJS=$(ls hma_amd/build/*.o | grep -v -E "/chain.o")
+  OBJS=$(ls hma_amd/build/*.o | grep -v -E "/chain.o|/gemm_[a-z0-9_]+.o")
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment $flags -c hma_amd/csrc/chain.hip -o variants/chain_$name.o 2>&1 | grep -E "error" ;
