@@ -511,7 +511,11 @@ __device__ __forceinline__ void store_lines(stage_t& st, void* tile_base, const 
     stage_block<WAIT>(st, reinterpret_cast<char*>(tile_base) + off, (uint32_t)L.pitch, L.s0, L.s1, q0, q1);
     return;
   }
-  if (CH_ABL & 1) return;
+  if (CH_ABL & 1) {  // (measurement: no store instruction, but the values stay live -- without this the compiler also drops the GEMMs
+                     // whose results are only stored: chain A's qkv, chain B's next-block qkv)
+    asm volatile("" ::"v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w));
+    return;
+  }
   const uint4 r = dpp_swap8(q1);
   uint4 da, db;
   da.x = L.lo ? q0.x : r.x; da.y = L.lo ? q0.y : r.y; da.z = L.lo ? q0.z : r.z; da.w = L.lo ? q0.w : r.w;
