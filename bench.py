@@ -379,6 +379,40 @@ def decode_bench(args, dev, steps=None, warmup=None, batch=None):
     return res
 
 
+def sample_clock_power(run):
+    """Shader clock (MHz) and package power (W) of the device WHILE `run()` replays the timed steps once more (behind the timed region:
+    nothing of this is inside it): one `rocm-smi --showclocks --showpower` sample taken from a helper thread ~0.4 s into the loop.
+    None when rocm-smi is missing or says nothing -- the line then simply has no `power` object."""
+    import re
+    import subprocess
+    import threading
+    out = {}
+
+    def probe():
+        time.sleep(0.4)
+        try:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10)
+            m = re.search(r"sclk clock level[^(]*\((\d+)Mhz\)", r.stdout)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", r.stdout)
+            if m:
+                out["sclk_mhz"] = int(m.group(1))
+            if w:
+                out["watts"] = float(w.group(1))
+        except Exception:
+            pass
+
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    run()
+    torch.cuda.synchronize()
+    th.join(timeout=12)
+    if not out:
+        return None
+    out["note"] = ("one rocm-smi sample while the timed steps are replayed once more after the timed region; the part's clock maximum is "
+                   "2400 MHz and its package power limit 1400 W (DESIGN.md section 6.0 item 5)")
+    return out
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a child process, relay rank 0's JSON line, return the child's exit code.  Runs BEFORE anything initialises the
@@ -540,6 +574,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer = None
+    power = None
+    if not args.no_kernel_timing and world == 1:
+        power = sample_clock_power(lambda: [one(args.warmup + (k % max(1, args.steps))) for k in range(14)])
     if not args.no_kernel_timing:
         # per-launch HIP events need eager launches: an instrumented pass of the same steps right after the timed
         # region (the timed region itself replays hipGraphs on the N = 1 path)
@@ -573,6 +610,8 @@ def main():
             "mfma_roofline_frac_step": value / world * FLOP_PER_TOKEN_FWD_BWD / MFMA_PEAK,
             "final_loss": loss,
         }
+        if power is not None:
+            out["power"] = power
         if timer is not None:
             summ = timer.summary()
             step_ms = 1e3 * dt / args.steps
