@@ -1624,6 +1624,9 @@ bool weights_ok(const hma_chain_weights_t& w, int expect) {
 // compute waves for a pass of M rows: 5 when 7-wave tiles would leave CUs without a tile and 5-wave tiles fill more of them
 int chain_waves(int64_t M) {
   if (NCW < 6) return NCW;
+#ifdef CH_NO5  // (measurement: always full tiles -- fewer CUs, less weight traffic out of L2)
+  return NCW;
+#endif
   const int64_t tn = (M + 16 * NCW - 1) / (16 * NCW), t5 = (M + 79) / 80;
   return (tn < num_cus() && t5 > tn) ? 5 : NCW;
 }
