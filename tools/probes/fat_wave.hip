@@ -22,7 +22,7 @@ __device__ __forceinline__ void glds16(const void* g, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
 }
 
-template <int NCW, bool FAT, bool PIPE = false>
+template <int NCW, bool FAT, bool PIPE = false, int TMODE = 0>
 __global__ __launch_bounds__((NCW + 1) * 64, 1) void skel(const char* __restrict__ w, float* __restrict__ out, int rounds, int steps,
                                                          int nbundles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,8 +61,29 @@ __global__ __launch_bounds__((NCW + 1) * 64, 1) void skel(const char* __restrict
   for (int i = 0; i < 8; ++i) b[i] = __builtin_bit_cast(bf16x8_t, u32x4_t{(uint32_t)lane, (uint32_t)i, 0x3f803f80u, 0x3f803f80u});
   LDSP(char)* ring = lds + lane * 16;
   float sum = 0.f;
-  if constexpr (!FAT) {
+  if constexpr (!FAT && TMODE == 3) {
     f32x4_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    for (int g = 0; g < groups; ++g) {
+      __builtin_amdgcn_s_barrier();
+      bf16x8_t a[2][16];
+#pragma unroll
+      for (int s = 0; s < PB; ++s) {
+        LDSP(char)* wb = ring + ((g % 3) * PB + s) * SLOT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[s][i] = __builtin_bit_cast(bf16x8_t, *(LDSP(u32x4_t)*)(wb + i * 1024));
+      }
+#pragma unroll
+      for (int s = 0; s < PB; ++s)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][2 * k], b[k], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][2 * k + 1], b[k], c1, 0, 0, 0);
+        }
+    }
+    sum = c0[0] + c1[1] + c0[2] + c1[3];
+  } else if constexpr (!FAT) {
+    f32x4_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    uint32_t x = 0;
     for (int g = 0; g < groups; ++g) {
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -70,16 +91,23 @@ __global__ __launch_bounds__((NCW + 1) * 64, 1) void skel(const char* __restrict
         LDSP(char)* wb = ring + ((g % 3) * PB + s) * SLOT;
         bf16x8_t a[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = __builtin_bit_cast(bf16x8_t, *(LDSP(u32x4_t)*)(wb + i * 1024));
+        for (int i = 0; i < 16; ++i)
+          a[i] = TMODE == 2 ? __builtin_bit_cast(bf16x8_t, u32x4_t{(uint32_t)g, (uint32_t)i, (uint32_t)s, 1u})
+                            : __builtin_bit_cast(bf16x8_t, *(LDSP(u32x4_t)*)(wb + i * 1024));
+        if (TMODE == 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * k], b[k], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * k + 1], b[k], c1, 0, 0, 0);
+          for (int i = 0; i < 16; ++i) x ^= __builtin_bit_cast(u32x4_t, a[i])[0];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * k], b[k], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2 * k + 1], b[k], c1, 0, 0, 0);
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    sum = c0[0] + c1[1] + c0[2] + c1[3];
+    sum = c0[0] + c1[1] + c0[2] + c1[3] + (float)x;
   } else if constexpr (PIPE) {
     f32x16_t c0, c1;
 #pragma unroll
@@ -130,17 +158,17 @@ __global__ __launch_bounds__((NCW + 1) * 64, 1) void skel(const char* __restrict
   if (sum == 123.456f) out[blockIdx.x * 512 + threadIdx.x] = sum;
 }
 
-template <int NCW, bool FAT, bool PIPE = false>
+template <int NCW, bool FAT, bool PIPE = false, int TMODE = 0>
 float run(const char* w, float* out, int rounds, int steps, int nb) {
   const int smem = NS * SLOT;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(skel<NCW, FAT, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(skel<NCW, FAT, PIPE, TMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((skel<NCW, FAT, PIPE>), dim3(256), dim3((NCW + 1) * 64), smem, 0, w, out, rounds, steps, nb);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((skel<NCW, FAT, PIPE, TMODE>), dim3(256), dim3((NCW + 1) * 64), smem, 0, w, out, rounds, steps, nb);
   hipEventRecord(e0);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((skel<NCW, FAT, PIPE>), dim3(256), dim3((NCW + 1) * 64), smem, 0, w, out, rounds, steps, nb);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((skel<NCW, FAT, PIPE, TMODE>), dim3(256), dim3((NCW + 1) * 64), smem, 0, w, out, rounds, steps, nb);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -164,11 +192,17 @@ int main() {
   const float thin5 = run<5, false>(w, out, 8, steps, nb);  // 80-row tiles: 2048 -> 8 rounds
   const float fat3_6 = run<3, true>(w, out, 6, steps, nb);  // (what a 7th fat round costs)
   const float fat3p = run<3, true, true>(w, out, 7, steps, nb);  // both steps' fragments of a barrier group read before its MFMAs
+  const float t_nomfma = run<7, false, false, 1>(w, out, 6, steps, nb);
+  const float t_nolds = run<7, false, false, 2>(w, out, 6, steps, nb);
+  const float t_pipe = run<7, false, false, 3>(w, out, 6, steps, nb);
   printf("chain B skeleton at M = 163840 (LDS-DMA ring + fragment reads + MFMA + barriers only, 96 steps per tile):\n");
   printf("  thin, 7 x 16 rows, 16x16x32, 6 rounds: %7.1f us   (%5.0f cycles per step at 2.3 GHz)\n", thin7, thin7 * 2300 / (6 * steps));
   printf("  thin, 5 x 16 rows, 16x16x32, 8 rounds: %7.1f us   (%5.0f)\n", thin5, thin5 * 2300 / (8 * steps));
   printf("  fat,  3 x 32 rows, 32x32x16, 7 rounds: %7.1f us   (%5.0f)\n", fat3, fat3 * 2300 / (7 * steps));
   printf("  fat,  3 x 32 rows, 32x32x16, 6 rounds: %7.1f us\n", fat3_6);
   printf("  fat,  the same, a barrier group's 32 fragments read before its 32 MFMAs, 7 rounds: %7.1f us   (%5.0f)\n", fat3p, fat3p * 2300 / (7 * steps));
+  printf("  thin 7 x 16, fragment reads only (no MFMA):          %7.1f us   (%5.0f)\n", t_nomfma, t_nomfma * 2300 / (6 * steps));
+  printf("  thin 7 x 16, MFMAs only (no fragment reads):         %7.1f us   (%5.0f)\n", t_nolds, t_nolds * 2300 / (6 * steps));
+  printf("  thin 7 x 16, a barrier group's 32 fragments read before its 32 MFMAs: %7.1f us   (%5.0f)\n", t_pipe, t_pipe * 2300 / (6 * steps));
   return 0;
 }
