@@ -92,7 +92,10 @@ constexpr int SLOT = 16384;                  // one bundle
 constexpr int TILE_ROWS = 16 * NCW;
 constexpr int L_BIAS = NS * SLOT;            // up to 2304 floats of bias vectors (chain B)
 constexpr int L_SS = L_BIAS + (ST ? 9216 : 8192);  // 2 tiles x NCW waves x 2 KB: the frames' shift | scale rows (CH_ST = 0: chain B's biases run into it)
-constexpr int L_SYNC = L_SS + 2 * NCW * 2048;      // storer mode: [0] ready | [8 + w] done | [16 + w] freed (32-bit words)
+#ifndef CH_SS_BYTES  // (measurement builds of chain B alone with a deeper ring, -DCH_NS=8 -DCH_SS_BYTES=1024: chain B has no shift / scale rows)
+#define CH_SS_BYTES (2 * NCW * 2048)
+#endif
+constexpr int L_SYNC = L_SS + CH_SS_BYTES;         // storer mode: [0] ready | [8 + w] done | [16 + w] freed (32-bit words)
 constexpr int RB = CH_R;                           // staging blocks per compute wave
 #ifndef CH_RG   // blocks reserved per wait: small groups let a wave refill its ring while the storer drains the rest of it
 #define CH_RG 2
