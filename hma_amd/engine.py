@@ -248,7 +248,7 @@ class STEngine:
         # without, 90.18 (MLP pair), 89.92 (+ spatial pair), 92.37 with all four -- the temporal pair and linear_out would run beside
         # chain A backward / the attention backward, whose 100-156 KB of LDS leave their workgroups no room on a CU.  Bits: 1 MLP pair,
         # 2 temporal pair, 4 linear_out, 8 spatial pair.
-        self.fork_wgrad = 9
+        self.fork_wgrad = int(os.environ.get("HMA_FORK_WGRAD", "9"))  # (bit mask of the forked weight-gradient launches; env: measurement)
         # the per-domain adaLN stacks' backward runs per group of this many layers (a data-parallel driver sets it to its layers per
         # gradient bucket, so that a domain's slice of a bucket is final when the bucket is)
         self.ada_group = 8
