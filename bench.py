@@ -39,7 +39,8 @@ FREQ = [20, 10, 20, 20, 5, 30, 2, 20, 20, 10, 2, 2, 10, 1, 10, 5, 5, 5, 10, 3, 1
 FLOP_PER_TOKEN_FWD_BWD = 3.104e8
 # every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
 FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_attn_spatial_fwd",
-            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd"]
+            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd",
+            "hma_chain_s_bwd", "hma_readout_ce"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
 
 
@@ -81,31 +82,12 @@ def domain_sequence(n_domains, n_draws, seed=0):
     return torch.multinomial(w / w.sum(), n_draws, replacement=True, generator=g).tolist()
 
 
-def pmc_traffic_per_launch(kernel_substr="gemm_nt"):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_hbm_r3.json, else the
-    older rounds': separate FETCH_SIZE / WRITE_SIZE runs of this bench on an 8-layer model; counters are in KB and, on
-    gfx950, FETCH_SIZE reports half of a wide coalesced read -- MI355X_MICROARCH.md section HBM -- so it is doubled)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (3, 2, 1)) if os.path.exists(q)), "")
-    try:
-        d = json.load(open(path))
-        tot, launches = 0.0, 0
-        for name, v in d["fetch"].items():
-            if kernel_substr in name:
-                tot += 2.0 * v["counter_sum_kb"] * 1024.0
-                launches += v["launches"]
-        for name, v in d["write"].items():
-            if kernel_substr in name:
-                tot += v["counter_sum_kb"] * 1024.0
-        return tot / launches if launches else None
-    except (OSError, KeyError, ValueError):
-        return None
-
-
 def pmc_traffic_per_call(kernels, count_kernel):
     """HBM bytes per C-ABI call of a kernel family from the newest committed PMC passes: the FETCH_SIZE (x 2, see above) and WRITE_SIZE
     sums of EVERY kernel the call launches (`kernels`: name substrings, e.g. the weight-gradient ring kernel AND its reduction) over the
-    number of calls (= launches of `count_kernel`).  Comparable with `bytes_per_launch` (algorithmic bytes per call)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), "")
+    number of calls (= launches of `count_kernel`).  Comparable with `bytes_per_launch` (algorithmic bytes per call).  FETCH_SIZE is
+    doubled: on gfx950 it reports half of a wide coalesced read (MI355X_MICROARCH.md, section HBM)."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), "")
     try:
         d = json.load(open(path))
         tot, calls = 0.0, 0
@@ -573,6 +555,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    loss, acc = trainer.loss_and_acc(ws)  # (of the LAST TIMED step: read before the power / instrumented passes below run more steps)
+    loss = float(loss.item())
     timer = None
     power = None
     if not args.no_kernel_timing and world == 1:
@@ -591,8 +575,6 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    loss, acc = trainer.loss_and_acc(ws)
-    loss = float(loss.item())
 
     if rank == 0:
         tokens = world * B * T * 256 * args.steps
@@ -643,6 +625,12 @@ def main():
                 if dom_name == "hma_gemm_tn_pair":  # (three pairs + linear_out's single call per layer share the ring kernel)
                     same_scope = (3.0 * d0["bytes_per_launch"] + (B * T * 320 * 1024.0 + 4.0 * 65536)) / 4.0
                 mfma = {"achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s", "frac": d0["frac"]}
+                if power is not None and power.get("sclk_mhz"):
+                    # the dense-MFMA peak at the clock the step actually runs at (the part's 2.5 PF are quoted at 2 400 MHz; the step sits
+                    # at the package power limit): the same launches against that roof
+                    mfma["peak_in_situ"] = 2500.0 * power["sclk_mhz"] / 2400.0
+                    mfma["frac_in_situ"] = d0["achieved"] / mfma["peak_in_situ"]
+                    mfma["sclk_mhz"] = power["sclk_mhz"]
                 hbm = {"achieved": d0["hbm_achieved_gbs"], "peak": 8000.0, "unit": "GB/s", "frac": d0["hbm_frac"]}
                 # headline = the MFMA roof (SURVEY.md 8d / north_star: dense contraction => MFMA); the HBM view of the same
                 # launches (algorithmic bytes / time) rides beside it as `hbm`
@@ -658,10 +646,14 @@ def main():
                                                    "launch time; bound = hbm when FLOP per algorithmic byte < 2500e12 / 8e12",
                                    "launches": d0["launches"], "avg_launch_us": d0["avg_launch_us"], "flops_per_launch": d0["flops_per_launch"],
                                    "share_of_step_time": d0["share_of_step_time"],
+                                   "rocprof_kernels": list(fam_kernels[0]),
                                    "measured": f"HIP events around every launch of the MFMA kernel families in {inst_steps} eager steps run "
-                                               "right after the timed region on ONE stream (the timed region replays hipGraphs in which two "
-                                               "weight-gradient pairs per layer are forked to a side stream: the shares are of the un-forked sum; "
-                                               "algorithmic FLOPs: recomputation is not counted)",
+                                               "right after the timed region, on the stream the kernels run on.  The timed region replays the "
+                                               "SAME launches in the SAME order on one stream as a hipGraph (round 5: no forked launches), so "
+                                               "avg_launch_us is comparable with the per-kernel averages of a rocprofv3 --kernel-trace --stats "
+                                               "run of this command (profiles/kernel_stats_r5.csv; tools/roofline_check.py adds the kernels of a "
+                                               "C-ABI call -- for the weight gradients the ring kernel AND its reduction -- and compares).  "
+                                               "Algorithmic FLOPs: recomputation is not counted",
                                    "families": fams}
             out["config"]["prepare_steps"] = prepare_steps
         if world == 1 and not args.no_cpu_baseline:

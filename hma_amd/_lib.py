@@ -107,6 +107,16 @@ class ChainBFwd(C.Structure):
     ]
 
 
+class ChainSBwd(C.Structure):
+    _fields_ = [
+        ("w", ChainWeights),
+        ("dqkv", c_vp), ("ldq", c_i64), ("dx", c_vp),
+        ("xhat", c_vp), ("rstd", c_vp),
+        ("dx_bf16", c_vp),
+        ("M", c_i64),
+    ]
+
+
 class ReadoutCE(C.Structure):
     _fields_ = [
         ("w", ChainWeights),
@@ -177,6 +187,7 @@ _PROTOS = {
     "hma_chain_b_fwd": [c_vp, C.POINTER(ChainBFwd)],
     "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
     "hma_chain_a_bwd": [c_vp, C.POINTER(ChainABwd)],
+    "hma_chain_s_bwd": [c_vp, C.POINTER(ChainSBwd)],
     "hma_zero_f32": [c_vp, c_vp, c_i64],
     "hma_abi_version": [],
 }

@@ -588,6 +588,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
   __syncthreads();
   constexpr int S3 = MOD ? 16 : 8;       // first qkv step
   constexpr int PER_TILE = S3 + 24;
+  static_assert(PER_TILE % PB == 0, "whole barrier groups per tile (the loader refills PB slots per barrier)");
   if (ST && wave > NCW) {
     storer_run<NW>(lds, lane, wave - NCW - 1);
     return;
@@ -814,11 +815,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
     if (r0 >= p.M) {  // (whole wave past the matrix: possible in a workgroup's last tile only)
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
-        slot = (slot + PER_TILE) % NS;
       } else {
 #pragma unroll 1
         for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
       }
+      slot = (slot + PER_TILE) % NS;  // (the ring position moves on with the loader whether or not this wave reads the bundles)
       continue;
     }
     tile(tl, r0);
@@ -859,6 +860,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
   const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
   constexpr int S3 = MOD ? 32 : 24;      // first d_o step
   constexpr int PER_TILE = S3 + 8;
+  static_assert(PER_TILE % PB == 0, "whole barrier groups per tile (the loader refills PB slots per barrier)");
   start_stagger();
   if constexpr (ST) {
     sync_init(lds, tid);
@@ -1133,11 +1135,188 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
     if (r0 >= p.M) {
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
-        slot = (slot + PER_TILE) % NS;
       } else {
 #pragma unroll 1
         for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
       }
+      slot = (slot + PER_TILE) % NS;  // (the ring position moves on with the loader whether or not this wave reads the bundles)
+      continue;
+    }
+    tile(tl, r0);
+  }
+  stage_finish(stg_);
+}
+
+// ------------------------------------------------------------------------------------------------ chain S, backward
+// The spatial side of a block's backward between the attention backward and the previous block (st_transformer.py:85-86 norm1 + qkv of
+// attention.py:39, autograd mirror): g = dqkv Wqkv diag(gamma) (gamma folded into the packed weight's output rows), the LayerNorm
+// backward of the row and the residual add, dx <- dx + rstd (g - mean(g) - xhat mean(g xhat)), and bf16(dx) for the next consumer --
+// what hma_gemm_nt (dqkv -> t256) + hma_ln_bwd did in two launches with a bf16 round trip of g through HBM.  24 steps per tile (the
+// three k-chunks of dqkv); a tile's rows arrive a load or two per step (CH_PF_SPREAD's schedule): k-chunks 1 and 2 over steps 0..11,
+// the saved xhat row over 8..15, the fp32 dx row over 12..19, the next tile's first k-chunk behind the last step's MFMAs.  norm1's dgamma / dbeta come
+// out of the qkv weight-gradient reduction (hma_gemm_tn: w_master / dgamma / dbeta), as norm2's do.
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_bwd_t p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
+  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  constexpr int PER_TILE = 24;
+  static_assert(PER_TILE % PB == 0, "whole barrier groups per tile");
+#ifndef CH_S_DX0
+#define CH_S_DX0 16
+#endif
+  constexpr int DX0 = CH_S_DX0;  // the step the fp32 dx row's loads start at (two per step)
+  start_stagger();
+  if constexpr (ST) {
+    sync_init(lds, tid);
+    __syncthreads();
+    if (wave > NCW) {
+      storer_run<NCW>(lds, lane, wave - NCW - 1);
+      return;
+    }
+  }
+  if (wave == NCW) {
+    const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
+                         reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
+                         p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
+    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1, lds);
+    return;
+  }
+  stage_t stg_ = make_stage(lds, wave, lane);
+  const int tok = lane & 15, g = lane >> 4;
+  auto row0_of = [&](int tl) __attribute__((always_inline)) {
+    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+  };
+  bf16x8_t dq[3][8], xr[8];
+  f32x4v_t acc[16], dxr[16];
+  float rs = 1.f;
+  auto load_part = [&](int64_t mc, int c, bf16x8_t (&d)[8], auto j0_, auto n_) __attribute__((always_inline)) {
+    constexpr int j0 = decltype(j0_)::value, n = decltype(n_)::value;
+    if (CH_ABL & 2) return;
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(p.dqkv) + mc * p.ldq + 256 * c + 8 * g;
+#pragma unroll
+    for (int j = j0; j < j0 + n; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
+  };
+  auto next_row = [&](int tl) __attribute__((always_inline)) {
+    int64_t m = row0_of(tl + 1 < nt ? tl + 1 : tl) + tok;
+    return m < p.M ? m : p.M - 1;
+  };
+  if (CH_ABL & 2) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dq[c][j] = as_frag(make_uint4(lane, j, c, j));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[j] = as_frag(make_uint4(lane, j, lane, j));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dxr[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
+  }
+  {
+    int64_t m = row0_of(0) + tok;
+    m = m < p.M ? m : p.M - 1;
+    load_part(m, 0, dq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+  }
+  CH_TOUCH_A(dq[0]);
+  int slot = 0;
+  HMA_LDS(char)* ring = lds + lane * 16;
+  const line_offs Lb = make_lines(512, tok, 16 * g, 64);
+  const line_offs Lf = make_lines(1024, tok, 32 * g, 16);
+
+  auto tile = [&](int tl, int64_t r0) __attribute__((always_inline)) {
+    const int64_t m = r0 + tok;
+    float* xt = p.dx + r0 * 256;
+    uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx_bf16) + r0 * 256;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+    static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      if constexpr (ST) step_begin(stg_); else if constexpr (s % PB == 0) CH_BARRIER();
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      constexpr int c = s >> 3, pr = s & 7;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      if constexpr (s < 4) load_part(m, 1, dq[1], std::integral_constant<int, 2 * s>{}, I2{});
+      if constexpr (s >= 4 && s < 12) load_part(m, 2, dq[2], std::integral_constant<int, s - 4>{}, I1{});
+      if constexpr (s >= 8 && s < 16) {
+        if (!(CH_ABL & 2)) {
+          const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
+          xr[s - 8] = as_frag(*reinterpret_cast<const uint4*>(hrow + 32 * (s - 8)));
+          if constexpr (s == 8) rs = p.rstd[m];
+        }
+      }
+      if constexpr (s >= DX0 && s < DX0 + 8) {
+        if (!(CH_ABL & 2)) {
+          const float* xrow = p.dx + m * 256 + 8 * g;
+          dxr[2 * (s - DX0)] = ld4(xrow + 32 * (s - DX0));
+          dxr[2 * (s - DX0) + 1] = ld4(xrow + 32 * (s - DX0) + 4);
+        }
+      }
+      nb_mma(wb, dq[c], acc[2 * pr], acc[2 * pr + 1]);
+      step_end(stg_);
+      if constexpr (s == 23) {
+        // the next tile's first k-chunk: requested here, in front of this tile's 24 store instructions (the queue is in order), into the
+        // registers the last k-chunk has just left -- eight steps earlier they would not fit beside dx, xhat and the accumulators
+        load_part(next_row(tl), 0, dq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+        // ---- LayerNorm backward of the row (its four lanes tok, tok + 16, tok + 32, tok + 48 hold it) + residual
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int pr2 = 0; pr2 < 8; ++pr2) {
+          float xh[8];
+          unpack8(__builtin_bit_cast(uint4, xr[pr2]), xh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gq = acc[2 * pr2 + (e >> 2)][e & 3];
+            s1 += gq;
+            s2 = __builtin_fmaf(gq, xh[e], s2);
+          }
+        }
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        s1 *= (1.0f / 256.0f);
+        s2 *= (1.0f / 256.0f);
+        CH_TOUCH_A(xr);  // (opaque: otherwise the unpacked xhat of the pass above -- 64 registers -- is kept for the pass below)
+#pragma unroll
+        for (int pr2 = 0; pr2 < 8; ++pr2) {
+          float xh[8];
+          unpack8(__builtin_bit_cast(uint4, xr[pr2]), xh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gq = acc[2 * pr2 + (e >> 2)][e & 3];
+            dxr[2 * pr2 + (e >> 2)][e & 3] += rs * (gq - s1 - xh[e] * s2);
+          }
+        }
+#pragma unroll
+        for (int pr2 = 0; pr2 < 8; ++pr2) {
+          if (pr2 % RG == 0) stage_reserve(stg_, RG);
+          store_lines<false>(stg_, xt, Lf, 128 * pr2, as_u4(dxr[2 * pr2]), as_u4(dxr[2 * pr2 + 1]));
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          if (pp % RG == 0) stage_reserve(stg_, RG);
+          store_lines<false>(stg_, d1, Lb, 128 * pp, pack_pair(dxr[4 * pp], dxr[4 * pp + 1]), pack_pair(dxr[4 * pp + 2], dxr[4 * pp + 3]));
+        }
+      }
+    });
+    CH_TOUCH_A(dq[0]);
+  };
+
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t r0 = row0_of(tl);
+    if (r0 >= p.M) {
+      if constexpr (ST) {
+        steps_skip(stg_, PER_TILE);
+      } else {
+#pragma unroll 1
+        for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
+      }
+      slot = (slot + PER_TILE) % NS;
       continue;
     }
     tile(tl, r0);
@@ -1194,6 +1373,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   __syncthreads();
   constexpr int SM = 8, SQ = 8 + 64;           // first MLP step, first qkv step
   constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
+  static_assert(PER_TILE % PB == 0, "whole barrier groups per tile (the loader refills PB slots per barrier)");
   if (ST && wave > NCW) {
     storer_run<NW>(lds, lane, wave - NCW - 1);
     return;
@@ -1303,11 +1483,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     if (r0 >= p.M) {
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
-        slot = (slot + PER_TILE) % NS;
       } else {
 #pragma unroll 1
         for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
       }
+      slot = (slot + PER_TILE) % NS;  // (the ring position moves on with the loader whether or not this wave reads the bundles)
       continue;
     }
     float* xt = p.x + r0 * 256;
@@ -1482,17 +1662,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
   int slot = 0;
   bf16x8_t a[8];
   f32x4v_t lg[32];
+  static_assert(32 % PB == 0, "whole barrier groups per tile");
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
     if (r0 >= p.rows) {
       if constexpr (ST) {
         steps_skip(stg_, 32);
-        slot = (slot + 32) % NS;
       } else {
 #pragma unroll 1
         for (int s = 0; s < 32; s += PB) CH_BARRIER();
       }
+      slot = (slot + 32) % NS;
       continue;
     }
     const int64_t i = r0 + tok, frame = i / p.S;
@@ -1709,6 +1890,16 @@ extern "C" int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p) {
     if (int rc = set_lds<chain_a_bwd_kernel<false>>(SMEM)) return rc;
     hipLaunchKernelGGL(chain_a_bwd_kernel<false>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
   }
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p) {
+  if (!p || !p->dqkv || !p->dx || !p->xhat || !p->rstd || !p->dx_bf16 || p->M <= 0 || p->M % 16 || p->ldq < 768) return HMA_EINVAL;
+  if (!weights_ok(p->w, 24)) return HMA_EINVAL;
+  const int grid = chain_grid(p->M);
+  if (int rc = set_lds<chain_s_bwd_kernel>(SMEM)) return rc;
+  hipLaunchKernelGGL(chain_s_bwd_kernel, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
   HMA_CHECK_LAUNCH();
   return 0;
 }

@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
-from .ops import make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_readout_ce, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
+from .ops import make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_chain_s_bwd, make_readout_ce, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
 from .params import ALIGN, ParamLayout
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -33,23 +33,15 @@ class Plan:
     """A recorded sequence of C-ABI launches with fixed arguments; `run` replays it on a stream."""
 
     # Per GPU, for the life of the process (recorded plans and captured graphs hold the raw pointers): the scratch of the two-stage
-    # weight-gradient reduction, a second one for launches forked to the side stream, and that stream.  Keyed by device index, so
-    # that engines on different devices of one process do not share a workspace or launch on a stream of the wrong device.
+    # weight-gradient reduction.  Keyed by device index, so that engines on different devices of one process do not share it.
     _tn_workspaces: Dict[object, torch.Tensor] = {}
-    _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
     @property
     def tn_workspace(self) -> Optional[torch.Tensor]:
         return Plan._tn_workspaces.get(self.dev)
 
-    @property
-    def tn_workspace_side(self) -> Optional[torch.Tensor]:
-        return Plan._tn_workspaces.get(("side", self.dev))
-
     def __init__(self, dev: Optional[int] = None):
         self.dev = torch.cuda.current_device() if (dev is None and torch.cuda.is_available()) else dev
-        self.side: Dict[int, bool] = {}     # call index -> runs on the side stream
-        self.join: Dict[int, bool] = {}     # call index -> the caller's stream first waits for the side stream
         self.calls: List[Tuple[Callable, str, tuple]] = []
         self.flops: List[float] = []   # algorithmic FLOPs of each call (0 for non-GEMM launches)
         self.bytes: List[float] = []   # algorithmic HBM bytes of each call: every operand read once, every result written once
@@ -80,38 +72,25 @@ class Plan:
         self.keep.append(g)
         self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._nt_bytes(g))
 
-    def gemm_tn(self, side: bool = False, **kw) -> None:
-        side = side and self.tn_workspace_side is not None
-        wsb = self.tn_workspace_side if side else self.tn_workspace
+    def gemm_tn(self, **kw) -> None:
+        wsb = self.tn_workspace
         if wsb is not None:
             kw.setdefault("ws", wsb.data_ptr())
             kw.setdefault("ws_elems", wsb.numel())
         g = make_gemm_tn(**kw)
         self.keep.append(g)
-        if side:
-            self.side[len(self.calls)] = True
         self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._tn_bytes(g))
 
-    unpair_mlp = bool(os.environ.get("HMA_UNPAIR_MLP"))  # measurement switch: the MLP's two weight gradients as two launches
-
-    def gemm_tn_pair(self, kw0: dict, kw1: dict, side: bool = False) -> None:
-        """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair).  `side`: on the side
-        stream (nothing on the caller's stream depends on it until the next `join_next()` call or the end of the run)."""
-        if Plan.unpair_mlp and 1024 in (kw0.get("K"), kw1.get("N")):
-            self.gemm_tn(side=side, **kw0)
-            self.gemm_tn(side=side, **kw1)
-            return
+    def gemm_tn_pair(self, kw0: dict, kw1: dict) -> None:
+        """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair)."""
         gs = []
-        wsb = self.tn_workspace_side if (side and self.tn_workspace_side is not None) else self.tn_workspace
-        side = side and self.tn_workspace_side is not None
+        wsb = self.tn_workspace
         for kw in (kw0, kw1):
             if wsb is not None:
                 kw.setdefault("ws", wsb.data_ptr())
                 kw.setdefault("ws_elems", wsb.numel())
             gs.append(make_gemm_tn(**kw))
         self.keep.extend(gs)
-        if side:
-            self.side[len(self.calls)] = True
         self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
                  flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
 
@@ -150,6 +129,12 @@ class Plan:
         nbytes = (1536 + 1024 + 1024 + 512 + 512 + (1024 if use_mod else 0)) * float(M)
         self.add("hma_chain_a_bwd", C.byref(g), flops=2.0 * M * 256 * n_in, nbytes=nbytes)
 
+    def chain_s_bwd(self, M: int, **kw) -> None:
+        g = make_chain_s_bwd(M=M, **kw)
+        self.keep.append(g)
+        # dqkv 1536 + xhat 512 + dx 1024 in; dx 1024 + bf16(dx) 512 out
+        self.add("hma_chain_s_bwd", C.byref(g), flops=2.0 * M * 256 * 768, nbytes=(1536 + 512 + 1024 + 1024 + 512) * float(M))
+
     def readout_ce(self, rows: int, **kw) -> None:
         g = make_readout_ce(rows=rows, **kw)
         self.keep.append(g)
@@ -159,41 +144,12 @@ class Plan:
     def mark(self, label: str) -> None:
         self.marks[label] = len(self.calls)
 
-    def join_next(self) -> None:
-        """The next recorded call waits for everything launched on the side stream so far."""
-        self.join[len(self.calls)] = True
-
     def run(self, stream: int, start: int = 0, stop: Optional[int] = None, timer: "Optional[LaunchTimer]" = None) -> None:
-        if timer is None and not self.side:
+        if timer is None:
             for fn, name, args in self.calls[start:stop]:
                 rc = fn(stream, *args)
                 if rc != 0:
                     raise _lib.HmaKernelError(f"{name} failed with code {rc}")
-            return
-        if timer is None:
-            # fork / join: a `side` call starts when everything enqueued so far on the caller's stream is done and runs beside what
-            # follows; a `join` call (and the end of this run) waits for the side stream.  Under hipGraph capture these become edges.
-            main = torch.cuda.current_stream(self.dev)
-            if self.dev not in Plan._side_streams:
-                Plan._side_streams[self.dev] = torch.cuda.Stream(device=self.dev)
-            sd = Plan._side_streams[self.dev]
-            pending = False
-            stop_ = len(self.calls) if stop is None else stop
-            for i in range(start, stop_):
-                fn, name, args = self.calls[i]
-                if pending and self.join.get(i):
-                    main.wait_stream(sd)
-                    pending = False
-                if self.side.get(i):
-                    sd.wait_stream(main)
-                    rc = fn(sd.cuda_stream, *args)
-                    pending = True
-                else:
-                    rc = fn(stream, *args)
-                if rc != 0:
-                    raise _lib.HmaKernelError(f"{name} failed with code {rc}")
-            if pending:
-                main.wait_stream(sd)
             return
         stop = len(self.calls) if stop is None else stop
         for i in range(start, stop):
@@ -242,13 +198,6 @@ class STEngine:
         # LayerNorm (attention.py:31-35,44-48; st_transformer.py:55,62).  Runs on the GEMM-per-Linear plans (the chain / fused-MLP
         # kernels have the block's LayerNorms built in) with hma_qknorm_fwd / _bwd behind the qkv projections.
         self.qkn = bool(cfg.qk_norm)
-        # Weight gradients beside the backward's critical path: nothing downstream reads them, so the MLP pair and the spatial pair run on a
-        # side stream (a fork / join in the recorded plan; graph edges under hipGraph capture) while the main stream goes on with the
-        # temporal projection / attention and the qkv dgrad / LayerNorm backward.  Measured on one box (bench.py --mode train): 91.49 ms
-        # without, 90.18 (MLP pair), 89.92 (+ spatial pair), 92.37 with all four -- the temporal pair and linear_out would run beside
-        # chain A backward / the attention backward, whose 100-156 KB of LDS leave their workgroups no room on a CU.  Bits: 1 MLP pair,
-        # 2 temporal pair, 4 linear_out, 8 spatial pair.
-        self.fork_wgrad = int(os.environ.get("HMA_FORK_WGRAD", "9"))  # (bit mask of the forked weight-gradient launches; env: measurement)
         # the per-domain adaLN stacks' backward runs per group of this many layers (a data-parallel driver sets it to its layers per
         # gradient bucket, so that a domain's slice of a bucket is final when the bucket is)
         self.ada_group = 8
@@ -312,8 +261,10 @@ class STEngine:
         # linear_out (8) and its transpose.
         self.use_chain = True
         self.chain_min_rows = 0
+        self.chain_s = os.environ.get("HMA_CHAIN_S", "1") != "0"  # (0: measurement -- the spatial qkv dgrad + hma_ln_bwd as two launches)
         BUN = 8192
-        self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN)}
+        self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN),
+                   "qkv_s_T": mk(L, 24 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
         # readout + cross-entropy in one launch (hma_readout_ce) for training steps that do not hand the logits to the caller
         self.fused_ce = True
         self.CP["out"] = mk(32 * BUN)
@@ -355,8 +306,6 @@ class STEngine:
         self._dev_index = idx
         if idx not in Plan._tn_workspaces:
             Plan._tn_workspaces[idx] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))  # 64 MB + bias partials
-        if self.fork_wgrad and ("side", idx) not in Plan._tn_workspaces:
-            Plan._tn_workspaces[("side", idx)] = torch.empty(256 * (65536 + 256), dtype=F32, device=torch.device("cuda", idx))
 
     # ------------------------------------------------------------------------------ Adam update counts (device-resident)
     def _steps_now(self) -> List[int]:
@@ -445,6 +394,10 @@ class STEngine:
                 for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
                     _lib.call("hma_chain_pack", stream, wq + 4 * c * d * d, 1, d, None, None,
                               self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
+                wqs_, g1_ = self._p(pre + "spatial_attn.qkv.weight"), self._p(pre + "norm1.weight")
+                for c in range(3):  # the same for the spatial qkv, times norm1's gamma per OUTPUT row (d xhat = gamma . (dqkv W))
+                    _lib.call("hma_chain_pack", stream, wqs_ + 4 * c * d * d, 1, d, g1_, None,
+                              self.CP["qkv_s_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
                 if self.chain_b_ok:
                     # chain B (inference): proj_t, the fc1 (norm2's gamma folded in) / fc2 bundles interleaved per hidden block, and the
                     # spatial qkv with norm1's gamma folded in (consumed by the PREVIOUS block's chain)
@@ -558,12 +511,6 @@ class STEngine:
             if self._use_chain(M, SA) and A > 0 and self.modulate:
                 buf("dx2b", (M, 256), BF16)  # bf16(dx) in front of the modulate block: dY of linear_out's weight gradient
             buf("dqkv", (M, 768), BF16)
-            if self.fork_wgrad and fused and self._use_chain(M, SA):
-                # forked weight gradients (a side stream beside the backward's critical path) read bf16(dx) / dqkv while the main stream
-                # goes on: every producer of bf16(dx) writes the next of four buffers, the spatial attention gets its own dqkv
-                buf("dqkv_s", (M, 768), BF16)
-                buf("dxb3", (M, 256), BF16)
-                buf("dxb4", (M, 256), BF16)
             buf("delta", (M, 8), F32)
             if A > 0:
                 buf("dss", (L, Fr, 512), F32)
@@ -801,7 +748,7 @@ class STEngine:
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
         key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group,
-               int(self.fork_wgrad))
+               self.chain_s)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -811,14 +758,7 @@ class STEngine:
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
         dxb = ws["dxb"].data_ptr()
-        fork = bool(self.fork_wgrad) and "dqkv_s" in ws and self._use_fused(M, True, SA) and self._use_chain(M, SA)
-        fbit = lambda b: fork and bool(self.fork_wgrad & b)
-        ring = [ws[k].data_ptr() for k in ("dxb", "dxb2", "dxb3", "dxb4")] if fork else []
-
-        def rot(cur):  # the next bf16(dx) buffer (forked weight gradients may still read the current and the two before it)
-            return ring[(ring.index(cur) + 1) % 4]
-
-        dqkv_s = ws["dqkv_s"].data_ptr() if fork else dqkv
+        dqkv_s = dqkv
         # readout
         pl.gemm_tn(dY=ws["dlogits"].data_ptr(), ldy=1024, y_kind=A_BF16, A=x, lda=256, a_kind=A_F32, a_group=(S, SA), M=Mi,
                    N=1024, K=256, dW=self._g("out_x_proj.weight"), lddw=256, dBias=self._g("out_x_proj.bias"))
@@ -847,13 +787,12 @@ class STEngine:
                 # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
                 # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
                 # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
-                dxb_new = rot(dxb) if fork else (ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr())
+                dxb_new = ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr()
                 hg, du = ws["hg1"].data_ptr(), ws["du1"].data_ptr()
                 dkw = self._drop_fused(True, l)
                 dy2 = dxb  # dY of the fc2 weight gradient: behind the output Dropout when there is one (written by hma_mlp_bwd)
                 if dkw:
                     dy2 = dkw["dy_drop"] = ws["dxm"].data_ptr()
-                pl.join_next()  # (the previous layer's forked weight gradients still read hg / du / the old bf16 dx this kernel overwrites)
                 pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
                            w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
                            b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du, **dkw)
@@ -863,7 +802,7 @@ class STEngine:
                                      gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
                                      K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias),
                                      w_master=self._lw(l, "mlp.fc1.weight", "p"), dgamma=gw("norm2.weight"),
-                                     dbeta=gw("norm2.bias")), side=fbit(1))
+                                     dbeta=gw("norm2.bias")))
                 dxb = dxb_new
             else:
                 u, hg = dp(ws["u"], l, M * 1024), dp(ws["hg"], l, M * 1024)
@@ -898,7 +837,7 @@ class STEngine:
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
                             dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
-                                 dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)), side=fbit(2))
+                                 dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)))
             if self._use_chain(M, SA):
                 # ---- chain A backward (csrc/chain.hip): temporal qkv dgrad + residual -> linear_out dgrad -> modulate-LN backward
                 # -> spatial projection dgrad, one launch; dss accumulates by atomics (zeroed at the top of the plan)
@@ -911,12 +850,10 @@ class STEngine:
                     kwm = dict(xhat=xhm, rstd=rstdm, ss=dp(ws["ss"], l, Fr * 512), dx2_bf16=ws["dx2b"].data_ptr(),
                                dss=dp(ws["dss"], l, Fr * 512))
                 segs.append((self.CP["proj_s_T"][l].data_ptr(), 8))
-                if fork:
-                    dxb = rot(dxb)  # (the forked temporal weight gradients still read the previous buffer)
                 pl.chain_a_bwd(M, use_mod, segs=segs, dqkv=dqkv, dx=dx, dx1_bf16=dxb, d_o=t256, rows_per_frame=SA, **kwm)
                 if use_mod:
                     pl.gemm_tn(dY=ws["dx2b"].data_ptr(), ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"), side=fbit(4))
+                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
             else:
                 pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
@@ -938,20 +875,24 @@ class STEngine:
             if self.qkn:
                 pl.add("hma_qknorm_bwd", dqkv_s, 768, dp(ws["qraw_s"], l, M * 512), self._lw(l, "spatial_attn.norm.weight", "p"), 1e-5,
                        gw("spatial_attn.norm.weight"), gw("spatial_attn.norm.bias"), M)
+            # (on the chain path norm1's dgamma / dbeta come out of the qkv weight gradient's reduction, as norm2's do out of fc1's)
+            chain_s = self.chain_s and (not self.qkn) and self._use_chain(M, SA)
             aff1 = dict(a_kind=A_BF16) if self.qkn else dict(a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
                                                              beta=self._lw(l, "norm1.bias", "p"))
+            if chain_s:
+                aff1.update(w_master=self._lw(l, "spatial_attn.qkv.weight", "p"), dgamma=gw("norm1.weight"), dbeta=gw("norm1.bias"))
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
                             dict(dY=dqkv_s, ldy=768, y_kind=A_BF16, A=xh1, lda=256, M=M, N=768, K=256,
-                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1),
-                            side=fbit(8))
+                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
             if self.qkn:  # norm1 is the identity
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
+            elif chain_s:
+                # ---- chain S backward (csrc/chain.hip): spatial qkv dgrad -> norm1 backward -> residual, one launch
+                pl.chain_s_bwd(M, segs=[(self.CP["qkv_s_T"][l].data_ptr(), 24)], dqkv=dqkv_s, dx=dx, xhat=xh1, rstd=rstd1, dx_bf16=dxb)
             else:
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
-                if fork:
-                    dxb = rot(dxb)  # (the forked spatial weight gradients still read the previous buffer)
                 pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
                        dxb)
             # ---- the adaLN stacks of a finished group of layers (batched over the group): their weight gradients are final with the
@@ -1033,6 +974,7 @@ class STEngine:
             ws["actions"][: B * T * d_a].copy_(actions[:, :T].reshape(-1), non_blocking=True)
         if train:
             self.bump_dropout()
+            self._invalidate_trunk_stamps()
         fce = labels is not None and train and loss_grad and not need_logits and self._use_fused_ce(B, T, S)
         pl = self._forward_plan(B, T, S, A, train, domain if (A > 0 and not policy) else None, readout=not fce)
         self._act, self.act_scale = None, 0.0
@@ -1069,6 +1011,16 @@ class STEngine:
             self._loss_plan(B, T, S, train and loss_grad, fused=fce, A=A).run(stream, timer=self.timer)
         return ws
 
+    def _invalidate_trunk_stamps(self, keep: Optional[range] = None) -> None:
+        """A training forward is about to overwrite saved per-layer activations: block-level autograd nodes (trunk_autograd_forward)
+        whose backward has not run yet must not use them.  `keep`: the layers the caller re-stamps itself."""
+        stamps = getattr(self, "_trunk_stamps", None)
+        if stamps is None:
+            return
+        for l in range(len(stamps)):
+            if keep is None or l not in keep:
+                stamps[l] = 0
+
     # ------------------------------------------------------------------------------ trunk-only training (STMAR)
     def trunk_train_forward(self, B: int, T: int, S: int, actions: Optional[torch.Tensor], domain: Optional[str],
                             build_x: Callable[[dict], None], train: bool = True) -> dict:
@@ -1083,6 +1035,7 @@ class STEngine:
             build_x(ws)
             if train:
                 self.bump_dropout()
+                self._invalidate_trunk_stamps()
             self._forward_plan(B, T, S, 0, train, None, embed=False, readout=False).run(stream, timer=self.timer)
             if train:
                 self._last = (B, T, S, 0, None)
@@ -1104,6 +1057,7 @@ class STEngine:
         build_x(ws)
         if train:
             self.bump_dropout()
+            self._invalidate_trunk_stamps()
         self._forward_plan(B, T, S, A, train, domain, embed=False, readout=False).run(stream, timer=self.timer)
         if train:
             self._last = (B, T, S, A, domain)
@@ -1165,6 +1119,13 @@ class STEngine:
         stamps = getattr(self, "_trunk_stamps", None)
         if stamps is None or len(stamps) != L:
             stamps = self._trunk_stamps = [0] * L
+        if A > 0:
+            # the adaLN stacks above ran for ALL layers from this call's action embeddings (one batched GEMM pair): the saved shift /
+            # scale rows of layers outside [l0, l1) now belong to this call's a_emb -- unless it is the tensor the previous call had
+            akey = (a_emb.data_ptr(), a_emb._version, tuple(a_emb.shape), dom)
+            if akey != getattr(self, "_trunk_aemb_key", None):
+                self._invalidate_trunk_stamps(keep=range(l0, l1))
+            self._trunk_aemb_key = akey
         self._trunk_counter = getattr(self, "_trunk_counter", 0) + 1
         for l in range(l0, l1):
             stamps[l] = self._trunk_counter
@@ -1172,7 +1133,7 @@ class STEngine:
 
     def trunk_autograd_backward(self, dy_BTSD: torch.Tensor, stamp: tuple) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """d loss / d (stream out) -> (d loss / d (stream in), d loss / d a_emb); the layers' weight gradients are ADDED into the flat
-        gradient buffer.  Runs the layers' part of the recorded backward plan (no forked weight gradients, one adaLN group per layer:
+        gradient buffer.  Runs the layers' part of the recorded backward plan (one adaLN group per layer:
         a range of layers is then a contiguous run of the plan)."""
         B, T, S, A, dom, l0, l1, gen, count, drops = stamp
         L = self.cfg.num_layers
@@ -1185,12 +1146,12 @@ class STEngine:
         ws = self._ws
         SA, M, Fr = S + A, B * T * (S + A), B * T
         stream = torch.cuda.current_stream().cuda_stream
-        saved = (self.fork_wgrad, self.ada_group)
-        self.fork_wgrad, self.ada_group = 0, 1
+        saved = self.ada_group
+        self.ada_group = 1
         try:
             pl = self._backward_plan(B, T, S, A, dom)
         finally:
-            self.fork_wgrad, self.ada_group = saved
+            self.ada_group = saved
         ws["dx"].view(B, T, SA, 256).copy_(dy_BTSD, non_blocking=True)
         if A > 0:
             ws["da_emb"].zero_()

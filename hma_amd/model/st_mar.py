@@ -123,6 +123,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         """st_mar.py:80-99: the discrete model's per-domain stems / projectors plus one DiffLoss head per domain."""
         core = self._core
         core.init_action_projectors(domains, d_actions, action_stats, action_network)  # (its unused action_out_projectors stay internal)
+        self._ver_params = None  # (the parameter set the engine's version check sums over has changed)
         self.config.init_actions = True
         self.config.action_domains, self.config.d_actions, self.config.action_stats = list(domains), list(d_actions), action_stats
         self.action_preprocessor = core.action_preprocessor
@@ -159,7 +160,13 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
     def _engine(self, dev):
         core = self._core
         eng = core._get_engine(dev)
-        ver = tuple(p._version for p in (self.decoder.layers[0].mlp.fc1.weight, self.decoder.layers[-1].mlp.fc2.weight))
+        ps = getattr(self, "_ver_params", None)
+        if ps is None:  # (the trunk's parameters: what the engine keeps derived copies of)
+            am = getattr(self, "action_mlp", None)
+            ps = self._ver_params = list(self.decoder.parameters()) + (list(am.parameters()) if am is not None else [])
+        ver = 0
+        for q in ps:
+            ver += q._version
         if ver != getattr(self, "_seen_versions", None):  # load_state_dict / an optimizer wrote through the named parameters
             self._seen_versions = ver
             eng.weights_changed()

@@ -302,9 +302,16 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
 
     def _check_versions(self, eng) -> None:
         """In-place writes through the named parameters (load_state_dict, a torch optimizer) bump the parameters' own version
-        counters, not the flat buffer's: watch a few sentinels and re-derive the bf16 / packed weight copies when they move."""
-        ver = (self.out_x_proj.weight._version, self.pos_embed_TSC._version, self.decoder.layers[0].mlp.fc1.weight._version,
-               self.decoder.layers[-1].mlp.fc2.weight._version)
+        counters, not the flat buffer's: re-derive the bf16 / packed weight copies when ANY of them moved (the sum over all
+        parameters -- a few thousand integer reads; four sentinel tensors used to miss an optimizer that only steps, say, one
+        domain's action projectors or the attention weights)."""
+        ps = getattr(self, "_ver_params", None)
+        if ps is None or len(ps) != getattr(self, "_ver_count", -1):
+            ps = self._ver_params = list(self.parameters())
+            self._ver_count = len(ps)
+        ver = 0
+        for q in ps:
+            ver += q._version
         if ver != getattr(self, "_seen_versions", None):
             self._seen_versions = ver
             eng.weights_changed()

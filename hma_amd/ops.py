@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, ChainBFwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
+                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, ChainBFwd, ChainSBwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -172,6 +172,16 @@ def make_chain_a_bwd(*, M: int, segs, dqkv: int, dx: int, dx1_bf16: int, d_o: in
     g.xhat, g.rstd, g.ss = xhat, rstd, ss
     g.dx2_bf16, g.dx1_bf16, g.d_o, g.dss = dx2_bf16, dx1_bf16, d_o, dss
     g.M, g.rows_per_frame, g.use_mod = M, rows_per_frame, 1 if use_mod else 0
+    return g
+
+
+def make_chain_s_bwd(*, M: int, segs, dqkv: int, dx: int, xhat: int, rstd: int, dx_bf16: int, ldq: int = 768) -> ChainSBwd:
+    """segs: packed qkv^T (3 x 8) of the spatial attention with norm1's gamma folded into the output rows."""
+    g = ChainSBwd()
+    _chain_weights(g.w, segs)
+    g.dqkv, g.ldq, g.dx = dqkv, ldq, dx
+    g.xhat, g.rstd, g.dx_bf16 = xhat, rstd, dx_bf16
+    g.M = M
     return g
 
 

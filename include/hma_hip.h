@@ -444,6 +444,23 @@ typedef struct {
 } hma_chain_a_bwd_t;
 int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p);
 
+/* Chain S backward -- the spatial side of a block's backward behind the attention backward (st_transformer.py:85-86: norm1 and the
+ * qkv Linear of attention.py:39, autograd mirror), what hma_gemm_nt (dqkv -> bf16 g) + hma_ln_bwd did in two launches:
+ *   g = dqkv Wqkv diag(gamma);  dx <- dx + rstd (g - mean(g) - xhat mean(g xhat));  dx_bf16 = bf16(dx)
+ * in: dqkv [M, ldq >= 768] bf16 (spatial attention backward), xhat [M,256] bf16 / rstd [M] saved by the forward (norm1's output
+ * without its affine), dx [M,256] fp32 (updated in place); out: dx_bf16 [M,256].  M % 16 == 0.
+ * weights: 24 N-block bundles of Wqkv^T in three k-chunks as in chain A backward, with norm1's gamma folded into the OUTPUT rows
+ * (hma_chain_pack row_scale).  norm1's dgamma / dbeta are not produced here: they come out of the qkv weight gradient's reduction
+ * (hma_gemm_tn_t w_master / dgamma / dbeta). */
+typedef struct {
+  hma_chain_weights_t w;
+  const void* dqkv; int64_t ldq; float* dx;
+  const void* xhat; const float* rstd;
+  void* dx_bf16;
+  int64_t M;
+} hma_chain_s_bwd_t;
+int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p);
+
 /* Chain B forward (inference / decode passes, and training passes with the fields at the end of the struct): st_transformer.py:111
  * proj, :112 norm2 + Mlp (:24-27), and the NEXT block's :85-86 norm1 + qkv (attention.py:39):
  *   x1 = x + o Wproj^T + b_proj;  x2 = x1 + fc2(gelu(fc1(LN(x1)))) ;  qkv = LN(x2) Wqkv'^T + b_qkv'

@@ -160,6 +160,42 @@ def test_chain_a_bwd(M, rpf, mod):
     assert (do.float().cpu() - d_o).abs().max() < 0.2 * (do.float().cpu() - d_o.flip(1)).abs().max()
 
 
+@pytest.mark.parametrize("M", [16, 112, 1008, 320 * 7, 40960, 163840])
+def test_chain_s_bwd(M):
+    """Spatial qkv input gradient -> norm1 backward -> residual, one launch (what hma_gemm_nt + hma_ln_bwd did in two).  Reference:
+    hma/model/st_transformer.py:85-86, hma/model/attention.py:39 (autograd mirror); gamma folded into the packed weight's output rows."""
+    _, _, wq, _, _, _ = _weights(500)
+    gamma = 1.0 + 0.2 * torch.randn(256, generator=g(20))
+    dqkv = rb(torch.randn(M, 768, generator=g(21)) * 0.02)
+    dx = torch.randn(M, 256, generator=g(22)) * 0.02
+    x0 = torch.randn(M, 256, generator=g(23)) * 1.5 + 0.2
+    mean, var = x0.mean(1, keepdim=True), x0.var(1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + 1e-5)
+    xh = rb((x0 - mean) * rstd)
+    # reference: the weight the kernel multiplies is bf16(gamma[k] W[n][k])
+    wg = rb(wq * gamma[None, :])
+    gq = dqkv @ wg
+    dx1 = dx + rstd * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))
+    # kernel
+    gd = gamma.to(DEV)
+    wd = wq.to(DEV).contiguous()
+    wt = torch.cat([ops.chain_pack(wd[256 * c:], kind=0, rows=256, cols=256, row_stride=1, col_stride=256, row_scale=gd) for c in range(3)])
+    dxd = dx.to(DEV).clone()
+    dqd = dqkv.to(DEV).bfloat16()
+    xhd, rsd = xh.to(DEV).bfloat16(), rstd.reshape(-1).to(DEV).contiguous()
+    d1 = torch.zeros(M, 256, dtype=torch.bfloat16, device=DEV)
+    a = ops.make_chain_s_bwd(M=M, segs=[(ops.ptr(wt), 24)], dqkv=ops.ptr(dqd), dx=ops.ptr(dxd), xhat=ops.ptr(xhd), rstd=ops.ptr(rsd),
+                             dx_bf16=ops.ptr(d1))
+    _lib.call("hma_chain_s_bwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    close(dxd, dx1, 3e-3, "dx")
+    assert rms(dxd, dx1) < 3e-3
+    assert rms(dxd.cpu() - dx, dx1 - dx) < 4e-3  # (the part the kernel adds, not the residual it passes through)
+    close(d1, dx1, 2 * BF, "dx bf16")
+    assert (dxd.cpu() - dx1).abs().max() < 0.2 * (dxd.cpu() - dx1.flip(1)).abs().max()
+    assert (dxd.cpu() - dx1).abs().max() < 0.2 * (dxd.cpu() - dx1.flip(0)).abs().max()
+
+
 @pytest.mark.parametrize("M,with_qkv,save", [(112, True, False), (1008, True, True), (20480, True, False), (40960, True, True), (163840, True, True),
                                              (2560, False, False), (2560, False, True)])
 def test_chain_b_fwd(M, with_qkv, save):

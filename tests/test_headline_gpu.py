@@ -1,13 +1,13 @@
 """Parity of the TIMED configuration: the shape bench.py's headline number is measured on -- B = 32, T = 16,
 16 x 16 tokens + 64 action tokens per frame (M = 163 840 token rows), 40 action domains -- through the path the timed region takes:
-`Trainer` with hipGraph replay and the weight gradients forked to the side stream (`fork_wgrad = 9`: the four-buffer bf16(dx) ring,
-the second dqkv).  The full-depth tests against the oracle run at B = 1 (tests/test_fulldepth_gpu.py); what can go wrong only at
-size (tiles per workgroup, M-slices per weight gradient, buffer lifetimes of the forked launches, graph edges) is pinned here by
-properties that do not need an oracle run of that size:
+`Trainer` with hipGraph replay (round 5: the forked weight gradients are gone -- their measured gain had fallen to zero -- so the
+replayed graph is a straight line of launches).  The full-depth tests against the oracle run at B = 1 / B = 2
+(tests/test_fulldepth_gpu.py); what can go wrong only at size (tiles per workgroup, M-slices per weight gradient, buffer lifetimes
+under replay) is pinned here by properties that do not need an oracle run of that size:
 
   (a) gradient decomposition: the loss is a masked mean (hma/model/st_mask_git.py:620-627), so the flat gradient of one B = 32 step
-      equals the masked-token-weighted sum of the gradients of its four B = 8 chunks -- taken EAGERLY and UNFORKED;
-  (b) graph replay + forks against eager unforked launches on the same batches, over consecutive optimizer steps;
+      equals the masked-token-weighted sum of the gradients of its four B = 8 chunks -- taken EAGERLY;
+  (b) graph replay against eager launches on the same batches, over consecutive optimizer steps;
   (c) the spatial attention backward at 512 frames against fp32 math (the other kernels' M = 163 840 cases are parametrisations of
       tests/test_chain_gpu.py / tests/test_kernels_gpu.py);
   (d) the same decomposition for `MarTrainer` at configs[3]'s per-GPU batch 16;
@@ -61,11 +61,10 @@ def _region_errs(lay, G, Gref, dom):
     return out
 
 
-def _trainer(layers, fork, graphs, seed_offset=0):
+def _trainer(layers, graphs, seed_offset=0):
     model, domains, d_actions = bench.build_model(40, 16, layers)
     model = model.to(DEV).train()
     tr = Trainer(model, lr=1e-4, warmup_steps=0, device=torch.device(DEV, torch.cuda.current_device()))
-    tr.engine.fork_wgrad = fork
     tr.use_graphs = graphs
     return tr, domains, d_actions
 
@@ -84,7 +83,7 @@ def _grad_of(tr, ids, labels, act, dom):
 @pytest.mark.parametrize("layers", [4, 32])
 def test_gradient_decomposition_at_headline_shape(layers):
     di = 3
-    tr, domains, d_actions = _trainer(layers, fork=9, graphs=True)
+    tr, domains, d_actions = _trainer(layers, graphs=True)
     eng = tr.engine
     dom = domains[di]
     ids, labels, act = bench.synthetic_batch(32, 16, 100 + di, d_actions[di], DEV)
@@ -95,17 +94,14 @@ def test_gradient_decomposition_at_headline_shape(layers):
     G32b, loss32b = _grad_of(tr, ids, labels, act, dom)
     errs = _region_errs(eng.layout, G32b, G32, dom)
     assert max(errs.values()) <= 1e-3, f"two replays of the same step differ: {errs}"
-    assert "dqkv_s" in eng._ws, "the forked plan's buffers are not in use"
-    # the four chunks, eagerly and unforked
+    # the four chunks, eagerly
     tr.use_graphs = False
-    eng.fork_wgrad = 0
     eng._plans = {}
     Gsum = torch.zeros_like(G32)
     num = den = 0.0
     for c in range(0, 32, 8):
         sl = slice(c, c + 8)
         Gc, lc = _grad_of(tr, ids[sl], labels[sl], act[sl], dom)
-        assert "dqkv_s" not in eng._ws
         n = float((ids[sl].reshape(8, 16, 256)[:, 1:] == MASK).sum())
         Gsum += Gc * n
         num += lc * n
@@ -117,7 +113,7 @@ def test_gradient_decomposition_at_headline_shape(layers):
     _note(f"decomposition.L{layers}.worst_region_rms", max(errs.values()))
     _note(f"decomposition.L{layers}.regions", errs)
     bad = {k: v for k, v in errs.items() if not v <= 1e-2}
-    assert not bad, f"gradient of the B = 32 graph-replayed forked step != weighted sum of its eager B = 8 chunks: {bad}"
+    assert not bad, f"gradient of the B = 32 graph-replayed step != weighted sum of its eager B = 8 chunks: {bad}"
     # untouched domains received nothing
     for d2 in (domains[0], domains[39]):
         a, b = eng.layout.regions[f"dom:{d2}"]
@@ -125,45 +121,43 @@ def test_gradient_decomposition_at_headline_shape(layers):
 
 
 @pytest.mark.timeout(1200)
-def test_graph_replay_with_forks_equals_eager_unforked_over_steps():
-    """Two trainers on identical models and batches: A replays hipGraphs with fork_wgrad = 9 (also 15: all four forks), B launches
-    eagerly with no fork.  Per step: the flat gradient (rms per region) and the loss; at the end the weights, against the distance
-    they moved."""
-    for fork in (9, 15):
-        trA, domains, d_actions = _trainer(4, fork=fork, graphs=True)
-        trB, _, _ = _trainer(4, fork=0, graphs=False)
-        assert torch.equal(trA.engine.P, trB.engine.P)
-        P0 = trA.engine.P.clone()
-        di = 5
-        dom = domains[di]
-        batches = [bench.synthetic_batch(32, 16, 300 + k, d_actions[di], DEV) for k in range(5)]
-        for k, (ids, labels, act) in enumerate(batches):
-            out = []
-            for tr in (trA, trB):
-                ws = tr.micro_step(ids, labels, act, [dom] * 32, step_domains=[dom])
-                out.append((tr.engine.G.clone(), float(tr.loss_and_acc(ws)[0].item())))
-                tr.optimizer_step()
-            (GA, lA), (GB, lB) = out
-            errs = _region_errs(trA.engine.layout, GA, GB, dom)
-            _note(f"replay_vs_eager.fork{fork}.step{k}.worst_region_rms", max(errs.values()))
-            assert abs(lA - lB) <= 1e-3, (k, lA, lB)
-            # (steps 0 / 1 run eagerly in A as well; from step 2 on A replays.  Later steps start from weights that differ by the
-            # earlier steps' rounding noise through Adam: the bound covers that)
-            assert max(errs.values()) <= 1e-2, (fork, k, errs)
-        assert trA._graphs and not trB._graphs
-        moved = (trB.engine.P - P0).double().pow(2).sum().sqrt().item()
-        diff = (trA.engine.P - trB.engine.P).double().pow(2).sum().sqrt().item()
-        _note(f"replay_vs_eager.fork{fork}.weights_diff_over_moved", diff / moved)
-        assert diff <= 2e-2 * moved, (diff, moved)
-        del trA, trB
-        torch.cuda.empty_cache()
+def test_graph_replay_equals_eager_over_steps():
+    """Two trainers on identical models and batches: A replays hipGraphs, B launches eagerly.  Per step: the flat gradient (rms per
+    region) and the loss; at the end the weights, against the distance they moved."""
+    trA, domains, d_actions = _trainer(4, graphs=True)
+    trB, _, _ = _trainer(4, graphs=False)
+    assert torch.equal(trA.engine.P, trB.engine.P)
+    P0 = trA.engine.P.clone()
+    di = 5
+    dom = domains[di]
+    batches = [bench.synthetic_batch(32, 16, 300 + k, d_actions[di], DEV) for k in range(5)]
+    for k, (ids, labels, act) in enumerate(batches):
+        out = []
+        for tr in (trA, trB):
+            ws = tr.micro_step(ids, labels, act, [dom] * 32, step_domains=[dom])
+            out.append((tr.engine.G.clone(), float(tr.loss_and_acc(ws)[0].item())))
+            tr.optimizer_step()
+        (GA, lA), (GB, lB) = out
+        errs = _region_errs(trA.engine.layout, GA, GB, dom)
+        _note(f"replay_vs_eager.step{k}.worst_region_rms", max(errs.values()))
+        assert abs(lA - lB) <= 1e-3, (k, lA, lB)
+        # (steps 0 / 1 run eagerly in A as well; from step 2 on A replays.  Later steps start from weights that differ by the
+        # earlier steps' rounding noise through Adam: the bound covers that)
+        assert max(errs.values()) <= 1e-2, (k, errs)
+    assert trA._graphs and not trB._graphs
+    moved = (trB.engine.P - P0).double().pow(2).sum().sqrt().item()
+    diff = (trA.engine.P - trB.engine.P).double().pow(2).sum().sqrt().item()
+    _note("replay_vs_eager.weights_diff_over_moved", diff / moved)
+    assert diff <= 2e-2 * moved, (diff, moved)
+    del trA, trB
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.timeout(900)
-def test_segmented_graphs_with_forks_equal_one_graph():
-    """The data-parallel form of the replay (one graph per gradient bucket, `force_segments`) against the single graph, forks on."""
-    trA, domains, d_actions = _trainer(4, fork=9, graphs=True)
-    trB, _, _ = _trainer(4, fork=9, graphs=True)
+def test_segmented_graphs_equal_one_graph():
+    """The data-parallel form of the replay (one graph per gradient bucket, `force_segments`) against the single graph."""
+    trA, domains, d_actions = _trainer(4, graphs=True)
+    trB, _, _ = _trainer(4, graphs=True)
     trB.force_segments = True
     trB.layers_per_bucket = 2
     di = 7
