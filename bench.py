@@ -547,9 +547,23 @@ def main():
     if world > 1 or force:
         dist.barrier()
     torch.cuda.synchronize()
+    # HMA_BENCH_DP_CHECK=1 (debug, tests/test_dp_gpu.py): after every timed step the ranks compare a digest of their weights, and the
+    # line reports how many gradient buckets were all-reduced from inside the backward and how many bytes went through all-reduce
+    dp_check = {"steps": 0, "weights_equal": True, "early_buckets": [], "bytes_per_step": [], "buckets": len(trainer.reducer.dense_buckets)} \
+        if (os.environ.get("HMA_BENCH_DP_CHECK") == "1" and (world > 1 or force)) else None
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
         ws = one(k)
+        if dp_check is not None:
+            P = trainer.engine.P
+            idx = torch.arange(P.numel(), device=P.device, dtype=torch.float64)
+            dig = torch.stack([P.double().sum(), P.double().abs().sum(), (P.double() * (1.0 + (idx % 977.0))).sum()])
+            alld = [torch.zeros_like(dig) for _ in range(world)]
+            dist.all_gather(alld, dig)
+            dp_check["weights_equal"] = dp_check["weights_equal"] and all(torch.equal(a, alld[0]) for a in alld)
+            dp_check["steps"] += 1
+            dp_check["early_buckets"].append(int(trainer.reducer.early_buckets))
+            dp_check["bytes_per_step"].append(int(trainer.reducer.bytes_step))
     torch.cuda.synchronize()
     if world > 1 or force:
         dist.barrier()
@@ -594,6 +608,8 @@ def main():
         }
         if power is not None:
             out["power"] = power
+        if dp_check is not None:
+            out["dp_check"] = dp_check
         if timer is not None:
             summ = timer.summary()
             step_ms = 1e3 * dt / args.steps

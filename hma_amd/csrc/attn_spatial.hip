@@ -10,6 +10,8 @@
 //
 // Reference: BasicSelfAttention.forward, hma/model/attention.py:37-61 (causal=False), called from
 // STBlock.forward hma/model/st_transformer.py:85-86; backward = its autograd mirror.
+#include <type_traits>
+
 #include "hma_common.h"
 #include "../../include/hma_hip.h"
 
@@ -491,9 +493,9 @@ __device__ __forceinline__ bf16x8_t frag_tr_f(const uint16_t* tile, int row0, in
 // LDS-only barrier: waits for this wave's LDS operations, not for its global loads (the next item's rows stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NT, int KT = 1>
+template <int NT, int KT = 1, int THREADS_ = (NT / KT + 2) * 64, bool NEG_DELTA = false>
 struct FusedStage {
-  static constexpr int N = NT * 32, ITEMS = N * 4, THREADS = (NT / KT + 2) * 64, R = (ITEMS + THREADS - 1) / THREADS;
+  static constexpr int N = NT * 32, ITEMS = N * 4, THREADS = THREADS_, R = (ITEMS + THREADS - 1) / THREADS;
   // (vectors, not arrays: carried around the item loop as arrays, hipcc leaves three of them in scratch)
   typedef uint32_t vec_t __attribute__((ext_vector_type(4 * R)));
   vec_t rq, rk, rv, rg, ro;
@@ -549,7 +551,7 @@ struct FusedStage {
       dsum += __shfl_xor(dsum, 1, 64);
       dsum += __shfl_xor(dsum, 2, 64);
       if ((c & 3) == 0) {
-        Dls[c >> 2] = dsum;
+        Dls[c >> 2] = NEG_DELTA ? -dsum : dsum;  // (NEG_DELTA: the dP accumulators start from -delta, see attn_bwd_bal_kernel)
         delta[(frame * N + (c >> 2)) * NH + head] = dsum;
       }
     }
@@ -725,6 +727,188 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------------- the fused backward, balanced over the SIMDs
+// Round 5.  The 7-wave form above puts TWO tile waves of two key tiles each on one SIMD (waves w and w + 4 share a SIMD: four tiles
+// per step there) and one tile wave alone on another (two tiles): the step -- every wave meets at its barrier -- runs at the pace
+// of the four-tile SIMD.  Here n = 320 runs EIGHT waves: waves 0..2 own two key tiles each (tiles 0..5), waves 3..6 one each
+// (tiles 6..9), wave 7 forms dQ of EVERY query tile; the SIMD pairs are then (w0, w4) = 3 tiles, (w1, w5) = 3, (w2, w6) = 3,
+// (w3, w7) = 1 tile + the dQ job.  Also:
+//   * the dP accumulators START from -delta[q] (the MFMA's C operand, read from LDS where the staging put the negated values), which
+//     removes the subtraction from dS = P (dP - delta) -- one VALU operation in five per score element;
+//   * the next item's rows are fetched by the five LIGHT waves only (waves 3..7: 320 threads x 4 chunks of each of q, k, v, dO, o);
+//     the two-tile waves carry no prefetch registers (60 of them, which the 7-wave form had to fit beside two tiles' accumulators)
+//     and keep their K / V fragments in registers instead of re-reading them every step.  Each role runs its OWN copy of the item
+//     loop (the hardware barrier counts arrivals, not program counters), so the prefetch registers are dead code on the heavy path.
+#ifndef ATTN_BAL   // (0: measurement builds -- the 7-wave form for n = 320 as well)
+#define ATTN_BAL 1
+#endif
+template <int NT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
+                                                              const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                              int64_t frames, float c_log2, float scale) {
+  static_assert(NT == 10, "the wave -> key tile table below is for ten key tiles");
+  constexpr int N = NT * 32;
+  constexpr int HEAVY = 3;  // waves 0 .. HEAVY - 1: two key tiles each; HEAVY .. 6: one each; 7: dQ
+  constexpr int FT = (8 - HEAVY) * 64;
+  static_assert(FT == N, "one lse value per fetching thread");
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t* Qs = smem;                 // [N][LDF]
+  uint16_t* Ks = Qs + N * LDF;
+  uint16_t* Vs = Ks + N * LDF;
+  uint16_t* Gs = Vs + N * LDF;         // dO
+  uint16_t* Ts = Gs + N * LDF;         // 2 x [N keys][LDF]: dS of one query tile, [key][query]
+  float* L2s = reinterpret_cast<float*>(Ts + 2 * N * LDF);  // [N]
+  float* Dls = L2s + N;                                      // [N]: -delta
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int64_t nitems = frames * NH;
+
+  // ---- one (frame, head) item of a tile wave: KT key tiles from tile kt0 on
+  auto tile_item = [&](auto kt_c, const int kt0, const int64_t frame, const int head) __attribute__((always_inline)) {
+    constexpr int KT = decltype(kt_c)::value;
+    bf16x8_t kf[KT][2], vf[KT][2];
+    f32x16_t dk[KT], dv[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      kf[t][0] = frag_rows_f(Ks, (kt0 + t) * 32, 0, lane); kf[t][1] = frag_rows_f(Ks, (kt0 + t) * 32, 1, lane);
+      vf[t][0] = frag_rows_f(Vs, (kt0 + t) * 32, 0, lane); vf[t][1] = frag_rows_f(Vs, (kt0 + t) * 32, 1, lane);
+      dk[t] = zero16(); dv[t] = zero16();
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+      // S[q][key], dP[q][key]: lane = key, rows = q.  The query tile's fragments serve every key tile of the wave.
+      const bf16x8_t aq0 = frag_rows_f(Qs, qt * 32, 0, lane), aq1 = frag_rows_f(Qs, qt * 32, 1, lane);
+      const bf16x8_t ag0 = frag_rows_f(Gs, qt * 32, 0, lane), ag1 = frag_rows_f(Gs, qt * 32, 1, lane);
+      f32x16_t sc[KT], dp[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        // dP starts from -delta of the tile's query rows 8 g + 4 hi + {0..3} (the accumulator's order), read straight into the
+        // accumulator registers
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 d4 = make_float4(c_log2, scale, c_log2, scale);
+          if (!(ATTN_ABL & 1)) d4 = *reinterpret_cast<const float4*>(&Dls[qt * 32 + 8 * g + 4 * hi]);
+          dp[t][4 * g] = d4.x; dp[t][4 * g + 1] = d4.y; dp[t][4 * g + 2] = d4.z; dp[t][4 * g + 3] = d4.w;
+        }
+        sc[t] = mfma32(aq0, kf[t][0], zero16());
+        sc[t] = mfma32(aq1, kf[t][1], sc[t]);
+        dp[t] = mfma32(ag0, vf[t][0], dp[t]);
+        dp[t] = mfma32(ag1, vf[t][1], dp[t]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // rows 8 g + 4 hi + {0..3}: one 16-byte LDS read for lse, shared by the key tiles
+        float4 l4 = make_float4(c_log2, scale, c_log2, scale);
+        if (!(ATTN_ABL & 1)) l4 = *reinterpret_cast<const float4*>(&L2s[qt * 32 + 8 * g + 4 * hi]);
+        const float lq[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float arg = sc[t][4 * g + e] * c_log2 - lq[e];
+            const float pr = (ATTN_ABL & 4) ? arg : fast_exp2(arg);
+            sc[t][4 * g + e] = pr;
+            dp[t][4 * g + e] = pr * dp[t][4 * g + e];
+          }
+          // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
+          if (!(ATTN_ABL & 8)) {
+            uint16_t* T = Ts + (qt & 1) * N * LDF + foff((kt0 + t) * 32 + (lane & 31), g);
+            *reinterpret_cast<uint2*>(T + 4 * hi) =
+                make_uint2(pack_bf16(dp[t][4 * g], dp[t][4 * g + 1]), pack_bf16(dp[t][4 * g + 2], dp[t][4 * g + 3]));
+          }
+        }
+      }
+      // (dS tile of query tile qt complete after this barrier; the buffer's previous reader -- the dQ job of qt - 2 -- is past its
+      // reads: the dQ wave arrived at the barrier of qt - 1 only after them)
+      lds_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t gt = frag_tr_f(Gs, qt * 32 + 16 * s2, lane), qtr = frag_tr_f(Qs, qt * 32 + 16 * s2, lane);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          dv[t] = mfma32(gt, pack_acc_half(sc[t], s2), dv[t]);
+          dk[t] = mfma32(qtr, pack_acc_half(dp[t], s2), dk[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int64_t row0 = frame * N + (kt0 + t) * 32;
+      if (!(ATTN_ABL & 128)) {
+        store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[t], scale, lane);
+        store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv[t], 1.0f, lane);
+      }
+    }
+  };
+  // ---- one item of the dQ wave: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], while the tile waves
+  // work on query tile qt + 1 (which goes to the other dS buffer)
+  auto dq_item = [&](const int64_t frame, const int head) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+      lds_barrier();
+      if (!(ATTN_ABL & 2)) {
+        const uint16_t* Tq = Ts + (qt & 1) * N * LDF;
+        f32x16_t a0 = zero16(), a1 = zero16();
+        static_assert((2 * NT) % 4 == 0, "groups of four k-steps");
+        bf16x8_t fa[4], fb[4], na[4], nb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i] = frag_tr_f(Ks, 16 * i, lane); fb[i] = frag_tr_f(Tq, 16 * i, lane); }
+#pragma unroll
+        for (int grp = 0; grp < NT / 2; ++grp) {
+          if (grp + 1 < NT / 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              na[i] = frag_tr_f(Ks, 16 * (4 * grp + 4 + i), lane);
+              nb[i] = frag_tr_f(Tq, 16 * (4 * grp + 4 + i), lane);
+            }
+          }
+          a0 = mfma32(fa[0], fb[0], a0);
+          a1 = mfma32(fa[1], fb[1], a1);
+          a0 = mfma32(fa[2], fb[2], a0);
+          a1 = mfma32(fa[3], fb[3], a1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a0[e] += a1[e];
+        if (!(ATTN_ABL & 128)) store_dt(dqkv + (frame * N + qt * 32) * QKV_LD + head * HD, QKV_LD, a0, scale, lane);
+      }
+    }
+  };
+
+  if (wave < HEAVY) {
+    // ---- the two-tile waves: no staging work (barriers only around it)
+#pragma unroll 1
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+      lds_barrier();  // the item is staged
+      int64_t frame; int head;
+      decode_block(item, frames, frame, head);
+      tile_item(std::integral_constant<int, 2>{}, 2 * wave, frame, head);
+      lds_barrier();  // every wave is done with this item's LDS before the next one is staged
+    }
+  } else {
+    // ---- the light waves stage the items: 320 threads x 4 sixteen-byte chunks of each array
+    FusedStage<NT, 1, FT, true> st;
+    const int ftid = tid - HEAVY * 64;
+    int64_t item = blockIdx.x;
+    if (item < nitems) st.fetch(qkv, o, d_o, lse, item, frames, ftid);
+#pragma unroll 1
+    for (; item < nitems; item += gridDim.x) {
+      st.stage(Qs, Ks, Vs, Gs, L2s, Dls, delta, item, frames, ftid);
+      lds_barrier();  // (LDS-only barriers throughout: a __syncthreads would also drain the previous item's dqkv stores)
+      const int64_t nxt = item + gridDim.x;
+      if (nxt < nitems && !(ATTN_ABL & 64)) st.fetch(qkv, o, d_o, lse, nxt, frames, ftid);
+      int64_t frame; int head;
+      decode_block(item, frames, frame, head);
+      if (wave == 7) dq_item(frame, head);
+      else tile_item(std::integral_constant<int, 1>{}, 2 * HEAVY + (wave - HEAVY), frame, head);
+      lds_barrier();
+    }
+  }
+}
+
 template <auto Kern>
 int set_lds(int bytes) {
   static bool done = false;
@@ -768,6 +952,19 @@ template <int NT>
 int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                      int64_t frames, float scale) {
   constexpr int N = NT * 32;
+#if ATTN_BAL
+  if constexpr (NT == 10) {
+    constexpr int bytes = 6 * N * LDF * 2 + 2 * N * 4;
+    int rc = set_lds<attn_bwd_bal_kernel<NT>>(bytes);
+    if (rc) return rc;
+    const int64_t items = frames * NH;
+    const int grid = (int)(items < cu_count() ? items : cu_count());
+    hipLaunchKernelGGL((attn_bwd_bal_kernel<NT>), dim3((unsigned)grid), dim3(512), bytes, s, (const uint16_t*)qkv, (const uint16_t*)o,
+                       (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale);
+    HMA_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   constexpr int KT = (NT >= 8 && NT % ATTN_KT == 0) ? ATTN_KT : 1;
   constexpr int bytes = 6 * N * LDF * 2 + 2 * N * 4;
   int rc = set_lds<attn_bwd_fused_kernel<NT, KT>>(bytes);

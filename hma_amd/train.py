@@ -55,6 +55,8 @@ class GradReducer:
         # a domain's block is layer-major (params.py): its slice for the layers of dense bucket i is contiguous and final with the bucket
         self._dom_buckets = {d: layout.dom_buckets(d, layers_per_bucket) for d in layout.domains}
         self._active: List[str] = []
+        self.early_buckets = 0
+        self.bytes_step = 0
 
     def active_domains(self, local_domain: Optional[str]) -> List[str]:
         """Union over ranks of this micro-batch's domains, in layout order (same list on every rank).  FALLBACK for callers
@@ -79,6 +81,7 @@ class GradReducer:
     def _launch(self, a: int, b: int) -> None:
         if not self.collective or b <= a:
             return
+        self.bytes_step += 4 * (b - a)
         sl = self.G[a:b]
         if self.side is not None:
             ev = torch.cuda.Event()
@@ -93,6 +96,8 @@ class GradReducer:
         """`active`: the step's domains (known before its last backward starts): their slices ride with the dense buckets."""
         self._pending, self._next = [], 0
         self._active = list(active)
+        self.early_buckets = 0   # dense buckets (each with the active domains' slices) reduced from INSIDE the backward this step
+        self.bytes_step = 0      # bytes handed to all-reduce this step (gradient slices; `extra` tensors not counted)
 
     def _launch_bucket(self, i: int) -> None:
         self._launch(*self.dense_buckets[i])
@@ -105,6 +110,7 @@ class GradReducer:
         while self._next < len(self.dense_buckets) and label == self.bucket_label[self._next]:
             self._launch_bucket(self._next)
             self._next += 1
+            self.early_buckets += 1
 
     def _launch_tensor(self, t: torch.Tensor) -> None:
         if not self.collective or t.numel() == 0:

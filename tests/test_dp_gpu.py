@@ -181,6 +181,19 @@ def test_bench_gpus_2_spawns_two_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 8
     assert line["backend"] == "gloo" and line["value"] > 0
+    # ---- the same launch over SIX timed steps with the ranks checking each other (HMA_BENCH_DP_CHECK=1): after EVERY optimizer step the
+    # two ranks hold the same weights (each drew its own domain: dense slices + two domains' slices summed, one clip, one AdamW), and
+    # every gradient bucket's all-reduce was issued from inside the backward (between the per-bucket graphs), not after it
+    env["HMA_BENCH_DP_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "4", "--steps", "6", "--warmup", "1",
+                        "--domains", "40", "--batch", "4", "--mode", "train", "--no-cpu-baseline", "--no-kernel-timing"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    chk = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["dp_check"]
+    assert chk["steps"] == 6 and chk["weights_equal"], chk
+    assert chk["buckets"] >= 1 and all(e == chk["buckets"] for e in chk["early_buckets"]), chk
+    assert all(b > 0 for b in chk["bytes_per_step"]), chk
+    env.pop("HMA_BENCH_DP_CHECK")
     # more ranks than visible devices (no one-device override): a loud failure, not a silent single-rank line
     env.pop("HMA_BENCH_ONE_DEVICE")
     n = torch.cuda.device_count() + 1

@@ -157,6 +157,55 @@ def test_full_depth_forward_backward_vs_oracle(dom):
     _note(f"{dom}.worst_grad_rms", worst)
 
 
+@pytest.mark.timeout(1200)
+def test_trainer_graph_replay_b2_vs_oracle():
+    """The TIMED code path against something that is not itself: `Trainer.micro_step` -- embed, the chains,
+    the fused MLP backward, readout + cross-entropy in one launch, the whole step replayed as a hipGraph -- at L = 32, T = 16, B = 2
+    against the oracle's loss and gradients on the host cores.  (tests/test_headline_gpu.py pins the B = 32 shape against eager
+    B = 8 chunks of the same engine; this is the same path against the CPU restatement of hma/train_multi.py:556-599's
+    forward / backward.)"""
+    from hma_amd.train import Trainer
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 128)))
+    dom, d_a, B = "domA", 7, 2
+    ids, labels, act = _inputs(B, 77, d_a)
+    cfg = _ref_cfg()
+    sd = _state_dict()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not (k.endswith(".mean") or k.endswith(".std"))}
+    full = dict(sd)
+    full.update(leaf)
+    loss_ref, _, _ = R.forward(full, cfg, ids, labels, act, [dom] * B)
+    loss_ref.backward()
+    m = _model()
+    tr = Trainer(m, lr=1e-4, warmup_steps=0, device=torch.device(DEV, torch.cuda.current_device()))
+    eng = tr.engine
+    eng.fused_mlp_min_rows = 0  # (B = 2 is 10 240 token rows: below the fused MLP block's policy threshold, which B = 32 is not)
+    dv = lambda t: t.to(DEV)
+    for it in range(4):  # eager, eager + capture, two replays
+        ws = tr.micro_step(dv(ids), dv(labels), dv(act), [dom] * B, step_domains=[dom])
+        loss = float(tr.loss_and_acc(ws)[0].item())
+        G = eng.G.clone()
+        tr._micro = 0  # (no optimizer step: the weights stay put, the next call starts a new accumulation window)
+    assert tr._graphs, "the step was not captured"
+    plan_names = {name for pl in eng._plans.values() for _, name, _ in pl.calls}
+    assert {"hma_chain_a_fwd", "hma_chain_b_fwd", "hma_mlp_bwd", "hma_chain_a_bwd", "hma_chain_s_bwd", "hma_readout_ce"} <= plan_names, plan_names
+    dl = abs(loss - loss_ref.item())
+    _note("trainer_b2.loss_abs_err", dl)
+    assert dl <= 1e-3, (loss, loss_ref.item())
+    picks = ["token_embed.factored_embeds.0.weight", "pos_embed_TSC", "out_x_proj.weight", "out_x_proj.bias", f"action_mlp.{dom}.model.3.weight"]
+    for l in (0, 15, 31):
+        p = f"decoder.layers.{l}."
+        picks += [p + "norm1.weight", p + "norm1.bias", p + "spatial_attn.qkv.weight", p + "spatial_attn.proj.weight", p + "temporal_attn.qkv.weight",
+                  p + "temporal_attn.proj.bias", p + "norm2.weight", p + "mlp.fc1.weight", p + "mlp.fc2.weight",
+                  p + f"action_projectors.{dom}.linear_out.weight", p + f"action_projectors.{dom}.adaLN_modulation.2.weight"]
+    worst = 0.0
+    for name in picks:
+        e = rms_err(eng.view(name, G), leaf[name].grad)
+        worst = max(worst, e)
+        _note(f"trainer_b2.grad_rms.{name}", e)
+        assert e <= 1.5e-2, f"{name}: rms rel err {e:.3e}"
+    _note("trainer_b2.worst_grad_rms", worst)
+
+
 @pytest.mark.timeout(600)
 def test_full_size_batch_properties():
     """configs[1] batch (B = 32): finite, and the masked-mean loss decomposes over batch chunks."""

@@ -93,6 +93,25 @@ print(f"skew {SKEW:8d} ", end="")
 print(f"{os.environ.get('HMA_LIB', 'default'):>24s}  chain A fwd {t_f:7.1f} us ({by_f / t_f / 1e6:5.2f} TB/s)  [3 launches: "
       f"{' + '.join(f'{t:.0f}' for t in t_old)} = {sum(t_old):.0f} us]   chain A bwd {t_b:7.1f} us ({M * 5632.0 / t_b / 1e6:5.2f} TB/s)")
 
+# ---- chain S backward (spatial qkv dgrad + norm1 backward + residual) beside the two launches it replaces
+if hasattr(_lib.load(), "hma_chain_s_bwd") and not B_ONLY:
+    gam = torch.rand(256, device=dev) + 0.5
+    tws = torch.cat([ops.chain_pack(wq.contiguous()[256 * c:], kind=0, rows=256, cols=256, row_stride=1, col_stride=256, row_scale=gam)
+                     for c in range(3)])
+    sb = ops.make_chain_s_bwd(M=M, segs=[(tws.data_ptr(), 24)], dqkv=dqkv.data_ptr(), dx=dx.data_ptr(), xhat=xhat.data_ptr(),
+                              rstd=rstd.data_ptr(), dx_bf16=d1.data_ptr())
+    t_s = timeit(lambda: _lib.call("hma_chain_s_bwd", st, C.byref(sb)))
+    wqt = wq.t().contiguous().to(bf)  # [256, 768]
+    t256 = carve((M, 256), bf)
+    gq_ = ops.make_gemm_nt(A=dqkv.data_ptr(), lda=768, a_kind=A_BF16, W=wqt.data_ptr(), ldw=768, M=M, N=256, K=768, epi=EPI_BF16,
+                           Cp=t256.data_ptr(), ldc=256)
+    dgam, dbet = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+    t_g = timeit(lambda: _lib.call("hma_gemm_nt", st, C.byref(gq_)))
+    t_l = timeit(lambda: _lib.call("hma_ln_bwd", st, t256.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), gam.data_ptr(), dx.data_ptr(),
+                                   dgam.data_ptr(), dbet.data_ptr(), M, d1.data_ptr()))
+    print(f"{os.environ.get('HMA_LIB', 'default'):>24s}  chain S bwd {t_s:7.1f} us ({M * 4608.0 / t_s / 1e6:5.2f} TB/s)  [2 launches: {t_g:.0f} + {t_l:.0f} = "
+          f"{t_g + t_l:.0f} us]")
+
 if os.environ.get("CH_PROF"):
     lib = _lib.load()
     lib.hma_chain_debug_prof.argtypes = [C.c_void_p]

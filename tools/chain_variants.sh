@@ -19,8 +19,8 @@ if [ "$mode" = build ]; then
 else
   mkdir -p gpurun_out
   : > gpurun_out/chain_variants.txt
-  timeout 120 python3 tools/chain_bench.py 2>&1 | grep "chain [AB]" | tee -a gpurun_out/chain_variants.txt
+  timeout 120 python3 tools/chain_bench.py 2>&1 | grep "chain [ABS]" | tee -a gpurun_out/chain_variants.txt
   for so in variants/libhma_ch_*.so; do
-    HMA_LIB=$so timeout 120 python3 tools/chain_bench.py 2>&1 | grep "chain [AB]" | tee -a gpurun_out/chain_variants.txt
+    HMA_LIB=$so timeout 120 python3 tools/chain_bench.py 2>&1 | grep "chain [ABS]" | tee -a gpurun_out/chain_variants.txt
   done
 fi
