@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhma_hip.so")
 
-A_BF16, A_F32, A_BF16_AFFINE, A_BF16_FRAG32 = 0, 1, 2, 3
+A_BF16, A_F32, A_BF16_AFFINE, A_BF16_FRAG32, A_BF16_HEADBLK = 0, 1, 2, 3, 4
 EPI_BF16, EPI_F32, EPI_RESID, EPI_GELU2, EPI_SILU2, EPI_DGELU, EPI_DSILU, EPI_ATOMIC_F32 = range(8)
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -114,6 +114,7 @@ class ChainSBwd(C.Structure):
         ("xhat", c_vp), ("rstd", c_vp),
         ("dx_bf16", c_vp),
         ("M", c_i64),
+        ("hb_rows", c_i64),
     ]
 
 
@@ -140,6 +141,7 @@ _PROTOS = {
     "hma_modln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "hma_attn_spatial_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
     "hma_attn_spatial_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
+    "hma_attn_spatial_bwd_blocked": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32],
     "hma_attn_temporal_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32],
     "hma_attn_temporal_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32],
     "hma_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64],

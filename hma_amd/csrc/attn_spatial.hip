@@ -170,6 +170,35 @@ __device__ __forceinline__ void store_dt(uint16_t* base, int64_t ld, const f32x1
   }
 }
 
+// The same tile into the HEAD-BLOCKED layout (HMA_A_BF16_HEADBLK, include/hma_hip.h): the [32 token][32 d] tile is 2 KB of contiguous
+// memory at `blk`.  Same lane mapping as above -- lane (r, hi) holds chunks 2 q + hi (16 bytes each) of token r -- so the two store
+// instructions each write 32 bytes of every 64-byte row: 16 cache lines per instruction, each completed by the same wave's next
+// instruction, against 32 lines with 32 bytes each whose other pieces come from another CU (row-major [token][768]).  (A form that
+// traded chunks between lanes r and r ^ 16 for two fully contiguous 1 KB instructions was slower: its four cross-lane moves sit in
+// the dQ wave's path of every step.)
+__device__ __forceinline__ void store_dt_blk(uint16_t* blk, const f32x16_t& a, float mul, int lane) {
+  const int hi = lane >> 5;
+  uint16_t* row = blk + (lane & 31) * 32;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = 2 * q;
+    uint32_t ax = pack_bf16(a[4 * g] * mul, a[4 * g + 1] * mul), ay = pack_bf16(a[4 * g + 2] * mul, a[4 * g + 3] * mul);
+    uint32_t bx = pack_bf16(a[4 * g + 4] * mul, a[4 * g + 5] * mul), by = pack_bf16(a[4 * g + 6] * mul, a[4 * g + 7] * mul);
+    auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+    *reinterpret_cast<uint4*>(row + 16 * q + 8 * hi) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  }
+}
+// a [32 token][32 d] gradient tile of part `which` (0 dq, 1 dk, 2 dv) of (frame, head), tokens tok0 .. tok0 + 31: row-major
+// [token][768] or head-blocked
+__device__ __forceinline__ void store_grad_tile(uint16_t* dqkv, int hb, int64_t frame, int head, int which, int n, int tok0,
+                                                const f32x16_t& a, float mul, int lane) {
+  if (hb)
+    store_dt_blk(dqkv + ((((frame * NH + head) * 3 + which) * n + tok0) << 5), a, mul, lane);
+  else
+    store_dt(dqkv + (frame * n + tok0) * QKV_LD + which * DM + head * HD, QKV_LD, a, mul, lane);
+}
+
 // ------------------------------------------------------------------------------------- forward
 template <int NT>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
@@ -284,7 +313,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                              const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, uint16_t* __restrict__ dqkv,
-                                                             int64_t frames, float c_log2, float scale) {
+                                                             int64_t frames, float c_log2, float scale, int hb) {
   constexpr int N = NT * 32;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Ks = smem;                 // [N][LDR]
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) acc = mfma32(frag_tr(Ks, LDR, kt * 32 + 16 * s2, lane), pack_acc_half(s, s2), acc);
     }
-    store_dt(dqkv + row0 * QKV_LD + head * HD, QKV_LD, acc, scale, lane);
+    store_grad_tile(dqkv, hb, frame, head, 0, N, (int)(row0 - frame * N), acc, scale, lane);
   }
 }
 
@@ -357,7 +386,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               uint16_t* __restrict__ dqkv, int64_t frames, float c_log2,
-                                                              float scale) {
+                                                              float scale, int hb) {
   constexpr int N = NT * 32;
   constexpr int NQ = NT / 2;          // query tiles per half
   constexpr int NR = NQ * 32;         // query rows per half
@@ -443,8 +472,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const int kt = wrot + 4 * j;
     if (kt < NT) {
       const int64_t row0 = frame * N + kt * 32;
-      store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[j], scale, lane);
-      store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv[j], 1.0f, lane);
+      store_grad_tile(dqkv, hb, frame, head, 1, N, kt * 32, dk[j], scale, lane);
+      store_grad_tile(dqkv, hb, frame, head, 2, N, kt * 32, dv[j], 1.0f, lane);
     }
   }
 }
@@ -567,7 +596,7 @@ template <int NT, int KT>
 __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                                     const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                     float* __restrict__ delta, uint16_t* __restrict__ dqkv,
-                                                                    int64_t frames, float c_log2, float scale) {
+                                                                    int64_t frames, float c_log2, float scale, int hb) {
   static_assert(NT % KT == 0, "whole key tiles per wave");
   constexpr int TW = NT / KT;   // tile waves; waves TW, TW + 1 are the dQ waves
   constexpr int N = NT * 32;
@@ -639,7 +668,7 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) a0[e] += a1[e];
-          if (!(ATTN_ABL & 128)) store_dt(dqkv + (frame * N + qt * 32) * QKV_LD + head * HD, QKV_LD, a0, scale, lane);
+          if (!(ATTN_ABL & 128)) store_grad_tile(dqkv, hb, frame, head, 0, N, qt * 32, a0, scale, lane);
         }
       }
     } else {
@@ -718,8 +747,8 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
       for (int t = 0; t < KT; ++t) {
         const int64_t row0 = frame * N + (wave * KT + t) * 32;
         if (!(ATTN_ABL & 128)) {
-          store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[t], scale, lane);
-          store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv[t], 1.0f, lane);
+          store_grad_tile(dqkv, hb, frame, head, 1, N, (wave * KT + t) * 32, dk[t], scale, lane);
+          store_grad_tile(dqkv, hb, frame, head, 2, N, (wave * KT + t) * 32, dv[t], 1.0f, lane);
         }
       }
     }
@@ -746,7 +775,7 @@ template <int NT>
 __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o,
                                                               const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                               float* __restrict__ delta, uint16_t* __restrict__ dqkv,
-                                                              int64_t frames, float c_log2, float scale) {
+                                                              int64_t frames, float c_log2, float scale, int hb) {
   static_assert(NT == 10, "the wave -> key tile table below is for ten key tiles");
   constexpr int N = NT * 32;
   constexpr int HEAVY = 3;  // waves 0 .. HEAVY - 1: two key tiles each; HEAVY .. 6: one each; 7: dQ
@@ -836,14 +865,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
     for (int t = 0; t < KT; ++t) {
       const int64_t row0 = frame * N + (kt0 + t) * 32;
       if (!(ATTN_ABL & 128)) {
-        store_dt(dqkv + row0 * QKV_LD + DM + head * HD, QKV_LD, dk[t], scale, lane);
-        store_dt(dqkv + row0 * QKV_LD + 2 * DM + head * HD, QKV_LD, dv[t], 1.0f, lane);
+        store_grad_tile(dqkv, hb, frame, head, 1, N, (kt0 + t) * 32, dk[t], scale, lane);
+        store_grad_tile(dqkv, hb, frame, head, 2, N, (kt0 + t) * 32, dv[t], 1.0f, lane);
       }
     }
   };
   // ---- one item of the dQ wave: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], while the tile waves
   // work on query tile qt + 1 (which goes to the other dS buffer)
   auto dq_item = [&](const int64_t frame, const int head) __attribute__((always_inline)) {
+    // K^T of the item as A-operand fragments: the first KREG of the 2 NT k-steps of 16 keys stay in registers this wave has (it owns
+    // no tile) and are read ONCE per item instead of once per query tile -- the dQ wave is the slowest wave of a step (no dQ job:
+    // 325 -> 271 us), and half of its job's read -> MFMA round trips are K^T reads
+#ifndef ATTN_DQ_KREG   // k-steps whose K^T fragments stay in registers (a multiple of 4, <= 2 NT)
+#define ATTN_DQ_KREG 0
+#endif
+    constexpr int KREG = ATTN_DQ_KREG;
+    bf16x8_t kt[2 * NT];
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) kt[i] = frag_tr_f(Ks, 16 * i, lane);
 #pragma unroll 1
     for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
       lds_barrier();
@@ -851,29 +890,30 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
         const uint16_t* Tq = Ts + (qt & 1) * N * LDF;
         f32x16_t a0 = zero16(), a1 = zero16();
         static_assert((2 * NT) % 4 == 0, "groups of four k-steps");
-        bf16x8_t fa[4], fb[4], na[4], nb[4];
+        bf16x8_t fb[4], nb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { fa[i] = frag_tr_f(Ks, 16 * i, lane); fb[i] = frag_tr_f(Tq, 16 * i, lane); }
+        for (int i = 0; i < 4; ++i) fb[i] = frag_tr_f(Tq, 16 * i, lane);
 #pragma unroll
         for (int grp = 0; grp < NT / 2; ++grp) {
           if (grp + 1 < NT / 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              na[i] = frag_tr_f(Ks, 16 * (4 * grp + 4 + i), lane);
-              nb[i] = frag_tr_f(Tq, 16 * (4 * grp + 4 + i), lane);
-            }
+            for (int i = 0; i < 4; ++i) nb[i] = frag_tr_f(Tq, 16 * (4 * grp + 4 + i), lane);
           }
-          a0 = mfma32(fa[0], fb[0], a0);
-          a1 = mfma32(fa[1], fb[1], a1);
-          a0 = mfma32(fa[2], fb[2], a0);
-          a1 = mfma32(fa[3], fb[3], a1);
+          if (4 * grp >= KREG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kt[4 * grp + i] = frag_tr_f(Ks, 16 * (4 * grp + i), lane);
+          }
+          a0 = mfma32(kt[4 * grp + 0], fb[0], a0);
+          a1 = mfma32(kt[4 * grp + 1], fb[1], a1);
+          a0 = mfma32(kt[4 * grp + 2], fb[2], a0);
+          a1 = mfma32(kt[4 * grp + 3], fb[3], a1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+          for (int i = 0; i < 4; ++i) fb[i] = nb[i];
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) a0[e] += a1[e];
-        if (!(ATTN_ABL & 128)) store_dt(dqkv + (frame * N + qt * 32) * QKV_LD + head * HD, QKV_LD, a0, scale, lane);
+        if (!(ATTN_ABL & 128)) store_grad_tile(dqkv, hb, frame, head, 0, N, qt * 32, a0, scale, lane);
       }
     }
   };
@@ -950,7 +990,7 @@ int cu_count() {
 #endif
 template <int NT>
 int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                     int64_t frames, float scale) {
+                     int64_t frames, float scale, int hb) {
   constexpr int N = NT * 32;
 #if ATTN_BAL
   if constexpr (NT == 10) {
@@ -960,7 +1000,7 @@ int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* 
     const int64_t items = frames * NH;
     const int grid = (int)(items < cu_count() ? items : cu_count());
     hipLaunchKernelGGL((attn_bwd_bal_kernel<NT>), dim3((unsigned)grid), dim3(512), bytes, s, (const uint16_t*)qkv, (const uint16_t*)o,
-                       (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale);
+                       (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale, hb);
     HMA_CHECK_LAUNCH();
     return 0;
   }
@@ -972,16 +1012,16 @@ int launch_bwd_fused(hipStream_t s, const void* qkv, const void* o, const void* 
   const int64_t items = frames * NH;
   const int grid = (int)(items < cu_count() ? items : cu_count());
   hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, KT>), dim3((unsigned)grid), dim3((NT / KT + 2) * 64), bytes, s, (const uint16_t*)qkv, (const uint16_t*)o,
-                     (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale);
+                     (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames, scale * LOG2E, scale, hb);
   HMA_CHECK_LAUNCH();
   return 0;
 }
 
 template <int NT>
 int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-               void* dqkv, int64_t frames, float scale) {
+               void* dqkv, int64_t frames, float scale, int hb) {
 #ifndef ATTN_BWD_SPLIT  // (debug builds: the two-kernel form, tools/attn_bench.py compares)
-  if (NT >= 8) return launch_bwd_fused<NT>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
+  if (NT >= 8) return launch_bwd_fused<NT>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale, hb);
 #endif
   constexpr int N = NT * 32, LDV = N + 4;
   constexpr int bytes_dq = 2 * N * LDR * 2;
@@ -993,11 +1033,11 @@ int launch_bwd(hipStream_t s, const void* qkv, const void* o, const void* d_o, c
   if (rc) return rc;
   hipLaunchKernelGGL(attn_bwd_dq_kernel<NT>, dim3((unsigned)(frames * NH)), dim3(256), bytes_dq, s,
                      (const uint16_t*)qkv, (const uint16_t*)o, (const uint16_t*)d_o, lse, delta, (uint16_t*)dqkv, frames,
-                     scale * LOG2E, scale);
+                     scale * LOG2E, scale, hb);
   HMA_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<NT>, dim3((unsigned)(frames * NH)), dim3(256), bytes_dkv, s,
                      (const uint16_t*)qkv, (const uint16_t*)d_o, lse, (const float*)delta, (uint16_t*)dqkv, frames,
-                     scale * LOG2E, scale);
+                     scale * LOG2E, scale, hb);
   HMA_CHECK_LAUNCH();
   return 0;
 }
@@ -1017,15 +1057,25 @@ extern "C" int hma_attn_spatial_fwd(void* stream, const void* qkv, void* o, floa
   }
 }
 
-extern "C" int hma_attn_spatial_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
-                                    float* delta, void* dqkv, int64_t frames, int32_t n, float scale) {
+static int attn_spatial_bwd_any(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                                int64_t frames, int32_t n, float scale, int hb) {
   if (!qkv || !o || !d_o || !lse || !delta || !dqkv) return HMA_EINVAL;
   if (frames <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   switch (n) {
-    case 320: return launch_bwd<10>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
-    case 256: return launch_bwd<8>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
-    case 64: return launch_bwd<2>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale);
+    case 320: return launch_bwd<10>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale, hb);
+    case 256: return launch_bwd<8>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale, hb);
+    case 64: return launch_bwd<2>(s, qkv, o, d_o, lse, delta, dqkv, frames, scale, hb);
     default: return HMA_EINVAL;
   }
+}
+
+extern "C" int hma_attn_spatial_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                                    float* delta, void* dqkv, int64_t frames, int32_t n, float scale) {
+  return attn_spatial_bwd_any(stream, qkv, o, d_o, lse, delta, dqkv, frames, n, scale, 0);
+}
+
+extern "C" int hma_attn_spatial_bwd_blocked(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                                            float* delta, void* dqkv, int64_t frames, int32_t n, float scale) {
+  return attn_spatial_bwd_any(stream, qkv, o, d_o, lse, delta, dqkv, frames, n, scale, 1);
 }

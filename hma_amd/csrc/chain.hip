@@ -1193,16 +1193,29 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
   bf16x8_t dq[3][8], xr[8];
   f32x4v_t acc[16], dxr[16];
   float rs = 1.f;
-  auto load_part = [&](int64_t mc, int c, bf16x8_t (&d)[8], auto j0_, auto n_) __attribute__((always_inline)) {
+  // fragment j of k-chunk c = columns 256 c + 32 j + 8 g .. + 7 of a row: head j of part c.  Head-blocked dqkv (hb_rows = rows per
+  // frame n > 0, HMA_A_BF16_HEADBLK): element at (((frame 8 + j) 3 + c) n + row in frame) 32 + 8 g -- a load instruction then reads
+  // 16 rows x 64 bytes = 1 KB of contiguous memory instead of sixteen 64-byte pieces 1536 bytes apart.  `qrow` = this lane's row
+  // pointer (row_ptr: ONE integer division per tile, by the wave-uniform first row), cs / js = element strides of a k-chunk / a head.
+  const int hbn = (int)p.hb_rows;
+  const int64_t cs = hbn > 0 ? (int64_t)hbn * 32 : 256, js = hbn > 0 ? (int64_t)hbn * 96 : 32;
+  auto row_ptr = [&](int64_t r0w) __attribute__((always_inline)) {  // r0w: the wave's first row (16 rows never straddle a frame)
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(p.dqkv);
+    if (hbn > 0) {
+      const uint32_t fr = (uint32_t)r0w / (uint32_t)hbn, rr = (uint32_t)r0w - fr * (uint32_t)hbn;
+      return b + (((int64_t)fr * 24 * hbn + rr + tok) << 5) + 8 * g;
+    }
+    return b + (r0w + tok) * p.ldq + 8 * g;
+  };
+  auto load_part = [&](const uint16_t* qrow, int c, bf16x8_t (&d)[8], auto j0_, auto n_) __attribute__((always_inline)) {
     constexpr int j0 = decltype(j0_)::value, n = decltype(n_)::value;
     if (CH_ABL & 2) return;
-    const uint16_t* row = reinterpret_cast<const uint16_t*>(p.dqkv) + mc * p.ldq + 256 * c + 8 * g;
 #pragma unroll
-    for (int j = j0; j < j0 + n; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(row + 32 * j));
+    for (int j = j0; j < j0 + n; ++j) d[j] = as_frag(*reinterpret_cast<const uint4*>(qrow + c * cs + j * js));
   };
-  auto next_row = [&](int tl) __attribute__((always_inline)) {
-    int64_t m = row0_of(tl + 1 < nt ? tl + 1 : tl) + tok;
-    return m < p.M ? m : p.M - 1;
+  auto next_r0 = [&](int tl) __attribute__((always_inline)) {
+    const int64_t r = row0_of(tl + 1 < nt ? tl + 1 : tl);
+    return r < p.M ? r : p.M - 16;
   };
   if (CH_ABL & 2) {
 #pragma unroll
@@ -1215,9 +1228,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
     for (int t = 0; t < 16; ++t) dxr[t] = f32x4v_t{0.f, 1.f, 2.f, 3.f};
   }
   {
-    int64_t m = row0_of(0) + tok;
-    m = m < p.M ? m : p.M - 1;
-    load_part(m, 0, dq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+    const int64_t r = row0_of(0);
+    load_part(row_ptr(r < p.M ? r : p.M - 16), 0, dq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
   }
   CH_TOUCH_A(dq[0]);
   int slot = 0;
@@ -1227,6 +1239,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
 
   auto tile = [&](int tl, int64_t r0) __attribute__((always_inline)) {
     const int64_t m = r0 + tok;
+    const uint16_t* qrow = row_ptr(r0);
     float* xt = p.dx + r0 * 256;
     uint16_t* d1 = reinterpret_cast<uint16_t*>(p.dx_bf16) + r0 * 256;
 #pragma unroll
@@ -1239,8 +1252,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
       constexpr int c = s >> 3, pr = s & 7;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
-      if constexpr (s < 4) load_part(m, 1, dq[1], std::integral_constant<int, 2 * s>{}, I2{});
-      if constexpr (s >= 4 && s < 12) load_part(m, 2, dq[2], std::integral_constant<int, s - 4>{}, I1{});
+      if constexpr (s < 4) load_part(qrow, 1, dq[1], std::integral_constant<int, 2 * s>{}, I2{});
+      if constexpr (s >= 4 && s < 12) load_part(qrow, 2, dq[2], std::integral_constant<int, s - 4>{}, I1{});
       if constexpr (s >= 8 && s < 16) {
         if (!(CH_ABL & 2)) {
           const uint16_t* hrow = reinterpret_cast<const uint16_t*>(p.xhat) + m * 256 + 8 * g;
@@ -1260,7 +1273,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
       if constexpr (s == 23) {
         // the next tile's first k-chunk: requested here, in front of this tile's 24 store instructions (the queue is in order), into the
         // registers the last k-chunk has just left -- eight steps earlier they would not fit beside dx, xhat and the accumulators
-        load_part(next_row(tl), 0, dq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+        load_part(row_ptr(next_r0(tl)), 0, dq[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
         // ---- LayerNorm backward of the row (its four lanes tok, tok + 16, tok + 32, tok + 48 hold it) + residual
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1896,6 +1909,7 @@ extern "C" int hma_chain_a_bwd(void* stream, const hma_chain_a_bwd_t* p) {
 
 extern "C" int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p) {
   if (!p || !p->dqkv || !p->dx || !p->xhat || !p->rstd || !p->dx_bf16 || p->M <= 0 || p->M % 16 || p->ldq < 768) return HMA_EINVAL;
+  if (p->hb_rows < 0 || (p->hb_rows > 0 && (p->hb_rows % 16 || p->M % p->hb_rows || p->ldq != 768 || p->hb_rows > (1 << 20)))) return HMA_EINVAL;
   if (!weights_ok(p->w, 24)) return HMA_EINVAL;
   const int grid = chain_grid(p->M);
   if (int rc = set_lds<chain_s_bwd_kernel>(SMEM)) return rc;

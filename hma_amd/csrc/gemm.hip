@@ -1522,6 +1522,7 @@ struct tn_prob {
   int nb;            // workgroups of this problem
   int colsum;        // write the column-sum partials
   int yfrag, afrag;  // operand stored in the fused-MLP fragment order (HMA_A_BF16_FRAG32): only the DMA source address differs
+  int yhb, ahb;      // > 0: operand in the head-blocked order of the spatial attention (HMA_A_BF16_HEADBLK), rows per frame
 };
 struct tn_pair_args {
   tn_prob q[2];      // problem 1's workgroup ids follow problem 0's (q[1].nb == 0: a single problem)
@@ -1599,9 +1600,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
         return base + (((((m >> 7) * (ld >> 5) + (col >> 5)) << 2) + ((m >> 5) & 3)) << 10) + (((col >> 3) & 1) << 9) +
                (((((col >> 4) & 1) << 5) + (m & 31)) << 3);
       };
+      // HMA_A_BF16_HEADBLK: element (m, c) of a [M, 256 W] matrix at (((frame 8 + head) W + c / 256) n + m % n) 32 + c % 32 with
+      // frame = m / n, head = (c % 256) / 32 -- what the spatial attention backward writes as whole contiguous 2 KB tiles
+      // (a stage's 32 rows lie inside one frame: ONE 32-bit division per stage, by the wave-uniform first row)
+      auto hb_at = [&](const uint16_t* base, int64_t ld, int64_t col, int n) __attribute__((always_inline)) {
+        const uint32_t fr = (uint32_t)m0 / (uint32_t)n;
+        const int64_t rr = m - (int64_t)fr * n;
+        return base + (((((int64_t)fr * 8 + ((col & 255) >> 5)) * (ld >> 8) + (col >> 8)) * n + rr) << 5) + (col & 31);
+      };
       const uint16_t* ys = p.yfrag ? frag_at(reinterpret_cast<const uint16_t*>(p.dY), p.ldy, n0 + lc * 8)
-                                   : Yb + m * p.ldy + lc * 8;  // host: no row groups on this path
-      const uint16_t* as = p.afrag ? frag_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8) : Ab + m * p.lda + lc * 8;
+                           : p.yhb > 0 ? hb_at(reinterpret_cast<const uint16_t*>(p.dY), p.ldy, n0 + lc * 8, p.yhb)
+                                       : Yb + m * p.ldy + lc * 8;  // host: no row groups on this path
+      const uint16_t* as = p.afrag ? frag_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8)
+                           : p.ahb > 0 ? hb_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8, p.ahb)
+                                       : Ab + m * p.lda + lc * 8;
       glds16(ys, slot_b + (wave * 4 + q * 2) * 512);
       glds16(as, slot_b + DM_TILE_BYTES + (wave * 4 + q * 2) * 512);
     }
@@ -2419,10 +2431,14 @@ extern "C" int hma_gemm_nt(void* stream, const hma_gemm_nt_t* p) {
 // ---- LDS-DMA ring weight gradients: eligibility, split planning and launch of one or two problems
 static bool tn_dma_eligible(const hma_gemm_tn_t& q) {
   const bool yf = q.y_kind == HMA_A_BF16_FRAG32, af = q.a_kind == HMA_A_BF16_FRAG32;
-  if ((yf || af) && q.batch > 1) return false;
+  const bool yh = q.y_kind == HMA_A_BF16_HEADBLK, ah = q.a_kind == HMA_A_BF16_HEADBLK;
+  if ((yf || af || yh || ah) && q.batch > 1) return false;
   if ((yf && q.ldy != q.N) || (af && q.lda != q.K)) return false;  // the fragment order has no row pitch: the operand is the whole matrix
-  return q.N % WT == 0 && q.K % WT == 0 && (q.y_kind == HMA_A_BF16 || yf) &&
-         (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE || af) && q.M > 0 && q.M % DM_ROWS == 0 && q.y_group_rows <= 0 && q.a_group_rows <= 0 && q.ldy % 8 == 0 && q.lda % 8 == 0 &&
+  // head-blocked: *_group_rows carries the rows per frame (a stage's 32 rows lie inside one frame), ld = 256 W says how many 256-column parts
+  if (yh && (q.y_group_rows <= 0 || q.y_group_rows % DM_ROWS || q.M % q.y_group_rows || q.ldy % 256 || q.ldy != q.N)) return false;
+  if (ah && (q.a_group_rows <= 0 || q.a_group_rows % DM_ROWS || q.M % q.a_group_rows || q.lda % 256 || q.lda != q.K)) return false;
+  return q.N % WT == 0 && q.K % WT == 0 && (q.y_kind == HMA_A_BF16 || yf || yh) &&
+         (q.a_kind == HMA_A_BF16 || q.a_kind == HMA_A_BF16_AFFINE || af || ah) && q.M > 0 && q.M % DM_ROWS == 0 && (yh || q.y_group_rows <= 0) && (ah || q.a_group_rows <= 0) && q.ldy % 8 == 0 && q.lda % 8 == 0 &&
          q.sY % 8 == 0 && q.sA % 8 == 0 && (reinterpret_cast<uintptr_t>(q.dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.A) & 15) == 0;
 }
 // splits for a problem that may use at most `budget` workgroups; 0 if it cannot take the two-stage path
@@ -2444,6 +2460,8 @@ static tn_prob tn_make_prob(const hma_gemm_tn_t& q, float* ws, int splits) {
   t.colsum = (q.dBias != nullptr) || q.a_kind == HMA_A_BF16_AFFINE;
   t.yfrag = q.y_kind == HMA_A_BF16_FRAG32;
   t.afrag = q.a_kind == HMA_A_BF16_FRAG32;
+  t.yhb = q.y_kind == HMA_A_BF16_HEADBLK ? (int)q.y_group_rows : 0;
+  t.ahb = q.a_kind == HMA_A_BF16_HEADBLK ? (int)q.a_group_rows : 0;
   return t;
 }
 template <bool TR>

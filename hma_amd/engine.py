@@ -21,170 +21,17 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
+from ._lib import (A_BF16, A_BF16_AFFINE, A_BF16_FRAG32, A_BF16_HEADBLK, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
                    EPI_RESID, EPI_SILU2)
 from .ops import make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_chain_s_bwd, make_readout_ce, make_gemm_nt, make_gemm_tn, make_mlp_bwd, make_mlp_fwd
+from .engine_decode import DecodeMixin
 from .params import ALIGN, ParamLayout
+from .plan import LaunchTimer, Plan  # noqa: F401  (re-exported: bench.py / tests import them from here)
 
 BF16, F32 = torch.bfloat16, torch.float32
 
 
-class Plan:
-    """A recorded sequence of C-ABI launches with fixed arguments; `run` replays it on a stream."""
-
-    # Per GPU, for the life of the process (recorded plans and captured graphs hold the raw pointers): the scratch of the two-stage
-    # weight-gradient reduction.  Keyed by device index, so that engines on different devices of one process do not share it.
-    _tn_workspaces: Dict[object, torch.Tensor] = {}
-
-    @property
-    def tn_workspace(self) -> Optional[torch.Tensor]:
-        return Plan._tn_workspaces.get(self.dev)
-
-    def __init__(self, dev: Optional[int] = None):
-        self.dev = torch.cuda.current_device() if (dev is None and torch.cuda.is_available()) else dev
-        self.calls: List[Tuple[Callable, str, tuple]] = []
-        self.flops: List[float] = []   # algorithmic FLOPs of each call (0 for non-GEMM launches)
-        self.bytes: List[float] = []   # algorithmic HBM bytes of each call: every operand read once, every result written once
-        self.marks: Dict[str, int] = {}
-        self.keep: list = []
-
-    def add(self, name: str, *args, flops: float = 0.0, nbytes: float = 0.0) -> None:
-        self.calls.append((getattr(_lib.load(), name), name, args))
-        self.flops.append(flops)
-        self.bytes.append(nbytes)
-
-    @staticmethod
-    def _nt_bytes(g) -> float:
-        """A once + the weight + what the epilogue reads and writes."""
-        b = max(g.batch, 1)
-        mn = float(g.M) * g.N * b
-        out = {EPI_BF16: 2, EPI_F32: 4, EPI_RESID: 8, EPI_GELU2: 4, EPI_SILU2: 4, EPI_DGELU: 4, EPI_DSILU: 4, EPI_ATOMIC_F32: 8}[g.epi]
-        extra = (2 if (g.epi == EPI_RESID and g.C2) else 0) + (2 if g.ln_xhat else 0) + (2 if g.ln_xm else 0)
-        return float(g.M) * g.K * b * (4 if g.a_kind == A_F32 else 2) + 2.0 * g.N * g.K * b + mn * (out + extra)
-
-    @staticmethod
-    def _tn_bytes(g) -> float:
-        b = max(g.batch, 1)
-        return b * (float(g.M) * g.N * (4 if g.y_kind == A_F32 else 2) + float(g.M) * g.K * (4 if g.a_kind == A_F32 else 2) + 4.0 * g.N * g.K)
-
-    def gemm_nt(self, **kw) -> None:
-        g = make_gemm_nt(**kw)
-        self.keep.append(g)
-        self.add("hma_gemm_nt", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._nt_bytes(g))
-
-    def gemm_tn(self, **kw) -> None:
-        wsb = self.tn_workspace
-        if wsb is not None:
-            kw.setdefault("ws", wsb.data_ptr())
-            kw.setdefault("ws_elems", wsb.numel())
-        g = make_gemm_tn(**kw)
-        self.keep.append(g)
-        self.add("hma_gemm_tn", C.byref(g), flops=2.0 * g.M * g.N * g.K * max(g.batch, 1), nbytes=self._tn_bytes(g))
-
-    def gemm_tn_pair(self, kw0: dict, kw1: dict) -> None:
-        """Two weight gradients whose operands are live at the same time, in one launch (hma_gemm_tn_pair)."""
-        gs = []
-        wsb = self.tn_workspace
-        for kw in (kw0, kw1):
-            if wsb is not None:
-                kw.setdefault("ws", wsb.data_ptr())
-                kw.setdefault("ws_elems", wsb.numel())
-            gs.append(make_gemm_tn(**kw))
-        self.keep.extend(gs)
-        self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
-                 flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
-
-    def mlp_fwd(self, M: int, **kw) -> None:
-        g = make_mlp_fwd(M=M, **kw)
-        self.keep.append(g)
-        self.add("hma_mlp_fwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2, nbytes=3072.0 * M)  # xhat 512 + x 1024 in, x 1024 + xhat 512 out
-
-    def mlp_bwd(self, M: int, **kw) -> None:
-        g = make_mlp_bwd(M=M, **kw)
-        self.keep.append(g)
-        # algorithmic dgrad FLOPs (the recompute is not counted); xhat 2 x 512 + dy 512 + dx 1024 in, dx 1024 + dxb 512 + hg / du 2 x 2048 out
-        self.add("hma_mlp_bwd", C.byref(g), flops=2.0 * M * 256 * 1024 * 2, nbytes=8192.0 * M)
-
-    def chain_a_fwd(self, M: int, use_mod: bool, save: bool, **kw) -> None:
-        g = make_chain_a_fwd(M=M, use_mod=use_mod, **kw)
-        self.keep.append(g)
-        n_out = 256 * (2 if use_mod else 1) + 768
-        # o 512 + x 1024 in; x 1024 + qkv 1536 out (+ xhat, xm, bf16(x): 512 each when they are saved)
-        nbytes = (512 + 1024 + 1024 + 1536 + (512 * (3 if use_mod else 1) if save else 0)) * float(M)
-        self.add("hma_chain_a_fwd", C.byref(g), flops=2.0 * M * 256 * n_out, nbytes=nbytes)
-
-    def chain_b_fwd(self, M: int, with_qkv: bool, **kw) -> None:
-        g = make_chain_b_fwd(M=M, **kw)
-        self.keep.append(g)
-        # o 512 + x 1024 in; x 1024 (+ qkv 1536) out (+ the saved LayerNorm outputs, 512 each, in training)
-        saved = 512 * ((1 if kw.get("xhat2") else 0) + (1 if kw.get("xhat1n") else 0))
-        self.add("hma_chain_b_fwd", C.byref(g), flops=2.0 * M * 256 * (256 + 2048 + (768 if with_qkv else 0)),
-                 nbytes=(512 + 1024 + 1024 + (1536 if with_qkv else 0) + saved) * float(M))
-
-    def chain_a_bwd(self, M: int, use_mod: bool, **kw) -> None:
-        g = make_chain_a_bwd(M=M, use_mod=use_mod, **kw)
-        self.keep.append(g)
-        n_in = 768 + 256 * (2 if use_mod else 1)
-        # dqkv 1536 + dx 1024 (+ xhat 512) in; dx 1024 + bf16(dx1) 512 + d_o 512 (+ bf16(dx2) 512) out
-        nbytes = (1536 + 1024 + 1024 + 512 + 512 + (1024 if use_mod else 0)) * float(M)
-        self.add("hma_chain_a_bwd", C.byref(g), flops=2.0 * M * 256 * n_in, nbytes=nbytes)
-
-    def chain_s_bwd(self, M: int, **kw) -> None:
-        g = make_chain_s_bwd(M=M, **kw)
-        self.keep.append(g)
-        # dqkv 1536 + xhat 512 + dx 1024 in; dx 1024 + bf16(dx) 512 out
-        self.add("hma_chain_s_bwd", C.byref(g), flops=2.0 * M * 256 * 768, nbytes=(1536 + 512 + 1024 + 1024 + 512) * float(M))
-
-    def readout_ce(self, rows: int, **kw) -> None:
-        g = make_readout_ce(rows=rows, **kw)
-        self.keep.append(g)
-        # x 1024 in, dlogits 2048 out per image row (+ ids / labels); the logits themselves stay in registers
-        self.add("hma_readout_ce", C.byref(g), flops=2.0 * rows * 256 * 1024, nbytes=(1024.0 + (2048 if kw.get("dlogits") else 0) + 16) * rows)
-
-    def mark(self, label: str) -> None:
-        self.marks[label] = len(self.calls)
-
-    def run(self, stream: int, start: int = 0, stop: Optional[int] = None, timer: "Optional[LaunchTimer]" = None) -> None:
-        if timer is None:
-            for fn, name, args in self.calls[start:stop]:
-                rc = fn(stream, *args)
-                if rc != 0:
-                    raise _lib.HmaKernelError(f"{name} failed with code {rc}")
-            return
-        stop = len(self.calls) if stop is None else stop
-        for i in range(start, stop):
-            fn, name, args = self.calls[i]
-            if name in timer.names:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = fn(stream, *args)
-                e1.record()
-                timer.pairs.append((name, self.flops[i], e0, e1, self.bytes[i]))
-            else:
-                rc = fn(stream, *args)
-            if rc != 0:
-                raise _lib.HmaKernelError(f"{name} failed with code {rc}")
-
-
-class LaunchTimer:
-    """HIP-event brackets around chosen launches, recorded on the stream the kernels run on."""
-
-    def __init__(self, names: Sequence[str]):
-        self.names = set(names)
-        self.pairs: list = []
-
-    def summary(self) -> Dict[str, Dict[str, float]]:
-        out: Dict[str, Dict[str, float]] = {}
-        for name, flops, e0, e1, nbytes in self.pairs:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += flops
-            d["bytes"] += nbytes
-        return out
-
-
-class STEngine:
+class STEngine(DecodeMixin):
     def __init__(self, cfg, domains: Sequence[str], d_actions: Sequence[int], action_dims: Sequence[int], device):
         if cfg.d_model != 256 or cfg.num_heads != 8:
             raise NotImplementedError("the gfx950 kernels are specialised for d_model=256, 8 heads of 32 (HMA-base)")
@@ -262,6 +109,7 @@ class STEngine:
         self.use_chain = True
         self.chain_min_rows = 0
         self.chain_s = os.environ.get("HMA_CHAIN_S", "1") != "0"  # (0: measurement -- the spatial qkv dgrad + hma_ln_bwd as two launches)
+        self.attn_hb = os.environ.get("HMA_ATTN_HB", "1") != "0"  # (0: measurement -- the spatial attention backward's dqkv row-major)
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN),
                    "qkv_s_T": mk(L, 24 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
@@ -748,7 +596,7 @@ class STEngine:
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
         key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group,
-               self.chain_s)
+               self.chain_s, self.attn_hb)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -868,7 +716,11 @@ class STEngine:
                     pl.add("hma_modln_bwd", t256, xhm, rstdm, dp(ws["ss"], l, Fr * 512), dx, dp(ws["dss"], l, Fr * 512), Fr, SA, dxb)
                 # ---- spatial attention
                 pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv_s, Fr, SA, self.scale,
+            # (on the chain path the attention backward writes dqkv HEAD-BLOCKED -- whole contiguous 2 KB tiles instead of 32-byte pieces
+            # of 32 cache lines per store instruction -- and its two consumers, the qkv weight gradient and chain S, read that order)
+            chain_s = self.chain_s and (not self.qkn) and self._use_chain(M, SA)
+            hb = chain_s and self.attn_hb and SA % 32 == 0
+            pl.add("hma_attn_spatial_bwd_blocked" if hb else "hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv_s, Fr, SA, self.scale,
                    flops=10.0 * Fr * SA * SA * 256,  # 5 products of 2 n^2 d per head (the recomputed S is not counted)
                    nbytes=(1536.0 + 512 + 512 + 32 + 1536) * Fr * SA)  # qkv, o, dO, lse read once; dqkv written
             # projection and qkv weight gradients in one launch (dxb is next updated by the LayerNorm backward below)
@@ -876,21 +728,22 @@ class STEngine:
                 pl.add("hma_qknorm_bwd", dqkv_s, 768, dp(ws["qraw_s"], l, M * 512), self._lw(l, "spatial_attn.norm.weight", "p"), 1e-5,
                        gw("spatial_attn.norm.weight"), gw("spatial_attn.norm.bias"), M)
             # (on the chain path norm1's dgamma / dbeta come out of the qkv weight gradient's reduction, as norm2's do out of fc1's)
-            chain_s = self.chain_s and (not self.qkn) and self._use_chain(M, SA)
             aff1 = dict(a_kind=A_BF16) if self.qkn else dict(a_kind=A_BF16_AFFINE, gamma=self._lw(l, "norm1.weight", "p"),
                                                              beta=self._lw(l, "norm1.bias", "p"))
             if chain_s:
                 aff1.update(w_master=self._lw(l, "spatial_attn.qkv.weight", "p"), dgamma=gw("norm1.weight"), dbeta=gw("norm1.bias"))
             pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                  dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
-                            dict(dY=dqkv_s, ldy=768, y_kind=A_BF16, A=xh1, lda=256, M=M, N=768, K=256,
-                                 dW=gw("spatial_attn.qkv.weight"), lddw=256, dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
+                            dict(dY=dqkv_s, ldy=768, y_kind=A_BF16_HEADBLK if hb else A_BF16, y_group=(SA, 0) if hb else (0, 0), A=xh1, lda=256,
+                                 M=M, N=768, K=256, dW=gw("spatial_attn.qkv.weight"), lddw=256,
+                                 dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
             if self.qkn:  # norm1 is the identity
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
             elif chain_s:
                 # ---- chain S backward (csrc/chain.hip): spatial qkv dgrad -> norm1 backward -> residual, one launch
-                pl.chain_s_bwd(M, segs=[(self.CP["qkv_s_T"][l].data_ptr(), 24)], dqkv=dqkv_s, dx=dx, xhat=xh1, rstd=rstd1, dx_bf16=dxb)
+                pl.chain_s_bwd(M, segs=[(self.CP["qkv_s_T"][l].data_ptr(), 24)], dqkv=dqkv_s, dx=dx, xhat=xh1, rstd=rstd1, dx_bf16=dxb,
+                               hb_rows=SA if hb else 0)
             else:
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
                 pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
@@ -1181,197 +1034,6 @@ class STEngine:
             ws["a_emb"].view(B, T, D).copy_(a_emb[:, :T], non_blocking=True)
         self._forward_plan(B, T, S, A, False, domain if A > 0 else None, embed=False, l0=l0, l1=l1, readout=False).run(stream)
         return ws["x"].view(B, T, SA, D).clone()
-
-    def maskgit_step(self, prompt_BTS: torch.Tensor, unmasked: torch.Tensor, out_t: int, n_mask: int, last: bool,
-                     conf_override: Optional[torch.Tensor] = None, conf_out: Optional[torch.Tensor] = None,
-                     logits_T: int = 0, logits_t: int = 0, logits: Optional[torch.Tensor] = None,
-                     sample_noise: Optional[torch.Tensor] = None) -> None:
-        """One sampling step on the logits of the last forward (st_mask_git.py:397-453); updates in place.  `sample_noise`
-        (f32 [B, S, 2, 512], Exp(1) draws) selects the categorical branch (:411-416)."""
-        B, T, S = prompt_BTS.shape
-        assert prompt_BTS.is_contiguous() and prompt_BTS.dtype == torch.int64 and unmasked.dtype == torch.uint8
-        stream = torch.cuda.current_stream().cuda_stream
-        lg = self._ws["logits"] if logits is None else logits
-        co = None if conf_override is None else conf_override.data_ptr()
-        cout = None if conf_out is None else conf_out.data_ptr()
-        if sample_noise is not None:
-            assert sample_noise.is_contiguous() and sample_noise.dtype == F32 and sample_noise.numel() == B * S * 1024
-        if B * S <= 64 * 256:
-            # few samples (a decode step: 64): sampling as one wave per token over the whole chip, then the per-sample ranking
-            sc = getattr(self, "_mg_scratch", None)
-            if sc is None or sc[0].numel() < B * S or sc[0].device != prompt_BTS.device:
-                sc = self._mg_scratch = (torch.empty(B * S, dtype=F32, device=prompt_BTS.device),
-                                         torch.empty(B * S, dtype=torch.int32, device=prompt_BTS.device))
-            _lib.call("hma_maskgit_step_wide", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co,
-                      cout if cout is not None else sc[0].data_ptr(), sc[1].data_ptr(),
-                      None if sample_noise is None else sample_noise.data_ptr(), B, T, S, out_t, n_mask, int(last),
-                      self.cfg.image_vocab_size, logits_T, logits_t)
-            return
-        if sample_noise is None:
-            _lib.call("hma_maskgit_step", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co, cout,
-                      B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
-        else:
-            assert sample_noise.is_contiguous() and sample_noise.dtype == F32 and sample_noise.numel() == B * S * 1024
-            _lib.call("hma_maskgit_step_sampled", stream, lg.data_ptr(), prompt_BTS.data_ptr(), unmasked.data_ptr(), co, cout,
-                      sample_noise.data_ptr(), B, T, S, out_t, n_mask, int(last), self.cfg.image_vocab_size, logits_T, logits_t)
-
-    # ------------------------------------------------------------------------------ incremental decode
-    # Frame t of the trunk depends on frames <= t only (spatial attention, modulation, MLP, positions and the
-    # action tokens are per frame; temporal attention is causal), so per-layer temporal K/V of finished frames
-    # are constants of the rollout: only the 320 rows of the frame being decoded flow through the layers.
-    def decode_begin(self, B: int, T_total: int, S: int, A: int) -> Dict[str, torch.Tensor]:
-        key = (B, T_total, S, A)
-        if getattr(self, "_dws_key", None) == key:
-            return self._dws
-        self._dws, self._dplans, self._dgraphs, self._dseen = {}, {}, {}, {}
-        L = self.cfg.num_layers
-        SA, M1 = S + A, B * (S + A)
-        dev = self.device
-        d: Dict[str, torch.Tensor] = {}
-
-        def buf(name, shape, dtype):
-            d[name] = torch.empty(shape, dtype=dtype, device=dev)
-
-        buf("ids", (B, 1, S), torch.int64)
-        buf("x", (M1, 256), F32)
-        for nm in ("xh1", "o_s", "x2b", "o_t", "xh2", "xhm", "xm"):
-            buf(nm, (M1, 256), BF16)
-        buf("qkv_s", (M1, 768), BF16)
-        buf("lse_s", (M1, 8), F32)
-        for nm in ("rstd1", "rstd2", "rstdm"):
-            buf(nm, (M1,), F32)
-        if not self._use_fused(M1, False):
-            buf("u", (M1, 1024), BF16)
-            buf("hg", (M1, 1024), BF16)
-        buf("logits", (B * S, 1024), F32)
-        buf("cache", (L, B * T_total * SA, 768), BF16)
-        if A > 0:
-            buf("actions", (B * self.max_d_a,), F32)
-            buf("an", (B * self.max_d_a,), F32)
-            buf("sxhat", (B, 256), F32)
-            buf("srstd", (B,), F32)
-            buf("sh", (B, 256), F32)
-            buf("a_emb", (B, 256), F32)
-            buf("ada_pre", (L, B, 256), BF16)
-            buf("ada_act", (L, B, 256), BF16)
-            buf("ss", (L, B, 512), F32)
-        self._dws, self._dws_key = d, key
-        return d
-
-    def _decode_plan(self, B: int, T_total: int, S: int, A: int, domain: Optional[str], t: int, readout: bool,
-                     same_actions: bool = False) -> Plan:
-        """`same_actions`: the frame's actions are those of the previous pass (the 2nd .. last MaskGIT iteration of a frame and its
-        K / V refresh): the action stem and the adaLN stacks -- a_emb and the per-layer shift / scale rows -- are reused, not re-run."""
-        key = (B, T_total, S, A, domain, t, readout, self._skip_norm, same_actions)
-        if key in self._dplans:
-            return self._dplans[key]
-        cfg, d = self.cfg, self._dws
-        L = cfg.num_layers
-        SA, M1 = S + A, B * (S + A)
-        pl = Plan(self._dev_index)
-        use_mod = A > 0 and self.modulate
-        if A > 0 and not same_actions:
-            am = f"action_mlp.{domain}.model"
-            pl.add("hma_action_stem_fwd", d["actions"].data_ptr(), self.buffers[domain][0].data_ptr(),
-                   self.buffers[domain][1].data_ptr(), self.action_dims[domain], self._p(f"{am}.0.weight"), self._p(f"{am}.0.bias"),
-                   self._p(f"{am}.1.weight"), self._p(f"{am}.1.bias"), self._p(f"{am}.3.weight"), self._p(f"{am}.3.bias"),
-                   d["an"].data_ptr(), d["sxhat"].data_ptr(), d["srstd"].data_ptr(), d["sh"].data_ptr(), d["a_emb"].data_ptr(), B,
-                   self.d_actions[domain], self._skip_norm)
-            if use_mod:
-                ap = f"decoder.layers.0.action_projectors.{domain}"
-                pl.gemm_nt(A=d["a_emb"].data_ptr(), lda=256, a_kind=A_F32, W=self._wb(f"{ap}.adaLN_modulation.0.weight"), ldw=256,
-                           M=B, N=256, K=256, epi=EPI_SILU2, Cp=d["ada_pre"].data_ptr(), ldc=256,
-                           bias=self._p(f"{ap}.adaLN_modulation.0.bias"), C2=d["ada_act"].data_ptr(), ldc2=256, batch=L, sA=0,
-                           sW=self.layout.dom_layer_stride, sBias=self.layout.dom_layer_stride, sC=B * 256, sC2=B * 256)
-                pl.gemm_nt(A=d["ada_act"].data_ptr(), lda=256, a_kind=A_BF16, W=self._wb(f"{ap}.adaLN_modulation.2.weight"),
-                           ldw=256, M=B, N=512, K=256, epi=EPI_F32, Cp=d["ss"].data_ptr(), ldc=512,
-                           bias=self._p(f"{ap}.adaLN_modulation.2.bias"), batch=L, sA=B * 256, sW=self.layout.dom_layer_stride,
-                           sBias=self.layout.dom_layer_stride, sC=B * 512)
-        pfr = cfg.S + cfg.action_token_size
-        pl.add("hma_embed_fwd", d["ids"].data_ptr(), self._p("token_embed.factored_embeds.0.weight"),
-               self._p("token_embed.factored_embeds.1.weight"), self._p("token_embed.mask_token_embed"),
-               self._p("pos_embed_TSC") + 4 * t * pfr * 256, d["a_emb"].data_ptr() if A > 0 else None, d["x"].data_ptr(), B, 1, S, A,
-               pfr, cfg.factored_vocab_size, cfg.image_vocab_size)
-        x = d["x"].data_ptr()
-        fused = self._use_fused(M1, False)
-        names = ("xh1", "rstd1", "qkv_s", "o_s", "lse_s", "x2b", "o_t", "xh2", "rstd2", "xhm", "xm", "rstdm") + (
-            () if fused else ("u", "hg"))
-        for l in range(L):
-            bufs = {k: d[k].data_ptr() for k in names}
-            bufs["qkv_t"] = None
-            if use_mod:
-                bufs["ss"] = d["ss"].data_ptr() + l * B * 512 * 4
-            kv = {"cache": d["cache"][l].data_ptr(), "row_off": t * SA, "c_group": (SA, T_total * SA), "t_query": t,
-                  "T_cache": T_total}
-            cb = self.chain_b_ok and self._use_chain(M1, SA)
-            self._emit_layer(pl, l, x, bufs, M1, B, B, t + 1, SA, use_mod, domain, kv=kv, have_ln1=fused and l > 0,
-                             ln_next=(d["xh1"].data_ptr(), d["rstd1"].data_ptr()) if fused and l + 1 < L else None, fused=fused,
-                             have_qkv_s=cb and l > 0, chain_b=cb, next_qkv_s=bufs["qkv_s"] if (cb and l + 1 < L) else None)
-        if readout:
-            pl.gemm_nt(A=x, lda=256, a_kind=A_F32, a_group=(S, SA), W=self._wb("out_x_proj.weight"), ldw=256, M=B * S, N=1024,
-                       K=256, epi=EPI_F32, Cp=d["logits"].data_ptr(), ldc=1024, bias=self._p("out_x_proj.bias"))
-        self._dplans[key] = pl
-        return pl
-
-    def decode_prefill(self, ids_BPS: torch.Tensor, actions: Optional[torch.Tensor], domain: Optional[str], T_total: int,
-                       skip_normalization: bool = False) -> None:
-        """Run the prompt frames through the trunk, filling the per-layer temporal qkv cache."""
-        B, P, S = ids_BPS.shape
-        A = self.cfg.action_token_size if actions is not None else 0
-        d = self.decode_begin(B, T_total, S, A)
-        skip = 1 if skip_normalization else 0
-        if skip != self._skip_norm:
-            self._skip_norm, self._plans, self._dplans = skip, {}, {}
-        ws = self._workspace(B, P, S, A, False)
-        stream = torch.cuda.current_stream().cuda_stream
-        self.refresh_weights(domain if actions is not None else None, stream)
-        ws["ids"].copy_(ids_BPS, non_blocking=True)
-        if actions is not None:
-            d_a = self.d_actions[domain]
-            ws["actions"][: B * P * d_a].copy_(actions[:, :P].reshape(-1), non_blocking=True)
-        pl = self._forward_plan(B, P, S, A, False, domain if A > 0 else None, readout=False, kv_cache=d["cache"], T_cache=T_total)
-        if self.jpa and A > 0:
-            # jointly_predict_actions: the plan's embedding reads `a_tok` (what the concatenated action tokens carry).  Prompt frames
-            # are never action-masked in a rollout (st_mask_git.py:656-660 with no relevant_action_mask): a_tok = the embedded actions.
-            pl.run(stream, 0, pl.marks["post_stem"])
-            ws["a_tok"].copy_(ws["a_emb"])
-            pl.run(stream, pl.marks["post_stem"], None)
-        else:
-            pl.run(stream)
-
-    def decode_frame(self, ids_BS: torch.Tensor, actions_t: Optional[torch.Tensor], domain: Optional[str], t: int, T_total: int,
-                     readout: bool = True, same_actions: bool = False) -> torch.Tensor:
-        """One pass of frame t (tokens ids_BS, possibly partly masked) against the cached frames < t; refreshes
-        frame t's own cache rows.  Returns the (B*S, 1024) fp32 logits buffer of that frame."""
-        B, S = ids_BS.shape
-        A = self.cfg.action_token_size if actions_t is not None else 0
-        d = self.decode_begin(B, T_total, S, A)
-        stream = torch.cuda.current_stream().cuda_stream
-        d["ids"].view(B, S).copy_(ids_BS, non_blocking=True)
-        same_actions = same_actions and actions_t is not None
-        if actions_t is not None and not same_actions:
-            d_a = self.d_actions[domain]
-            d["actions"][: B * d_a].copy_(actions_t.reshape(-1), non_blocking=True)
-        pl = self._decode_plan(B, T_total, S, A, domain if A > 0 else None, t, readout, same_actions)
-        if not self.decode_graphs:
-            pl.run(stream)
-            return d["logits"]
-        # ~420 launches of M = B * 320 rows each: replayed as one hipGraph per (frame index, readout) after two eager runs
-        key = (B, T_total, S, A, domain if A > 0 else None, t, readout, self._skip_norm, same_actions)
-        g = self._dgraphs.get(key)
-        if g is None:
-            pl.run(stream)
-            n = self._dseen.get(key, 0) + 1
-            self._dseen[key] = n
-            if n >= 2:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    pl.run(torch.cuda.current_stream().cuda_stream)
-                self._dgraphs[key] = g
-        else:
-            g.replay()
-        return d["logits"]
 
     def zero_grad(self, active_domains: Optional[Sequence[str]] = None) -> None:
         """Zero the whole gradient buffer, or only the ranges that can receive gradients this step."""

@@ -175,13 +175,14 @@ def make_chain_a_bwd(*, M: int, segs, dqkv: int, dx: int, dx1_bf16: int, d_o: in
     return g
 
 
-def make_chain_s_bwd(*, M: int, segs, dqkv: int, dx: int, xhat: int, rstd: int, dx_bf16: int, ldq: int = 768) -> ChainSBwd:
-    """segs: packed qkv^T (3 x 8) of the spatial attention with norm1's gamma folded into the output rows."""
+def make_chain_s_bwd(*, M: int, segs, dqkv: int, dx: int, xhat: int, rstd: int, dx_bf16: int, ldq: int = 768, hb_rows: int = 0) -> ChainSBwd:
+    """segs: packed qkv^T (3 x 8) of the spatial attention with norm1's gamma folded into the output rows.  hb_rows > 0: dqkv in the
+    head-blocked order of hma_attn_spatial_bwd_blocked (rows per frame)."""
     g = ChainSBwd()
     _chain_weights(g.w, segs)
     g.dqkv, g.ldq, g.dx = dqkv, ldq, dx
     g.xhat, g.rstd, g.dx_bf16 = xhat, rstd, dx_bf16
-    g.M = M
+    g.M, g.hb_rows = M, hb_rows
     return g
 
 
@@ -249,12 +250,26 @@ def attn_spatial_fwd(qkv: torch.Tensor, frames: int, n: int, scale: float):
     return o, lse
 
 
-def attn_spatial_bwd(qkv, o, d_o, lse, frames: int, n: int, scale: float):
+def attn_spatial_bwd(qkv, o, d_o, lse, frames: int, n: int, scale: float, blocked: bool = False):
+    """dqkv [frames * n, 768] row-major; `blocked`: in the head-blocked order (`headblk_to_rows` turns it back)."""
     delta = torch.empty_like(lse)
     dqkv = torch.empty_like(qkv)
-    _lib.call("hma_attn_spatial_bwd", stream_ptr(), ptr(qkv), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dqkv), frames, n,
-              scale)
+    _lib.call("hma_attn_spatial_bwd_blocked" if blocked else "hma_attn_spatial_bwd", stream_ptr(), ptr(qkv), ptr(o), ptr(d_o), ptr(lse),
+              ptr(delta), ptr(dqkv), frames, n, scale)
     return dqkv
+
+
+def headblk_to_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    """[M, 256 W] head-blocked (HMA_A_BF16_HEADBLK: [frame][head][part][n][32]) -> row-major [M, 256 W]."""
+    M, C = t.shape
+    W = C // 256
+    return t.reshape(M // n, 8, W, n, 32).permute(0, 3, 2, 1, 4).reshape(M, C).contiguous()
+
+
+def rows_to_headblk(t: torch.Tensor, n: int) -> torch.Tensor:
+    M, C = t.shape
+    W = C // 256
+    return t.reshape(M // n, n, W, 8, 32).permute(0, 3, 2, 1, 4).reshape(M, C).contiguous()
 
 
 def attn_temporal_fwd(qkv: torch.Tensor, batch: int, T: int, n_s: int, scale: float):

@@ -28,7 +28,13 @@ enum { HMA_A_BF16 = 0, HMA_A_F32 = 1, HMA_A_BF16_AFFINE = 2,
         * hma_mlp_bwd stores gelu(u) / dL/du -- element (m, c) at ((((m / 128) (ld / 32) + c / 32) 4 + (m / 32) % 4) 1024 +
         * ((c / 8) % 2) 512 + (((c / 16) % 2) 32 + m % 32) 8 + c % 8: every (128-row tile, 32-column block, 32-row group) is 2 KB that
         * one wave writes with two contiguous 1 KB store instructions.  Allocate ceil(M / 128) 128 rows. */
-       HMA_A_BF16_FRAG32 = 3 };
+       HMA_A_BF16_FRAG32 = 3,
+       /* hma_gemm_tn's dY / A on its workspace (LDS-DMA) path only: a [M, 256 W] bf16 matrix (W = ld / 256) in the HEAD-BLOCKED order
+        * of the spatial attention -- element (m, c) at (((frame 8 + head) W + c / 256) n + m % n) 32 + c % 32 with frame = m / n,
+        * head = (c % 256) / 32, n = rows per frame passed in y_group_rows / a_group_rows (a multiple of 32 that divides M): every
+        * (frame, head, q | k | v part) is one contiguous [n][32] block, so the attention backward writes whole 2 KB tiles
+        * (hma_attn_spatial_bwd_blocked) and the consumers' 64-byte row pieces of one head are adjacent. */
+       HMA_A_BF16_HEADBLK = 4 };
 enum {
   HMA_EPI_BF16 = 0,      /* C(bf16)  = acc (+bias)                                            */
   HMA_EPI_F32 = 1,       /* C(f32)   = acc (+bias)                                            */
@@ -148,6 +154,10 @@ int hma_attn_spatial_fwd(void* stream, const void* qkv, void* o, float* lse, int
  * kernel per launch (q / k / v / dO of a (frame, head) staged in LDS once, dS shared through LDS); n = 64: the dq + dkv pair. */
 int hma_attn_spatial_bwd(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
                          float* delta, void* dqkv, int64_t frames, int32_t n, float scale);
+/* The same backward with dqkv written in the HEAD-BLOCKED order (HMA_A_BF16_HEADBLK above, W = 3, rows per frame n): every gradient
+ * tile leaves as 2 KB of contiguous memory.  Consumers: hma_gemm_tn (y_kind = HMA_A_BF16_HEADBLK) and hma_chain_s_bwd (hb_rows). */
+int hma_attn_spatial_bwd_blocked(void* stream, const void* qkv, const void* o, const void* d_o, const float* lse,
+                                 float* delta, void* dqkv, int64_t frames, int32_t n, float scale);
 /* Causal temporal self-attention over the T frames of each (b, s) column, attention.py:37-61 with
  * causal=True as called from st_transformer.py:111; rows are (b, t, s): stride between frames is
  * n_s rows.  T <= 16. */
@@ -458,6 +468,9 @@ typedef struct {
   const void* xhat; const float* rstd;
   void* dx_bf16;
   int64_t M;
+  /* > 0: dqkv is in the head-blocked order of hma_attn_spatial_bwd_blocked (rows per frame, a multiple of 16 that divides M; ldq = 768);
+   * 0: row-major [M, ldq] */
+  int64_t hb_rows;
 } hma_chain_s_bwd_t;
 int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p);
 

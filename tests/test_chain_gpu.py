@@ -188,6 +188,17 @@ def test_chain_s_bwd(M):
                              dx_bf16=ops.ptr(d1))
     _lib.call("hma_chain_s_bwd", ops.stream_ptr(), C.byref(a))
     torch.cuda.synchronize()
+    # the same from dqkv in the head-blocked order (what hma_attn_spatial_bwd_blocked writes): bit-identical
+    for n in (16, 320):
+        if M % n == 0:
+            dxh = dx.to(DEV).clone()
+            d1h = torch.zeros_like(d1)
+            dqh = ops.rows_to_headblk(dqd, n)
+            ah = ops.make_chain_s_bwd(M=M, segs=[(ops.ptr(wt), 24)], dqkv=ops.ptr(dqh), dx=ops.ptr(dxh), xhat=ops.ptr(xhd), rstd=ops.ptr(rsd),
+                                      dx_bf16=ops.ptr(d1h), hb_rows=n)
+            _lib.call("hma_chain_s_bwd", ops.stream_ptr(), C.byref(ah))
+            torch.cuda.synchronize()
+            assert torch.equal(dxh, dxd) and torch.equal(d1h, d1), f"head-blocked dqkv, n = {n}"
     close(dxd, dx1, 3e-3, "dx")
     assert rms(dxd, dx1) < 3e-3
     assert rms(dxd.cpu() - dx, dx1 - dx) < 4e-3  # (the part the kernel adds, not the residual it passes through)

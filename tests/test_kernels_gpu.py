@@ -389,6 +389,52 @@ def test_attn_spatial(frames, n):
         close(dqkv[:, sl], qr.grad[:, sl], 4 * BF, f"spatial {name}")
 
 
+@pytest.mark.parametrize("frames,n", [(3, 320), (20, 320), (9, 256), (2, 64)])
+def test_attn_spatial_bwd_blocked_equals_row_major(frames, n):
+    """hma_attn_spatial_bwd_blocked writes the same gradients in the head-blocked order (HMA_A_BF16_HEADBLK): bit-identical values,
+    [frame][head][q | k | v][n][32] instead of [row][768]."""
+    scale = 0.25
+    qkv = rb(torch.randn(frames * n, 768, generator=g(140))).to(DEV).bfloat16()
+    d_o = rb(torch.randn(frames * n, 256, generator=g(141))).to(DEV).bfloat16()
+    o, lse = ops.attn_spatial_fwd(qkv, frames, n, scale)
+    rows = ops.attn_spatial_bwd(qkv, o, d_o, lse, frames, n, scale)
+    blk = ops.attn_spatial_bwd(qkv, o, d_o, lse, frames, n, scale, blocked=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ops.headblk_to_rows(blk, n), rows)
+    assert torch.equal(ops.rows_to_headblk(rows, n), blk)
+
+
+@pytest.mark.parametrize("frames,n", [(4, 320), (7, 64)])
+def test_gemm_tn_headblocked_operand(frames, n):
+    """hma_gemm_tn / _pair with dY (the spatial qkv gradient, W = 3) or A (W = 1) in the head-blocked order: the weight gradient the
+    row-major operand gives, bit for bit (only the LDS-DMA source addresses differ)."""
+    from hma_amd._lib import A_BF16_HEADBLK
+    M = frames * n
+    ws = torch.full((256 * (65536 + 256),), float("nan"), device=DEV)
+    dy = rb(torch.randn(M, 768, generator=g(150)) * 0.5).to(DEV).bfloat16()
+    x = rb(torch.randn(M, 256, generator=g(151))).to(DEV).bfloat16()
+    gam, bet = (torch.randn(256, generator=g(152)) * 0.2 + 1).to(DEV), (torch.randn(256, generator=g(153)) * 0.2).to(DEV)
+    out = {}
+    for hb in (False, True):
+        dW, db = torch.zeros(768, 256, device=DEV), torch.zeros(768, device=DEV)
+        dW2, db2 = torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)
+        dyb = ops.rows_to_headblk(dy, n) if hb else dy
+        xb = ops.rows_to_headblk(x, n) if hb else x
+        ga = ops.make_gemm_tn(dY=ops.ptr(dyb), ldy=768, y_kind=A_BF16_HEADBLK if hb else A_BF16, y_group=(n, 0) if hb else (0, 0), A=ops.ptr(x), lda=256,
+                              a_kind=A_BF16_AFFINE, gamma=ops.ptr(gam), beta=ops.ptr(bet), M=M, N=768, K=256, dW=ops.ptr(dW), lddw=256,
+                              dBias=ops.ptr(db), ws=ops.ptr(ws), ws_elems=ws.numel())
+        gb = ops.make_gemm_tn(dY=ops.ptr(dy[:, :256].contiguous()), ldy=256, y_kind=A_BF16, A=ops.ptr(xb), lda=256,
+                              a_kind=A_BF16_HEADBLK if hb else A_BF16, a_group=(n, 0) if hb else (0, 0), M=M, N=256, K=256, dW=ops.ptr(dW2),
+                              lddw=256, dBias=ops.ptr(db2), ws=ops.ptr(ws), ws_elems=ws.numel())
+        _lib.call("hma_gemm_tn_pair", ops.stream_ptr(), C.byref(ga), C.byref(gb))
+        torch.cuda.synchronize()
+        out[hb] = (dW, db, dW2, db2)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+    ref = dy.double().t() @ (x.double() * gam.double() + bet.double())
+    close(out[True][0], ref.float(), BF, "head-blocked dW")
+
+
 @pytest.mark.parametrize("B,T,n_s", [(2, 16, 5), (3, 3, 7), (1, 1, 4), (2, 12, 5)])
 def test_attn_temporal(B, T, n_s):
     scale = 0.25

@@ -29,3 +29,5 @@ def timeit(fn, reps=12):
 
 print(f"fwd {timeit(lambda i: ops.attn_spatial_fwd(qkvs[i % NB], frames, n, scale)):8.1f} us")
 print(f"bwd {timeit(lambda i: ops.attn_spatial_bwd(qkvs[i % NB], outs[i % NB][0], dos[i % NB], outs[i % NB][1], frames, n, scale)):8.1f} us")
+if hasattr(_lib.load(), "hma_attn_spatial_bwd_blocked"):
+    print(f"bwd, head-blocked dqkv {timeit(lambda i: ops.attn_spatial_bwd(qkvs[i % NB], outs[i % NB][0], dos[i % NB], outs[i % NB][1], frames, n, scale, blocked=True)):8.1f} us")

@@ -19,9 +19,9 @@ else
   : > gpurun_out/attn_variants.txt
   for NTOK in 320 256; do
     echo "# n = $NTOK" | tee -a gpurun_out/attn_variants.txt
-    (echo -n "default: "; NTOK=$NTOK timeout 120 python3 tools/attn_bench.py 2>&1 | tail -2 | tr '\n' ' '; echo) | tee -a gpurun_out/attn_variants.txt
+    (echo -n "default: "; NTOK=$NTOK timeout 120 python3 tools/attn_bench.py 2>&1 | tail -3 | tr '\n' ' '; echo) | tee -a gpurun_out/attn_variants.txt
     for so in variants/libhma_at_*.so; do
-      (echo -n "$so: "; NTOK=$NTOK HMA_DEBUG_LIB=$so timeout 120 python3 tools/attn_bench.py 2>&1 | tail -2 | tr '\n' ' '; echo) | tee -a gpurun_out/attn_variants.txt
+      (echo -n "$so: "; NTOK=$NTOK HMA_DEBUG_LIB=$so timeout 120 python3 tools/attn_bench.py 2>&1 | tail -3 | tr '\n' ' '; echo) | tee -a gpurun_out/attn_variants.txt
     done
   done
 fi

@@ -109,6 +109,10 @@ if hasattr(_lib.load(), "hma_chain_s_bwd") and not B_ONLY:
     t_g = timeit(lambda: _lib.call("hma_gemm_nt", st, C.byref(gq_)))
     t_l = timeit(lambda: _lib.call("hma_ln_bwd", st, t256.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), gam.data_ptr(), dx.data_ptr(),
                                    dgam.data_ptr(), dbet.data_ptr(), M, d1.data_ptr()))
+    sbh = ops.make_chain_s_bwd(M=M, segs=[(tws.data_ptr(), 24)], dqkv=dqkv.data_ptr(), dx=dx.data_ptr(), xhat=xhat.data_ptr(),
+                               rstd=rstd.data_ptr(), dx_bf16=d1.data_ptr(), hb_rows=RPF)
+    t_sh = timeit(lambda: _lib.call("hma_chain_s_bwd", st, C.byref(sbh)))
+    print(f"chain S bwd from head-blocked dqkv {t_sh:7.1f} us")
     print(f"{os.environ.get('HMA_LIB', 'default'):>24s}  chain S bwd {t_s:7.1f} us ({M * 4608.0 / t_s / 1e6:5.2f} TB/s)  [2 launches: {t_g:.0f} + {t_l:.0f} = "
           f"{t_g + t_l:.0f} us]")
 
