@@ -627,6 +627,21 @@ def main():
                               "launches": sm["launches"], "avg_launch_us": 1e3 * sm["ms"] / sm["launches"],
                               "flops_per_launch": sm["flops"] / sm["launches"], "bytes_per_launch": sm["bytes"] / sm["launches"],
                               "share_of_step_time": (sm["ms"] / inst_steps) / step_ms}
+            # The weight-gradient ring kernel (gemm_tn_dma_kernel + its reduction tn_reduce_native_kernel) serves the three
+            # hma_gemm_tn_pair calls of a layer AND linear_out's single hma_gemm_tn call: one entry for every C-ABI call that runs
+            # it, so that its average is the number a rocprofv3 kernel summary gives (sum of the two kernels' time / ring launches)
+            lin_flops = 2.0 * B * T * 320 * 256 * 256
+            ring = [p_ for p_ in timer.pairs if p_[0] == "hma_gemm_tn_pair" or (p_[0] == "hma_gemm_tn" and p_[1] == lin_flops)]
+            if ring:
+                ms = sum(p_[2].elapsed_time(p_[3]) for p_ in ring)
+                fl, by = sum(p_[1] for p_ in ring), sum(p_[4] for p_ in ring)
+                ach, gbs, ai = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9, fl / by
+                fams["wgrad_ring"] = {"bound": "hbm" if ai < MFMA_PEAK / 8e12 else "mfma", "achieved": ach, "frac": ach / 2500.0,
+                                      "hbm_achieved_gbs": gbs, "hbm_frac": gbs / 8000.0, "flop_per_byte": ai, "launches": len(ring),
+                                      "avg_launch_us": 1e3 * ms / len(ring), "flops_per_launch": fl / len(ring),
+                                      "bytes_per_launch": by / len(ring), "share_of_step_time": (ms / inst_steps) / step_ms,
+                                      "note": "every C-ABI call that runs gemm_tn_dma_kernel + tn_reduce_native_kernel: per layer three "
+                                              "hma_gemm_tn_pair calls and linear_out's hma_gemm_tn (both also listed on their own)"}
             # `roofline` = the family with the largest share of the step, against the roof its arithmetic intensity puts it under
             dom_name = max(fams, key=lambda k: fams[k]["share_of_step_time"]) if fams else None
             if dom_name:
@@ -634,12 +649,14 @@ def main():
                 # (every kernel the C-ABI call launches, per CALL: the weight-gradient entry points launch the ring kernel and its reduction)
                 fam_kernels = {"hma_gemm_nt": (("gemm_nt",), "gemm_nt"), "hma_mlp_bwd": (("mlp_bwd",), "mlp_bwd"), "hma_mlp_fwd": (("mlp_fwd",), "mlp_fwd"),
                                "hma_gemm_tn_pair": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_a_fwd": (("chain_a_fwd",), "chain_a_fwd"),
+                               "wgrad_ring": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_s_bwd": (("chain_s_bwd",), "chain_s_bwd"),
                                "hma_chain_a_bwd": (("chain_a_bwd",), "chain_a_bwd"), "hma_chain_b_fwd": (("chain_b_fwd",), "chain_b_fwd"),
                                "hma_attn_spatial_bwd": (("attn_bwd_fused",), "attn_bwd_fused")}.get(dom_name, ((dom_name,), dom_name))
                 traffic, pmc_file = pmc_traffic_per_call(*fam_kernels)
                 same_scope = d0["bytes_per_launch"]
                 if dom_name == "hma_gemm_tn_pair":  # (three pairs + linear_out's single call per layer share the ring kernel)
                     same_scope = (3.0 * d0["bytes_per_launch"] + (B * T * 320 * 1024.0 + 4.0 * 65536)) / 4.0
+                # (wgrad_ring: its bytes_per_launch already is the average over the layer's four calls)
                 mfma = {"achieved": d0["achieved"], "peak": 2500.0, "unit": "TFLOP/s", "frac": d0["frac"]}
                 if power is not None and power.get("sclk_mhz"):
                     # the dense-MFMA peak at the clock the step actually runs at (the part's 2.5 PF are quoted at 2 400 MHz; the step sits

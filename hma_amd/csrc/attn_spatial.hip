@@ -942,7 +942,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
       if (nxt < nitems && !(ATTN_ABL & 64)) st.fetch(qkv, o, d_o, lse, nxt, frames, ftid);
       int64_t frame; int head;
       decode_block(item, frames, frame, head);
-      if (wave == 7) dq_item(frame, head);
+      if (wave == 7) {
+#ifdef ATTN_DQ_PRIO  // (measurement builds: the dQ wave, the slowest of every step, ahead of the tile wave it shares a SIMD with)
+        __builtin_amdgcn_s_setprio(ATTN_DQ_PRIO);
+#endif
+        dq_item(frame, head);
+      }
       else tile_item(std::integral_constant<int, 1>{}, 2 * HEAVY + (wave - HEAVY), frame, head);
       lds_barrier();
     }

@@ -12,12 +12,15 @@ MODE=${MODE:-train}
 OUT=gpurun_out/prof_${R}_$MODE
 rm -rf $OUT; mkdir -p $OUT
 case $MODE in
-  train)  TR="--steps 3 --warmup 1 --mode train --no-cpu-baseline --no-kernel-timing"; PM="--steps 1 --warmup 1 --layers 8 --mode train --no-cpu-baseline --no-kernel-timing";;
+  # (train: the train leg of the driver's command -- `bench.py --steps 20 --warmup 5` -- WITH its HIP-event pass, so that the printed line and
+  # the kernel summary come from one process: tools/roofline_check.py compares them)
+  train)  TR="--steps 20 --warmup 5 --mode train --no-cpu-baseline"; PM="--steps 1 --warmup 1 --layers 8 --mode train --no-cpu-baseline --no-kernel-timing";;
   decode) TR="--steps 2 --warmup 2 --mode decode --no-cpu-baseline --no-latency"; PM="--steps 1 --warmup 1 --layers 4 --mode decode --no-cpu-baseline --no-latency";;
   mar)    TR="--steps 3 --warmup 2 --mode mar --no-cpu-baseline"; PM="--steps 1 --warmup 2 --mode mar --no-cpu-baseline";;
 esac
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $R -- python3 bench.py $TR > $OUT/bench_trace.log 2>&1 < /dev/null
 echo "trace rc=$?"
+grep -h '^{"metric"' $OUT/bench_trace.log | tail -1 > $OUT/bench_line_$R.json
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $R -- python3 bench.py $PM > $OUT/bench_pmc_fetch.log 2>&1 < /dev/null
 echo "pmc fetch rc=$?"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $R -- python3 bench.py $PM > $OUT/bench_pmc_write.log 2>&1 < /dev/null

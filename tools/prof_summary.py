@@ -10,9 +10,10 @@ if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out, f"kernel_stats_{tag}.csv"), "w") as f:
         w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
-        for r in rows[:40]:
-            w.writerow([r.get("Name"), r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")])
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:60]:
+            w.writerow([r.get("Name"), r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage"), r.get("MinNs"),
+                        r.get("MaxNs"), r.get("StdDev")])
     for r in rows[:12]:
         print(f"{float(r['Percentage']):6.2f}%  {int(r['Calls']):6d} x {float(r['AverageNs'])/1e3:9.1f} us  {r['Name'][:90]}")
 for kind in ("fetch", "write"):
