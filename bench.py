@@ -38,7 +38,7 @@ FREQ = [20, 10, 20, 20, 5, 30, 2, 20, 20, 10, 2, 2, 10, 1, 10, 5, 5, 5, 10, 3, 1
         3, 3, 15, 20, 10, 30, 5, 10, 5]
 FLOP_PER_TOKEN_FWD_BWD = 3.104e8
 # every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
-FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_attn_spatial_fwd", "hma_attn_spatial_bwd_blocked",
+FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_gemm_tn_multi", "hma_attn_spatial_fwd", "hma_attn_spatial_bwd_blocked",
             "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd",
             "hma_chain_s_bwd", "hma_readout_ce"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
@@ -631,7 +631,7 @@ def main():
             # hma_gemm_tn_pair calls of a layer AND linear_out's single hma_gemm_tn call: one entry for every C-ABI call that runs
             # it, so that its average is the number a rocprofv3 kernel summary gives (sum of the two kernels' time / ring launches)
             lin_flops = 2.0 * B * T * 320 * 256 * 256
-            ring = [p_ for p_ in timer.pairs if p_[0] == "hma_gemm_tn_pair" or (p_[0] == "hma_gemm_tn" and p_[1] == lin_flops)]
+            ring = [p_ for p_ in timer.pairs if p_[0] in ("hma_gemm_tn_pair", "hma_gemm_tn_multi") or (p_[0] == "hma_gemm_tn" and p_[1] == lin_flops)]
             if ring:
                 ms = sum(p_[2].elapsed_time(p_[3]) for p_ in ring)
                 fl, by = sum(p_[1] for p_ in ring), sum(p_[4] for p_ in ring)
@@ -640,8 +640,9 @@ def main():
                                       "hbm_achieved_gbs": gbs, "hbm_frac": gbs / 8000.0, "flop_per_byte": ai, "launches": len(ring),
                                       "avg_launch_us": 1e3 * ms / len(ring), "flops_per_launch": fl / len(ring),
                                       "bytes_per_launch": by / len(ring), "share_of_step_time": (ms / inst_steps) / step_ms,
-                                      "note": "every C-ABI call that runs gemm_tn_dma_kernel + tn_reduce_native_kernel: per layer three "
-                                              "hma_gemm_tn_pair calls and linear_out's hma_gemm_tn (both also listed on their own)"}
+                                      "note": "every C-ABI call that runs gemm_tn_dma_kernel + tn_reduce_native_kernel: per layer ONE "
+                                              "hma_gemm_tn_multi call with the block's seven weight gradients (round 5; before: three "
+                                              "hma_gemm_tn_pair calls and linear_out's hma_gemm_tn)"}
             # `roofline` = the family with the largest share of the step, against the roof its arithmetic intensity puts it under
             dom_name = max(fams, key=lambda k: fams[k]["share_of_step_time"]) if fams else None
             if dom_name:
@@ -650,6 +651,7 @@ def main():
                 fam_kernels = {"hma_gemm_nt": (("gemm_nt",), "gemm_nt"), "hma_mlp_bwd": (("mlp_bwd",), "mlp_bwd"), "hma_mlp_fwd": (("mlp_fwd",), "mlp_fwd"),
                                "hma_gemm_tn_pair": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_a_fwd": (("chain_a_fwd",), "chain_a_fwd"),
                                "wgrad_ring": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_s_bwd": (("chain_s_bwd",), "chain_s_bwd"),
+                               "hma_gemm_tn_multi": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"),
                                "hma_chain_a_bwd": (("chain_a_bwd",), "chain_a_bwd"), "hma_chain_b_fwd": (("chain_b_fwd",), "chain_b_fwd"),
                                "hma_attn_spatial_bwd": (("attn_bwd_fused",), "attn_bwd_fused")}.get(dom_name, ((dom_name,), dom_name))
                 traffic, pmc_file = pmc_traffic_per_call(*fam_kernels)

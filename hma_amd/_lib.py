@@ -133,6 +133,7 @@ _PROTOS = {
     "hma_gemm_nt": [c_vp, C.POINTER(GemmNT)],
     "hma_gemm_tn": [c_vp, C.POINTER(GemmTN)],
     "hma_gemm_tn_pair": [c_vp, C.POINTER(GemmTN), C.POINTER(GemmTN)],
+    "hma_gemm_tn_multi": [c_vp, C.POINTER(C.POINTER(GemmTN)), c_i32],
     "hma_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32],
     "hma_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hma_qknorm_fwd": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_i64, c_i64, c_i64],

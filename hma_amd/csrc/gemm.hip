@@ -1524,8 +1524,10 @@ struct tn_prob {
   int yfrag, afrag;  // operand stored in the fused-MLP fragment order (HMA_A_BF16_FRAG32): only the DMA source address differs
   int yhb, ahb;      // > 0: operand in the head-blocked order of the spatial attention (HMA_A_BF16_HEADBLK), rows per frame
 };
+constexpr int TN_MAXP = 8;
 struct tn_pair_args {
-  tn_prob q[2];      // problem 1's workgroup ids follow problem 0's (q[1].nb == 0: a single problem)
+  tn_prob q[TN_MAXP];  // problem i's workgroup ids follow problem i - 1's; n problems (hma_gemm_tn: 1, _pair: 2, _multi: up to 8)
+  int n;
 };
 
 template <bool TR, bool COLSUM, int ABL = 0>
@@ -1542,9 +1544,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
   // workgroup b runs on XCD b & 7: give every XCD one contiguous run of virtual ids, so that the workgroups of one split
   // (consecutive ids: the n / k groups that re-read the same rows of A or dY) share an L2 -- for any G
   const int gvid = (b & 7) * (G >> 3) + min(b & 7, G & 7) + (b >> 3);
-  const bool second = gvid >= args.q[0].nb;
-  const tn_prob p = second ? args.q[1] : args.q[0];
-  const int vid = gvid - (second ? args.q[0].nb : 0);
+  int pi = 0, vbase = 0;
+#pragma unroll 1
+  while (pi + 1 < args.n && gvid >= vbase + args.q[pi].nb) {
+    vbase += args.q[pi].nb;
+    ++pi;
+  }
+  const tn_prob p = args.q[pi];
+  const int vid = gvid - vbase;
   const int groups_n = p.gn, groups_k = p.gk;
   const int groups = groups_n * groups_k;
   const int per_batch = groups * p.splits;
@@ -1787,18 +1794,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
 // affine != 0: dW += gamma[k] * P[n][k] + beta[k] * colsum(dY)[n] (the LayerNorm affine of A, which the DMA kernel cannot
 // apply on the way into LDS); colsum comes from the bias partials of the n-block's k0 == 0 group.
 struct tn_reduce_args {
-  hma_gemm_tn_t p[2];  // ws / splits already set per problem
-  int gn[2], gk[2], affine[2];
-  int gy0;             // grid.y rows of problem 0 (problem 1's follow)
+  hma_gemm_tn_t p[TN_MAXP];  // ws / splits already set per problem
+  int gn[TN_MAXP], gk[TN_MAXP], affine[TN_MAXP];
+  int gy_end[TN_MAXP];       // grid.y rows of problems 0 .. i (prefix sums)
+  int n;
 };
 __global__ __launch_bounds__(256) void tn_reduce_native_kernel(tn_reduce_args ra) {
   __shared__ float red[8][32][8];
   __shared__ float csum[8][32];
-  const bool second = (int)blockIdx.y >= ra.gy0;
-  const hma_gemm_tn_t& p = second ? ra.p[1] : ra.p[0];
-  const int groups_n = second ? ra.gn[1] : ra.gn[0], groups_k = second ? ra.gk[1] : ra.gk[0];
-  const int affine = second ? ra.affine[1] : ra.affine[0];
-  const int by = (int)blockIdx.y - (second ? ra.gy0 : 0);
+  int pi = 0;
+#pragma unroll 1
+  while (pi + 1 < ra.n && (int)blockIdx.y >= ra.gy_end[pi]) ++pi;
+  const hma_gemm_tn_t& p = ra.p[pi];
+  const int groups_n = ra.gn[pi], groups_k = ra.gk[pi];
+  const int affine = ra.affine[pi];
+  const int by = (int)blockIdx.y - (pi > 0 ? ra.gy_end[pi - 1] : 0);
   const int groups = groups_n * groups_k;
   const int g = by % groups;
   const int64_t bz = by / groups;
@@ -2466,8 +2476,13 @@ static tn_prob tn_make_prob(const hma_gemm_tn_t& q, float* ws, int splits) {
 }
 template <bool TR>
 static int tn_dma_launch(hipStream_t s, const tn_pair_args& a) {
-  const bool cs = a.q[0].colsum || (a.q[1].nb > 0 && a.q[1].colsum);
-  const dim3 grid((unsigned)(a.q[0].nb + a.q[1].nb));
+  bool cs = false;
+  unsigned nb = 0;
+  for (int i = 0; i < a.n; ++i) {
+    cs = cs || a.q[i].colsum;
+    nb += (unsigned)a.q[i].nb;
+  }
+  const dim3 grid(nb);
   int rc;
   if (cs) {
     if ((rc = set_smem_bytes<gemm_tn_dma_kernel<TR, true>>(DM_SMEM_BYTES))) return rc;
@@ -2479,23 +2494,19 @@ static int tn_dma_launch(hipStream_t s, const tn_pair_args& a) {
   HMA_CHECK_LAUNCH();
   return 0;
 }
-// one reduction launch for one problem (b == nullptr) or for both problems of a pair
-static int tn_dma_reduce(hipStream_t s, const hma_gemm_tn_t& a, const tn_prob& ta, const hma_gemm_tn_t* b = nullptr,
-                         const tn_prob* tb = nullptr) {
+// one reduction launch for the n problems of a ring-kernel launch
+static int tn_dma_reduce(hipStream_t s, const hma_gemm_tn_t* const* probs, const tn_pair_args& a) {
   tn_reduce_args ra;
-  ra.p[0] = a;
-  ra.p[0].splits = ta.splits;
-  ra.p[0].ws = ta.ws;
-  ra.gn[0] = ta.gn; ra.gk[0] = ta.gk; ra.affine[0] = a.a_kind == HMA_A_BF16_AFFINE;
-  ra.gy0 = ta.gn * ta.gk * (a.batch > 0 ? a.batch : 1);
-  unsigned gy = (unsigned)ra.gy0;
-  ra.p[1] = ra.p[0]; ra.gn[1] = ra.gn[0]; ra.gk[1] = ra.gk[0]; ra.affine[1] = ra.affine[0];
-  if (b) {
-    ra.p[1] = *b;
-    ra.p[1].splits = tb->splits;
-    ra.p[1].ws = tb->ws;
-    ra.gn[1] = tb->gn; ra.gk[1] = tb->gk; ra.affine[1] = b->a_kind == HMA_A_BF16_AFFINE;
-    gy += (unsigned)(tb->gn * tb->gk * (b->batch > 0 ? b->batch : 1));
+  ra.n = a.n;
+  unsigned gy = 0;
+  for (int i = 0; i < TN_MAXP; ++i) {
+    const int j = i < a.n ? i : 0;
+    ra.p[i] = *probs[j];
+    ra.p[i].splits = a.q[j].splits;
+    ra.p[i].ws = a.q[j].ws;
+    ra.gn[i] = a.q[j].gn; ra.gk[i] = a.q[j].gk; ra.affine[i] = probs[j]->a_kind == HMA_A_BF16_AFFINE;
+    if (i < a.n) gy += (unsigned)(a.q[j].gn * a.q[j].gk * (probs[j]->batch > 0 ? probs[j]->batch : 1));
+    ra.gy_end[i] = (int)gy;
   }
   hipLaunchKernelGGL(tn_reduce_native_kernel, dim3((unsigned)(WT * WT / 256), gy), dim3(256), 0, s, ra);
   HMA_CHECK_LAUNCH();
@@ -2538,9 +2549,8 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
     const bool bias_room = q.ws && q.ws_elems >= (int64_t)nblocks * (WT * WT + WT);
     if (q.ws && tn_dma_eligible(q) && (bias_room || (!q.dBias && q.a_kind != HMA_A_BF16_AFFINE))) {
       tn_pair_args args;
-      args.q[0] = tn_make_prob(q, q.ws, splits);
-      args.q[1] = args.q[0];
-      args.q[1].nb = 0;
+      args.n = 1;
+      for (int i = 0; i < TN_MAXP; ++i) args.q[i] = tn_make_prob(q, q.ws, splits);
 #ifdef HMA_PROF
 #define HMA_TND_ABL(A)                                                                                        \
   case A:                                                                                                     \
@@ -2558,7 +2568,8 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
       } else
 #endif
       if ((rc = tn_dma_launch<true>(s, args))) return rc;
-      return tn_dma_reduce(s, q, args.q[0]);
+      const hma_gemm_tn_t* one[1] = {&q};
+      return tn_dma_reduce(s, one, args);
     }
     if (q.dgamma) return HMA_EINVAL;  // the folded-affine gradients exist on the LDS-DMA path only
 #define HMA_TNW_CASE(YK, AK)                                                                        \
@@ -2593,39 +2604,81 @@ extern "C" int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p) {
   return HMA_EINVAL;
 }
 
-extern "C" int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_gemm_tn_t* b) {
-  if (!a || !b) return HMA_EINVAL;
+#ifndef TN_MULTI_EQUAL_ROWS
+#define TN_MULTI_EQUAL_ROWS 1
+#endif
+static double tn_weight(const hma_gemm_tn_t& q, int n) {
+  const double b = q.batch > 0 ? q.batch : 1;
+  if (n > 2 && TN_MULTI_EQUAL_ROWS) return (double)q.M * (double)((q.N / WT) * (q.K / WT)) * b;
+  return (double)q.M * (double)(q.N + q.K) * b;
+}
+
+extern "C" int hma_gemm_tn_multi(void* stream, const hma_gemm_tn_t* const* probs, int32_t n) {
+  if (!probs || n < 1 || n > TN_MAXP) return HMA_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (!probs[i]) return HMA_EINVAL;
   const int64_t need = (int64_t)256 * (WT * WT + WT);
-  bool ok = a->dY && a->A && a->dW && b->dY && b->A && b->dW && a->ws && a->ws == b->ws &&
-            a->ws_elems >= need && b->ws_elems >= need && tn_dma_eligible(*a) && tn_dma_eligible(*b) &&
-            !(a->a_kind == HMA_A_BF16_AFFINE && (!a->gamma || !a->beta)) && !(b->a_kind == HMA_A_BF16_AFFINE && (!b->gamma || !b->beta)) &&
-            !(a->dgamma && (!a->dbeta || !a->w_master)) && !(b->dgamma && (!b->dbeta || !b->w_master));
+  bool ok = n >= 2;
+  double wsum = 0.0;
+  for (int i = 0; i < n && ok; ++i) {
+    const hma_gemm_tn_t& q = *probs[i];
+    ok = q.dY && q.A && q.dW && q.ws && q.ws == probs[0]->ws && q.ws_elems >= need && tn_dma_eligible(q) &&
+         !(q.a_kind == HMA_A_BF16_AFFINE && (!q.gamma || !q.beta)) && !(q.dgamma && (!q.dbeta || !q.w_master));
+    // workgroups in proportion to the operand bytes of each problem (two problems: hma_gemm_tn_pair's historical split) or -- more
+    // than two, TN_MULTI_EQUAL_ROWS -- to rows x 256 x 256 output blocks: a workgroup streams the rows of ONE block, so equal rows per
+    // workgroup means every workgroup of the launch runs the same number of 32-row stages
+    wsum += tn_weight(q, n);
+  }
 #ifdef HMA_PROF
   if (getenv("HMA_GEMM_TN_NOPAIR") || getenv("HMA_GEMM_TN_ABLATE")) ok = false;  // debug build only
 #endif
-  int s0 = 0, s1 = 0;
+  int splits[TN_MAXP] = {0};
   if (ok) {
-    // workgroups in proportion to the operand bytes of each problem
-    const double w0 = (double)a->M * (double)(a->N + a->K) * (a->batch > 0 ? a->batch : 1);
-    const double w1 = (double)b->M * (double)(b->N + b->K) * (b->batch > 0 ? b->batch : 1);
-    int b0 = (int)(256.0 * w0 / (w0 + w1) + 0.5);
-    b0 = b0 < 1 ? 1 : (b0 > 255 ? 255 : b0);
-    s0 = tn_plan_splits(*a, b0);
-    s1 = tn_plan_splits(*b, 256 - b0);
-    ok = s0 > 0 && s1 > 0;
+    int total = 0, budget0 = 0;
+    for (int i = 0; i < n && ok; ++i) {
+      const hma_gemm_tn_t& q = *probs[i];
+      const int groups = (int)(q.N / WT) * (int)(q.K / WT) * (q.batch > 0 ? q.batch : 1);
+      const double share = 256.0 * tn_weight(q, n) / wsum;
+      int budget = (int)share;
+      if (n == 2) {  // (two problems: rounded, the second takes the rest -- the split hma_gemm_tn_pair has always made)
+        if (i == 0) {
+          budget0 = (int)(share + 0.5);
+          budget0 = budget0 < 1 ? 1 : (budget0 > 255 ? 255 : budget0);
+          budget = budget0;
+        } else {
+          budget = 256 - budget0;
+        }
+      }
+      if (budget < groups) budget = groups;
+      splits[i] = tn_plan_splits(q, budget);
+      ok = splits[i] > 0;
+      total += splits[i] * groups;
+    }
+    ok = ok && total <= 256;
   }
   if (!ok) {
-    const int rc = hma_gemm_tn(stream, a);
-    return rc ? rc : hma_gemm_tn(stream, b);
+    for (int i = 0; i < n; ++i)
+      if (int rc = hma_gemm_tn(stream, probs[i])) return rc;
+    return 0;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   tn_pair_args args;
-  args.q[0] = tn_make_prob(*a, a->ws, s0);
-  args.q[1] = tn_make_prob(*b, a->ws + (int64_t)args.q[0].nb * (WT * WT + WT), s1);
-  if (args.q[0].nb + args.q[1].nb > 256) return HMA_EINVAL;
+  args.n = n;
+  int64_t off = 0;
+  for (int i = 0; i < TN_MAXP; ++i) {
+    const int j = i < n ? i : 0;
+    args.q[i] = tn_make_prob(*probs[j], probs[0]->ws + (i < n ? off : 0) * (WT * WT + WT), splits[j]);
+    if (i < n) off += args.q[i].nb;
+  }
   int rc;
   if ((rc = tn_dma_launch<true>(s, args))) return rc;
-  return tn_dma_reduce(s, *a, args.q[0], b, &args.q[1]);
+  return tn_dma_reduce(s, probs, args);
+}
+
+extern "C" int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_gemm_tn_t* b) {
+  if (!a || !b) return HMA_EINVAL;
+  const hma_gemm_tn_t* two[2] = {a, b};
+  return hma_gemm_tn_multi(stream, two, 2);
 }
 
 #ifdef HMA_PROF

@@ -110,6 +110,10 @@ class STEngine(DecodeMixin):
         self.chain_min_rows = 0
         self.chain_s = os.environ.get("HMA_CHAIN_S", "1") != "0"  # (0: measurement -- the spatial qkv dgrad + hma_ln_bwd as two launches)
         self.attn_hb = os.environ.get("HMA_ATTN_HB", "1") != "0"  # (0: measurement -- the spatial attention backward's dqkv row-major)
+        # The seven weight gradients of a block in ONE launch at the end of its backward (hma_gemm_tn_multi): nothing reads a weight
+        # gradient before the optimizer, so they wait until every operand exists -- four bf16(dx) buffers and a second dqkv keep the
+        # operands alive.  (0: measurement -- three pair launches + linear_out's, each behind its operands)
+        self.wgrad_multi = os.environ.get("HMA_WGRAD_MULTI", "1") != "0"
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN),
                    "qkv_s_T": mk(L, 24 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
@@ -359,6 +363,12 @@ class STEngine(DecodeMixin):
             if self._use_chain(M, SA) and A > 0 and self.modulate:
                 buf("dx2b", (M, 256), BF16)  # bf16(dx) in front of the modulate block: dY of linear_out's weight gradient
             buf("dqkv", (M, 768), BF16)
+            if self.wgrad_multi and fused and self._use_chain(M, SA):
+                # the deferred weight gradients read bf16(dx) as it was at three points of the block and both attentions' dqkv: every
+                # producer of bf16(dx) writes the next of four buffers, the spatial attention gets its own dqkv
+                buf("dxb3", (M, 256), BF16)
+                buf("dxb4", (M, 256), BF16)
+                buf("dqkv_s", (M, 768), BF16)
             buf("delta", (M, 8), F32)
             if A > 0:
                 buf("dss", (L, Fr, 512), F32)
@@ -596,7 +606,7 @@ class STEngine(DecodeMixin):
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
         key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group,
-               self.chain_s, self.attn_hb)
+               self.chain_s, self.attn_hb, self.wgrad_multi)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -606,7 +616,10 @@ class STEngine(DecodeMixin):
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
         dxb = ws["dxb"].data_ptr()
-        dqkv_s = dqkv
+        multi = self.wgrad_multi and "dqkv_s" in ws and self._use_fused(M, True, SA) and self._use_chain(M, SA) and self.chain_s and not self.qkn
+        dqkv_s = ws["dqkv_s"].data_ptr() if multi else dqkv
+        ring = [ws[k].data_ptr() for k in ("dxb", "dxb2", "dxb3", "dxb4")] if multi else []
+        nxt = lambda cur: ring[(ring.index(cur) + 1) % 4]  # the next bf16(dx) buffer (deferred weight gradients still read the earlier ones)
         # readout
         pl.gemm_tn(dY=ws["dlogits"].data_ptr(), ldy=1024, y_kind=A_BF16, A=x, lda=256, a_kind=A_F32, a_group=(S, SA), M=Mi,
                    N=1024, K=256, dW=self._g("out_x_proj.weight"), lddw=256, dBias=self._g("out_x_proj.bias"))
@@ -635,7 +648,8 @@ class STEngine(DecodeMixin):
                 # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
                 # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
                 # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
-                dxb_new = ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr()
+                pend = []  # this block's weight gradients, launched together at its end when `multi`
+                dxb_new = nxt(dxb) if multi else (ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr())
                 hg, du = ws["hg1"].data_ptr(), ws["du1"].data_ptr()
                 dkw = self._drop_fused(True, l)
                 dy2 = dxb  # dY of the fc2 weight gradient: behind the output Dropout when there is one (written by hma_mlp_bwd)
@@ -644,13 +658,17 @@ class STEngine(DecodeMixin):
                 pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
                            w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
                            b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du, **dkw)
-                pl.gemm_tn_pair(dict(dY=dy2, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16_FRAG32, M=M, N=256, K=1024,
-                                     dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
-                                dict(dY=du, ldy=1024, y_kind=A_BF16_FRAG32, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
-                                     gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
-                                     K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias),
-                                     w_master=self._lw(l, "mlp.fc1.weight", "p"), dgamma=gw("norm2.weight"),
-                                     dbeta=gw("norm2.bias")))
+                kw_mlp = (dict(dY=dy2, ldy=256, y_kind=A_BF16, A=hg, lda=1024, a_kind=A_BF16_FRAG32, M=M, N=256, K=1024,
+                               dW=gw("mlp.fc2.weight"), lddw=1024, dBias=gb("mlp.fc2.bias", cfg.mlp_bias)),
+                          dict(dY=du, ldy=1024, y_kind=A_BF16_FRAG32, A=xh2, lda=256, a_kind=A_BF16_AFFINE,
+                               gamma=self._lw(l, "norm2.weight", "p"), beta=self._lw(l, "norm2.bias", "p"), M=M, N=1024,
+                               K=256, dW=gw("mlp.fc1.weight"), lddw=256, dBias=gb("mlp.fc1.bias", cfg.mlp_bias),
+                               w_master=self._lw(l, "mlp.fc1.weight", "p"), dgamma=gw("norm2.weight"),
+                               dbeta=gw("norm2.bias")))
+                if multi:
+                    pend.extend(kw_mlp)
+                else:
+                    pl.gemm_tn_pair(*kw_mlp)
                 dxb = dxb_new
             else:
                 u, hg = dp(ws["u"], l, M * 1024), dp(ws["hg"], l, M * 1024)
@@ -682,10 +700,14 @@ class STEngine(DecodeMixin):
                 pl.add("hma_qknorm_bwd", dqkv, 768, dp(ws["qraw_t"], l, M * 512), self._lw(l, "temporal_attn.norm.weight", "p"), 1e-5,
                        gw("temporal_attn.norm.weight"), gw("temporal_attn.norm.bias"), M)
             # projection and qkv weight gradients in one launch (dxb is not updated before the dqkv dgrad below)
-            pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                                 dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
-                            dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
-                                 dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)))
+            kw_t = (dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_t, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                         dW=gw("temporal_attn.proj.weight"), lddw=256, dBias=gb("temporal_attn.proj.bias", cfg.proj_bias)),
+                    dict(dY=dqkv, ldy=768, y_kind=A_BF16, A=x2b, lda=256, a_kind=A_BF16, M=M, N=768, K=256,
+                         dW=gw("temporal_attn.qkv.weight"), lddw=256, dBias=gb("temporal_attn.qkv.bias", cfg.qkv_bias)))
+            if multi:
+                pend.extend(kw_t)
+            else:
+                pl.gemm_tn_pair(*kw_t)
             if self._use_chain(M, SA):
                 # ---- chain A backward (csrc/chain.hip): temporal qkv dgrad + residual -> linear_out dgrad -> modulate-LN backward
                 # -> spatial projection dgrad, one launch; dss accumulates by atomics (zeroed at the top of the plan)
@@ -698,10 +720,16 @@ class STEngine(DecodeMixin):
                     kwm = dict(xhat=xhm, rstd=rstdm, ss=dp(ws["ss"], l, Fr * 512), dx2_bf16=ws["dx2b"].data_ptr(),
                                dss=dp(ws["dss"], l, Fr * 512))
                 segs.append((self.CP["proj_s_T"][l].data_ptr(), 8))
+                if multi:
+                    dxb = nxt(dxb)  # (the deferred temporal projection gradient still reads the previous buffer)
                 pl.chain_a_bwd(M, use_mod, segs=segs, dqkv=dqkv, dx=dx, dx1_bf16=dxb, d_o=t256, rows_per_frame=SA, **kwm)
                 if use_mod:
-                    pl.gemm_tn(dY=ws["dx2b"].data_ptr(), ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                               dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
+                    kw_lin = dict(dY=ws["dx2b"].data_ptr(), ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                                  dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
+                    if multi:
+                        pend.append(kw_lin)
+                    else:
+                        pl.gemm_tn(**kw_lin)
             else:
                 pl.gemm_nt(A=dqkv, lda=768, a_kind=A_BF16, W=wt("qkv_t"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
@@ -732,18 +760,27 @@ class STEngine(DecodeMixin):
                                                              beta=self._lw(l, "norm1.bias", "p"))
             if chain_s:
                 aff1.update(w_master=self._lw(l, "spatial_attn.qkv.weight", "p"), dgamma=gw("norm1.weight"), dbeta=gw("norm1.bias"))
-            pl.gemm_tn_pair(dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
-                                 dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
-                            dict(dY=dqkv_s, ldy=768, y_kind=A_BF16_HEADBLK if hb else A_BF16, y_group=(SA, 0) if hb else (0, 0), A=xh1, lda=256,
-                                 M=M, N=768, K=256, dW=gw("spatial_attn.qkv.weight"), lddw=256,
-                                 dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
+            kw_s = (dict(dY=dxb, ldy=256, y_kind=A_BF16, A=o_s, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                         dW=gw("spatial_attn.proj.weight"), lddw=256, dBias=gb("spatial_attn.proj.bias", cfg.proj_bias)),
+                    dict(dY=dqkv_s, ldy=768, y_kind=A_BF16_HEADBLK if hb else A_BF16, y_group=(SA, 0) if hb else (0, 0), A=xh1, lda=256,
+                         M=M, N=768, K=256, dW=gw("spatial_attn.qkv.weight"), lddw=256,
+                         dBias=gb("spatial_attn.qkv.bias", cfg.qkv_bias), **aff1))
+            if multi:
+                pend.extend(kw_s)
+            else:
+                pl.gemm_tn_pair(*kw_s)
             if self.qkn:  # norm1 is the identity
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_RESID, Cp=dx, ldc=256,
                            C2=dxb, ldc2=256)
             elif chain_s:
                 # ---- chain S backward (csrc/chain.hip): spatial qkv dgrad -> norm1 backward -> residual, one launch
+                if multi:
+                    dxb = nxt(dxb)  # (the deferred spatial projection gradient still reads the previous buffer)
                 pl.chain_s_bwd(M, segs=[(self.CP["qkv_s_T"][l].data_ptr(), 24)], dqkv=dqkv_s, dx=dx, xhat=xh1, rstd=rstd1, dx_bf16=dxb,
                                hb_rows=SA if hb else 0)
+                if multi:
+                    # ---- the block's seven (six without the modulation) weight gradients: one launch, one reduction
+                    pl.gemm_tn_multi(pend)
             else:
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
                 pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,

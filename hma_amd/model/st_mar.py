@@ -161,12 +161,11 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         core = self._core
         eng = core._get_engine(dev)
         ps = getattr(self, "_ver_params", None)
-        if ps is None:  # (the trunk's parameters: what the engine keeps derived copies of)
+        if ps is None or getattr(self, "_ver_engine", None) is not eng:  # (the trunk's parameters: what the engine keeps derived copies of)
+            self._ver_engine = eng
             am = getattr(self, "action_mlp", None)
             ps = self._ver_params = list(self.decoder.parameters()) + (list(am.parameters()) if am is not None else [])
-        ver = 0
-        for q in ps:
-            ver += q._version
+        ver = STMaskGIT._version_sum(ps)
         if ver != getattr(self, "_seen_versions", None):  # load_state_dict / an optimizer wrote through the named parameters
             self._seen_versions = ver
             eng.weights_changed()

@@ -78,6 +78,21 @@ class Plan:
         self.add("hma_gemm_tn_pair", C.byref(gs[0]), C.byref(gs[1]),
                  flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
 
+    def gemm_tn_multi(self, kws: Sequence[dict]) -> None:
+        """Up to 8 weight gradients whose operands are all live, in one launch + one reduction (hma_gemm_tn_multi)."""
+        gs = []
+        wsb = self.tn_workspace
+        for kw in kws:
+            if wsb is not None:
+                kw.setdefault("ws", wsb.data_ptr())
+                kw.setdefault("ws_elems", wsb.numel())
+            gs.append(make_gemm_tn(**kw))
+        arr = (C.POINTER(type(gs[0])) * len(gs))(*[C.pointer(g) for g in gs])
+        self.keep.extend(gs)
+        self.keep.append(arr)
+        self.add("hma_gemm_tn_multi", arr, len(gs),
+                 flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
+
     def mlp_fwd(self, M: int, **kw) -> None:
         g = make_mlp_fwd(M=M, **kw)
         self.keep.append(g)

@@ -286,6 +286,52 @@ def test_gemm_tn_pair(M):
                 close(t["db"], t["refb"], 2e-5, "paired dbias")
 
 
+def test_gemm_tn_multi_seven_problems():
+    """hma_gemm_tn_multi: the seven weight gradients of an STBlock (MLP pair with the fragment-ordered fc operands left out here: plain
+    bf16 operands of the same shapes; fc1 / qkv_s with the deferred LayerNorm affine + its dgamma / dbeta; qkv_s's dY head-blocked) in one
+    launch give what seven hma_gemm_tn calls give."""
+    from hma_amd._lib import A_BF16_HEADBLK
+    n, frames = 320, 8
+    M = frames * n
+    ws = torch.full((256 * (65536 + 256),), float("nan"), device=DEV)
+    shapes = [(256, 1024, True, False, False), (1024, 256, True, True, False), (256, 256, True, False, False), (768, 256, False, False, False),
+              (256, 256, True, False, False), (256, 256, True, False, False), (768, 256, False, True, True)]
+    res = {}
+    for mode in ("multi", "single"):
+        gs, outs = [], []
+        for i, (N, K, bias, affine, hb) in enumerate(shapes):
+            dy = rb(torch.randn(M, N, generator=g(200 + 10 * i)) * 0.5).to(DEV).bfloat16()
+            x = rb(torch.randn(M, K, generator=g(201 + 10 * i))).to(DEV).bfloat16()
+            gam = (torch.randn(K, generator=g(202 + 10 * i)) * 0.2 + 1).to(DEV) if affine else None
+            bet = (torch.randn(K, generator=g(203 + 10 * i)) * 0.2).to(DEV) if affine else None
+            wm = torch.randn(N, K, generator=g(204 + 10 * i)).to(DEV) if affine else None
+            dW, db = torch.zeros(N, K, device=DEV), (torch.zeros(N, device=DEV) if bias else None)
+            dg, dbt = (torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)) if affine else (None, None)
+            dyb = ops.rows_to_headblk(dy, n) if hb else dy
+            gs.append(ops.make_gemm_tn(dY=ops.ptr(dyb), ldy=N, y_kind=A_BF16_HEADBLK if hb else A_BF16, y_group=(n, 0) if hb else (0, 0),
+                                       A=ops.ptr(x), lda=K, a_kind=A_BF16_AFFINE if affine else A_BF16, M=M, N=N, K=K, dW=ops.ptr(dW), lddw=K,
+                                       dBias=ops.ptr(db), gamma=ops.ptr(gam), beta=ops.ptr(bet), w_master=ops.ptr(wm), dgamma=ops.ptr(dg),
+                                       dbeta=ops.ptr(dbt), ws=ops.ptr(ws), ws_elems=ws.numel()))
+            outs.append((dW, db, dg, dbt, dy, x, gam, bet, wm, dyb))  # (wm / dyb: kept alive until the launches below have run)
+        if mode == "multi":
+            arr = (C.POINTER(type(gs[0])) * len(gs))(*[C.pointer(q) for q in gs])
+            _lib.call("hma_gemm_tn_multi", ops.stream_ptr(), arr, len(gs))
+        else:
+            for q in gs:
+                _lib.call("hma_gemm_tn", ops.stream_ptr(), C.byref(q))
+        torch.cuda.synchronize()
+        res[mode] = outs
+    for i, ((dW, db, dg, dbt, dy, x, gam, bet, *_keep), (dW1, db1, dg1, dbt1, *_rest)) in enumerate(zip(res["multi"], res["single"])):
+        xe = x.double() * gam.double() + bet.double() if gam is not None else x.double()
+        close(dW, (dy.double().t() @ xe).float(), BF, f"multi dW, problem {i}")
+        close(dW, dW1, BF, f"multi vs single dW, problem {i}")
+        if db is not None:
+            close(db, dy.double().sum(0).float(), 2e-5, f"multi dbias, problem {i}")
+        if dg is not None:
+            close(dg, dg1, 2e-2, f"multi dgamma, problem {i}")
+            close(dbt, dbt1, 2e-2, f"multi dbeta, problem {i}")
+
+
 def test_gemm_tn_remap_and_batch():
     frames, S, SA, N, K = 3, 64, 80, 128, 256
     dy = rb(torch.randn(frames * S, N, generator=g(26)))
