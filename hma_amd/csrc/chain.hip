@@ -349,6 +349,40 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict
   *reinterpret_cast<uint4*>(dst + ((int64_t)b * bundle_stride * 1024 + (idx & 1023)) * 8) = pack8(v);
 }
 
+// ------------------------------------------------------------------------------------------------ rows of a workgroup
+// CH_RAGGED = 1 (round 5): a workgroup owns ONE contiguous run of rows -- ceil(M / workgroups) rounded up to 16 -- and walks it in
+// tiles of 16 NW rows; the LAST tile of every workgroup is ragged (some waves past the run's end only keep the barriers company).  With
+// whole tiles dealt round-robin (CH_RAGGED = 0), M = 163 840 is 1 463 tiles of 112 rows on 256 workgroups: 183 of them run six tiles, 73
+// five, and the launch takes six tile times for 5.71 tiles of work per CU; now every workgroup has 640 rows = five tiles + one of 80 rows,
+// whose loads and stores -- what a chain's time is made of -- are 5 / 7 of a full tile's.
+#ifndef CH_RAGGED
+#define CH_RAGGED 1
+#endif
+struct tile_map {
+  int64_t base, end;  // this workgroup's rows [base, end)
+  int nt;             // its tiles
+};
+__device__ __forceinline__ tile_map make_tile_map(int64_t M, int nw) {
+  tile_map t;
+  if (CH_RAGGED) {
+    const int64_t per = (((M + gridDim.x - 1) / gridDim.x) + 15) / 16 * 16;
+    t.base = (int64_t)blockIdx.x * per;
+    t.end = t.base + per < M ? t.base + per : M;
+    t.nt = t.end > t.base ? (int)((t.end - t.base + 16 * nw - 1) / (16 * nw)) : 0;
+  } else {
+    const int64_t ntiles = (M + 16 * nw - 1) / (16 * nw);
+    t.base = 0;
+    t.end = M;
+    t.nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  }
+  return t;
+}
+// first row of wave `wave` in the workgroup's tile tl
+__device__ __forceinline__ int64_t tile_row0(const tile_map& t, int tl, int nw, int wave) {
+  if (CH_RAGGED) return t.base + ((int64_t)tl * nw + wave) * 16;
+  return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * nw + wave) * 16;
+}
+
 // ------------------------------------------------------------------------------------------------ the loader wave
 // Streams the chain's bundles, `per_tile` per tile and `nt` tiles, through the ring: bundle s goes to slot s % NS and is
 // complete (this wave's vmcnt) before the wave arrives at barrier s; the slot it frees -- the compute waves are past their
@@ -360,17 +394,16 @@ struct ring_src {
 };
 template <int PROF_K, int NW = NCW>
 __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
-                                           int64_t M, int rows_per_frame, HMA_LDS(char)* lds = nullptr) {
+                                           int64_t M, int rows_per_frame, HMA_LDS(char)* lds = nullptr, const tile_map* tmap = nullptr) {
   if constexpr (ST) __builtin_amdgcn_s_setprio(2);
   const int total = per_tile * nt;
   int issued = 0, seg = 0, left = ws.n0, tl_issue = 0, slot_issue = 0;
   const char* cur = ws.s0;
   auto issue = [&]() __attribute__((always_inline)) {
     if (seg == 0 && left == ws.n0 && ss) {  // a tile's first bundle: its shift / scale rows first
-      const int64_t t = (int64_t)blockIdx.x + (int64_t)tl_issue * gridDim.x;
 #pragma unroll 1
       for (int w = 0; w < NW; ++w) {
-        int64_t r0 = (t * NW + w) * 16;
+        int64_t r0 = tile_row0(*tmap, tl_issue, NW, w);
         r0 = r0 < M ? r0 : M - 1;
         const char* s = reinterpret_cast<const char*>(ss) + (r0 / rows_per_frame) * 2048 + lane * 16;
         const uint32_t d = __builtin_amdgcn_readfirstlane(lds_b + L_SS + ((tl_issue & 1) * NCW + w) * 2048);
@@ -571,8 +604,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.M + 16 * NW - 1) / (16 * NW);
-  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const tile_map tmap = make_tile_map(p.M, NW);
+  const int nt = tmap.nt;
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | lin 256..511 | qkv 512..1279
     for (int i = tid; i < 1280; i += CH_THREADS) {
@@ -598,13 +631,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame, lds);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame, lds, &tmap);
     return;
   }
   stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
+    return tile_row0(tmap, tl, NW, wave);
   };
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
@@ -812,7 +845,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_fwd_kernel(hma_chain_a_
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
-    if (r0 >= p.M) {  // (whole wave past the matrix: possible in a workgroup's last tile only)
+    if (r0 >= tmap.end) {  // (whole wave past the matrix: possible in a workgroup's last tile only)
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
       } else {
@@ -856,8 +889,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
-  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const tile_map tmap = make_tile_map(p.M, NCW);
+  const int nt = tmap.nt;
   constexpr int S3 = MOD ? 32 : 24;      // first d_o step
   constexpr int PER_TILE = S3 + 8;
   static_assert(PER_TILE % PB == 0, "whole barrier groups per tile (the loader refills PB slots per barrier)");
@@ -874,13 +907,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame, lds);
+    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, p.M, p.rows_per_frame, lds, &tmap);
     return;
   }
   stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+    return tile_row0(tmap, tl, NCW, wave);
   };
   bf16x8_t dq[3][8], xr[8], a1[8], a2[8];
   f32x4v_t acc[16], dxr[16], dm[16];
@@ -1132,7 +1165,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_a_bwd_kernel(hma_chain_a_
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
-    if (r0 >= p.M) {
+    if (r0 >= tmap.end) {
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
       } else {
@@ -1161,8 +1194,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.M + TILE_ROWS - 1) / TILE_ROWS;
-  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const tile_map tmap = make_tile_map(p.M, NCW);
+  const int nt = tmap.nt;
   constexpr int PER_TILE = 24;
   static_assert(PER_TILE % PB == 0, "whole barrier groups per tile");
 #ifndef CH_S_DX0
@@ -1182,13 +1215,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1, lds);
+    loader_run<1>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1, lds, &tmap);
     return;
   }
   stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NCW + wave) * 16;
+    return tile_row0(tmap, tl, NCW, wave);
   };
   bf16x8_t dq[3][8], xr[8];
   f32x4v_t acc[16], dxr[16];
@@ -1322,7 +1355,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_s_bwd_kernel(hma_chain_s_
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
-    if (r0 >= p.M) {
+    if (r0 >= tmap.end) {
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
       } else {
@@ -1368,8 +1401,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.M + 16 * NW - 1) / (16 * NW);
-  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const tile_map tmap = make_tile_map(p.M, NW);
+  const int nt = tmap.nt;
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);  // proj 0..255 | fc2 256..511 | fc1 512..1535 | qkv 1536..2303
     for (int i = tid; i < 2304; i += CH_THREADS) {
@@ -1396,13 +1429,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
     const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
                          reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
                          p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
-    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1, lds);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, p.M, 1, lds, &tmap);
     return;
   }
   stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
   auto row0_of = [&](int tl) __attribute__((always_inline)) {
-    return (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
+    return tile_row0(tmap, tl, NW, wave);
   };
   bf16x8_t a0[8], a1[8];
   f32x4v_t acc[16];
@@ -1493,7 +1526,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
     const int64_t r0 = row0_of(tl);
-    if (r0 >= p.M) {
+    if (r0 >= tmap.end) {
       if constexpr (ST) {
         steps_skip(stg_, PER_TILE);
       } else {
@@ -1642,8 +1675,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
   const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.rows + 16 * NW - 1) / (16 * NW);
-  const int nt = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const tile_map tmap = make_tile_map(p.rows, NW);
+  const int nt = tmap.nt;
   {
     HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);
     for (int i = tid; i < 1024; i += CH_THREADS) bl[i] = p.bias ? p.bias[i] : 0.f;
@@ -1678,8 +1711,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
   static_assert(32 % PB == 0, "whole barrier groups per tile");
 #pragma unroll 1
   for (int tl = 0; tl < nt; ++tl) {
-    const int64_t r0 = (((int64_t)blockIdx.x + (int64_t)tl * gridDim.x) * NW + wave) * 16;
-    if (r0 >= p.rows) {
+    const int64_t r0 = tile_row0(tmap, tl, NW, wave);
+    if (r0 >= tmap.end) {
       if constexpr (ST) {
         steps_skip(stg_, 32);
       } else {
