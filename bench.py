@@ -39,7 +39,7 @@ FREQ = [20, 10, 20, 20, 5, 30, 2, 20, 20, 10, 2, 2, 10, 1, 10, 5, 5, 5, 10, 3, 1
 FLOP_PER_TOKEN_FWD_BWD = 3.104e8
 # every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
 FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_gemm_tn_multi", "hma_attn_spatial_fwd", "hma_attn_spatial_bwd_blocked",
-            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd",
+            "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd", "hma_chain_ab_fwd",
             "hma_chain_s_bwd", "hma_readout_ce"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
 

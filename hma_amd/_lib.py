@@ -118,6 +118,19 @@ class ChainSBwd(C.Structure):
     ]
 
 
+class ChainABFwd(C.Structure):
+    _fields_ = [
+        ("seg", c_vp * 6), ("bundles", c_i32 * 6),
+        ("o_s", c_vp), ("x", c_vp), ("ss", c_vp),
+        ("b_proj_s", c_vp), ("b_lin", c_vp), ("b_qkv_t", c_vp), ("b_proj_t", c_vp), ("b1", c_vp), ("b2", c_vp), ("b_qkv_s", c_vp),
+        ("xhat_m", c_vp), ("xm", c_vp), ("rstd_m", c_vp), ("x2b", c_vp),
+        ("qkv_t", c_vp), ("o_t", c_vp),
+        ("xhat2", c_vp), ("rstd2", c_vp), ("xhat1n", c_vp), ("rstd1n", c_vp), ("qkv_s", c_vp),
+        ("B", c_i64), ("T", c_i32), ("SA", c_i32),
+        ("attn_scale", C.c_float), ("ln_eps", C.c_float),
+    ]
+
+
 class ReadoutCE(C.Structure):
     _fields_ = [
         ("w", ChainWeights),
@@ -191,6 +204,7 @@ _PROTOS = {
     "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
     "hma_chain_a_bwd": [c_vp, C.POINTER(ChainABwd)],
     "hma_chain_s_bwd": [c_vp, C.POINTER(ChainSBwd)],
+    "hma_chain_ab_fwd": [c_vp, C.POINTER(ChainABFwd)],
     "hma_zero_f32": [c_vp, c_vp, c_i64],
     "hma_abi_version": [],
 }

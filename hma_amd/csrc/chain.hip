@@ -391,6 +391,8 @@ __device__ __forceinline__ int64_t tile_row0(const tile_map& t, int tl, int nw, 
 struct ring_src {
   const char *s0, *s1, *s2, *s3;
   int n0, n1, n2, n3;
+  const char *s4 = nullptr, *s5 = nullptr;  // (the fused chain A + temporal attention + chain B kernel streams six segments)
+  int n4 = 0, n5 = 0;
 };
 template <int PROF_K, int NW = NCW>
 __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
@@ -424,13 +426,13 @@ __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int
     cur += SLOT;
     if (--left == 0) {
       ++seg;
-      int nn = seg == 1 ? ws.n1 : seg == 2 ? ws.n2 : seg == 3 ? ws.n3 : 0;
+      int nn = seg == 1 ? ws.n1 : seg == 2 ? ws.n2 : seg == 3 ? ws.n3 : seg == 4 ? ws.n4 : seg == 5 ? ws.n5 : 0;
       if (nn == 0) {
         seg = 0;
         nn = ws.n0;
         ++tl_issue;
       }
-      cur = seg == 0 ? ws.s0 : seg == 1 ? ws.s1 : seg == 2 ? ws.s2 : ws.s3;
+      cur = seg == 0 ? ws.s0 : seg == 1 ? ws.s1 : seg == 2 ? ws.s2 : seg == 3 ? ws.s3 : seg == 4 ? ws.s4 : ws.s5;
       left = nn;
     }
   };
@@ -1663,6 +1665,355 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   stage_finish(stg_);
 }
 
+// ------------------------------------------------------------------------------------------------ chain A + temporal attention + chain B
+// The whole of a block between its spatial attention and the next block's (st_transformer.py:86 proj ... :111 temporal attention ...
+// :112 MLP, :85-86 of the next block) in ONE launch, for training passes over windows of exactly T = 16 frames.  A compute wave owns a
+// COLUMN: the 16 frames of one (sample, token position), lane tok = frame -- rows SA apart, so every row pointer / line offset of the
+// chains is the same with the row pitch multiplied by SA, and each lane takes its OWN frame's shift / scale.  With a column in a wave the
+// causal temporal attention (attention.py:37-61, 16 x 16 scores per head) is wave-local: the qkv blocks chain A's last 24 steps leave
+// in the accumulators ARE the attention's MFMA operands (q / k of a head: one v_mfma_f32_16x16x32_bf16 gives S^T[key][query], lane =
+// query, 4 keys in registers, soft-max = 4 registers + 2 shuffles; P^T packed is the B operand of the 16 x 16 x 16 product with V^T,
+// which goes through a 1 KB per-wave LDS scratch to be read transposed), its output -- through the same scratch -- is chain B's first
+// B operand, and the residual row x never leaves the accumulators between the two chains.  Against the three launches it replaces
+// (hma_chain_a_fwd, hma_attn_temporal_fwd, hma_chain_b_fwd) a row moves 4 096 bytes less: x out and back (2 048), qkv_t back (1 536),
+// o_t back (512); everything the backward needs is still written (xhat_m, xm, bf16(x2), qkv_t, o_t, xhat2, the next xhat1, rstd's).
+// Steps per tile: 16 + 24 (chain A) + 8 + 64 (+ 24) (chain B); the next tile's rows are requested beside chain B's qkv steps.
+struct col_map {
+  int64_t base, end;  // this workgroup's columns [base, end)
+  int nt;
+};
+__device__ __forceinline__ col_map make_col_map(int64_t cols, int nw) {
+  col_map t;
+  const int64_t per = (cols + gridDim.x - 1) / gridDim.x;
+  t.base = (int64_t)blockIdx.x * per;
+  t.end = t.base + per < cols ? t.base + per : cols;
+  t.nt = t.end > t.base ? (int)((t.end - t.base + nw - 1) / nw) : 0;
+  return t;
+}
+typedef __attribute__((ext_vector_type(4))) short s16x4v_t;
+template <bool QKV>
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_ab_fwd_t p) {
+  static_assert(!ST, "the fused chain has no storer mode");
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = NCW;
+  const int SA = p.SA;
+  const col_map cmap = make_col_map(p.B * (int64_t)SA, NW);
+  const int nt = cmap.nt;
+  // biases: chain A proj 0..255 | lin 256..511 | qkv_t 512..1279; chain B (at 1280) proj_t 0..255 | fc2 256..511 | fc1 512..1535 | qkv_s 1536..2303
+  constexpr int BB = 1280;
+  {
+    HMA_LDS(float)* bl = (HMA_LDS(float)*)(lds + L_BIAS);
+    for (int i = tid; i < BB + 2304; i += CH_THREADS) {
+      float v = 0.f;
+      if (i < 256) v = p.b_proj_s ? p.b_proj_s[i] : 0.f;
+      else if (i < 512) v = p.b_lin ? p.b_lin[i - 256] : 0.f;
+      else if (i < BB) v = p.b_qkv_t ? p.b_qkv_t[i - 512] : 0.f;
+      else if (i < BB + 256) v = p.b_proj_t ? p.b_proj_t[i - BB] : 0.f;
+      else if (i < BB + 512) v = p.b2 ? p.b2[i - BB - 256] : 0.f;
+      else if (i < BB + 1536) v = p.b1[i - BB - 512];
+      else v = (QKV && p.b_qkv_s) ? p.b_qkv_s[i - BB - 1536] : 0.f;
+      bl[i] = v;
+    }
+  }
+  __syncthreads();
+  constexpr int SL = 8, SQT = 16, SB = 40;            // first linear_out step, first temporal-qkv step, first chain B step
+  constexpr int SM = SB + 8, SQ = SM + 64;            // first MLP step, first spatial-qkv step
+  constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
+  static_assert(PER_TILE % PB == 0, "whole barrier groups per tile");
+  constexpr int L_SCR = L_BIAS + 4 * (BB + 2304);     // per compute wave: 1 KB V^T scratch + 1 KB output scratch
+  static_assert(L_SCR + NW * 2048 <= SMEM, "the attention scratch fits beside the ring");
+  if (wave > NCW) return;
+  if (wave == NCW) {
+    ring_src ws = {reinterpret_cast<const char*>(p.seg[0]), reinterpret_cast<const char*>(p.seg[1]), reinterpret_cast<const char*>(p.seg[2]),
+                   reinterpret_cast<const char*>(p.seg[3]), p.bundles[0], p.bundles[1], p.bundles[2], p.bundles[3]};
+    ws.s4 = reinterpret_cast<const char*>(p.seg[4]);
+    ws.s5 = reinterpret_cast<const char*>(p.seg[5]);
+    ws.n4 = p.bundles[4];
+    ws.n5 = p.bundles[5];
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, 0, 1, lds, nullptr);
+    return;
+  }
+  stage_t stg_ = make_stage(lds, wave, lane);
+  const int tok = lane & 15, g = lane >> 4;
+  // first row of the column of wave `wave` in tile tl: (b 16 + 0) SA + s; row of frame tok = that + tok SA
+  auto col_of = [&](int tl) __attribute__((always_inline)) { return cmap.base + (int64_t)tl * NW + wave; };
+  auto row_of = [&](int64_t c) __attribute__((always_inline)) {
+    const int64_t b = c / SA;
+    return b * 16 * SA + (c - b * SA);
+  };
+  bf16x8_t a0[8], a1[8];
+  f32x4v_t acc[16];
+  uint4 hqs[8];   // packed xhat_m of the tile in flight
+  uint4 qv[24];   // the temporal q | k | v blocks (block pq = head pq & 7 of part pq >> 3)
+  uint4 qb[8];    // the next block's spatial qkv blocks waiting for their burst
+  auto prefetch = [&](int tl, auto part_) __attribute__((always_inline)) {  // the next tile's o_s (8 loads) and x (16) rows
+    constexpr int part = decltype(part_)::value;
+    int64_t c = col_of(tl);
+    c = c < cmap.end ? c : cmap.end - 1;
+    const int64_t m = row_of(c) + (int64_t)tok * SA;
+    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o_s) + m * 256 + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (part < 0 || j / 2 == part) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
+    const float* xrow = p.x + m * 256 + 8 * g;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      if (part < 0 || pr + 4 == part) {
+        acc[2 * pr] = ld4(xrow + 32 * pr);
+        acc[2 * pr + 1] = ld4(xrow + 32 * pr + 4);
+      }
+    }
+  };
+  prefetch(0, std::integral_constant<int, -1>{});
+  CH_TOUCH_A(a1);
+  CH_TOUCH_ACC(acc);
+  HMA_LDS(char)* ring = lds + lane * 16;
+  HMA_LDS(char)* biasA = lds + L_BIAS + 32 * g;
+  HMA_LDS(char)* biasB = lds + L_BIAS + 4 * BB + 32 * g;
+  HMA_LDS(char)* scrV = lds + L_SCR + wave * 2048;
+  HMA_LDS(char)* scrO = scrV + 1024;
+  const line_offs Lb = make_lines(512 * SA, tok, 16 * g, 64);        // bf16 [., 256] arrays, rows SA apart
+  const line_offs Lf = make_lines(1024 * SA, tok, 32 * g, 16);       // fp32 [., 256]
+  const line_offs Lq = make_lines(1536 * SA, tok, 16 * g, 64);       // qkv [., 768]
+  const float c_log2 = p.attn_scale * 1.4426950408889634f;
+  int slot = 0;
+  // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand, saved with 1 / sigma for the backward
+  auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t rc, float eps) __attribute__((always_inline)) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / 256.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[t][r] - mean;
+        sq = __builtin_fmaf(d, d, sq);
+      }
+    }
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = rsqrtf(sq * (1.0f / 256.0f) + eps);
+    const float nb = -mean * rstd;
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr) {
+      float h[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
+      dst[pr] = as_frag(pack8(h));
+    }
+    uint16_t* xo = reinterpret_cast<uint16_t*>(xhat_out) + rc * 256;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp)
+      store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
+    rstd_out[rc + (int64_t)tok * SA] = rstd;
+  };
+
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t col = col_of(tl);
+    if (col >= cmap.end) {  // (a wave past the workgroup's last column: possible in its last tile only)
+#pragma unroll 1
+      for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
+      slot = (slot + PER_TILE) % NS;
+      continue;
+    }
+    const int64_t rc = row_of(col);                       // row of frame 0; frame tok is rc + tok SA
+    const int64_t frame0 = (col / SA) * 16;               // (b, t = 0)
+    float* xt = p.x + rc * 256;
+    uint16_t* xb = reinterpret_cast<uint16_t*>(p.x2b) + rc * 256;
+    uint16_t* xh = reinterpret_cast<uint16_t*>(p.xhat_m) + rc * 256;
+    uint16_t* xm = reinterpret_cast<uint16_t*>(p.xm) + rc * 256;
+    uint16_t* qt = reinterpret_cast<uint16_t*>(p.qkv_t) + rc * 768;
+    uint16_t* ot = reinterpret_cast<uint16_t*>(p.o_t) + rc * 256;
+    uint16_t* qs = QKV ? reinterpret_cast<uint16_t*>(p.qkv_s) + rc * 768 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+    bf16x8_t hf;
+    static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      if constexpr (s % PB == 0) CH_BARRIER();
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      if constexpr (s < SL) {
+        // ---- chain A: x1 = x + o_s Wproj_s^T + b
+        nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
+        add4(acc[2 * s], lds_f4(biasA + 128 * s));
+        add4(acc[2 * s + 1], lds_f4(biasA + 128 * s + 16));
+        if constexpr (s == SL - 1) {
+          // LayerNorm (no affine, eps 1e-6) of the row, then the modulation with THIS lane's frame's shift / scale (L2-resident table)
+          float sum = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) sum += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          const float mean = sum * (1.0f / 256.0f);
+          float sq = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = acc[t][r] - mean;
+              sq = __builtin_fmaf(d, d, sq);
+            }
+          }
+          sq += __shfl_xor(sq, 16, 64);
+          sq += __shfl_xor(sq, 32, 64);
+          const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
+          const float nb = -mean * rstd;
+          const float* ssr = p.ss + (frame0 + tok) * 512 + 8 * g;
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) {
+            float h[8], mm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
+            const float4 sh0 = *reinterpret_cast<const float4*>(ssr + 32 * pr), sh1 = *reinterpret_cast<const float4*>(ssr + 32 * pr + 4);
+            const float4 sc0 = *reinterpret_cast<const float4*>(ssr + 256 + 32 * pr), sc1 = *reinterpret_cast<const float4*>(ssr + 256 + 32 * pr + 4);
+            const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+            const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+            hqs[pr] = pack8(h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(h[e], 1.0f + sc[e], sh[e]);
+            a1[pr] = as_frag(pack8(mm));
+          }
+          p.rstd_m[rc + (int64_t)tok * SA] = rstd;
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) store_lines<false>(stg_, xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp)
+            store_lines<false>(stg_, xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+        }
+      } else if constexpr (s < SQT) {
+        // ---- x2 = x1 + xm Wlin^T + b: the residual row (it stays in acc until chain B's end); its bf16 copy is the qkv GEMM's operand
+        constexpr int pr = s - SL;
+        nb_mma(wb, a1, acc[2 * pr], acc[2 * pr + 1]);
+        add4(acc[2 * pr], lds_f4(biasA + 1024 + 128 * pr));
+        add4(acc[2 * pr + 1], lds_f4(biasA + 1024 + 128 * pr + 16));
+        a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
+        if constexpr (s == SQT - 1) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp)
+            store_lines<false>(stg_, xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
+        }
+      } else if constexpr (s < SB) {
+        // ---- temporal qkv = bf16(x2) Wqkv^T + b: kept for the attention below, written out for the backward
+        constexpr int pq = s - SQT;
+        f32x4v_t c0 = lds_f4v(biasA + 2048 + 128 * pq), c1 = lds_f4v(biasA + 2048 + 128 * pq + 16);
+        nb_mma(wb, a0, c0, c1);
+        qv[pq] = pack_pair(c0, c1);
+        if constexpr ((pq & 7) == 7) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) store_lines(stg_, qt, Lq, 64 * (pq - 7) + 128 * pp, qv[pq - 7 + 2 * pp], qv[pq - 6 + 2 * pp]);
+        }
+        if constexpr (s == SB - 1) {
+          // ---- causal temporal attention of the column, head by head (lane tok = query frame)
+#pragma unroll
+          for (int h = 0; h < 8; ++h) {
+            const bf16x8_t aQ = as_frag(qv[h]), aK = as_frag(qv[8 + h]);
+            *(HMA_LDS(u32x4_t)*)(scrV + tok * 64 + 16 * g) = __builtin_bit_cast(u32x4_t, qv[16 + h]);  // V of head h: [frame][32]
+            const f32x4v_t z4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4v_t st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aK, aQ, z4, 0, 0, 0);  // [key = 4 g + r][query = tok]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              st[r] = (4 * g + r <= tok) ? st[r] * c_log2 : -INFINITY;
+              mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              st[r] = __builtin_amdgcn_exp2f(st[r] - mx);
+              l += st[r];
+            }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.0f / l;
+            const uint2 pw = make_uint2(pack_bf16(st[0] * inv, st[1] * inv), pack_bf16(st[2] * inv, st[3] * inv));
+            const s16x4v_t pT = __builtin_bit_cast(s16x4v_t, pw);  // B: k = key, n = query
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+              // A = V^T: lane (d = 16 dd + tok, keys 4 g .. 4 g + 3)
+              s16x4v_t vT;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) vT[j] = (short)*(HMA_LDS(uint16_t)*)(scrV + (4 * g + j) * 64 + (16 * dd + tok) * 2);
+              const f32x4v_t od = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vT, pT, z4, 0, 0, 0);  // [d = 16 dd + 4 g + r][query = tok]
+              typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+              *(HMA_LDS(u32x2_t)*)(scrO + tok * 64 + (16 * dd + 4 * g) * 2) = u32x2_t{pack_bf16(od[0], od[1]), pack_bf16(od[2], od[3])};
+            }
+            asm volatile("" ::: "memory");
+            a1[h] = as_frag(__builtin_bit_cast(uint4, *(HMA_LDS(u32x4_t)*)(scrO + tok * 64 + 16 * g)));  // o_t of head h as a B operand
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp)
+            store_lines<false>(stg_, ot, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+        }
+      } else if constexpr (s < SM) {
+        // ---- chain B: x1 = x2 + o_t Wproj_t^T + b
+        constexpr int pr = s - SB;
+        nb_mma(wb, a0, acc[2 * pr], acc[2 * pr + 1]);
+        add4(acc[2 * pr], lds_f4(biasB + 128 * pr));
+        add4(acc[2 * pr + 1], lds_f4(biasB + 128 * pr + 16));
+        if constexpr (s == SM - 1) {
+          ln_pack(a1, p.xhat2, p.rstd2, rc, p.ln_eps);  // xhat2 (norm2's affine sits in the packed fc1 weights / bias)
+#pragma unroll
+          for (int pr2 = 0; pr2 < 8; ++pr2) {  // + fc2 bias, once
+            add4(acc[2 * pr2], lds_f4(biasB + 1024 + 128 * pr2));
+            add4(acc[2 * pr2 + 1], lds_f4(biasB + 1024 + 128 * pr2 + 16));
+          }
+        }
+      } else if constexpr (s < SQ) {
+        constexpr int h = (s - SM) >> 1;
+        if constexpr (((s - SM) & 1) == 0) {
+          f32x4v_t c0 = lds_f4v(biasB + 2048 + 128 * h), c1 = lds_f4v(biasB + 2048 + 128 * h + 16);
+          nb_mma(wb, a1, c0, c1);
+          float uv[8], hv[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uv[e] = c0[e];
+            uv[4 + e] = c1[e];
+          }
+          gelu_n<8>(uv, hv);
+          hf = as_frag(pack8(hv));
+        } else {
+          ks_mma(wb, hf, acc);
+          if constexpr (s == SQ - 1) {
+#pragma unroll
+            for (int pr2 = 0; pr2 < 8; ++pr2) store_lines<false>(stg_, xt, Lf, 128 * pr2, as_u4(acc[2 * pr2]), as_u4(acc[2 * pr2 + 1]));
+            if constexpr (QKV) ln_pack(a0, p.xhat1n, p.rstd1n, rc, p.ln_eps);
+            if constexpr (!QKV) prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, -1>{});
+          }
+        }
+      } else {
+        // ---- the next block's spatial qkv (the next tile's rows are requested a pair per step beside it)
+        constexpr int pq = s - SQ;
+        if constexpr (pq >= 2 && pq < 14) prefetch(tl + 1 < nt ? tl + 1 : tl, std::integral_constant<int, pq - 2>{});
+        f32x4v_t c0 = lds_f4v(biasB + 6144 + 128 * pq), c1 = lds_f4v(biasB + 6144 + 128 * pq + 16);
+        nb_mma(wb, a0, c0, c1);
+        qb[pq & 7] = pack_pair(c0, c1);
+        if constexpr ((pq & 7) == 7) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) store_lines(stg_, qs, Lq, 64 * (pq - 7) + 128 * pp, qb[2 * pp], qb[2 * pp + 1]);
+        }
+      }
+    });
+    CH_TOUCH_A(a1);
+    CH_TOUCH_ACC(acc);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ readout + cross-entropy
 // out_x_proj (st_mask_git.py:681-683) + the factorised cross-entropy (compute_video_loss_and_acc, :603-630) of the image rows in one
 // launch: the fp32 logits (2 x 512 per row) exist only as one factor's 128 accumulator registers per lane; what reaches HBM is the
@@ -1947,6 +2298,30 @@ extern "C" int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p) {
   const int grid = chain_grid(p->M);
   if (int rc = set_lds<chain_s_bwd_kernel>(SMEM)) return rc;
   hipLaunchKernelGGL(chain_s_bwd_kernel, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_ab_fwd(void* stream, const hma_chain_ab_fwd_t* p) {
+  if (!p || !p->o_s || !p->x || !p->ss || !p->b1 || p->B <= 0 || p->SA <= 0 || p->T != 16) return HMA_EINVAL;
+  if (!p->xhat_m || !p->xm || !p->rstd_m || !p->x2b || !p->qkv_t || !p->o_t || !p->xhat2 || !p->rstd2) return HMA_EINVAL;
+  const bool qkv = p->qkv_s != nullptr;
+  if (qkv && (!p->xhat1n || !p->rstd1n)) return HMA_EINVAL;
+  if ((int64_t)p->SA * 1536 * 15 >= (int64_t)1 << 31) return HMA_EINVAL;  // (line offsets are 32-bit)
+  const int expect[6] = {8, 8, 24, 8, 64, qkv ? 24 : 0};
+  for (int i = 0; i < 6; ++i)
+    if (p->bundles[i] != expect[i] || (expect[i] > 0 && !p->seg[i])) return HMA_EINVAL;
+  const int64_t cols = p->B * (int64_t)p->SA;
+  const int64_t ntiles = (cols + NCW - 1) / NCW;
+  const int slots = num_cus() * WGS_PER_CU;
+  const int grid = (int)(ntiles < slots ? ntiles : slots);
+  if (qkv) {
+    if (int rc = set_lds<chain_ab_fwd_kernel<true>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_ab_fwd_kernel<true>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+  } else {
+    if (int rc = set_lds<chain_ab_fwd_kernel<false>>(SMEM)) return rc;
+    hipLaunchKernelGGL(chain_ab_fwd_kernel<false>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+  }
   HMA_CHECK_LAUNCH();
   return 0;
 }

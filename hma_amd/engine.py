@@ -110,6 +110,7 @@ class STEngine(DecodeMixin):
         self.chain_min_rows = 0
         self.chain_s = os.environ.get("HMA_CHAIN_S", "1") != "0"  # (0: measurement -- the spatial qkv dgrad + hma_ln_bwd as two launches)
         self.attn_hb = os.environ.get("HMA_ATTN_HB", "1") != "0"  # (0: measurement -- the spatial attention backward's dqkv row-major)
+        self.chain_ab = os.environ.get("HMA_CHAIN_AB", "1") != "0"  # (0: measurement -- chain A, temporal attention, chain B as three launches)
         # The seven weight gradients of a block in ONE launch at the end of its backward (hma_gemm_tn_multi): nothing reads a weight
         # gradient before the optimizer, so they wait until every operand exists -- four bf16(dx) buffers and a second dqkv keep the
         # operands alive.  (0: measurement -- three pair launches + linear_out's, each behind its operands)
@@ -416,6 +417,23 @@ class STEngine(DecodeMixin):
                nbytes=(1536.0 + 512 + 32) * Fr * SA)
         qkv_dst = b["qkv_t"] if kv is None else kv["cache"] + kv["row_off"] * 768 * 2
         qkv_grp = (0, 0) if kv is None else kv["c_group"]
+        if (self.chain_ab and train and chain_b and use_mod and kv is None and T == 16 and self.mlp_drop <= 0.0 and not qkn
+                and self._use_chain(M, SA)):
+            # ---- chain A + causal temporal attention + chain B over columns of 16 frames, ONE launch (csrc/chain.hip): the residual row
+            # stays in registers between the chains, the attention is wave-local
+            ap = f"decoder.layers.{l}.action_projectors.{domain}"
+            segs = [(dp_(self.CP["proj_s"], l), 8), (dp_(self.CP[f"lin:{domain}"], l), 8), (dp_(self.CP["qkv_t"], l), 24),
+                    (self.CP["proj_t"][l].data_ptr(), 8), (self.CP["mlp"][l].data_ptr(), 64),
+                    (self.CP["qkv_s"][l + 1].data_ptr(), 24) if next_qkv_s is not None else (None, 0)]
+            kwq = {}
+            if next_qkv_s is not None:
+                kwq = dict(xhat1n=next_ln1[0], rstd1n=next_ln1[1], qkv_s=next_qkv_s, b_qkv_s=self.BF["qkv_s"][l + 1].data_ptr())
+            pl.chain_ab_fwd(M, next_qkv_s is not None, B=B, SA=SA, segs=segs, o_s=b["o_s"], x=x, ss=b["ss"], b1=self.BF["fc1"][l].data_ptr(),
+                            xhat_m=b["xhm"], xm=b["xm"], rstd_m=b["rstdm"], x2b=b["x2b"], qkv_t=b["qkv_t"], o_t=b["o_t"], xhat2=b["xh2"],
+                            rstd2=b["rstd2"], attn_scale=self.scale, b_proj_s=pb("spatial_attn"), b_lin=self._p(f"{ap}.linear_out.bias"),
+                            b_qkv_t=qb("temporal_attn"), b_proj_t=pb("temporal_attn"),
+                            b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None, **kwq)
+            return
         if self._use_chain(M, SA):
             # ---- chain A (csrc/chain.hip): proj + residual -> modulate-LN -> linear_out + residual -> temporal qkv, one launch
             ap = f"decoder.layers.{l}.action_projectors.{domain}"
@@ -507,7 +525,7 @@ class STEngine(DecodeMixin):
         l1 = self.cfg.num_layers if l1 is None else l1
         # (T_cache is part of the key: a re-allocated cache of another length can land on the old one's address)
         key = ("fwd", B, T, S, A, train, domain, embed, l0, l1, readout, None if kv_cache is None else (kv_cache.data_ptr(), T_cache),
-               self._use_fused(B * T * (S + A), train, S + A), self._use_chain(B * T * (S + A), S + A))
+               self._use_fused(B * T * (S + A), train, S + A), self._use_chain(B * T * (S + A), S + A), self.chain_ab)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, ChainABwd, ChainAFwd, ChainBFwd, ChainSBwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
+                   EPI_RESID, EPI_SILU2, ChainABFwd, ChainABwd, ChainAFwd, ChainBFwd, ChainSBwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -172,6 +172,25 @@ def make_chain_a_bwd(*, M: int, segs, dqkv: int, dx: int, dx1_bf16: int, d_o: in
     g.xhat, g.rstd, g.ss = xhat, rstd, ss
     g.dx2_bf16, g.dx1_bf16, g.d_o, g.dss = dx2_bf16, dx1_bf16, d_o, dss
     g.M, g.rows_per_frame, g.use_mod = M, rows_per_frame, 1 if use_mod else 0
+    return g
+
+
+def make_chain_ab_fwd(*, B: int, SA: int, segs, o_s: int, x: int, ss: int, b1: int, xhat_m: int, xm: int, rstd_m: int, x2b: int, qkv_t: int,
+                      o_t: int, xhat2: int, rstd2: int, attn_scale: float, b_proj_s: Optional[int] = None, b_lin: Optional[int] = None,
+                      b_qkv_t: Optional[int] = None, b_proj_t: Optional[int] = None, b2: Optional[int] = None, b_qkv_s: Optional[int] = None,
+                      xhat1n: Optional[int] = None, rstd1n: Optional[int] = None, qkv_s: Optional[int] = None, ln_eps: float = 1e-5,
+                      T: int = 16) -> ChainABFwd:
+    """segs: [(pointer, bundles)] x 6 = proj_s (8), linear_out (8), temporal qkv (24), proj_t (8), the 64 fc1 / fc2 bundles, the next
+    block's folded spatial qkv (24; (None, 0) for the last block)."""
+    g = ChainABFwd()
+    for i in range(6):
+        g.seg[i] = segs[i][0] if i < len(segs) else None
+        g.bundles[i] = segs[i][1] if i < len(segs) else 0
+    g.o_s, g.x, g.ss = o_s, x, ss
+    g.b_proj_s, g.b_lin, g.b_qkv_t, g.b_proj_t, g.b1, g.b2, g.b_qkv_s = b_proj_s, b_lin, b_qkv_t, b_proj_t, b1, b2, b_qkv_s
+    g.xhat_m, g.xm, g.rstd_m, g.x2b, g.qkv_t, g.o_t = xhat_m, xm, rstd_m, x2b, qkv_t, o_t
+    g.xhat2, g.rstd2, g.xhat1n, g.rstd1n, g.qkv_s = xhat2, rstd2, xhat1n, rstd1n, qkv_s
+    g.B, g.T, g.SA, g.attn_scale, g.ln_eps = B, T, SA, attn_scale, ln_eps
     return g
 
 

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID, EPI_SILU2
-from .ops import (make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_chain_s_bwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd,
+from .ops import (make_chain_ab_fwd, make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_chain_s_bwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd,
                   make_mlp_fwd, make_readout_ce)
 
 
@@ -119,6 +119,14 @@ class Plan:
         saved = 512 * ((1 if kw.get("xhat2") else 0) + (1 if kw.get("xhat1n") else 0))
         self.add("hma_chain_b_fwd", C.byref(g), flops=2.0 * M * 256 * (256 + 2048 + (768 if with_qkv else 0)),
                  nbytes=(512 + 1024 + 1024 + (1536 if with_qkv else 0) + saved) * float(M))
+
+    def chain_ab_fwd(self, M: int, with_qkv: bool, **kw) -> None:
+        g = make_chain_ab_fwd(**kw)
+        self.keep.append(g)
+        # o_s 512 + x 1024 in; xhat_m, xm, bf16(x2) 3 x 512 + qkv_t 1536 + o_t 512 + x 1024 + xhat2 512 (+ xhat1' 512 + qkv_s 1536) out
+        nbytes = (512 + 1024 + 1536 + 1536 + 512 + 1024 + 512 + ((512 + 1536) if with_qkv else 0)) * float(M)
+        flops = 2.0 * M * 256 * (256 * 2 + 768 + 256 + 2048 + (768 if with_qkv else 0)) + 4.0 * M * 16 * 256
+        self.add("hma_chain_ab_fwd", C.byref(g), flops=flops, nbytes=nbytes)
 
     def chain_a_bwd(self, M: int, use_mod: bool, **kw) -> None:
         g = make_chain_a_bwd(M=M, use_mod=use_mod, **kw)

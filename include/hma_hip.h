@@ -506,6 +506,29 @@ typedef struct {
 } hma_chain_b_fwd_t;
 int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p);
 
+/* Chain A + causal temporal attention + chain B in ONE launch (training passes over windows of exactly T = 16 frames): everything of
+ * an STBlock between its spatial attention and the next block's -- st_transformer.py:86 proj, :102-104 ModulateLayer, :111 temporal
+ * attention (attention.py:37-61, causal), :112 norm2 + Mlp, and :85-86 norm1 + qkv of the next block.  What hma_chain_a_fwd (use_mod = 1,
+ * every saved activation), hma_attn_temporal_fwd and hma_chain_b_fwd (training form, no dropout) compute in three launches; a compute
+ * wave owns the 16 frames of one (sample, token position) column, so the attention is wave-local and the residual row never leaves the
+ * registers between the chains (4 096 fewer bytes per row).  Rows are (b, t, s), s fastest, SA rows per frame, B samples.
+ * in: o_s [M,256] bf16, x [M,256] fp32 (updated in place to the block's output), ss [B*16, 512] = shift | scale.
+ * out (all saved for the backward): xhat_m, xm, x2b [M,256] bf16 + rstd_m [M]; qkv_t [M,768] bf16; o_t [M,256] bf16; xhat2 [M,256] +
+ * rstd2 [M]; with qkv_s != NULL also the next block's xhat1n + rstd1n and qkv_s [M,768] bf16 (NULL: last block).
+ * weights (hma_chain_pack bundles): seg 0 proj_s (8), 1 linear_out (8), 2 temporal qkv (24), 3 proj_t (8), 4 the 64 alternating fc1 / fc2
+ * bundles, 5 the next block's folded spatial qkv (24, or 0).  Biases as in the two chains (b1 = folded fc1 bias, required). */
+typedef struct {
+  const void* seg[6]; int32_t bundles[6];
+  const void* o_s; float* x; const float* ss;
+  const float* b_proj_s; const float* b_lin; const float* b_qkv_t; const float* b_proj_t; const float* b1; const float* b2; const float* b_qkv_s;
+  void* xhat_m; void* xm; float* rstd_m; void* x2b;
+  void* qkv_t; void* o_t;
+  void* xhat2; float* rstd2; void* xhat1n; float* rstd1n; void* qkv_s;
+  int64_t B; int32_t T; int32_t SA;
+  float attn_scale; float ln_eps;
+} hma_chain_ab_fwd_t;
+int hma_chain_ab_fwd(void* stream, const hma_chain_ab_fwd_t* p);
+
 /* Readout + factorised cross-entropy of the image rows in one launch (st_mask_git.py:681-683 out_x_proj; :603-630
  * compute_video_loss_and_acc with label_smoothing): what hma_gemm_nt (x -> fp32 logits) + hma_ce_fwd_bwd do, without the logits in
  * HBM.  rows = B * T * S image rows (a multiple of 16); row i reads x row (i / S) * SA + i % S of the [*, 256] fp32 residual stream.

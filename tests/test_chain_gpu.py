@@ -358,3 +358,72 @@ def test_readout_ce_fused(B, T, S, A):
     torch.cuda.synchronize()
     assert abs(stats2[0].item() - st[0].item()) <= 1e-5 * abs(st[0].item()) and stats2[1].item() == st[1].item()
     assert rms(dl2, dl) < 5e-3
+
+
+@pytest.mark.parametrize("B,SA,with_qkv", [(1, 16, True), (2, 48, True), (3, 320, True), (2, 320, False), (32, 320, True)])
+def test_chain_ab_fwd_equals_three_launches(B, SA, with_qkv):
+    """hma_chain_ab_fwd (chain A + causal temporal attention + chain B over columns of T = 16 frames, one launch) against the three
+    launches it replaces on the same inputs -- hma_chain_a_fwd (training form), hma_attn_temporal_fwd, hma_chain_b_fwd (training form):
+    the same arithmetic in the same order, so every output agrees to bf16 rounding of identical fp32 values (bit-identical where no
+    reduction order differs).  Reference: st_transformer.py:86-112 and :85-86 of the next block, attention.py:37-61."""
+    T, scale = 16, 0.25
+    M = B * T * SA
+    gq = lambda s_: torch.Generator().manual_seed(s_)
+    d = lambda t: t.to(DEV).contiguous()
+    wps, wl, wqt, bps, bl, bqt = _weights(700)
+    wpt = rb(torch.randn(256, 256, generator=gq(710)) * 0.06)
+    w1 = torch.randn(1024, 256, generator=gq(711)) * 0.06
+    w2 = rb(torch.randn(256, 1024, generator=gq(712)) * 0.04)
+    wqs = torch.randn(768, 256, generator=gq(713)) * 0.06
+    bpt, b1, b2, bqs = (torch.randn(n, generator=gq(714 + i)) * 0.1 for i, n in enumerate((256, 1024, 256, 768)))
+    g2, g1 = 1 + 0.1 * torch.randn(256, generator=gq(720)), 1 + 0.1 * torch.randn(256, generator=gq(721))
+    o_s = d(rb(torch.randn(M, 256, generator=gq(1)))).bfloat16()
+    x0 = d(torch.randn(M, 256, generator=gq(2)) * 1.5 + 0.2)
+    ss = d(torch.randn(B * T, 512, generator=gq(3)) * 0.3)
+    p_ps, p_l, p_qt = _pack_nt(wps), _pack_nt(wl), _pack_nt(wqt)
+    p_pt = _pack_nt(wpt)
+    mlp = torch.empty(64 * 8192, dtype=torch.bfloat16, device=DEV)
+    ops.chain_pack(d(w1), kind=0, rows=1024, cols=256, row_stride=256, col_stride=1, col_scale=d(g2), out=mlp, bundle_stride=2)
+    ops.chain_pack(d(w2), kind=1, rows=256, cols=1024, row_stride=1024, col_stride=1, out=mlp, bundle_stride=2, bundle_offset=1)
+    p_qs = ops.chain_pack(d(wqs), kind=0, rows=768, cols=256, row_stride=256, col_stride=1, col_scale=d(g1))
+    bd = {k: d(v) for k, v in dict(bps=bps, bl=bl, bqt=bqt, bpt=bpt, b1=b1, b2=b2, bqs=bqs).items()}
+    bf = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=DEV)
+    f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=DEV)
+
+    def outs():
+        return dict(xhat_m=bf(M, 256), xm=bf(M, 256), rstd_m=f32(M), x2b=bf(M, 256), qkv_t=bf(M, 768), o_t=bf(M, 256), xhat2=bf(M, 256),
+                    rstd2=f32(M), xhat1n=bf(M, 256), rstd1n=f32(M), qkv_s=bf(M, 768))
+
+    # ---- three launches
+    r, xr = outs(), x0.clone()
+    a = ops.make_chain_a_fwd(M=M, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_l), 8), (ops.ptr(p_qt), 24)], o=ops.ptr(o_s), x=ops.ptr(xr),
+                             qkv=ops.ptr(r["qkv_t"]), ss=ops.ptr(ss), b_proj=ops.ptr(bd["bps"]), b_lin=ops.ptr(bd["bl"]),
+                             b_qkv=ops.ptr(bd["bqt"]), xhat=ops.ptr(r["xhat_m"]), xm=ops.ptr(r["xm"]), rstd=ops.ptr(r["rstd_m"]),
+                             x_bf16=ops.ptr(r["x2b"]), rows_per_frame=SA, use_mod=True)
+    _lib.call("hma_chain_a_fwd", ops.stream_ptr(), C.byref(a))
+    _lib.call("hma_attn_temporal_fwd", ops.stream_ptr(), ops.ptr(r["qkv_t"]), ops.ptr(r["o_t"]), B, T, SA, scale)
+    kwq = dict(xhat1n=ops.ptr(r["xhat1n"]), rstd1n=ops.ptr(r["rstd1n"]), qkv=ops.ptr(r["qkv_s"]), b_qkv=ops.ptr(bd["bqs"])) if with_qkv else {}
+    b = ops.make_chain_b_fwd(M=M, segs=[(ops.ptr(p_pt), 8), (ops.ptr(mlp), 64)] + ([(ops.ptr(p_qs), 24)] if with_qkv else []),
+                             o=ops.ptr(r["o_t"]), x=ops.ptr(xr), b_proj=ops.ptr(bd["bpt"]), b1=ops.ptr(bd["b1"]), b2=ops.ptr(bd["b2"]),
+                             xhat2=ops.ptr(r["xhat2"]), rstd2=ops.ptr(r["rstd2"]), **kwq)
+    _lib.call("hma_chain_b_fwd", ops.stream_ptr(), C.byref(b))
+    # ---- one launch
+    f, xf = outs(), x0.clone()
+    kwq = dict(xhat1n=ops.ptr(f["xhat1n"]), rstd1n=ops.ptr(f["rstd1n"]), qkv_s=ops.ptr(f["qkv_s"]), b_qkv_s=ops.ptr(bd["bqs"])) if with_qkv else {}
+    ab = ops.make_chain_ab_fwd(B=B, SA=SA, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_l), 8), (ops.ptr(p_qt), 24), (ops.ptr(p_pt), 8), (ops.ptr(mlp), 64),
+                                                  (ops.ptr(p_qs) if with_qkv else None, 24 if with_qkv else 0)],
+                               o_s=ops.ptr(o_s), x=ops.ptr(xf), ss=ops.ptr(ss), b1=ops.ptr(bd["b1"]), xhat_m=ops.ptr(f["xhat_m"]),
+                               xm=ops.ptr(f["xm"]), rstd_m=ops.ptr(f["rstd_m"]), x2b=ops.ptr(f["x2b"]), qkv_t=ops.ptr(f["qkv_t"]),
+                               o_t=ops.ptr(f["o_t"]), xhat2=ops.ptr(f["xhat2"]), rstd2=ops.ptr(f["rstd2"]), attn_scale=scale,
+                               b_proj_s=ops.ptr(bd["bps"]), b_lin=ops.ptr(bd["bl"]), b_qkv_t=ops.ptr(bd["bqt"]), b_proj_t=ops.ptr(bd["bpt"]),
+                               b2=ops.ptr(bd["b2"]), **kwq)
+    _lib.call("hma_chain_ab_fwd", ops.stream_ptr(), C.byref(ab))
+    torch.cuda.synchronize()
+    names = ["xhat_m", "xm", "rstd_m", "x2b", "qkv_t", "o_t", "xhat2", "rstd2"] + (["xhat1n", "rstd1n", "qkv_s"] if with_qkv else [])
+    for k in names:
+        assert torch.isfinite(f[k].float()).all(), k
+        tol = 1e-5 if k.startswith("rstd") else 2 * BF
+        close(f[k], r[k].float(), tol, k)
+    close(xf, xr, 1e-5, "x")
+    # the temporal attention's output is what the three-launch path's kernel gives on the fused path's own qkv, exactly or to a rounding
+    assert (f["o_t"].float() - r["o_t"].float()).abs().max() <= BF * r["o_t"].float().abs().max()
