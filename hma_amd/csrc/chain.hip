@@ -396,13 +396,25 @@ struct ring_src {
 };
 template <int PROF_K, int NW = NCW>
 __device__ __forceinline__ void loader_run(const ring_src& ws, int per_tile, int nt, uint32_t lds_b, int lane, const float* ss,
-                                           int64_t M, int rows_per_frame, HMA_LDS(char)* lds = nullptr, const tile_map* tmap = nullptr) {
+                                           int64_t M, int rows_per_frame, HMA_LDS(char)* lds = nullptr, const tile_map* tmap = nullptr,
+                                           int64_t col_base = -1, int col_sa = 0, uint32_t col_lds = 0) {
   if constexpr (ST) __builtin_amdgcn_s_setprio(2);
   const int total = per_tile * nt;
   int issued = 0, seg = 0, left = ws.n0, tl_issue = 0, slot_issue = 0;
   const char* cur = ws.s0;
   auto issue = [&]() __attribute__((always_inline)) {
-    if (seg == 0 && left == ws.n0 && ss) {  // a tile's first bundle: its shift / scale rows first
+    if (seg == 0 && left == ws.n0 && ss && col_base >= 0) {
+      // column tiles (hma_chain_ab_fwd): the 16 frames' shift | scale rows of the sample of the tile's FIRST column, 2 KB each, rows
+      // 2064 bytes apart in LDS (a lane reads its own frame's row: the 16-byte skew spreads the 16 rows over the banks)
+      const int64_t b0 = (col_base + (int64_t)tl_issue * NW) / col_sa;
+      const char* s = reinterpret_cast<const char*>(ss) + b0 * 16 * 2048 + lane * 16;
+#pragma unroll 1
+      for (int f = 0; f < 16; ++f) {
+        const uint32_t d = __builtin_amdgcn_readfirstlane(lds_b + col_lds + f * 2064);
+        glds16(s + f * 2048, d);
+        glds16(s + f * 2048 + 1024, d + 1024);
+      }
+    } else if (seg == 0 && left == ws.n0 && ss) {  // a tile's first bundle: its shift / scale rows first
 #pragma unroll 1
       for (int w = 0; w < NW; ++w) {
         int64_t r0 = tile_row0(*tmap, tl_issue, NW, w);
@@ -1691,6 +1703,8 @@ __device__ __forceinline__ col_map make_col_map(int64_t cols, int nw) {
   return t;
 }
 typedef __attribute__((ext_vector_type(4))) short s16x4v_t;
+constexpr int AB_SMEM = NS * SLOT + 4 * (1280 + 2304) + NCW * 2048 + 16 * 2064;  // ring | biases | attention scratch | shift / scale rows
+static_assert(AB_SMEM <= 163840, "one workgroup per CU");
 template <bool QKV>
 __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_ab_fwd_t p) {
   static_assert(!ST, "the fused chain has no storer mode");
@@ -1725,7 +1739,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
   constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
   static_assert(PER_TILE % PB == 0, "whole barrier groups per tile");
   constexpr int L_SCR = L_BIAS + 4 * (BB + 2304);     // per compute wave: 1 KB V^T scratch + 1 KB output scratch
-  static_assert(L_SCR + NW * 2048 <= SMEM, "the attention scratch fits beside the ring");
+  constexpr int L_SSC = L_SCR + NW * 2048;            // the tile's sample: 16 frames x (2 KB shift | scale + 16 bytes of skew)
+  static_assert(L_SSC + 16 * 2064 <= AB_SMEM, "scratch and shift / scale rows fit beside the ring");
   if (wave > NCW) return;
   if (wave == NCW) {
     ring_src ws = {reinterpret_cast<const char*>(p.seg[0]), reinterpret_cast<const char*>(p.seg[1]), reinterpret_cast<const char*>(p.seg[2]),
@@ -1734,7 +1749,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
     ws.s5 = reinterpret_cast<const char*>(p.seg[5]);
     ws.n4 = p.bundles[4];
     ws.n5 = p.bundles[5];
-    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, 0, 1, lds, nullptr);
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, p.ss, 0, 1, lds, nullptr, cmap.base, SA, (uint32_t)L_SSC);
     return;
   }
   stage_t stg_ = make_stage(lds, wave, lane);
@@ -1868,14 +1883,29 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
           sq += __shfl_xor(sq, 32, 64);
           const float rstd = rsqrtf(sq * (1.0f / 256.0f) + 1e-6f);
           const float nb = -mean * rstd;
+          // The loader staged the shift | scale rows of the sample of the tile's FIRST column (32 global loads per lane here -- the
+          // L2-resident table read directly -- cost 25 us per launch: -DCH_AB_SSG); a wave whose column lies in the next sample
+          // (a tile that straddles two samples) takes its rows from the table itself.
           const float* ssr = p.ss + (frame0 + tok) * 512 + 8 * g;
+          HMA_LDS(char)* ssl = lds + L_SSC + tok * 2064 + 32 * g;
+#ifdef CH_AB_SSG
+          const bool staged = false;
+#else
+          const bool staged = frame0 == ((cmap.base + (int64_t)tl * NW) / SA) * 16;
+#endif
 #pragma unroll
           for (int pr = 0; pr < 8; ++pr) {
             float h[8], mm[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaf(acc[2 * pr + (e >> 2)][e & 3], rstd, nb);
-            const float4 sh0 = *reinterpret_cast<const float4*>(ssr + 32 * pr), sh1 = *reinterpret_cast<const float4*>(ssr + 32 * pr + 4);
-            const float4 sc0 = *reinterpret_cast<const float4*>(ssr + 256 + 32 * pr), sc1 = *reinterpret_cast<const float4*>(ssr + 256 + 32 * pr + 4);
+            float4 sh0, sh1, sc0, sc1;
+            if (staged) {
+              sh0 = lds_f4(ssl + 128 * pr); sh1 = lds_f4(ssl + 128 * pr + 16);
+              sc0 = lds_f4(ssl + 1024 + 128 * pr); sc1 = lds_f4(ssl + 1024 + 128 * pr + 16);
+            } else {
+              sh0 = *reinterpret_cast<const float4*>(ssr + 32 * pr); sh1 = *reinterpret_cast<const float4*>(ssr + 32 * pr + 4);
+              sc0 = *reinterpret_cast<const float4*>(ssr + 256 + 32 * pr); sc1 = *reinterpret_cast<const float4*>(ssr + 256 + 32 * pr + 4);
+            }
             const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
             const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
             hqs[pr] = pack8(h);
@@ -2316,11 +2346,11 @@ extern "C" int hma_chain_ab_fwd(void* stream, const hma_chain_ab_fwd_t* p) {
   const int slots = num_cus() * WGS_PER_CU;
   const int grid = (int)(ntiles < slots ? ntiles : slots);
   if (qkv) {
-    if (int rc = set_lds<chain_ab_fwd_kernel<true>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_ab_fwd_kernel<true>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+    if (int rc = set_lds<chain_ab_fwd_kernel<true>>(AB_SMEM)) return rc;
+    hipLaunchKernelGGL(chain_ab_fwd_kernel<true>, dim3(grid), dim3(CH_THREADS), AB_SMEM, (hipStream_t)stream, *p);
   } else {
-    if (int rc = set_lds<chain_ab_fwd_kernel<false>>(SMEM)) return rc;
-    hipLaunchKernelGGL(chain_ab_fwd_kernel<false>, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+    if (int rc = set_lds<chain_ab_fwd_kernel<false>>(AB_SMEM)) return rc;
+    hipLaunchKernelGGL(chain_ab_fwd_kernel<false>, dim3(grid), dim3(CH_THREADS), AB_SMEM, (hipStream_t)stream, *p);
   }
   HMA_CHECK_LAUNCH();
   return 0;
