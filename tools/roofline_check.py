@@ -6,7 +6,8 @@
 The bench line times C-ABI calls with HIP events in eager steps right after the timed region; rocprofv3 --kernel-trace --stats of the
 same command gives per-KERNEL totals over the whole run (prepare + warm-up + timed graph replays + the instrumented steps: the same
 launches every step).  For every family below: rocprof us per call = sum of the TotalDurationNs of the kernels the call launches /
-the number of launches of the family's counting kernel; it must agree with the line's avg_launch_us within TOL (5 %).
+the number of launches of the family's counting kernel; it must agree with the line's avg_launch_us within TOL (5 %; or ABS_US = 6 us:
+the event bracket of a C-ABI call also holds the launch boundary in front of its kernel).
 `roofline.frac` of the line = flops_per_launch / avg_launch_us / peak: with the rocprof us per call in its place anyone gets the same
 fraction from profiles/ with a calculator."""
 import csv
@@ -16,11 +17,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 0.05
+ABS_US = 6.0  # (a HIP-event bracket also holds the launch boundary in front of the kernel, 2-5 us: what a launch shorter than ~120 us may differ by)
 # family -> (kernel-name substrings whose time belongs to a call, substring of the kernel whose launches count the calls)
 FAMILY_KERNELS = {
     "wgrad_ring": (("gemm_tn_dma_kernel", "tn_reduce_native_kernel"), "gemm_tn_dma_kernel"),
     "hma_mlp_bwd": (("mlp_bwd_kernel",), "mlp_bwd_kernel"),
     "hma_chain_b_fwd": (("chain_b_fwd_kernel<true",), "chain_b_fwd_kernel<true"),
+    "hma_chain_ab_fwd": (("chain_ab_fwd_kernel",), "chain_ab_fwd_kernel"),
     "hma_chain_a_fwd": (("chain_a_fwd_kernel",), "chain_a_fwd_kernel"),
     "hma_chain_a_bwd": (("chain_a_bwd_kernel",), "chain_a_bwd_kernel"),
     "hma_chain_s_bwd": (("chain_s_bwd_kernel",), "chain_s_bwd_kernel"),
@@ -59,6 +62,8 @@ def check(line_path, stats_path, tol=TOL):
             continue
         ev = fams[fam]["avg_launch_us"]
         rel = abs(us - ev) / ev
+        if abs(us - ev) <= ABS_US:
+            rel = min(rel, TOL)
         frac_rocprof = fams[fam]["flops_per_launch"] / (us * 1e-6) / 1e12 / 2500.0
         out.append((fam, ev, us, calls, rel, fams[fam]["frac"], frac_rocprof))
         ok = ok and rel <= tol
