@@ -40,7 +40,7 @@ FLOP_PER_TOKEN_FWD_BWD = 3.104e8
 # every MFMA kernel family of the step (C-ABI entry points); the per-launch HIP-event pass times each of them
 FAMILIES = ["hma_gemm_nt", "hma_mlp_fwd", "hma_mlp_bwd", "hma_gemm_tn", "hma_gemm_tn_pair", "hma_gemm_tn_multi", "hma_attn_spatial_fwd", "hma_attn_spatial_bwd_blocked",
             "hma_attn_spatial_bwd", "hma_attn_temporal_fwd", "hma_attn_temporal_bwd", "hma_chain_a_fwd", "hma_chain_a_bwd", "hma_chain_b_fwd", "hma_chain_ab_fwd",
-            "hma_chain_s_bwd", "hma_readout_ce"]
+            "hma_chain_s_bwd", "hma_chain_t_bwd", "hma_readout_ce"]
 MFMA_PEAK = 2.5e15                 # dense bf16, MI355X_MICROARCH.md
 
 
@@ -651,6 +651,7 @@ def main():
                 fam_kernels = {"hma_gemm_nt": (("gemm_nt",), "gemm_nt"), "hma_mlp_bwd": (("mlp_bwd",), "mlp_bwd"), "hma_mlp_fwd": (("mlp_fwd",), "mlp_fwd"),
                                "hma_gemm_tn_pair": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_a_fwd": (("chain_a_fwd",), "chain_a_fwd"),
                                "wgrad_ring": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"), "hma_chain_s_bwd": (("chain_s_bwd",), "chain_s_bwd"),
+                               "hma_chain_t_bwd": (("chain_t_bwd",), "chain_t_bwd"),
                                "hma_gemm_tn_multi": (("gemm_tn_dma", "tn_reduce_native"), "gemm_tn_dma"),
                                "hma_chain_a_bwd": (("chain_a_bwd",), "chain_a_bwd"), "hma_chain_b_fwd": (("chain_b_fwd",), "chain_b_fwd"),
                                "hma_attn_spatial_bwd": (("attn_bwd_fused",), "attn_bwd_fused")}.get(dom_name, ((dom_name,), dom_name))

@@ -118,6 +118,15 @@ class ChainSBwd(C.Structure):
     ]
 
 
+class ChainTBwd(C.Structure):
+    _fields_ = [
+        ("w", ChainWeights),
+        ("dy_bf16", c_vp), ("qkv", c_vp), ("dqkv", c_vp),
+        ("B", c_i64), ("T", c_i32), ("SA", c_i32),
+        ("attn_scale", C.c_float), ("_pad", c_i32),
+    ]
+
+
 class ChainABFwd(C.Structure):
     _fields_ = [
         ("seg", c_vp * 6), ("bundles", c_i32 * 6),
@@ -204,6 +213,7 @@ _PROTOS = {
     "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
     "hma_chain_a_bwd": [c_vp, C.POINTER(ChainABwd)],
     "hma_chain_s_bwd": [c_vp, C.POINTER(ChainSBwd)],
+    "hma_chain_t_bwd": [c_vp, C.POINTER(ChainTBwd)],
     "hma_chain_ab_fwd": [c_vp, C.POINTER(ChainABFwd)],
     "hma_zero_f32": [c_vp, c_vp, c_i64],
     "hma_abi_version": [],

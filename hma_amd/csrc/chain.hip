@@ -2044,6 +2044,215 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
   }
 }
 
+// ------------------------------------------------------------------------------------------------ chain T, backward
+// The temporal attention's backward of a block (st_transformer.py:111, attention.py:37-61 causal, autograd mirror) in ONE launch, for
+// training passes over windows of exactly 16 frames: d_o = bf16(dx) Wproj (the temporal projection's input gradient, hma_gemm_nt before)
+// and the attention backward of the column (hma_attn_temporal_bwd before), without d_o's round trip through HBM.  A compute wave owns a
+// COLUMN as in the fused forward chain: the N-block bundle pr of Wproj^T leaves head pr's 32 channels of d_o in the accumulators, packed
+// they ARE the 16 x 16 x 32 MFMA operand (lane = frame, 8 channels); q / k / v of the head are read from the saved qkv rows in the same
+// operand form.  Per head: S^T = K Q^T and dP^T = V dO^T (lane = query, 4 keys in registers), soft-max and delta = sum P dP with two
+// shuffles each; dS and P in the other orientation (B operand with k = query) come back transposed from a 16 x 16 LDS slab by ONE
+// ds_read_b64_tr_b16 each (attn_t_bwd_kernel recomputes both products and fetches the query's statistics by lane reads: 2 MFMAs, 12
+// cross-lane reads and 4 exponentials more per head); the three time-contracting products dQ^T = K^T dS^T, dK^T = Q^T dS,
+// dV^T = dO^T P run on the 16 x 16 x 16 MFMA with the [frame][channel] matrices read transposed from a per-wave LDS scratch, again one
+// instruction per operand.  The read takes channel 8 (i >> 2) + 4 dd + (i & 3) for output row i of product dd, so a lane ends with
+// channels 8 g .. 8 g + 7 of its frame -- the chains' chunk form, i.e. whole-line
+// stores.  Eight steps per tile; the next tile's q / k / v of a head pair are requested into
+// the pair's registers as soon as it is done (the two heads' 64 bytes are the halves of one cache line).
+// Standalone at B = 32, SA = 320: 125 us (4.7 TB/s of 3 584 B per row) against 32 + 122 for the two launches; 56 us without its
+// memory instructions.
+constexpr int TB_PITCH = 80;                         // bytes per frame row of a scratch slab (32 channels + 16: the four frame groups of a gather hit four bank groups)
+constexpr int TB_SLAB = 16 * TB_PITCH;
+constexpr int TB_SP = 40;                            // bytes per query row of the dS / P slabs (16 keys + 8)
+constexpr int TB_SCR = 3 * TB_SLAB + 2 * 16 * TB_SP; // Q | K | dO of the head in flight + dS | P [query][key], per compute wave
+typedef short tb_v4s16_t __attribute__((ext_vector_type(4)));
+constexpr int TB_SMEM = NS * SLOT + NCW * TB_SCR;
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_bwd_t p) {
+  static_assert(!ST, "chain T has no storer mode");
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  HMA_LDS(char)* lds = (HMA_LDS(char)*)smem;
+  const uint32_t lds_b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = NCW;
+  const int SA = p.SA;
+  const col_map cmap = make_col_map(p.B * (int64_t)SA, NW);
+  const int nt = cmap.nt;
+  constexpr int PER_TILE = 8;
+  static_assert(PER_TILE % PB == 0, "whole barrier groups per tile");
+  if (wave > NCW) return;
+  if (wave == NCW) {
+    const ring_src ws = {reinterpret_cast<const char*>(p.w.seg[0]), reinterpret_cast<const char*>(p.w.seg[1]),
+                         reinterpret_cast<const char*>(p.w.seg[2]), reinterpret_cast<const char*>(p.w.seg[3]),
+                         p.w.bundles[0], p.w.bundles[1], p.w.bundles[2], p.w.bundles[3]};
+    loader_run<1, NW>(ws, PER_TILE, nt, lds_b, lane, nullptr, 0, 1, lds);
+    return;
+  }
+  stage_t stg_ = make_stage(lds, wave, lane);
+  const int tok = lane & 15, g = lane >> 4;
+  auto col_of = [&](int tl) __attribute__((always_inline)) { return cmap.base + (int64_t)tl * NW + wave; };
+  auto row_of = [&](int64_t c) __attribute__((always_inline)) {
+    const int64_t b = c / SA;
+    return b * 16 * SA + (c - b * SA);
+  };
+  auto lane_row = [&](int tl) __attribute__((always_inline)) {  // this lane's row (frame tok) of the wave's column in tile tl
+    int64_t c = col_of(tl);
+    c = c < cmap.end ? c : cmap.end - 1;
+    return row_of(c) + (int64_t)tok * SA;
+  };
+  bf16x8_t a0[8], a1[8];  // bf16(dx) rows: this tile's / the next one's
+  bf16x8_t qf[24];        // q | k | v of the column: fragment 8 part + head
+  auto load_dy = [&](int64_t m, auto j_) __attribute__((always_inline)) {
+    constexpr int j = decltype(j_)::value;
+    if (CH_ABL & 2) return;
+    a1[j] = as_frag(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.dy_bf16) + m * 256 + 8 * g + 32 * j));
+  };
+  auto load_head = [&](int64_t m, auto h_) __attribute__((always_inline)) {
+    constexpr int h = decltype(h_)::value;
+    if (CH_ABL & 2) return;
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(p.qkv) + m * 768 + 8 * g + 32 * h;
+    qf[h] = as_frag(*reinterpret_cast<const uint4*>(row));
+    qf[8 + h] = as_frag(*reinterpret_cast<const uint4*>(row + 256));
+    qf[16 + h] = as_frag(*reinterpret_cast<const uint4*>(row + 512));
+  };
+  if (CH_ABL & 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a1[j] = as_frag(make_uint4(lane, j, lane, j));
+#pragma unroll
+    for (int j = 0; j < 24; ++j) qf[j] = as_frag(make_uint4(0x3c003c00u + lane, 0x3c003c00u + j, 0x3c003c00u, 0x3c003c00u));
+  }
+  {
+    const int64_t m = lane_row(0);
+    static_for<8>([&](auto j_) __attribute__((always_inline)) {
+      load_dy(m, j_);
+      load_head(m, j_);
+    });
+  }
+  CH_TOUCH_A(a1);
+  HMA_LDS(char)* ring = lds + lane * 16;
+  HMA_LDS(char)* sQ = lds + NS * SLOT + wave * TB_SCR;
+  HMA_LDS(char)* sK = sQ + TB_SLAB;
+  HMA_LDS(char)* sG = sK + TB_SLAB;
+  HMA_LDS(char)* sD = sG + TB_SLAB;
+  HMA_LDS(char)* sP = sD + 16 * TB_SP;
+  const line_offs Lq = make_lines(1536 * SA, tok, 16 * g, 64);
+  const float c_log2 = p.attn_scale * 1.4426950408889634f, scale = p.attn_scale;
+  // ds_read_b64_tr_b16 (a 16-lane group reads a [4 row][16 column] block: lane i supplies the address of row i >> 2, columns
+  // 4 (i & 3) .. + 3, and receives column i of the 4 rows): the A operand of a time-contracting product -- output row tok = channel
+  // 8 (tok >> 2) + 4 dd + (tok & 3), frames 4 g .. 4 g + 3 -- is one such read of a [frame][channel] slab with the supplying lane at
+  // channels 8 (tok & 3) + 4 dd; the transposed dS / P (B operand: key = tok, queries 4 g .. 4 g + 3) one of a [query][key] slab.
+  const int tr_x = (4 * g + (tok >> 2)) * TB_PITCH + 16 * (tok & 3);
+  const int tr_s = (4 * g + (tok >> 2)) * TB_SP + 8 * (tok & 3);
+  int slot = 0;
+  uint4 hold[3];  // dq | dk | dv of the even head, waiting for the odd one (a 128-byte line = the two heads' 64 bytes)
+  const f32x4v_t z4 = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int tl = 0; tl < nt; ++tl) {
+    const int64_t col = col_of(tl);
+    if (col >= cmap.end) {  // (a wave past the workgroup's last column: possible in its last tile only)
+#pragma unroll 1
+      for (int s = 0; s < PER_TILE; s += PB) CH_BARRIER();
+      slot = (slot + PER_TILE) % NS;
+      continue;
+    }
+    const int64_t rc = row_of(col);
+    uint16_t* dq_out = reinterpret_cast<uint16_t*>(p.dqkv) + rc * 768;
+    const int64_t mn = lane_row(tl + 1 < nt ? tl + 1 : tl);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+    static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int h = decltype(sc_)::value;
+      if constexpr (h % PB == 0) CH_BARRIER();
+      HMA_LDS(char)* wb = ring + slot * SLOT;
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      // ---- d_o of head h = bf16(dx) Wproj[:, 32 h .. 32 h + 31]
+      f32x4v_t c0 = z4, c1 = z4;
+      nb_mma(wb, a0, c0, c1);
+      if constexpr ((h & 1) == 1) {  // the next tile's bf16(dx) row: the two 64-byte halves of a line by back-to-back loads
+        load_dy(mn, std::integral_constant<int, h - 1>{});
+        load_dy(mn, sc_);
+      }
+      const bf16x8_t aG = as_frag(pack_pair(c0, c1));
+      const bf16x8_t aQ = qf[h], aK = qf[8 + h], aV = qf[16 + h];
+      *(HMA_LDS(u32x4_t)*)(sQ + tok * TB_PITCH + 16 * g) = __builtin_bit_cast(u32x4_t, aQ);
+      *(HMA_LDS(u32x4_t)*)(sK + tok * TB_PITCH + 16 * g) = __builtin_bit_cast(u32x4_t, aK);
+      *(HMA_LDS(u32x4_t)*)(sG + tok * TB_PITCH + 16 * g) = __builtin_bit_cast(u32x4_t, aG);
+      asm volatile("" ::: "memory");
+      // orientation 1: lane = query (tok), registers = keys 4 g + r
+      f32x4v_t st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aK, aQ, z4, 0, 0, 0);
+      const f32x4v_t dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aV, aG, z4, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[r] = (4 * g + r <= tok) ? st[r] * c_log2 : -INFINITY;
+        mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[r] = __builtin_amdgcn_exp2f(st[r] - mx);
+        l += st[r];
+      }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      float delta = 0.f;  // sum_key P dP ( = dO . O)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[r] *= inv;
+        delta += st[r] * dpt[r];
+      }
+      delta += __shfl_xor(delta, 16, 64);
+      delta += __shfl_xor(delta, 32, 64);
+      const uint2 dsw = make_uint2(pack_bf16(st[0] * (dpt[0] - delta), st[1] * (dpt[1] - delta)),
+                                   pack_bf16(st[2] * (dpt[2] - delta), st[3] * (dpt[3] - delta)));
+      const uint2 pw = make_uint2(pack_bf16(st[0], st[1]), pack_bf16(st[2], st[3]));
+      const s16x4v_t dsT = __builtin_bit_cast(s16x4v_t, dsw);  // B: k = key, n = query
+      // the other orientation (B: k = query, n = key) through the [query][key] slabs
+      typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+      *(HMA_LDS(u32x2_t)*)(sD + tok * TB_SP + 8 * g) = u32x2_t{dsw.x, dsw.y};
+      *(HMA_LDS(u32x2_t)*)(sP + tok * TB_SP + 8 * g) = u32x2_t{pw.x, pw.y};
+      asm volatile("" ::: "memory");
+      const s16x4v_t dsB = __builtin_bit_cast(s16x4v_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(tb_v4s16_t)*)(sD + tr_s)));
+      const s16x4v_t pB = __builtin_bit_cast(s16x4v_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(tb_v4s16_t)*)(sP + tr_s)));
+      f32x4v_t dq[2], dk[2], dv[2];
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        const s16x4v_t qT = __builtin_bit_cast(s16x4v_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(tb_v4s16_t)*)(sQ + tr_x + 8 * dd)));
+        const s16x4v_t kT = __builtin_bit_cast(s16x4v_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(tb_v4s16_t)*)(sK + tr_x + 8 * dd)));
+        const s16x4v_t gT = __builtin_bit_cast(s16x4v_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(tb_v4s16_t)*)(sG + tr_x + 8 * dd)));
+        dq[dd] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsT, z4, 0, 0, 0);  // dQ^T [channel 8 g + 4 dd + r][query = tok]
+        dk[dd] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, dsB, z4, 0, 0, 0);  // dK^T [.][key = tok]
+        dv[dd] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gT, pB, z4, 0, 0, 0);   // dV^T [.][key = tok]
+      }
+      asm volatile("" ::: "memory");
+      const uint4 oq = make_uint4(pack_bf16(dq[0][0] * scale, dq[0][1] * scale), pack_bf16(dq[0][2] * scale, dq[0][3] * scale),
+                                  pack_bf16(dq[1][0] * scale, dq[1][1] * scale), pack_bf16(dq[1][2] * scale, dq[1][3] * scale));
+      const uint4 ok = make_uint4(pack_bf16(dk[0][0] * scale, dk[0][1] * scale), pack_bf16(dk[0][2] * scale, dk[0][3] * scale),
+                                  pack_bf16(dk[1][0] * scale, dk[1][1] * scale), pack_bf16(dk[1][2] * scale, dk[1][3] * scale));
+      const uint4 ov = make_uint4(pack_bf16(dv[0][0], dv[0][1]), pack_bf16(dv[0][2], dv[0][3]), pack_bf16(dv[1][0], dv[1][1]),
+                                  pack_bf16(dv[1][2], dv[1][3]));
+      if constexpr ((h & 1) == 0) {
+        hold[0] = oq;
+        hold[1] = ok;
+        hold[2] = ov;
+      } else {
+        store_lines(stg_, dq_out, Lq, 64 * (h - 1), hold[0], oq);
+        store_lines(stg_, dq_out, Lq, 64 * (h - 1) + 512, hold[1], ok);
+        store_lines(stg_, dq_out, Lq, 64 * (h - 1) + 1024, hold[2], ov);
+      }
+      if constexpr ((h & 1) == 1) {  // the next tile's q / k / v of this head pair (the halves of a line), into the registers just read
+        load_head(mn, std::integral_constant<int, h - 1>{});
+        load_head(mn, sc_);
+      }
+    });
+    CH_TOUCH_A(a1);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ readout + cross-entropy
 // out_x_proj (st_mask_git.py:681-683) + the factorised cross-entropy (compute_video_loss_and_acc, :603-630) of the image rows in one
 // launch: the fp32 logits (2 x 512 per row) exist only as one factor's 128 accumulator registers per lane; what reaches HBM is the
@@ -2328,6 +2537,20 @@ extern "C" int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p) {
   const int grid = chain_grid(p->M);
   if (int rc = set_lds<chain_s_bwd_kernel>(SMEM)) return rc;
   hipLaunchKernelGGL(chain_s_bwd_kernel, dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
+  HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_t_bwd(void* stream, const hma_chain_t_bwd_t* p) {
+  if (!p || !p->dy_bf16 || !p->qkv || !p->dqkv || p->B <= 0 || p->SA <= 0 || p->T != 16) return HMA_EINVAL;
+  if ((int64_t)p->SA * 1536 * 15 >= (int64_t)1 << 31) return HMA_EINVAL;  // (line offsets are 32-bit)
+  if (!weights_ok(p->w, 8)) return HMA_EINVAL;
+  const int64_t cols = p->B * (int64_t)p->SA;
+  const int64_t ntiles = (cols + NCW - 1) / NCW;
+  const int slots = num_cus() * WGS_PER_CU;
+  const int grid = (int)(ntiles < slots ? ntiles : slots);
+  if (int rc = set_lds<chain_t_bwd_kernel>(TB_SMEM)) return rc;
+  hipLaunchKernelGGL(chain_t_bwd_kernel, dim3(grid), dim3(CH_THREADS), TB_SMEM, (hipStream_t)stream, *p);
   HMA_CHECK_LAUNCH();
   return 0;
 }

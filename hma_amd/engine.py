@@ -111,13 +111,14 @@ class STEngine(DecodeMixin):
         self.chain_s = os.environ.get("HMA_CHAIN_S", "1") != "0"  # (0: measurement -- the spatial qkv dgrad + hma_ln_bwd as two launches)
         self.attn_hb = os.environ.get("HMA_ATTN_HB", "1") != "0"  # (0: measurement -- the spatial attention backward's dqkv row-major)
         self.chain_ab = os.environ.get("HMA_CHAIN_AB", "1") != "0"  # (0: measurement -- chain A, temporal attention, chain B as three launches)
+        self.chain_t = os.environ.get("HMA_CHAIN_T", "1") != "0"  # (0: measurement -- the temporal projection's dgrad + hma_attn_temporal_bwd as two launches)
         # The seven weight gradients of a block in ONE launch at the end of its backward (hma_gemm_tn_multi): nothing reads a weight
         # gradient before the optimizer, so they wait until every operand exists -- four bf16(dx) buffers and a second dqkv keep the
         # operands alive.  (0: measurement -- three pair launches + linear_out's, each behind its operands)
         self.wgrad_multi = os.environ.get("HMA_WGRAD_MULTI", "1") != "0"
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN),
-                   "qkv_s_T": mk(L, 24 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
+                   "qkv_s_T": mk(L, 24 * BUN), "proj_t_T": mk(L, 8 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
         # readout + cross-entropy in one launch (hma_readout_ce) for training steps that do not hand the logits to the caller
         self.fused_ce = True
         self.CP["out"] = mk(32 * BUN)
@@ -244,6 +245,8 @@ class STEngine(DecodeMixin):
                 _lib.call("hma_chain_pack", stream, wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN, 1)
                 _lib.call("hma_chain_pack", stream, self._p("out_x_proj.weight"), d, 1, None, None, self.CP["out"].data_ptr(), 0, 1024, d, 1, 0,
                           0, 1)
+                _lib.call("hma_chain_pack", stream, self._p(pre + "temporal_attn.proj.weight"), 1, d, None, None,
+                          self.CP["proj_t_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)  # (chain T backward)
                 for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
                     _lib.call("hma_chain_pack", stream, wq + 4 * c * d * d, 1, d, None, None,
                               self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
@@ -624,7 +627,7 @@ class STEngine(DecodeMixin):
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
         key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group,
-               self.chain_s, self.attn_hb, self.wgrad_multi)
+               self.chain_s, self.attn_hb, self.wgrad_multi, self.chain_t)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -712,8 +715,12 @@ class STEngine(DecodeMixin):
                     pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
                            dxb)
             # ---- temporal attention
-            pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
-            pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256, nbytes=3584.0 * M)
+            if self.chain_t and T == 16 and not self.qkn and self._use_chain(M, SA):
+                # chain T backward (csrc/chain.hip): the projection's input gradient and the attention backward of a column, one launch
+                pl.chain_t_bwd(B, SA, segs=[(self.CP["proj_t_T"][l].data_ptr(), 8)], dy_bf16=dxb, qkv=qkv_t, dqkv=dqkv, attn_scale=self.scale)
+            else:
+                pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
+                pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256, nbytes=3584.0 * M)
             if self.qkn:  # through the per-head LayerNorm of q and k (dqkv in place; the affine's gradients by atomics)
                 pl.add("hma_qknorm_bwd", dqkv, 768, dp(ws["qraw_t"], l, M * 512), self._lw(l, "temporal_attn.norm.weight", "p"), 1e-5,
                        gw("temporal_attn.norm.weight"), gw("temporal_attn.norm.bias"), M)

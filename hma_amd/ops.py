@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_BF16, A_BF16_AFFINE, A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2,
-                   EPI_RESID, EPI_SILU2, ChainABFwd, ChainABwd, ChainAFwd, ChainBFwd, ChainSBwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
+                   EPI_RESID, EPI_SILU2, ChainABFwd, ChainABwd, ChainAFwd, ChainBFwd, ChainSBwd, ChainTBwd, GemmNT, GemmTN, MlpBwd, MlpFwd, ReadoutCE)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -202,6 +202,15 @@ def make_chain_s_bwd(*, M: int, segs, dqkv: int, dx: int, xhat: int, rstd: int, 
     g.dqkv, g.ldq, g.dx = dqkv, ldq, dx
     g.xhat, g.rstd, g.dx_bf16 = xhat, rstd, dx_bf16
     g.M, g.hb_rows = M, hb_rows
+    return g
+
+
+def make_chain_t_bwd(*, B: int, SA: int, segs, dy_bf16: int, qkv: int, dqkv: int, attn_scale: float, T: int = 16) -> ChainTBwd:
+    """segs: the packed transposed temporal projection (8 bundles).  Rows (b, t, s), M = 16 B SA."""
+    g = ChainTBwd()
+    _chain_weights(g.w, segs)
+    g.dy_bf16, g.qkv, g.dqkv = dy_bf16, qkv, dqkv
+    g.B, g.T, g.SA, g.attn_scale = B, T, SA, attn_scale
     return g
 
 

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import A_F32, EPI_ATOMIC_F32, EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GELU2, EPI_RESID, EPI_SILU2
-from .ops import (make_chain_ab_fwd, make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_chain_s_bwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd,
+from .ops import (make_chain_ab_fwd, make_chain_a_bwd, make_chain_a_fwd, make_chain_b_fwd, make_chain_s_bwd, make_chain_t_bwd, make_gemm_nt, make_gemm_tn, make_mlp_bwd,
                   make_mlp_fwd, make_readout_ce)
 
 
@@ -141,6 +141,13 @@ class Plan:
         self.keep.append(g)
         # dqkv 1536 + xhat 512 + dx 1024 in; dx 1024 + bf16(dx) 512 out
         self.add("hma_chain_s_bwd", C.byref(g), flops=2.0 * M * 256 * 768, nbytes=(1536 + 512 + 1024 + 1024 + 512) * float(M))
+
+    def chain_t_bwd(self, B: int, SA: int, **kw) -> None:
+        g = make_chain_t_bwd(B=B, SA=SA, **kw)
+        self.keep.append(g)
+        M = 16.0 * B * SA
+        # bf16(dx) 512 + qkv 1536 in; dqkv 1536 out.  Projection dgrad + the attention's five products per head (as hma_attn_temporal_bwd)
+        self.add("hma_chain_t_bwd", C.byref(g), flops=2.0 * M * 256 * 256 + 10.0 * M * 16 * 256, nbytes=(512 + 1536 + 1536) * M)
 
     def readout_ce(self, rows: int, **kw) -> None:
         g = make_readout_ce(rows=rows, **kw)

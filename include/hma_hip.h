@@ -482,6 +482,21 @@ typedef struct {
 } hma_chain_s_bwd_t;
 int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p);
 
+/* Chain T backward -- the temporal attention's backward of a block in one launch (st_transformer.py:111; attention.py:37-61 causal and
+ * :60 proj, autograd mirror), training passes over windows of exactly T = 16 frames: what hma_gemm_nt (d_o = bf16(dx) Wproj) and
+ * hma_attn_temporal_bwd did in two launches with d_o's round trip through HBM.  A compute wave owns the 16 frames of a (sample, token
+ * position) column.  Rows are (b, t, s), s fastest, SA rows per frame, B samples, M = 16 B SA.
+ * in: dy_bf16 [M,256] bf16 (the gradient of the block's x behind the temporal attention's residual add), qkv [M,768] bf16 (saved by the
+ * forward); out: dqkv [M,768] bf16 (dq, dk scaled by attn_scale as hma_attn_temporal_bwd writes them).
+ * weights: the 8 N-block bundles of Wproj^T (hma_chain_pack of the transposed weight, kind 0). */
+typedef struct {
+  hma_chain_weights_t w;
+  const void* dy_bf16; const void* qkv; void* dqkv;
+  int64_t B; int32_t T; int32_t SA;
+  float attn_scale; int32_t _pad;
+} hma_chain_t_bwd_t;
+int hma_chain_t_bwd(void* stream, const hma_chain_t_bwd_t* p);
+
 /* Chain B forward (inference / decode passes, and training passes with the fields at the end of the struct): st_transformer.py:111
  * proj, :112 norm2 + Mlp (:24-27), and the NEXT block's :85-86 norm1 + qkv (attention.py:39):
  *   x1 = x + o Wproj^T + b_proj;  x2 = x1 + fc2(gelu(fc1(LN(x1)))) ;  qkv = LN(x2) Wqkv'^T + b_qkv'

@@ -207,6 +207,44 @@ def test_chain_s_bwd(M):
     assert (dxd.cpu() - dx1).abs().max() < 0.2 * (dxd.cpu() - dx1.flip(0)).abs().max()
 
 
+@pytest.mark.parametrize("B,SA", [(1, 1), (1, 16), (2, 48), (3, 320), (5, 77), (32, 320)])
+def test_chain_t_bwd(B, SA):
+    """hma_chain_t_bwd -- the temporal projection's input gradient + the causal attention backward of every (sample, token) column in
+    one launch -- against (a) the two launches it replaces (hma_gemm_nt, hma_attn_temporal_bwd) and (b) an fp32 autograd reference.
+    Reference: hma/model/st_transformer.py:111, hma/model/attention.py:37-61 (autograd mirror)."""
+    T, scale = 16, 0.25
+    M = B * T * SA
+    wp = rb(torch.randn(256, 256, generator=g(900)) * 0.06)          # proj.weight [out][in]
+    qkv = rb(torch.randn(M, 768, generator=g(901)))
+    dy = rb(torch.randn(M, 256, generator=g(902)) * 0.05)
+    qd, dyd = qkv.to(DEV).bfloat16(), dy.to(DEV).bfloat16()
+    wt = _pack_t(wp)
+    dq = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
+    a = ops.make_chain_t_bwd(B=B, SA=SA, segs=[(ops.ptr(wt), 8)], dy_bf16=ops.ptr(dyd), qkv=ops.ptr(qd), dqkv=ops.ptr(dq), attn_scale=scale)
+    _lib.call("hma_chain_t_bwd", ops.stream_ptr(), C.byref(a))
+    torch.cuda.synchronize()
+    # (a) two launches: d_o = dy Wproj as bf16, then the attention backward
+    d_o = ops.linear(dyd, wp.t().contiguous().to(DEV).bfloat16(), epi=ops.EPI_BF16)
+    o = ops.attn_temporal_fwd(qd, B, T, SA, scale)
+    dq2 = ops.attn_temporal_bwd(qd, o, d_o, B, T, SA, scale)
+    torch.cuda.synchronize()
+    close(dq, dq2, 2 * BF, "chain T vs two launches")
+    assert rms(dq, dq2) < 2e-3
+    # (b) fp32 autograd on the same bf16 inputs (small cases)
+    if M <= 16 * 3 * 320:
+        idx = torch.arange(M).reshape(B, T, SA).permute(0, 2, 1).reshape(-1)
+        qr = qkv.clone().requires_grad_(True)
+        cols = qr[idx].reshape(B * SA, T, 3, 8, 32)
+        q, k, v = (cols[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        att = (q @ k.transpose(-1, -2)) * scale
+        att = att.masked_fill(torch.ones(T, T).triu(1).bool(), float("-inf")).softmax(-1)
+        o_ref = (att @ v).permute(0, 2, 1, 3).reshape(B * SA * T, 256)
+        o_ref.backward(rb(dy @ wp)[idx])
+        close(dq, qr.grad, 4 * BF, "chain T vs autograd")
+        assert rms(dq, qr.grad) < 1e-2
+        assert (dq.float().cpu() - qr.grad).abs().max() < 0.2 * (dq.float().cpu() - qr.grad.flip(0)).abs().max()
+
+
 @pytest.mark.parametrize("M,with_qkv,save", [(112, True, False), (1008, True, True), (20480, True, False), (40960, True, True), (163840, True, True),
                                              (2560, False, False), (2560, False, True)])
 def test_chain_b_fwd(M, with_qkv, save):

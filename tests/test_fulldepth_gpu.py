@@ -189,7 +189,7 @@ def test_trainer_graph_replay_b2_vs_oracle():
     plan_names = {name for pl in eng._plans.values() for _, name, _ in pl.calls}
     # (the kernels of the timed step: the fused forward chain over 16-frame columns, the fused MLP backward, the backward chains, the
     # block's weight gradients in one launch, readout + cross-entropy in one launch)
-    assert {"hma_chain_ab_fwd", "hma_mlp_bwd", "hma_chain_a_bwd", "hma_chain_s_bwd", "hma_gemm_tn_multi", "hma_attn_spatial_bwd_blocked",
+    assert {"hma_chain_ab_fwd", "hma_mlp_bwd", "hma_chain_t_bwd", "hma_chain_a_bwd", "hma_chain_s_bwd", "hma_gemm_tn_multi", "hma_attn_spatial_bwd_blocked",
             "hma_readout_ce"} <= plan_names, plan_names
     dl = abs(loss - loss_ref.item())
     _note("trainer_b2.loss_abs_err", dl)

@@ -27,6 +27,7 @@ FAMILY_KERNELS = {
     "hma_chain_a_fwd": (("chain_a_fwd_kernel",), "chain_a_fwd_kernel"),
     "hma_chain_a_bwd": (("chain_a_bwd_kernel",), "chain_a_bwd_kernel"),
     "hma_chain_s_bwd": (("chain_s_bwd_kernel",), "chain_s_bwd_kernel"),
+    "hma_chain_t_bwd": (("chain_t_bwd_kernel",), "chain_t_bwd_kernel"),
     "hma_attn_spatial_fwd": (("attn_fwd_kernel",), "attn_fwd_kernel"),
     "hma_attn_spatial_bwd_blocked": (("attn_bwd_bal_kernel", "attn_bwd_fused_kernel"), "attn_bwd_"),
     "hma_attn_spatial_bwd": (("attn_bwd_bal_kernel", "attn_bwd_fused_kernel"), "attn_bwd_"),
