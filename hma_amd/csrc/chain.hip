@@ -1790,7 +1790,6 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
   HMA_LDS(char)* biasA = lds + L_BIAS + 32 * g;
   HMA_LDS(char)* biasB = lds + L_BIAS + 4 * BB + 32 * g;
   HMA_LDS(char)* scrV = lds + L_SCR + wave * 2048;
-  HMA_LDS(char)* scrO = scrV + 1024;
   const line_offs Lb = make_lines(512 * SA, tok, 16 * g, 64);        // bf16 [., 256] arrays, rows SA apart
   const line_offs Lf = make_lines(1024 * SA, tok, 32 * g, 16);       // fp32 [., 256]
   const line_offs Lq = make_lines(1536 * SA, tok, 16 * g, 64);       // qkv [., 768]
@@ -1970,19 +1969,20 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
             const uint2 pw = make_uint2(pack_bf16(st[0] * inv, st[1] * inv), pack_bf16(st[2] * inv, st[3] * inv));
             const s16x4v_t pT = __builtin_bit_cast(s16x4v_t, pw);  // B: k = key, n = query
             asm volatile("" ::: "memory");
+            // A = V^T by ONE ds_read_b64_tr_b16 per product (see chain T backward): output row i of product dd = channel
+            // 8 (i >> 2) + 4 dd + (i & 3), so the lane ends with channels 8 g .. 8 g + 7 of its frame -- o_t of head h in B-operand form
+            // without a second trip through LDS
+            typedef short ab_v4s16_t __attribute__((ext_vector_type(4)));
+            f32x4v_t od[2];
 #pragma unroll
             for (int dd = 0; dd < 2; ++dd) {
-              // A = V^T: lane (d = 16 dd + tok, keys 4 g .. 4 g + 3)
-              s16x4v_t vT;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) vT[j] = (short)*(HMA_LDS(uint16_t)*)(scrV + (4 * g + j) * 64 + (16 * dd + tok) * 2);
-              const f32x4v_t od = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vT, pT, z4, 0, 0, 0);  // [d = 16 dd + 4 g + r][query = tok]
-              typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
-              *(HMA_LDS(u32x2_t)*)(scrO + tok * 64 + (16 * dd + 4 * g) * 2) = u32x2_t{pack_bf16(od[0], od[1]), pack_bf16(od[2], od[3])};
+              const s16x4v_t vT = __builtin_bit_cast(
+                  s16x4v_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(ab_v4s16_t)*)(scrV + (4 * g + (tok >> 2)) * 64 + 16 * (tok & 3) + 8 * dd)));
+              od[dd] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vT, pT, z4, 0, 0, 0);  // [channel 8 g + 4 dd + r][query = tok]
             }
             asm volatile("" ::: "memory");
-            a1[h] = as_frag(__builtin_bit_cast(uint4, *(HMA_LDS(u32x4_t)*)(scrO + tok * 64 + 16 * g)));  // o_t of head h as a B operand
-            asm volatile("" ::: "memory");
+            a1[h] = as_frag(make_uint4(pack_bf16(od[0][0], od[0][1]), pack_bf16(od[0][2], od[0][3]), pack_bf16(od[1][0], od[1][1]),
+                                       pack_bf16(od[1][2], od[1][3])));
           }
 #pragma unroll
           for (int pp = 0; pp < 4; ++pp)
