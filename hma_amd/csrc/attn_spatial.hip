@@ -540,27 +540,32 @@ struct FusedStage {
                                         int64_t frames, int tid, int part = -1) {
     int64_t frame; int head;
     decode_block(item, frames, frame, head);
+    // Wave-uniform bases + 32-bit lane offsets recomputed from an OPAQUE thread index at every call: as loop invariants of the item loop
+    // the 64-bit row offsets of the R chunks (and stage()'s LDS offsets) stay in registers -- 27 of them went to scratch, and a scratch
+    // reload is a vector-memory load whose wait also drains the previous item's dqkv stores.
+    asm volatile("" : "+v"(tid));
     const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
     const uint16_t* gb = d_o + frame * N * DM + head * HD;
     const uint16_t* ob = o + frame * N * DM + head * HD;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       if (part >= 0 && part != i) continue;
-      const int c = min(tid + i * THREADS, ITEMS - 1);
-      const int64_t row = c >> 2;
-      const int ch = (c & 3) * 8;
-      put(rq, i, *reinterpret_cast<const uint4*>(base + row * QKV_LD + ch));
-      put(rk, i, *reinterpret_cast<const uint4*>(base + DM + row * QKV_LD + ch));
-      put(rv, i, *reinterpret_cast<const uint4*>(base + 2 * DM + row * QKV_LD + ch));
-      put(rg, i, *reinterpret_cast<const uint4*>(gb + row * DM + ch));
-      put(ro, i, *reinterpret_cast<const uint4*>(ob + row * DM + ch));
+      const uint32_t c = (uint32_t)min(tid + i * THREADS, ITEMS - 1);
+      const uint32_t row = c >> 2, ch = (c & 3) * 8;
+      const uint32_t oq = row * QKV_LD + ch, og = row * DM + ch;
+      put(rq, i, *reinterpret_cast<const uint4*>(base + oq));
+      put(rk, i, *reinterpret_cast<const uint4*>(base + DM + oq));
+      put(rv, i, *reinterpret_cast<const uint4*>(base + 2 * DM + oq));
+      put(rg, i, *reinterpret_cast<const uint4*>(gb + og));
+      put(ro, i, *reinterpret_cast<const uint4*>(ob + og));
     }
-    if (part <= 0) rl = lse[(frame * N + min(tid, N - 1)) * NH + head];
+    if (part <= 0) rl = (lse + frame * N * NH + head)[(uint32_t)min(tid, N - 1) * NH];
   }
   __device__ __forceinline__ void stage(uint16_t* Qs, uint16_t* Ks, uint16_t* Vs, uint16_t* Gs, float* L2s, float* Dls, float* delta,
                                         int64_t item, int64_t frames, int tid) const {
     int64_t frame; int head;
     decode_block(item, frames, frame, head);
+    asm volatile("" : "+v"(tid));  // (see fetch)
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int c = min(tid + i * THREADS, ITEMS - 1);
@@ -581,7 +586,7 @@ struct FusedStage {
       dsum += __shfl_xor(dsum, 2, 64);
       if ((c & 3) == 0) {
         Dls[c >> 2] = NEG_DELTA ? -dsum : dsum;  // (NEG_DELTA: the dP accumulators start from -delta, see attn_bwd_bal_kernel)
-        delta[(frame * N + (c >> 2)) * NH + head] = dsum;
+        (delta + frame * N * NH + head)[(uint32_t)(c >> 2) * NH] = dsum;
       }
     }
     if (tid < N) L2s[tid] = rl;

@@ -1765,16 +1765,21 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
   uint4 hqs[8];   // packed xhat_m of the tile in flight
   uint4 qv[24];   // the temporal q | k | v blocks (block pq = head pq & 7 of part pq >> 3)
   uint4 qb[8];    // the next block's spatial qkv blocks waiting for their burst
+  const uint32_t lofs = (uint32_t)tok * (uint32_t)SA * 256u + 8u * (uint32_t)g, tok_sa = (uint32_t)tok * (uint32_t)SA;
   auto prefetch = [&](int tl, auto part_) __attribute__((always_inline)) {  // the next tile's o_s (8 loads) and x (16) rows
     constexpr int part = decltype(part_)::value;
     int64_t c = col_of(tl);
     c = c < cmap.end ? c : cmap.end - 1;
-    const int64_t m = row_of(c) + (int64_t)tok * SA;
-    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o_s) + m * 256 + 8 * g;
+    // (a wave-uniform base + this lane's 32-bit element offset `lofs`: per-lane 64-bit row pointers are loop invariants the compiler
+    // keeps in registers -- and spills: a scratch reload is a vector-memory load, and waiting for it drains every store in flight)
+    const int64_t mu = row_of(c) * 256;
+    uint32_t lo = lofs;
+    asm volatile("" : "+v"(lo));  // (opaque: keeps `array + lofs` from being hoisted as a 64-bit pointer per array)
+    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o_s) + mu + lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (part < 0 || j / 2 == part) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
-    const float* xrow = p.x + m * 256 + 8 * g;
+    const float* xrow = p.x + mu + lo;
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
       if (part < 0 || pr + 4 == part) {
@@ -1827,7 +1832,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp)
       store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
-    rstd_out[rc + (int64_t)tok * SA] = rstd;
+    (rstd_out + rc)[tok_sa] = rstd;
   };
 
 #pragma unroll 1
@@ -1912,7 +1917,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
             for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(h[e], 1.0f + sc[e], sh[e]);
             a1[pr] = as_frag(pack8(mm));
           }
-          p.rstd_m[rc + (int64_t)tok * SA] = rstd;
+          (p.rstd_m + rc)[tok_sa] = rstd;
 #pragma unroll
           for (int pp = 0; pp < 4; ++pp) store_lines<false>(stg_, xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
 #pragma unroll
@@ -2157,7 +2162,9 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_
       continue;
     }
     const int64_t rc = row_of(col);
-    uint16_t* dq_out = reinterpret_cast<uint16_t*>(p.dqkv) + rc * 768;
+    // (CH_ABL & 32, measurement: every tile of the workgroup stores into its FIRST tile's rows -- the same store instructions, but the lines
+    // stay in L2 / MALL instead of going to HBM: what the stores cost when HBM writes are not the limit)
+    uint16_t* dq_out = reinterpret_cast<uint16_t*>(p.dqkv) + ((CH_ABL & 32) ? row_of(cmap.base + wave) : rc) * 768;
     const int64_t mn = lane_row(tl + 1 < nt ? tl + 1 : tl);
 #pragma unroll
     for (int j = 0; j < 8; ++j) a0[j] = a1[j];
@@ -2169,9 +2176,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_
       // ---- d_o of head h = bf16(dx) Wproj[:, 32 h .. 32 h + 31]
       f32x4v_t c0 = z4, c1 = z4;
       nb_mma(wb, a0, c0, c1);
-      if constexpr ((h & 1) == 1) {  // the next tile's bf16(dx) row: the two 64-byte halves of a line by back-to-back loads
-        load_dy(mn, std::integral_constant<int, h - 1>{});
-        load_dy(mn, sc_);
+      if constexpr (h == 0) {
+        // the next tile's bf16(dx) row, all of it in the first step: the opaque use of a1 at the end of the tile (where the compiler can
+        // count the stores issued since) then waits for loads that are seven steps old and for none of this tile's stores
+        static_for<8>([&](auto j_) __attribute__((always_inline)) { load_dy(mn, j_); });
       }
       const bf16x8_t aG = as_frag(pack_pair(c0, c1));
       const bf16x8_t aQ = qf[h], aK = qf[8 + h], aV = qf[16 + h];
