@@ -522,6 +522,14 @@ __device__ __forceinline__ bf16x8_t frag_tr_f(const uint16_t* tile, int row0, in
 // LDS-only barrier: waits for this wave's LDS operations, not for its global loads (the next item's rows stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_i_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N_, typename F>
+__device__ __forceinline__ void static_for_i(F&& f) {
+  static_for_i_impl(std::make_integer_sequence<int, N_>{}, static_cast<F&&>(f));
+}
 template <int NT, int KT = 1, int THREADS_ = (NT / KT + 2) * 64, bool NEG_DELTA = false>
 struct FusedStage {
   static constexpr int N = NT * 32, ITEMS = N * 4, THREADS = THREADS_, R = (ITEMS + THREADS - 1) / THREADS;
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
   const int64_t nitems = frames * NH;
 
   // ---- one (frame, head) item of a tile wave: KT key tiles from tile kt0 on
-  auto tile_item = [&](auto kt_c, const int kt0, const int64_t frame, const int head) __attribute__((always_inline)) {
+  auto tile_item = [&](auto kt_c, const int kt0, const int64_t frame, const int head, auto peel_c, auto&& hook) __attribute__((always_inline)) {
     constexpr int KT = decltype(kt_c)::value;
     bf16x8_t kf[KT][2], vf[KT][2];
     f32x16_t dk[KT], dv[KT];
@@ -810,8 +818,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
       vf[t][0] = frag_rows_f(Vs, (kt0 + t) * 32, 0, lane); vf[t][1] = frag_rows_f(Vs, (kt0 + t) * 32, 1, lane);
       dk[t] = zero16(); dv[t] = zero16();
     }
-#pragma unroll 1
-    for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+    auto step = [&](const int qt) __attribute__((always_inline)) {
       // S[q][key], dP[q][key]: lane = key, rows = q.  The query tile's fragments serve every key tile of the wave.
       const bf16x8_t aq0 = frag_rows_f(Qs, qt * 32, 0, lane), aq1 = frag_rows_f(Qs, qt * 32, 1, lane);
       const bf16x8_t ag0 = frag_rows_f(Gs, qt * 32, 0, lane), ag1 = frag_rows_f(Gs, qt * 32, 1, lane);
@@ -865,6 +872,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
           dk[t] = mfma32(qtr, pack_acc_half(dp[t], s2), dk[t]);
         }
       }
+    };
+    // the first PEEL steps are straight-line code with the hook's part index a compile-time constant (the fetch registers are indexed
+    // by it), the rest is a loop
+    constexpr int PEEL = decltype(peel_c)::value;
+    if (!(ATTN_ABL & 32)) {
+      static_for_i<PEEL>([&](auto i_) __attribute__((always_inline)) {
+        hook(i_);
+        step(decltype(i_)::value);
+      });
+#pragma unroll 1
+      for (int qt = PEEL; qt < NT; ++qt) step(qt);
     }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -877,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
   };
   // ---- one item of the dQ wave: dQ^T[d][q] of query tile qt = sum over the keys of K^T[d][key] dS^T[key][q], while the tile waves
   // work on query tile qt + 1 (which goes to the other dS buffer)
-  auto dq_item = [&](const int64_t frame, const int head) __attribute__((always_inline)) {
+  auto dq_item = [&](const int64_t frame, const int head, auto peel_c, auto&& hook) __attribute__((always_inline)) {
     // K^T of the item as A-operand fragments: the first KREG of the 2 NT k-steps of 16 keys stay in registers this wave has (it owns
     // no tile) and are read ONCE per item instead of once per query tile -- the dQ wave is the slowest wave of a step (no dQ job:
     // 325 -> 271 us), and half of its job's read -> MFMA round trips are K^T reads
@@ -888,8 +906,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
     bf16x8_t kt[2 * NT];
 #pragma unroll
     for (int i = 0; i < KREG; ++i) kt[i] = frag_tr_f(Ks, 16 * i, lane);
-#pragma unroll 1
-    for (int qt = 0; qt < ((ATTN_ABL & 32) ? 0 : NT); ++qt) {
+    auto step = [&](const int qt) __attribute__((always_inline)) {
       lds_barrier();
       if (!(ATTN_ABL & 2)) {
         const uint16_t* Tq = Ts + (qt & 1) * N * LDF;
@@ -920,6 +937,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
         for (int e = 0; e < 16; ++e) a0[e] += a1[e];
         if (!(ATTN_ABL & 128)) store_grad_tile(dqkv, hb, frame, head, 0, N, qt * 32, a0, scale, lane);
       }
+    };
+    constexpr int PEEL = decltype(peel_c)::value;
+    if (!(ATTN_ABL & 32)) {
+      static_for_i<PEEL>([&](auto i_) __attribute__((always_inline)) {
+        hook(i_);
+        step(decltype(i_)::value);
+      });
+#pragma unroll 1
+      for (int qt = PEEL; qt < NT; ++qt) step(qt);
     }
   };
 
@@ -930,7 +956,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
       lds_barrier();  // the item is staged
       int64_t frame; int head;
       decode_block(item, frames, frame, head);
-      tile_item(std::integral_constant<int, 2>{}, 2 * wave, frame, head);
+      tile_item(std::integral_constant<int, 2>{}, 2 * wave, frame, head, std::integral_constant<int, 0>{}, [](auto) {});
       lds_barrier();  // every wave is done with this item's LDS before the next one is staged
     }
   } else {
@@ -944,16 +970,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
       st.stage(Qs, Ks, Vs, Gs, L2s, Dls, delta, item, frames, ftid);
       lds_barrier();  // (LDS-only barriers throughout: a __syncthreads would also drain the previous item's dqkv stores)
       const int64_t nxt = item + gridDim.x;
-      if (nxt < nitems && !(ATTN_ABL & 64)) st.fetch(qkv, o, d_o, lse, nxt, frames, ftid);
+#ifndef ATTN_PF_SPREAD  // 1: the next item's rows are requested a part (five loads per thread) per step of this item instead of all at its start
+#define ATTN_PF_SPREAD 1
+#endif
+      const bool more = nxt < nitems && !(ATTN_ABL & 64);
+      if (more && !ATTN_PF_SPREAD) st.fetch(qkv, o, d_o, lse, nxt, frames, ftid);
+      constexpr int PEEL = ATTN_PF_SPREAD ? decltype(st)::R : 0;
+      const int64_t nxt_c = more ? nxt : item;  // (unconditional: the last item's loads are repeated rather than the register vectors written under a branch)
+      auto hook = [&](auto part_) __attribute__((always_inline)) {
+        st.fetch(qkv, o, d_o, lse, nxt_c, frames, ftid, decltype(part_)::value);
+      };
       int64_t frame; int head;
       decode_block(item, frames, frame, head);
       if (wave == 7) {
 #ifdef ATTN_DQ_PRIO  // (measurement builds: the dQ wave, the slowest of every step, ahead of the tile wave it shares a SIMD with)
         __builtin_amdgcn_s_setprio(ATTN_DQ_PRIO);
 #endif
-        dq_item(frame, head);
+        dq_item(frame, head, std::integral_constant<int, PEEL>{}, hook);
       }
-      else tile_item(std::integral_constant<int, 1>{}, 2 * HEAVY + (wave - HEAVY), frame, head);
+      else tile_item(std::integral_constant<int, 1>{}, 2 * HEAVY + (wave - HEAVY), frame, head, std::integral_constant<int, PEEL>{}, hook);
       lds_barrier();
     }
   }
