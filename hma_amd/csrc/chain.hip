@@ -2162,9 +2162,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_
       continue;
     }
     const int64_t rc = row_of(col);
-    // (CH_ABL & 32, measurement: every tile of the workgroup stores into its FIRST tile's rows -- the same store instructions, but the lines
-    // stay in L2 / MALL instead of going to HBM: what the stores cost when HBM writes are not the limit)
-    uint16_t* dq_out = reinterpret_cast<uint16_t*>(p.dqkv) + ((CH_ABL & 32) ? row_of(cmap.base + wave) : rc) * 768;
+    uint16_t* dq_out = reinterpret_cast<uint16_t*>(p.dqkv) + rc * 768;
     const int64_t mn = lane_row(tl + 1 < nt ? tl + 1 : tl);
 #pragma unroll
     for (int j = 0; j < 8; ++j) a0[j] = a1[j];
