@@ -168,7 +168,9 @@ def test_segmented_graphs_equal_one_graph():
         GB, lB = _grad_of(trB, ids, labels, act, dom)
     assert len(next(iter(trB._graphs.values()))) == 3 and len(next(iter(trA._graphs.values()))) == 1
     errs = _region_errs(trA.engine.layout, GA, GB, dom)
-    assert abs(lA - lB) <= 1e-5 and max(errs.values()) <= 1e-3, (lA, lB, errs)
+    # (the loss is a sum of per-wave partial sums by fp32 atomics: their order differs from run to run, +-1.3e-5 at a loss of 12.5 has
+    # been observed between two runs of the SAME graph; the gradients agree to 1e-8)
+    assert abs(lA - lB) <= 1e-4 and max(errs.values()) <= 1e-3, (lA, lB, errs)
 
 
 @pytest.mark.timeout(900)
