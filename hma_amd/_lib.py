@@ -244,7 +244,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = c_i32
-        if lib.hma_abi_version() != 0x484D4102:
+        if lib.hma_abi_version() != 0x484D4103:
             raise HmaKernelError("libhma_hip.so ABI mismatch: rebuild with `python -m hma_amd.build --force`")
         _lib = lib
     return _lib

@@ -2407,10 +2407,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void readout_ce_kernel(hma_readout_c
     loss_acc += __shfl_xor(loss_acc, o, 64);
     acc_acc += __shfl_xor(acc_acc, o, 64);
   }
-  if (lane == 0 && (loss_acc != 0.f || acc_acc != 0.f)) {
-    atomicAdd(p.stats + 0, loss_acc);
-    atomicAdd(p.stats + 1, acc_acc);
-  }
+  if (lane == 0 && acc_acc != 0.f) atomicAdd(p.stats + 1, acc_acc);
+  det_loss_add(p.stats, loss_acc, lane, gridDim.x * (unsigned)NW);  // (every compute wave gets here, also one whose rows lie past the matrix)
 }
 
 template <auto Kern>

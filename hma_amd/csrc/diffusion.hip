@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void diff_loss_kernel(const float* __restrict_
     dout[row * ldo + C + lane] = d_v * w;
   }
   }
-  if (lane == 0) atomicAdd(stats, acc);
+  det_loss_add(stats, acc, lane, gridDim.x * 4u);  // (order-independent: hma_common.h)
 }
 
 // ---------------------------------------------------------------- one reverse step of the sampler

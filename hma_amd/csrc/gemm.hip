@@ -1500,6 +1500,9 @@ constexpr int DM_STAGE_BYTES = 2 * DM_TILE_BYTES;
 #ifndef TN_INTERLEAVE
 #define TN_INTERLEAVE 0
 #endif
+#ifndef TN_SPREAD
+#define TN_SPREAD 1
+#endif
 constexpr int DM_STAGES = DM_STAGES_N;  // 4 x 32 KB (5 slots, the whole LDS, measured the same)
 constexpr int DM_SMEM_BYTES = DM_STAGES * DM_STAGE_BYTES;
 
@@ -1592,12 +1595,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
       for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
   // wave w fills rows 4 w .. 4 w + 3 of both tiles of a stage: two 1 KB pieces (two rows each) per tile
-  auto issue = [&](int st, int slot) __attribute__((always_inline)) {
+  // parts: bit mask of the stage's four pieces of this wave (bit 2 q + {0: dY, 1: A}); 15 = all four at once
+  auto issue_parts = [&](int st, int slot, int parts) __attribute__((always_inline)) {
     if (ablate & 1) return;
     const int64_t m0 = st_row0 + (int64_t)st * st_pitch;
     const uint32_t slot_b = lds_b + slot * DM_STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+      if (!((parts >> (2 * q)) & 3)) continue;
       const int rl = q * 2 + (lane >> 5);                 // row & 3 (4 w is a multiple of 4)
       const int lc = (lane & 31) ^ (rl << 2);             // logical chunk that lands in this lane's slot
       const int64_t m = m0 + wave * 4 + rl;
@@ -1621,10 +1626,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
       const uint16_t* as = p.afrag ? frag_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8)
                            : p.ahb > 0 ? hb_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8, p.ahb)
                                        : Ab + m * p.lda + lc * 8;
-      glds16(ys, slot_b + (wave * 4 + q * 2) * 512);
-      glds16(as, slot_b + DM_TILE_BYTES + (wave * 4 + q * 2) * 512);
+      if ((parts >> (2 * q)) & 1) glds16(ys, slot_b + (wave * 4 + q * 2) * 512);
+      if ((parts >> (2 * q)) & 2) glds16(as, slot_b + DM_TILE_BYTES + (wave * 4 + q * 2) * 512);
     }
   };
+  auto issue = [&](int st, int slot) __attribute__((always_inline)) { issue_parts(st, slot, 15); };
 
   const int r = lane & 31, hi = lane >> 5;
   const int i16 = lane & 15, g16 = lane >> 4;
@@ -1663,6 +1669,43 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     for (int i = 0; i < 4; ++i) f.y[i] = frag(Ys, wn2 * 128 + ((i + wk4) & 3) * 32, kk);  // y[i] = n-block (i + wk4) & 3
 #pragma unroll
     for (int j = 0; j < 2; ++j) f.a[j] = frag(As, wk4 * 64 + j * 32, kk);
+  };
+  // TN_SPREAD: the refill's four pieces are issued ONE AT A TIME between the MFMAs of a stage (piece k behind MFMA 4 k + 3 of the
+  // sixteen) instead of as a burst between the two groups: a wave blocks at the issue of a vector-memory instruction while the CU's
+  // memory pipeline is full (the kernel is HBM-bound: that is its normal state), and a burst of four makes the wave sit out ~1 000
+  // cycles per stage with the matrix pipe idle behind its last MFMA
+  auto mma_spread = [&](const Frags& f, int half, int st_next, int slot_next, bool refill) __attribute__((always_inline)) {
+    if (COLSUM) {  // (as in mma below)
+      const uint4 ys = __builtin_bit_cast(uint4, f.y[0]);
+      const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.x), ones, colsum, false);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.y), ones, colsum, false);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.z), ones, colsum, false);
+      colsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ys.w), ones, colsum, false);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (ablate & 2)
+          acc[i][j][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f.a[j]).x ^ __builtin_bit_cast(uint4, f.y[i]).y);
+        else
+          acc[i][j] = mfma32(f.a[j], f.y[i], acc[i][j]);
+      }
+#if TN_SPREAD == 2  // (measurement: the waves of a half issue at different MFMA positions -- wave wk4 behind group (i + wk4) & 3)
+      if (((i + wk4) & 1) == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (refill) issue_parts(st_next, slot_next, 1 << (2 * half + (((i + wk4) & 3) >> 1)));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+      if ((i & 1) == 1) {
+        __builtin_amdgcn_sched_barrier(0);  // (the piece stays where it is written: between the MFMA groups)
+        if (refill) issue_parts(st_next, slot_next, 1 << (2 * half + (i >> 1)));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    }
   };
   auto mma = [&](const Frags& f) __attribute__((always_inline)) {
     if (COLSUM) {
@@ -1713,22 +1756,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
   // then multiplies; the second multiplies the PREVIOUS stage's fragments (still in its registers) and then reads this
   // stage's -- so one wave's LDS reads sit under the other's MFMAs instead of all eight waves reading, then all eight
   // multiplying.  The lagging half finishes its reads before the next barrier (the slot is refilled behind it).
+  PROF_DECL;
   if (wn2 == 0) {
     for (int st = 0; st < nst; ++st) {
       wait_stage(st, DM_STAGES - 2);
+      PROF_MARK(0);
       if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
+      PROF_MARK(1);
 #if TN_PHASE == 2
       if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
 #endif
       read_frags(f0, slot, 0);
       read_frags(f1, slot, 1);
+#ifdef HMA_PROF
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      PROF_MARK(2);
+#if TN_SPREAD
+      {
+        const bool refill = st + DM_STAGES - 1 < nst;
+        const int sn = st + DM_STAGES - 1, sl = slot == 0 ? DM_STAGES - 1 : slot - 1;
+        mma_spread(f0, 0, sn, sl, refill);
+        mma_spread(f1, 1, sn, sl, refill);
+      }
+      PROF_MARK(3);
+#else
       mma(f0);
+      PROF_MARK(3);
 #if TN_PHASE != 2
       if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
 #endif
+      PROF_MARK(4);
       mma(f1);
+      PROF_MARK(3);
+#endif
       slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
     }
+    PROF_MARK(5);
+#ifdef HMA_PROF
+    if (wave == 0) PROF_FLUSH();
+#endif
   } else {
     wait_stage(0, DM_STAGES - 2);
     if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
@@ -1740,9 +1807,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     for (int st = 1; st < nst; ++st) {
       wait_stage(st, DM_STAGES - 2);
       if (!(ablate & 16)) __builtin_amdgcn_s_barrier();
+#if TN_SPREAD
+      {
+        const bool refill = st + DM_STAGES - 1 < nst;
+        const int sn = st + DM_STAGES - 1, sl = slot == 0 ? DM_STAGES - 1 : slot - 1;
+        mma_spread(f0, 0, sn, sl, refill);
+        mma_spread(f1, 1, sn, sl, refill);
+      }
+#else
       mma(f0);
       mma(f1);
       if (st + DM_STAGES - 1 < nst) issue(st + DM_STAGES - 1, slot == 0 ? DM_STAGES - 1 : slot - 1);
+#endif
       read_frags(f0, slot, 0);
       read_frags(f1, slot, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2484,6 +2560,22 @@ static int tn_dma_launch(hipStream_t s, const tn_pair_args& a) {
   }
   const dim3 grid(nb);
   int rc;
+#ifdef HMA_PROF
+  {
+    static const int abl = getenv("HMA_GEMM_TN_ABLATE") ? atoi(getenv("HMA_GEMM_TN_ABLATE")) : 0;  // debug build only
+#define HMA_TNM_ABL(A)                                                                                  \
+  case A:                                                                                               \
+    if ((rc = set_smem_bytes<gemm_tn_dma_kernel<true, true, A>>(DM_SMEM_BYTES))) return rc;             \
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<true, true, A>), grid, dim3(512), DM_SMEM_BYTES, s, a);      \
+    HMA_CHECK_LAUNCH();                                                                                 \
+    return 0;
+    switch (abl) {
+      HMA_TNM_ABL(1) HMA_TNM_ABL(2) HMA_TNM_ABL(4) HMA_TNM_ABL(8) HMA_TNM_ABL(16) HMA_TNM_ABL(6) HMA_TNM_ABL(7) HMA_TNM_ABL(15)
+      HMA_TNM_ABL(3) HMA_TNM_ABL(9) HMA_TNM_ABL(24)
+      default: break;
+    }
+  }
+#endif
   if (cs) {
     if ((rc = set_smem_bytes<gemm_tn_dma_kernel<TR, true>>(DM_SMEM_BYTES))) return rc;
     hipLaunchKernelGGL((gemm_tn_dma_kernel<TR, true>), grid, dim3(512), DM_SMEM_BYTES, s, a);
@@ -2630,7 +2722,7 @@ extern "C" int hma_gemm_tn_multi(void* stream, const hma_gemm_tn_t* const* probs
     wsum += tn_weight(q, n);
   }
 #ifdef HMA_PROF
-  if (getenv("HMA_GEMM_TN_NOPAIR") || getenv("HMA_GEMM_TN_ABLATE")) ok = false;  // debug build only
+  if (getenv("HMA_GEMM_TN_NOPAIR")) ok = false;  // debug build only
 #endif
   int splits[TN_MAXP] = {0};
   if (ok) {

@@ -165,6 +165,28 @@ __device__ __forceinline__ void gelu_bwd_n(const float (&u)[N], const float (&d)
   if constexpr (N == 8) HMA_PIN8(du, 0); else HMA_PIN16(du);
 }
 
+// ---- order-independent loss sums.  A launch's per-wave fp32 partials are added as 64-bit FIXED-POINT integers (2^-32 units; integer
+// addition is associative, so the total does not depend on the order the waves arrive in -- fp32 atomics moved the reported loss by
+// ~1e-5 between two replays of one graph), and the last wave of the launch to arrive (a ticket counter) writes the total as stats[0].
+// Layout of a `stats` buffer (HMA_CE_STATS_FLOATS = 8 floats, zeroed by the caller before the first launch that adds to it):
+// [0] loss sum (fp32, written by the last wave) [1] hits (integer-valued: fp32 atomics are exact) [2] masked rows [3] ticket (u32)
+// [4..5] the fixed-point accumulator (i64) [6..7] spare.  `waves` = how many waves of the launch call this (each exactly once).
+__device__ __forceinline__ void det_loss_add(float* stats, float v, int lane, unsigned waves) {
+  if (lane != 0) return;
+  if (v != 0.f) {
+    const long long q = __double2ll_rn((double)v * 4294967296.0);
+    atomicAdd(reinterpret_cast<unsigned long long*>(stats + 4), (unsigned long long)q);
+  }
+  __threadfence();
+  const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(stats + 3), 1u);
+  if (t == waves - 1) {
+    __threadfence();
+    const long long tot = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(stats + 4), 0ull);
+    stats[0] = (float)((double)tot * (1.0 / 4294967296.0));
+    *reinterpret_cast<unsigned*>(stats + 3) = 0u;  // (the next launch into the same buffer counts from zero again)
+  }
+}
+
 __device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
 __device__ __forceinline__ float dsilu_f(float u) {
   const float s = 1.0f / (1.0f + __expf(-u));

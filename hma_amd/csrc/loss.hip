@@ -121,10 +121,8 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     loss_acc += row_loss;
     acc_acc += ok ? 1.f : 0.f;
   }
-  if (lane == 0 && (loss_acc != 0.f || acc_acc != 0.f)) {
-    atomicAdd(stats + 0, loss_acc);
-    atomicAdd(stats + 1, acc_acc);
-  }
+  if (lane == 0 && acc_acc != 0.f) atomicAdd(stats + 1, acc_acc);
+  det_loss_add(stats, loss_acc, lane, gridDim.x * 4u);
 }
 
 // --------------------------------------------------------------------------------- MaskGIT step

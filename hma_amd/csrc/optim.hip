@@ -214,7 +214,7 @@ extern "C" int hma_fold_ln_bf16(void* stream, const float* W, const float* gamma
   return 0;
 }
 
-extern "C" int hma_abi_version(void) { return 0x484d4102; }
+extern "C" int hma_abi_version(void) { return 0x484d4103; }
 
 extern "C" int hma_dropout_bf16(void* stream, const float* src, void* dst, int64_t rows, int32_t cols, float p, const uint32_t* seed_dev,
                                 int32_t salt) {

@@ -351,7 +351,7 @@ class STEngine(DecodeMixin):
                 buf("amask", (Fr, 1), F32)
                 buf("da_tok", (Fr, 256), F32)
         buf("logits", (Mi, 1024), F32)
-        buf("stats", (4,), F32)
+        buf("stats", (8,), F32)  # HMA_CE_STATS_FLOATS: loss / hits / masked rows + the kernels' ticket and fixed-point accumulator
         if train:
             buf("dlogits", (Mi, 1024), BF16)
             buf("dx", (M, 256), F32)

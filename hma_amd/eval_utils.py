@@ -33,7 +33,7 @@ def compute_loss(labels_flat: torch.LongTensor, factored_logits: torch.Tensor, n
     labels = labels_flat.to(dev).reshape(B, t, S).contiguous()
     mask_id = 1 << 40  # an id no label has: every token of frames >= 1 is counted
     ids = torch.full_like(labels, mask_id)
-    stats = torch.zeros(4, dtype=torch.float32, device=dev)
+    stats = torch.zeros(8, dtype=torch.float32, device=dev)  # HMA_CE_STATS_FLOATS
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.call("hma_count_masked", stream, ids.data_ptr(), stats.data_ptr(), B, t, S, mask_id)
     _lib.call("hma_ce_fwd_bwd", stream, logits.data_ptr(), ids.data_ptr(), labels.data_ptr(), stats.data_ptr(), None, None, 1.0,

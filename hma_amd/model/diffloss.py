@@ -309,11 +309,11 @@ class DiffLoss(nn.Module):
                   ptr(xt_pad), ptr(tfreq), N, Cc, _PAD)
         out, sv = self._net_forward(stream, Wb, bias, xt_pad, tfreq, zc, keep=need_grad)
         denom = (maskf.sum() + 1e-8).reshape(1) if maskf is not None else torch.full((1,), float(N), device=dev)
-        stats = torch.zeros(1, dtype=F32, device=dev)
+        stats = torch.zeros(8, dtype=F32, device=dev)  # HMA_CE_STATS_FLOATS
         dout = torch.zeros(N, _PAD, dtype=F32, device=dev) if need_grad else None
         _lib.call("hma_diff_loss", stream, ptr(out), _PAD, ptr(target), ptr(xt), ptr(noise), ptr(t), ptr(sch["t6"]), self._train.n, ptr(maskf),
                   ptr(denom), 1.0, ptr(stats), None, ptr(dout), N, Cc)
-        loss = (stats / denom).reshape(())
+        loss = (stats[:1] / denom).reshape(())
         self.last_net_out = out[:, : 2 * Cc]
         if not need_grad:
             return loss

@@ -396,7 +396,7 @@ class STMaskGIT(nn.Module, PyTorchModelHubMixin):
         labels = targets_THW.reshape(B, T * S).contiguous()
         ids = torch.zeros(B, T, S, dtype=torch.int64, device=dev)
         ids[:, 1:] = torch.where(relevant_mask_THW.reshape(B, T - 1, S).bool(), self.mask_token_id, 0)
-        stats = torch.zeros(4, dtype=torch.float32, device=dev)
+        stats = torch.zeros(8, dtype=torch.float32, device=dev)  # HMA_CE_STATS_FLOATS
         _lib.call("hma_count_masked", stream_ptr(), ptr(ids), ptr(stats), B, T, S, self.mask_token_id)
         _lib.call("hma_ce_fwd_bwd", stream_ptr(), ptr(lg), ptr(ids), ptr(labels), ptr(stats), None, None, 1.0, B, T, S,
                   self.mask_token_id, 0.01)

@@ -320,13 +320,13 @@ def readout_ce(logits: torch.Tensor, input_ids: torch.Tensor, labels: torch.Tens
     frames >= 1 (st_mask_git.py:603-630): hma_count_masked + hma_ce_fwd_bwd on fp32 logits (B * T * S, 1024); ids / labels (B, T, S)"""
     _cuda(logits, input_ids, labels)
     B, T, S = input_ids.shape
-    stats = torch.zeros(4, dtype=F32, device=logits.device)
+    stats = torch.zeros(8, dtype=F32, device=logits.device)  # HMA_CE_STATS_FLOATS (the kernels keep a ticket and an accumulator behind the three sums)
     dlogits = torch.empty(logits.shape, dtype=BF16, device=logits.device)
     ids = input_ids.contiguous()
     _lib.call("hma_count_masked", stream_ptr(), ptr(ids), ptr(stats), B, T, S, mask_id)
     _lib.call("hma_ce_fwd_bwd", stream_ptr(), ptr(logits.contiguous()), ptr(ids), ptr(labels.contiguous()), ptr(stats), ptr(dlogits), None,
               grad_scale, B, T, S, mask_id, label_smoothing)
-    return stats, dlogits
+    return stats[:4].clone(), dlogits
 
 
 @readout_ce.register_fake

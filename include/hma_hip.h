@@ -204,10 +204,14 @@ int hma_action_stem_bwd(void* stream, const float* dout, const float* an, const 
 
 /* Factorised-vocabulary cross-entropy + accuracy + logits gradient, st_mask_git.py:603-630, 714-716.
  * logits f32 [B*T*S, 2*512] (row = (b,t,s)); frames t >= 1 only; label smoothing 0.01; masked mean.
- * stats[0] = sum loss*mask, stats[1] = sum acc*mask, stats[2] = num masked (fp32; zero them first).
+ * stats: fp32[HMA_CE_STATS_FLOATS], zeroed by the caller first.  stats[0] = sum loss*mask, stats[1] = sum acc*mask,
+ * stats[2] = num masked; [3..5] are the kernels' own (a ticket counter and a 64-bit fixed-point accumulator: the loss
+ * partials are added as integers and the last wave to arrive writes stats[0], so the sum does not depend on the order
+ * the waves finish in -- two replays of one graph report the same loss bit for bit); [6..7] spare.
  * dlogits (bf16, may be NULL) = grad_scale * (*grad_scale_dev if not NULL) * mask / num_masked *
  * (softmax - smoothed one-hot): needs the count
  * first, so call hma_count_masked before it. */
+#define HMA_CE_STATS_FLOATS 8
 int hma_count_masked(void* stream, const int64_t* input_ids, float* stats, int64_t B, int32_t T, int32_t S,
                      int64_t mask_id);
 int hma_ce_fwd_bwd(void* stream, const float* logits, const int64_t* input_ids, const int64_t* labels,
@@ -293,7 +297,8 @@ int hma_gate_bwd(void* stream, const float* dx, const void* mod, int64_t ldm, in
                  void* dmod, int64_t n, int32_t W);
 /* Per-row training loss mean_c (noise - eps)^2 + vb (LossType.MSE + ModelVarType.LEARNED_RANGE with the mean frozen:
  * KL to the true posterior, or the discretised-Gaussian decoder NLL at t == 0; gaussian_diffusion.py:650-745) from the
- * network output out [rows, ldo] = [eps | v | padding]; stats[0] += sum_rows loss * mask; rows_out (optional) = per-row
+ * network output out [rows, ldo] = [eps | v | padding]; stats (fp32[HMA_CE_STATS_FLOATS], zeroed first; layout and the
+ * order-independent sum as for hma_ce_fwd_bwd): stats[0] = sum_rows loss * mask; rows_out (optional) = per-row
  * loss; dout (optional, [rows, ldo], only the 2C used columns are written) = d loss / d out * grad_scale * mask / *denom.
  * tables6 = [sqrt_recip_ac | sqrt_recipm1_ac | posterior_mean_coef1 | coef2 | posterior_log_variance_clipped |
  * log(betas)], n_steps each. */
@@ -548,8 +553,9 @@ int hma_chain_ab_fwd(void* stream, const hma_chain_ab_fwd_t* p);
  * compute_video_loss_and_acc with label_smoothing): what hma_gemm_nt (x -> fp32 logits) + hma_ce_fwd_bwd do, without the logits in
  * HBM.  rows = B * T * S image rows (a multiple of 16); row i reads x row (i / S) * SA + i % S of the [*, 256] fp32 residual stream.
  * w: 32 N-block bundles (hma_chain_pack kind 0) of out_x_proj.weight [1024][256]; bias [1024] or NULL.  A row counts when its frame
- * index (i / S) % T >= 1 and input_ids[i] == mask_id.  stats[0] += sum of row losses, stats[1] += rows whose two factor arg-maxes
- * both hit; stats[2] (the masked-row count, hma_count_masked) is read.  dlogits (bf16 [rows, 1024], or NULL) = grad_scale *
+ * index (i / S) % T >= 1 and input_ids[i] == mask_id.  stats (fp32[HMA_CE_STATS_FLOATS], as for hma_ce_fwd_bwd): stats[0] = sum of
+ * row losses (order-independent), stats[1] += rows whose two factor arg-maxes both hit; stats[2] (the masked-row count,
+ * hma_count_masked) is read.  dlogits (bf16 [rows, 1024], or NULL) = grad_scale *
  * *grad_scale_dev / stats[2] * (softmax - smoothed one-hot) per factor, zero for rows that do not count. */
 typedef struct {
   hma_chain_weights_t w;
@@ -564,7 +570,7 @@ int hma_readout_ce(void* stream, const hma_readout_ce_t* p);
 /* n floats at p = 0 (captured in graphs in front of kernels that accumulate with atomics) */
 int hma_zero_f32(void* stream, float* p, int64_t n);
 
-/* library identity, for the loader: returns 0x484d4102 */
+/* library identity, for the loader: returns 0x484d4103 */
 int hma_abi_version(void);
 
 #ifdef __cplusplus

@@ -368,7 +368,7 @@ def test_readout_ce_fused(B, T, S, A):
     gref = torch.cat([lp0.exp() - oh(f0), lp1.exp() - oh(f1)], 1) * (gs / nmask) * live[:, None]
     d = lambda t: t.to(DEV).contiguous()
     pw = ops.chain_pack(d(w), kind=0, rows=1024, cols=256, row_stride=256, col_stride=1)
-    stats = torch.tensor([0.0, 0.0, float(nmask), 0.0], device=DEV)
+    stats = torch.tensor([0.0, 0.0, float(nmask), 0.0, 0.0, 0.0, 0.0, 0.0], device=DEV)
     dl = torch.full((Mi, 1024), 7.0, dtype=torch.bfloat16, device=DEV)
     xd, bd, idd, lbd = d(x), d(bias), d(ids), d(labels)
     a = ops.make_readout_ce(rows=Mi, segs=[(ops.ptr(pw), 32)], x=ops.ptr(xd), bias=ops.ptr(bd), input_ids=ops.ptr(idd), labels=ops.ptr(lbd),
@@ -389,7 +389,7 @@ def test_readout_ce_fused(B, T, S, A):
     ga = ops.make_gemm_nt(A=ops.ptr(xd), lda=256, a_kind=_lib.A_F32, a_group=(S, SA), W=ops.ptr(d(w).bfloat16()), ldw=256, M=Mi, N=1024, K=256,
                           epi=_lib.EPI_F32, Cp=ops.ptr(lg), ldc=1024, bias=ops.ptr(bd))
     _lib.call("hma_gemm_nt", ops.stream_ptr(), C.byref(ga))
-    stats2 = torch.tensor([0.0, 0.0, float(nmask), 0.0], device=DEV)
+    stats2 = torch.tensor([0.0, 0.0, float(nmask), 0.0, 0.0, 0.0, 0.0, 0.0], device=DEV)
     dl2 = torch.empty(Mi, 1024, dtype=torch.bfloat16, device=DEV)
     _lib.call("hma_ce_fwd_bwd", ops.stream_ptr(), ops.ptr(lg), ops.ptr(idd.view(B, T * S)), ops.ptr(lbd), ops.ptr(stats2), ops.ptr(dl2), None, gs, B, T, S,
               mask_id, eps)

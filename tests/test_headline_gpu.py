@@ -163,14 +163,18 @@ def test_segmented_graphs_equal_one_graph():
     di = 7
     dom = domains[di]
     ids, labels, act = bench.synthetic_batch(32, 16, 400, d_actions[di], DEV)
+    seen = []
     for _ in range(3):
         GA, lA = _grad_of(trA, ids, labels, act, dom)
         GB, lB = _grad_of(trB, ids, labels, act, dom)
+        seen.append(lA)
     assert len(next(iter(trB._graphs.values()))) == 3 and len(next(iter(trA._graphs.values()))) == 1
     errs = _region_errs(trA.engine.layout, GA, GB, dom)
-    # (the loss is a sum of per-wave partial sums by fp32 atomics: their order differs from run to run, +-1.3e-5 at a loss of 12.5 has
-    # been observed between two runs of the SAME graph; the gradients agree to 1e-8)
-    assert abs(lA - lB) <= 1e-4 and max(errs.values()) <= 1e-3, (lA, lB, errs)
+    # (the loss is summed in fixed point -- hma_common.h det_loss_add -- so the order the waves finish in does not reach it: replays
+    # of one graph on the same inputs report the same loss bit for bit, and the two graph forms, which run the same kernels on the
+    # same data, the same value)
+    assert len(set(seen)) == 1, seen  # (eager, eager + capture, replay: the same kernels on the same data)
+    assert abs(lA - lB) <= 1e-5 and max(errs.values()) <= 1e-3, (lA, lB, errs)
 
 
 @pytest.mark.timeout(900)

@@ -587,7 +587,7 @@ def test_ce_loss_acc_and_grad():
     loss, acc = R.video_loss_and_acc(cfg, lr.reshape(B, T, 16, 16, 1024).permute(0, 4, 1, 2, 3), labels,
                                      inputs.reshape(B, T, 16, 16))
     (loss * 3.0).backward()
-    stats = torch.zeros(4, device=DEV)
+    stats = torch.zeros(8, device=DEV)  # HMA_CE_STATS_FLOATS
     dl = torch.empty(B * T * S, 1024, dtype=torch.bfloat16, device=DEV)
     ld, idd, lbd = logits.to(DEV), inputs.to(DEV), labels.to(DEV)
     _lib.call("hma_count_masked", ops.stream_ptr(), idd.data_ptr(), stats.data_ptr(), B, T, S, mask_id)
