@@ -539,6 +539,7 @@ __device__ __forceinline__ uint4 dpp_swap8(const uint4& v) {
 }
 struct line_offs {
   int a, b;  // byte offsets from the tile's first row: this lane's piece in rows 0..7 (instruction A) / rows 8..15 (instruction B)
+  int ra;    // the row (0..7) this lane writes with instruction A; instruction B: ra + 8
   bool lo;
   int pitch, s0, s1;  // storer mode: the row pitch and the LDS byte offsets of q0 / q1 inside a staged block
 };
@@ -546,6 +547,7 @@ struct line_offs {
 __device__ __forceinline__ line_offs make_lines(int pitch, int tok, int g16, int d) {
   line_offs L;
   L.lo = tok < 8;
+  L.ra = tok & 7;
   L.a = (tok & 7) * pitch + g16 + (L.lo ? 0 : d);
   L.b = ((tok & 7) + 8) * pitch + g16 + (L.lo ? d : 0);
   L.pitch = pitch;
@@ -555,8 +557,11 @@ __device__ __forceinline__ line_offs make_lines(int pitch, int tok, int g16, int
 }
 // a 16-row x 128-byte block of an output array: rows from tile_base + off, the lane's pieces q0 | q1.  Storer mode: into the wave's
 // staging ring; otherwise straight to HBM as two whole-line instructions.
-template <bool WAIT = true>
-__device__ __forceinline__ void store_lines(stage_t& st, void* tile_base, const line_offs& L, int off, const uint4& q0, const uint4& q1) {
+// MASK (column tiles of windows with fewer than 16 frames): instruction A writes the tile's rows 0..7 (this lane: row L.ra), instruction B
+// rows 8..15 (row L.ra + 8); rows >= nrows do not exist and their lanes are switched off (exec-masked stores in straight-line code)
+template <bool WAIT = true, bool MASK = false>
+__device__ __forceinline__ void store_lines(stage_t& st, void* tile_base, const line_offs& L, int off, const uint4& q0, const uint4& q1,
+                                            int nrows = 16) {
   if constexpr (ST) {
     stage_block<WAIT>(st, reinterpret_cast<char*>(tile_base) + off, (uint32_t)L.pitch, L.s0, L.s1, q0, q1);
     return;
@@ -571,6 +576,11 @@ __device__ __forceinline__ void store_lines(stage_t& st, void* tile_base, const 
   da.x = L.lo ? q0.x : r.x; da.y = L.lo ? q0.y : r.y; da.z = L.lo ? q0.z : r.z; da.w = L.lo ? q0.w : r.w;
   db.x = L.lo ? r.x : q0.x; db.y = L.lo ? r.y : q0.y; db.z = L.lo ? r.z : q0.z; db.w = L.lo ? r.w : q0.w;
   char* b = reinterpret_cast<char*>(tile_base);
+  if constexpr (MASK) {
+    if (L.ra < nrows) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, da), reinterpret_cast<u32x4_t*>(b + (L.a + off)));
+    if (L.ra + 8 < nrows) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, db), reinterpret_cast<u32x4_t*>(b + (L.b + off)));
+    return;
+  }
 #ifndef CH_NO_NT  // (non-temporal: 8 % faster than the default policy in the forward chain, the lines are not read again soon)
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, da), reinterpret_cast<u32x4_t*>(b + (L.a + off)));
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, db), reinterpret_cast<u32x4_t*>(b + (L.b + off)));
@@ -2072,6 +2082,10 @@ constexpr int TB_SP = 40;                            // bytes per query row of t
 constexpr int TB_SCR = 3 * TB_SLAB + 2 * 16 * TB_SP; // Q | K | dO of the head in flight + dS | P [query][key], per compute wave
 typedef short tb_v4s16_t __attribute__((ext_vector_type(4)));
 constexpr int TB_SMEM = NS * SLOT + NCW * TB_SCR;
+// TV = false: T == 16 (every lane of a column tile is a frame); TV = true: windows of T < 16 frames -- lane tok >= T has no row: its loads
+// go to frame T - 1 (finite values), its gradient row enters as ZERO (an invalid query attends to valid keys: its dO must not reach
+// their dK / dV), its stores are masked.  The causal mask keeps invalid KEYS away from valid queries by itself.
+template <bool TV>
 __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_bwd_t p) {
   static_assert(!ST, "chain T has no storer mode");
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -2095,15 +2109,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_
   }
   stage_t stg_ = make_stage(lds, wave, lane);
   const int tok = lane & 15, g = lane >> 4;
+  const int T = TV ? p.T : 16;
+  const bool live = !TV || tok < T;           // this lane's frame exists
+  const int tok_ld = TV ? (tok < T ? tok : T - 1) : tok;
   auto col_of = [&](int tl) __attribute__((always_inline)) { return cmap.base + (int64_t)tl * NW + wave; };
   auto row_of = [&](int64_t c) __attribute__((always_inline)) {
     const int64_t b = c / SA;
-    return b * 16 * SA + (c - b * SA);
+    return b * T * SA + (c - b * SA);
   };
   auto lane_row = [&](int tl) __attribute__((always_inline)) {  // this lane's row (frame tok) of the wave's column in tile tl
     int64_t c = col_of(tl);
     c = c < cmap.end ? c : cmap.end - 1;
-    return row_of(c) + (int64_t)tok * SA;
+    return row_of(c) + (int64_t)tok_ld * SA;
   };
   bf16x8_t a0[8], a1[8];  // bf16(dx) rows: this tile's / the next one's
   bf16x8_t qf[24];        // q | k | v of the column: fragment 8 part + head
@@ -2165,7 +2182,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_
     uint16_t* dq_out = reinterpret_cast<uint16_t*>(p.dqkv) + rc * 768;
     const int64_t mn = lane_row(tl + 1 < nt ? tl + 1 : tl);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a0[j] = a1[j];
+    for (int j = 0; j < 8; ++j) {
+      a0[j] = a1[j];
+      if constexpr (TV) {
+        if (!live) a0[j] = as_frag(make_uint4(0, 0, 0, 0));
+      }
+    }
     static_for<PER_TILE>([&](auto sc_) __attribute__((always_inline)) {
       constexpr int h = decltype(sc_)::value;
       if constexpr (h % PB == 0) CH_BARRIER();
@@ -2246,9 +2268,9 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_t_bwd_kernel(hma_chain_t_
         hold[1] = ok;
         hold[2] = ov;
       } else {
-        store_lines(stg_, dq_out, Lq, 64 * (h - 1), hold[0], oq);
-        store_lines(stg_, dq_out, Lq, 64 * (h - 1) + 512, hold[1], ok);
-        store_lines(stg_, dq_out, Lq, 64 * (h - 1) + 1024, hold[2], ov);
+        store_lines<true, TV>(stg_, dq_out, Lq, 64 * (h - 1), hold[0], oq, T);
+        store_lines<true, TV>(stg_, dq_out, Lq, 64 * (h - 1) + 512, hold[1], ok, T);
+        store_lines<true, TV>(stg_, dq_out, Lq, 64 * (h - 1) + 1024, hold[2], ov, T);
       }
       if constexpr ((h & 1) == 1) {  // the next tile's q / k / v of this head pair (the halves of a line), into the registers just read
         load_head(mn, std::integral_constant<int, h - 1>{});
@@ -2546,15 +2568,20 @@ extern "C" int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p) {
 }
 
 extern "C" int hma_chain_t_bwd(void* stream, const hma_chain_t_bwd_t* p) {
-  if (!p || !p->dy_bf16 || !p->qkv || !p->dqkv || p->B <= 0 || p->SA <= 0 || p->T != 16) return HMA_EINVAL;
+  if (!p || !p->dy_bf16 || !p->qkv || !p->dqkv || p->B <= 0 || p->SA <= 0 || p->T < 1 || p->T > 16) return HMA_EINVAL;
   if ((int64_t)p->SA * 1536 * 15 >= (int64_t)1 << 31) return HMA_EINVAL;  // (line offsets are 32-bit)
   if (!weights_ok(p->w, 8)) return HMA_EINVAL;
   const int64_t cols = p->B * (int64_t)p->SA;
   const int64_t ntiles = (cols + NCW - 1) / NCW;
   const int slots = num_cus() * WGS_PER_CU;
   const int grid = (int)(ntiles < slots ? ntiles : slots);
-  if (int rc = set_lds<chain_t_bwd_kernel>(TB_SMEM)) return rc;
-  hipLaunchKernelGGL(chain_t_bwd_kernel, dim3(grid), dim3(CH_THREADS), TB_SMEM, (hipStream_t)stream, *p);
+  if (p->T == 16) {
+    if (int rc = set_lds<chain_t_bwd_kernel<false>>(TB_SMEM)) return rc;
+    hipLaunchKernelGGL(chain_t_bwd_kernel<false>, dim3(grid), dim3(CH_THREADS), TB_SMEM, (hipStream_t)stream, *p);
+  } else {
+    if (int rc = set_lds<chain_t_bwd_kernel<true>>(TB_SMEM)) return rc;
+    hipLaunchKernelGGL(chain_t_bwd_kernel<true>, dim3(grid), dim3(CH_THREADS), TB_SMEM, (hipStream_t)stream, *p);
+  }
   HMA_CHECK_LAUNCH();
   return 0;
 }

@@ -715,9 +715,9 @@ class STEngine(DecodeMixin):
                     pl.add("hma_ln_bwd", t256, xh2, rstd2, self._lw(l, "norm2.weight", "p"), dx, gw("norm2.weight"), gw("norm2.bias"), M,
                            dxb)
             # ---- temporal attention
-            if self.chain_t and T == 16 and not self.qkn and self._use_chain(M, SA):
+            if self.chain_t and 8 < T <= 16 and not self.qkn and self._use_chain(M, SA):  # (a column tile is 16 frame lanes: at T <= 8 half of them would idle)
                 # chain T backward (csrc/chain.hip): the projection's input gradient and the attention backward of a column, one launch
-                pl.chain_t_bwd(B, SA, segs=[(self.CP["proj_t_T"][l].data_ptr(), 8)], dy_bf16=dxb, qkv=qkv_t, dqkv=dqkv, attn_scale=self.scale)
+                pl.chain_t_bwd(B, SA, segs=[(self.CP["proj_t_T"][l].data_ptr(), 8)], dy_bf16=dxb, qkv=qkv_t, dqkv=dqkv, attn_scale=self.scale, T=T)
             else:
                 pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_t"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
                 pl.add("hma_attn_temporal_bwd", qkv_t, o_t, t256, dqkv, B, T, SA, self.scale, flops=10.0 * M * T * 256, nbytes=3584.0 * M)

@@ -206,7 +206,7 @@ def make_chain_s_bwd(*, M: int, segs, dqkv: int, dx: int, xhat: int, rstd: int, 
 
 
 def make_chain_t_bwd(*, B: int, SA: int, segs, dy_bf16: int, qkv: int, dqkv: int, attn_scale: float, T: int = 16) -> ChainTBwd:
-    """segs: the packed transposed temporal projection (8 bundles).  Rows (b, t, s), M = 16 B SA."""
+    """segs: the packed transposed temporal projection (8 bundles).  Rows (b, t, s), M = T B SA, 1 <= T <= 16."""
     g = ChainTBwd()
     _chain_weights(g.w, segs)
     g.dy_bf16, g.qkv, g.dqkv = dy_bf16, qkv, dqkv

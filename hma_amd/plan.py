@@ -145,9 +145,9 @@ class Plan:
     def chain_t_bwd(self, B: int, SA: int, **kw) -> None:
         g = make_chain_t_bwd(B=B, SA=SA, **kw)
         self.keep.append(g)
-        M = 16.0 * B * SA
+        M = float(g.T) * B * SA
         # bf16(dx) 512 + qkv 1536 in; dqkv 1536 out.  Projection dgrad + the attention's five products per head (as hma_attn_temporal_bwd)
-        self.add("hma_chain_t_bwd", C.byref(g), flops=2.0 * M * 256 * 256 + 10.0 * M * 16 * 256, nbytes=(512 + 1536 + 1536) * M)
+        self.add("hma_chain_t_bwd", C.byref(g), flops=2.0 * M * 256 * 256 + 10.0 * M * g.T * 256, nbytes=(512 + 1536 + 1536) * M)
 
     def readout_ce(self, rows: int, **kw) -> None:
         g = make_readout_ce(rows=rows, **kw)

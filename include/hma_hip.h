@@ -488,9 +488,10 @@ typedef struct {
 int hma_chain_s_bwd(void* stream, const hma_chain_s_bwd_t* p);
 
 /* Chain T backward -- the temporal attention's backward of a block in one launch (st_transformer.py:111; attention.py:37-61 causal and
- * :60 proj, autograd mirror), training passes over windows of exactly T = 16 frames: what hma_gemm_nt (d_o = bf16(dx) Wproj) and
- * hma_attn_temporal_bwd did in two launches with d_o's round trip through HBM.  A compute wave owns the 16 frames of a (sample, token
- * position) column.  Rows are (b, t, s), s fastest, SA rows per frame, B samples, M = 16 B SA.
+ * :60 proj, autograd mirror), training passes over windows of 1 <= T <= 16 frames: what hma_gemm_nt (d_o = bf16(dx) Wproj) and
+ * hma_attn_temporal_bwd did in two launches with d_o's round trip through HBM.  A compute wave owns the T frames of a (sample, token
+ * position) column (a tile has 16 frame lanes: with T < 16 the last 16 - T are masked -- loads clamped, gradient rows zeroed, stores
+ * switched off).  Rows are (b, t, s), s fastest, SA rows per frame, B samples, M = T B SA.
  * in: dy_bf16 [M,256] bf16 (the gradient of the block's x behind the temporal attention's residual add), qkv [M,768] bf16 (saved by the
  * forward); out: dqkv [M,768] bf16 (dq, dk scaled by attn_scale as hma_attn_temporal_bwd writes them).
  * weights: the 8 N-block bundles of Wproj^T (hma_chain_pack of the transposed weight, kind 0). */

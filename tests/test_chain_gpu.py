@@ -207,12 +207,14 @@ def test_chain_s_bwd(M):
     assert (dxd.cpu() - dx1).abs().max() < 0.2 * (dxd.cpu() - dx1.flip(0)).abs().max()
 
 
-@pytest.mark.parametrize("B,SA", [(1, 1), (1, 16), (2, 48), (3, 320), (5, 77), (32, 320)])
-def test_chain_t_bwd(B, SA):
+@pytest.mark.parametrize("B,SA,T", [(1, 1, 16), (1, 16, 16), (2, 48, 16), (3, 320, 16), (5, 77, 16), (32, 320, 16),
+                                    (3, 320, 12), (2, 48, 9), (5, 77, 5), (1, 16, 1), (32, 320, 12)])
+def test_chain_t_bwd(B, SA, T):
     """hma_chain_t_bwd -- the temporal projection's input gradient + the causal attention backward of every (sample, token) column in
     one launch -- against (a) the two launches it replaces (hma_gemm_nt, hma_attn_temporal_bwd) and (b) an fp32 autograd reference.
+    Windows of T < 16 frames (the reference's default is 12, train_multi.py:78-83): the column tile's lanes T .. 15 are masked.
     Reference: hma/model/st_transformer.py:111, hma/model/attention.py:37-61 (autograd mirror)."""
-    T, scale = 16, 0.25
+    scale = 0.25
     M = B * T * SA
     wp = rb(torch.randn(256, 256, generator=g(900)) * 0.06)          # proj.weight [out][in]
     qkv = rb(torch.randn(M, 768, generator=g(901)))
@@ -220,7 +222,7 @@ def test_chain_t_bwd(B, SA):
     qd, dyd = qkv.to(DEV).bfloat16(), dy.to(DEV).bfloat16()
     wt = _pack_t(wp)
     dq = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
-    a = ops.make_chain_t_bwd(B=B, SA=SA, segs=[(ops.ptr(wt), 8)], dy_bf16=ops.ptr(dyd), qkv=ops.ptr(qd), dqkv=ops.ptr(dq), attn_scale=scale)
+    a = ops.make_chain_t_bwd(B=B, SA=SA, T=T, segs=[(ops.ptr(wt), 8)], dy_bf16=ops.ptr(dyd), qkv=ops.ptr(qd), dqkv=ops.ptr(dq), attn_scale=scale)
     _lib.call("hma_chain_t_bwd", ops.stream_ptr(), C.byref(a))
     torch.cuda.synchronize()
     # (a) two launches: d_o = dy Wproj as bf16, then the attention backward

@@ -42,6 +42,12 @@ case "$1" in
         done
       done
     } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tn_libs.txt ;;
+  frames)  # frames LIB T...: the train leg at other window lengths (tokens/s = B T 256 / step)
+    lib=$2; shift 2
+    { for t in "$@"; do
+        line $lib --frames $t
+        python -c "import json; d=json.load(open('gpurun_out/_line.json')); print('  T=$t', '%.0f tokens/s' % d['value'], d['config'])"
+      done; } 2>&1 | tee gpurun_out/frames.txt ;;
   ab)  # ab LIB_A LIB_B [bench args]: interleaved same-box A / B of two libraries, twice each
     a=$2; b=$3; shift 3
     { for lib in $a $b $a $b; do line $lib "$@"; done; } 2>&1 | tee gpurun_out/ab.txt ;;
