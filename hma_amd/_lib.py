@@ -137,6 +137,7 @@ class ChainABFwd(C.Structure):
         ("xhat2", c_vp), ("rstd2", c_vp), ("xhat1n", c_vp), ("rstd1n", c_vp), ("qkv_s", c_vp),
         ("B", c_i64), ("T", c_i32), ("SA", c_i32),
         ("attn_scale", C.c_float), ("ln_eps", C.c_float),
+        ("drop_p", C.c_float), ("drop_salt", c_i32), ("drop_seed", c_vp),
     ]
 
 

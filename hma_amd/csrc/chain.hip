@@ -1467,13 +1467,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
   auto prefetch = [&](int tl, auto part_) __attribute__((always_inline)) {  // (part < 0: all 24 loads; 0..11: a pair)
     constexpr int part = decltype(part_)::value;
     if (CH_ABL & 2) return;
-    int64_t m = row0_of(tl) + tok;
-    m = m < p.M ? m : p.M - 1;
-    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m * 256 + 8 * g;
+    // (a wave's 16 rows are inside the matrix or past it together -- M % 16 == 0 -- so the clamp is wave-uniform; uniform base + an opaque
+    // 32-bit lane offset: `array + lane part` as a 64-bit pointer per lane is a loop invariant the compiler keeps, and in the dropout
+    // form spilled -- a scratch reload drains the store queue)
+    int64_t m0 = row0_of(tl);
+    m0 = m0 < p.M ? m0 : p.M - 16;
+    uint32_t lo = (uint32_t)tok * 256u + 8u * (uint32_t)g;
+    asm volatile("" : "+v"(lo));
+    const uint16_t* orow = reinterpret_cast<const uint16_t*>(p.o) + m0 * 256 + lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (part < 0 || j / 2 == part) a1[j] = as_frag(*reinterpret_cast<const uint4*>(orow + 32 * j));
-    const float* xrow = p.x + m * 256 + 8 * g;
+    const float* xrow = p.x + m0 * 256 + lo;
 #pragma unroll
     for (int pr = 0; pr < 8; ++pr) {
       if (part < 0 || pr + 4 == part) {
@@ -1543,7 +1548,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_b_fwd_kernel(hma_chain_b_
           store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
         }
       }
-      if (!(CH_ABL & 1)) rstd_out[r0 + tok] = rstd;
+      if (!(CH_ABL & 1)) {
+        uint32_t to = (uint32_t)tok;
+        asm volatile("" : "+v"(to));
+        (rstd_out + r0)[to] = rstd;
+      }
     }
   };
   constexpr bool BSP = CH_BSPREAD && !ST && QKV;
@@ -1715,7 +1724,10 @@ __device__ __forceinline__ col_map make_col_map(int64_t cols, int nw) {
 typedef __attribute__((ext_vector_type(4))) short s16x4v_t;
 constexpr int AB_SMEM = NS * SLOT + 4 * (1280 + 2304) + NCW * 2048 + 16 * 2064;  // ring | biases | attention scratch | shift / scale rows
 static_assert(AB_SMEM <= 163840, "one workgroup per CU");
-template <bool QKV>
+// MOD = false: blocks without action tokens (no ModulateLayer: chain A is the spatial projection + residual, its bf16 copy is the temporal
+// qkv's operand; nothing of xhat_m / xm / rstd_m is written).  DROP: mlp_drop > 0 -- the two nn.Dropout sites of Mlp.forward with the
+// counter-based masks of chain B / hma_mlp_bwd (the residual row is kept apart from the branch output, which is masked before the add).
+template <bool QKV, bool MOD = true, bool DROP = false>
 __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_ab_fwd_t p) {
   static_assert(!ST, "the fused chain has no storer mode");
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
@@ -1744,7 +1756,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
     }
   }
   __syncthreads();
-  constexpr int SL = 8, SQT = 16, SB = 40;            // first linear_out step, first temporal-qkv step, first chain B step
+  constexpr int SL = 8, SQT = MOD ? 16 : 8, SB = SQT + 24;  // first linear_out step, first temporal-qkv step, first chain B step
   constexpr int SM = SB + 8, SQ = SM + 64;            // first MLP step, first spatial-qkv step
   constexpr int PER_TILE = SQ + (QKV ? 24 : 0);
   static_assert(PER_TILE % PB == 0, "whole barrier groups per tile");
@@ -1753,13 +1765,17 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
   static_assert(L_SSC + 16 * 2064 <= AB_SMEM, "scratch and shift / scale rows fit beside the ring");
   if (wave > NCW) return;
   if (wave == NCW) {
-    ring_src ws = {reinterpret_cast<const char*>(p.seg[0]), reinterpret_cast<const char*>(p.seg[1]), reinterpret_cast<const char*>(p.seg[2]),
-                   reinterpret_cast<const char*>(p.seg[3]), p.bundles[0], p.bundles[1], p.bundles[2], p.bundles[3]};
-    ws.s4 = reinterpret_cast<const char*>(p.seg[4]);
-    ws.s5 = reinterpret_cast<const char*>(p.seg[5]);
-    ws.n4 = p.bundles[4];
-    ws.n5 = p.bundles[5];
-    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, p.ss, 0, 1, lds, nullptr, cmap.base, SA, (uint32_t)L_SSC);
+    // (the ring walks its segments in order and wraps at the first empty one: without the modulation segment 1 is left out)
+    constexpr int o = MOD ? 0 : 1;
+    ring_src ws = {reinterpret_cast<const char*>(p.seg[0]), reinterpret_cast<const char*>(p.seg[1 + o]), reinterpret_cast<const char*>(p.seg[2 + o]),
+                   reinterpret_cast<const char*>(p.seg[3 + o]), p.bundles[0], p.bundles[1 + o], p.bundles[2 + o], p.bundles[3 + o]};
+    ws.s4 = reinterpret_cast<const char*>(p.seg[4 + o]);
+    ws.n4 = p.bundles[4 + o];
+    if constexpr (MOD) {
+      ws.s5 = reinterpret_cast<const char*>(p.seg[5]);
+      ws.n5 = p.bundles[5];
+    }
+    loader_run<0, NW>(ws, PER_TILE, nt, lds_b, lane, MOD ? p.ss : nullptr, 0, 1, lds, nullptr, cmap.base, SA, (uint32_t)L_SSC);
     return;
   }
   stage_t stg_ = make_stage(lds, wave, lane);
@@ -1810,6 +1826,21 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
   const line_offs Lq = make_lines(1536 * SA, tok, 16 * g, 64);       // qkv [., 768]
   const float c_log2 = p.attn_scale * 1.4426950408889634f;
   int slot = 0;
+  uint32_t dseed = 0, dth = 0;
+  float dsc = 1.f;
+  f32x4v_t x1[DROP ? 16 : 1];  // (DROP: the residual row beside the branch output)
+  if constexpr (DROP) {
+    dseed = *p.drop_seed;
+    dth = drop_thresh(p.drop_p);
+    dsc = drop_scale(p.drop_p);
+  }
+  // a row statistic of this lane's frame: uniform base + an opaque 32-bit lane offset (a per-lane 64-bit pointer per array is a loop
+  // invariant the compiler keeps -- three of them spilled in the dropout form, and a scratch reload drains the store queue)
+  auto st_rstd = [&](float* arr, int64_t rc_, float v) __attribute__((always_inline)) {
+    uint32_t ts = tok_sa;
+    asm volatile("" : "+v"(ts));
+    (arr + rc_)[ts] = v;
+  };
   // LayerNorm (no affine) of the rows in acc -> packed bf16 B operand, saved with 1 / sigma for the backward
   auto ln_pack = [&](bf16x8_t (&dst)[8], void* xhat_out, float* rstd_out, int64_t rc, float eps) __attribute__((always_inline)) {
     float sum = 0.f;
@@ -1842,7 +1873,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp)
       store_lines<false>(stg_, xo, Lb, 128 * pp, __builtin_bit_cast(uint4, dst[2 * pp]), __builtin_bit_cast(uint4, dst[2 * pp + 1]));
-    (rstd_out + rc)[tok_sa] = rstd;
+    st_rstd(rstd_out, rc, rstd);
   };
 
 #pragma unroll 1
@@ -1876,7 +1907,15 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
         nb_mma(wb, a0, acc[2 * s], acc[2 * s + 1]);
         add4(acc[2 * s], lds_f4(biasA + 128 * s));
         add4(acc[2 * s + 1], lds_f4(biasA + 128 * s + 16));
-        if constexpr (s == SL - 1) {
+        if constexpr (s == SL - 1 && !MOD) {
+          // no action tokens: x1 is the temporal qkv's input; its bf16 copy is that GEMM's operand and the weight gradient's
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) a0[pr] = as_frag(pack_pair(acc[2 * pr], acc[2 * pr + 1]));
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp)
+            store_lines<false>(stg_, xb, Lb, 128 * pp, __builtin_bit_cast(uint4, a0[2 * pp]), __builtin_bit_cast(uint4, a0[2 * pp + 1]));
+        }
+        if constexpr (s == SL - 1 && MOD) {
           // LayerNorm (no affine, eps 1e-6) of the row, then the modulation with THIS lane's frame's shift / scale (L2-resident table)
           float sum = 0.f;
 #pragma unroll
@@ -1900,7 +1939,9 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
           // The loader staged the shift | scale rows of the sample of the tile's FIRST column (32 global loads per lane here -- the
           // L2-resident table read directly -- cost 25 us per launch: -DCH_AB_SSG); a wave whose column lies in the next sample
           // (a tile that straddles two samples) takes its rows from the table itself.
-          const float* ssr = p.ss + (frame0 + tok) * 512 + 8 * g;
+          uint32_t sso = (uint32_t)tok * 512u + 8u * (uint32_t)g;
+          asm volatile("" : "+v"(sso));  // (opaque, as the row offsets: `p.ss + lane part` is not kept as a 64-bit pointer per lane)
+          const float* ssr = p.ss + frame0 * 512 + sso;
           HMA_LDS(char)* ssl = lds + L_SSC + tok * 2064 + 32 * g;
 #ifdef CH_AB_SSG
           const bool staged = false;
@@ -1927,14 +1968,14 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
             for (int e = 0; e < 8; ++e) mm[e] = __builtin_fmaf(h[e], 1.0f + sc[e], sh[e]);
             a1[pr] = as_frag(pack8(mm));
           }
-          (p.rstd_m + rc)[tok_sa] = rstd;
+          st_rstd(p.rstd_m, rc, rstd);
 #pragma unroll
           for (int pp = 0; pp < 4; ++pp) store_lines<false>(stg_, xh, Lb, 128 * pp, hqs[2 * pp], hqs[2 * pp + 1]);
 #pragma unroll
           for (int pp = 0; pp < 4; ++pp)
             store_lines<false>(stg_, xm, Lb, 128 * pp, __builtin_bit_cast(uint4, a1[2 * pp]), __builtin_bit_cast(uint4, a1[2 * pp + 1]));
         }
-      } else if constexpr (s < SQT) {
+      } else if constexpr (MOD && s < SQT) {
         // ---- x2 = x1 + xm Wlin^T + b: the residual row (it stays in acc until chain B's end); its bf16 copy is the qkv GEMM's operand
         constexpr int pr = s - SL;
         nb_mma(wb, a1, acc[2 * pr], acc[2 * pr + 1]);
@@ -2013,6 +2054,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
         add4(acc[2 * pr + 1], lds_f4(biasB + 128 * pr + 16));
         if constexpr (s == SM - 1) {
           ln_pack(a1, p.xhat2, p.rstd2, rc, p.ln_eps);  // xhat2 (norm2's affine sits in the packed fc1 weights / bias)
+          if constexpr (DROP) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+              x1[t] = acc[t];
+              acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+            }
+          }
 #pragma unroll
           for (int pr2 = 0; pr2 < 8; ++pr2) {  // + fc2 bias, once
             add4(acc[2 * pr2], lds_f4(biasB + 1024 + 128 * pr2));
@@ -2031,9 +2079,32 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_ab_fwd_kernel(hma_chain_a
             uv[4 + e] = c1[e];
           }
           gelu_n<8>(uv, hv);
+          if constexpr (DROP) {  // (element index = row * 1024 + hidden unit, as chain B and hma_mlp_bwd count it)
+            const int64_t e0 = (rc + (int64_t)tok_sa) * 1024 + 32 * h + 8 * g;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              bool k0, k1;
+              drop_keep2(dseed, p.drop_salt, e0 + e, dth, k0, k1);
+              hv[e] = k0 ? hv[e] * dsc : 0.f;
+              hv[e + 1] = k1 ? hv[e + 1] * dsc : 0.f;
+            }
+          }
           hf = as_frag(pack8(hv));
         } else {
           ks_mma(wb, hf, acc);
+          if constexpr (s == SQ - 1 && DROP) {
+            const int64_t e0 = (rc + (int64_t)tok_sa) * 256 + 8 * g;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; r += 2) {
+                bool k0, k1;
+                drop_keep2(dseed, p.drop_salt + 1, e0 + 32 * (t >> 1) + 4 * (t & 1) + r, dth, k0, k1);
+                acc[t][r] = x1[t][r] + (k0 ? acc[t][r] * dsc : 0.f);
+                acc[t][r + 1] = x1[t][r + 1] + (k1 ? acc[t][r + 1] * dsc : 0.f);
+              }
+            }
+          }
           if constexpr (s == SQ - 1) {
 #pragma unroll
             for (int pr2 = 0; pr2 < 8; ++pr2) store_lines<false>(stg_, xt, Lf, 128 * pr2, as_u4(acc[2 * pr2]), as_u4(acc[2 * pr2 + 1]));
@@ -2587,25 +2658,35 @@ extern "C" int hma_chain_t_bwd(void* stream, const hma_chain_t_bwd_t* p) {
 }
 
 extern "C" int hma_chain_ab_fwd(void* stream, const hma_chain_ab_fwd_t* p) {
-  if (!p || !p->o_s || !p->x || !p->ss || !p->b1 || p->B <= 0 || p->SA <= 0 || p->T != 16) return HMA_EINVAL;
-  if (!p->xhat_m || !p->xm || !p->rstd_m || !p->x2b || !p->qkv_t || !p->o_t || !p->xhat2 || !p->rstd2) return HMA_EINVAL;
+  if (!p || !p->o_s || !p->x || !p->b1 || p->B <= 0 || p->SA <= 0 || p->T != 16) return HMA_EINVAL;
+  const bool mod = p->bundles[1] != 0;
+  if (mod && (!p->ss || !p->xhat_m || !p->xm || !p->rstd_m)) return HMA_EINVAL;
+  if (!p->x2b || !p->qkv_t || !p->o_t || !p->xhat2 || !p->rstd2) return HMA_EINVAL;
   const bool qkv = p->qkv_s != nullptr;
   if (qkv && (!p->xhat1n || !p->rstd1n)) return HMA_EINVAL;
+  const bool drop = p->drop_p > 0.f;
+  if (drop && (!p->drop_seed || p->drop_p >= 1.f || !mod)) return HMA_EINVAL;
   if ((int64_t)p->SA * 1536 * 15 >= (int64_t)1 << 31) return HMA_EINVAL;  // (line offsets are 32-bit)
-  const int expect[6] = {8, 8, 24, 8, 64, qkv ? 24 : 0};
+  const int expect[6] = {8, mod ? 8 : 0, 24, 8, 64, qkv ? 24 : 0};
   for (int i = 0; i < 6; ++i)
     if (p->bundles[i] != expect[i] || (expect[i] > 0 && !p->seg[i])) return HMA_EINVAL;
   const int64_t cols = p->B * (int64_t)p->SA;
   const int64_t ntiles = (cols + NCW - 1) / NCW;
   const int slots = num_cus() * WGS_PER_CU;
   const int grid = (int)(ntiles < slots ? ntiles : slots);
-  if (qkv) {
-    if (int rc = set_lds<chain_ab_fwd_kernel<true>>(AB_SMEM)) return rc;
-    hipLaunchKernelGGL(chain_ab_fwd_kernel<true>, dim3(grid), dim3(CH_THREADS), AB_SMEM, (hipStream_t)stream, *p);
+#define CH_LAUNCH_AB(QKV_, MOD_, DROP_)                                                                                          \
+  do {                                                                                                                          \
+    if (int rc = set_lds<chain_ab_fwd_kernel<QKV_, MOD_, DROP_>>(AB_SMEM)) return rc;                                           \
+    hipLaunchKernelGGL((chain_ab_fwd_kernel<QKV_, MOD_, DROP_>), dim3(grid), dim3(CH_THREADS), AB_SMEM, (hipStream_t)stream, *p); \
+  } while (0)
+  if (drop) {
+    if (qkv) CH_LAUNCH_AB(true, true, true); else CH_LAUNCH_AB(false, true, true);
+  } else if (mod) {
+    if (qkv) CH_LAUNCH_AB(true, true, false); else CH_LAUNCH_AB(false, true, false);
   } else {
-    if (int rc = set_lds<chain_ab_fwd_kernel<false>>(AB_SMEM)) return rc;
-    hipLaunchKernelGGL(chain_ab_fwd_kernel<false>, dim3(grid), dim3(CH_THREADS), AB_SMEM, (hipStream_t)stream, *p);
+    if (qkv) CH_LAUNCH_AB(true, false, false); else CH_LAUNCH_AB(false, false, false);
   }
+#undef CH_LAUNCH_AB
   HMA_CHECK_LAUNCH();
   return 0;
 }

@@ -420,22 +420,29 @@ class STEngine(DecodeMixin):
                nbytes=(1536.0 + 512 + 32) * Fr * SA)
         qkv_dst = b["qkv_t"] if kv is None else kv["cache"] + kv["row_off"] * 768 * 2
         qkv_grp = (0, 0) if kv is None else kv["c_group"]
-        if (self.chain_ab and train and chain_b and use_mod and kv is None and T == 16 and self.mlp_drop <= 0.0 and not qkn
+        # (T == 16 only: a column tile is 16 frame lanes and the kernel's time is per tile -- at T = 12 its 421 us of compute per 10 240-column
+        # launch would serve 3 / 4 of the rows, more than the fusion saves: DESIGN.md section 6.0; dropout needs the modulated form)
+        if (self.chain_ab and train and chain_b and kv is None and T == 16 and (use_mod or self.mlp_drop <= 0.0) and not qkn
                 and self._use_chain(M, SA)):
             # ---- chain A + causal temporal attention + chain B over columns of 16 frames, ONE launch (csrc/chain.hip): the residual row
             # stays in registers between the chains, the attention is wave-local
-            ap = f"decoder.layers.{l}.action_projectors.{domain}"
-            segs = [(dp_(self.CP["proj_s"], l), 8), (dp_(self.CP[f"lin:{domain}"], l), 8), (dp_(self.CP["qkv_t"], l), 24),
+            kwm = {}
+            seg_lin = (None, 0)
+            if use_mod:
+                ap = f"decoder.layers.{l}.action_projectors.{domain}"
+                seg_lin = (dp_(self.CP[f"lin:{domain}"], l), 8)
+                kwm = dict(ss=b["ss"], xhat_m=b["xhm"], xm=b["xm"], rstd_m=b["rstdm"], b_lin=self._p(f"{ap}.linear_out.bias"))
+            segs = [(dp_(self.CP["proj_s"], l), 8), seg_lin, (dp_(self.CP["qkv_t"], l), 24),
                     (self.CP["proj_t"][l].data_ptr(), 8), (self.CP["mlp"][l].data_ptr(), 64),
                     (self.CP["qkv_s"][l + 1].data_ptr(), 24) if next_qkv_s is not None else (None, 0)]
             kwq = {}
             if next_qkv_s is not None:
                 kwq = dict(xhat1n=next_ln1[0], rstd1n=next_ln1[1], qkv_s=next_qkv_s, b_qkv_s=self.BF["qkv_s"][l + 1].data_ptr())
-            pl.chain_ab_fwd(M, next_qkv_s is not None, B=B, SA=SA, segs=segs, o_s=b["o_s"], x=x, ss=b["ss"], b1=self.BF["fc1"][l].data_ptr(),
-                            xhat_m=b["xhm"], xm=b["xm"], rstd_m=b["rstdm"], x2b=b["x2b"], qkv_t=b["qkv_t"], o_t=b["o_t"], xhat2=b["xh2"],
-                            rstd2=b["rstd2"], attn_scale=self.scale, b_proj_s=pb("spatial_attn"), b_lin=self._p(f"{ap}.linear_out.bias"),
+            pl.chain_ab_fwd(M, next_qkv_s is not None, B=B, SA=SA, segs=segs, o_s=b["o_s"], x=x, b1=self.BF["fc1"][l].data_ptr(),
+                            x2b=b["x2b"], qkv_t=b["qkv_t"], o_t=b["o_t"], xhat2=b["xh2"],
+                            rstd2=b["rstd2"], attn_scale=self.scale, b_proj_s=pb("spatial_attn"),
                             b_qkv_t=qb("temporal_attn"), b_proj_t=pb("temporal_attn"),
-                            b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None, **kwq)
+                            b2=self._lw(l, "mlp.fc2.bias", "p") if cfg.mlp_bias else None, **kwm, **kwq, **self._drop_fused(train, l))
             return
         if self._use_chain(M, SA):
             # ---- chain A (csrc/chain.hip): proj + residual -> modulate-LN -> linear_out + residual -> temporal qkv, one launch
@@ -637,7 +644,10 @@ class STEngine(DecodeMixin):
         dp = lambda t, l=0, per=0: t.data_ptr() + (l * per) * t.element_size()
         x, dx, t256, dqkv = ws["x"].data_ptr(), ws["dx"].data_ptr(), ws["t256"].data_ptr(), ws["dqkv"].data_ptr()
         dxb = ws["dxb"].data_ptr()
-        multi = self.wgrad_multi and "dqkv_s" in ws and self._use_fused(M, True, SA) and self._use_chain(M, SA) and self.chain_s and not self.qkn
+        # chain S leaves norm1's dgamma / dbeta to the qkv weight gradient's reduction, which exists on the LDS-DMA path only: that path
+        # needs whole 32-row stages and at least two 64-row slabs (a split-M launch with a workspace); smaller passes keep hma_ln_bwd
+        chain_s_ok = self.chain_s and (not self.qkn) and self._use_chain(M, SA) and M % 32 == 0 and M >= 128
+        multi = self.wgrad_multi and "dqkv_s" in ws and self._use_fused(M, True, SA) and chain_s_ok
         dqkv_s = ws["dqkv_s"].data_ptr() if multi else dqkv
         ring = [ws[k].data_ptr() for k in ("dxb", "dxb2", "dxb3", "dxb4")] if multi else []
         nxt = lambda cur: ring[(ring.index(cur) + 1) % 4]  # the next bf16(dx) buffer (deferred weight gradients still read the earlier ones)
@@ -771,7 +781,7 @@ class STEngine(DecodeMixin):
                 pl.gemm_nt(A=dxb, lda=256, a_kind=A_BF16, W=wt("proj_s"), ldw=256, M=M, N=256, K=256, epi=EPI_BF16, Cp=t256, ldc=256)
             # (on the chain path the attention backward writes dqkv HEAD-BLOCKED -- whole contiguous 2 KB tiles instead of 32-byte pieces
             # of 32 cache lines per store instruction -- and its two consumers, the qkv weight gradient and chain S, read that order)
-            chain_s = self.chain_s and (not self.qkn) and self._use_chain(M, SA)
+            chain_s = chain_s_ok
             hb = chain_s and self.attn_hb and SA % 32 == 0
             pl.add("hma_attn_spatial_bwd_blocked" if hb else "hma_attn_spatial_bwd", qkv_s, o_s, t256, lse_s, ws["delta"].data_ptr(), dqkv_s, Fr, SA, self.scale,
                    flops=10.0 * Fr * SA * SA * 256,  # 5 products of 2 n^2 d per head (the recomputed S is not counted)

@@ -175,13 +175,15 @@ def make_chain_a_bwd(*, M: int, segs, dqkv: int, dx: int, dx1_bf16: int, d_o: in
     return g
 
 
-def make_chain_ab_fwd(*, B: int, SA: int, segs, o_s: int, x: int, ss: int, b1: int, xhat_m: int, xm: int, rstd_m: int, x2b: int, qkv_t: int,
-                      o_t: int, xhat2: int, rstd2: int, attn_scale: float, b_proj_s: Optional[int] = None, b_lin: Optional[int] = None,
+def make_chain_ab_fwd(*, B: int, SA: int, segs, o_s: int, x: int, b1: int, x2b: int, qkv_t: int, o_t: int, xhat2: int, rstd2: int,
+                      attn_scale: float, ss: Optional[int] = None, xhat_m: Optional[int] = None, xm: Optional[int] = None,
+                      rstd_m: Optional[int] = None, b_proj_s: Optional[int] = None, b_lin: Optional[int] = None,
                       b_qkv_t: Optional[int] = None, b_proj_t: Optional[int] = None, b2: Optional[int] = None, b_qkv_s: Optional[int] = None,
                       xhat1n: Optional[int] = None, rstd1n: Optional[int] = None, qkv_s: Optional[int] = None, ln_eps: float = 1e-5,
-                      T: int = 16) -> ChainABFwd:
-    """segs: [(pointer, bundles)] x 6 = proj_s (8), linear_out (8), temporal qkv (24), proj_t (8), the 64 fc1 / fc2 bundles, the next
-    block's folded spatial qkv (24; (None, 0) for the last block)."""
+                      T: int = 16, drop_p: float = 0.0, drop_salt: int = 0, drop_seed: Optional[int] = None) -> ChainABFwd:
+    """segs: [(pointer, bundles)] x 6 = proj_s (8), linear_out (8; (None, 0) for blocks without action tokens: then ss / xhat_m / xm /
+    rstd_m are not used), temporal qkv (24), proj_t (8), the 64 fc1 / fc2 bundles, the next block's folded spatial qkv (24; (None, 0)
+    for the last block).  drop_p > 0: the two nn.Dropout sites of the MLP (salts drop_salt, drop_salt + 1)."""
     g = ChainABFwd()
     for i in range(6):
         g.seg[i] = segs[i][0] if i < len(segs) else None
@@ -191,6 +193,7 @@ def make_chain_ab_fwd(*, B: int, SA: int, segs, o_s: int, x: int, ss: int, b1: i
     g.xhat_m, g.xm, g.rstd_m, g.x2b, g.qkv_t, g.o_t = xhat_m, xm, rstd_m, x2b, qkv_t, o_t
     g.xhat2, g.rstd2, g.xhat1n, g.rstd1n, g.qkv_s = xhat2, rstd2, xhat1n, rstd1n, qkv_s
     g.B, g.T, g.SA, g.attn_scale, g.ln_eps = B, T, SA, attn_scale, ln_eps
+    g.drop_p, g.drop_salt, g.drop_seed = drop_p, drop_salt, drop_seed
     return g
 
 

@@ -123,9 +123,10 @@ class Plan:
     def chain_ab_fwd(self, M: int, with_qkv: bool, **kw) -> None:
         g = make_chain_ab_fwd(**kw)
         self.keep.append(g)
-        # o_s 512 + x 1024 in; xhat_m, xm, bf16(x2) 3 x 512 + qkv_t 1536 + o_t 512 + x 1024 + xhat2 512 (+ xhat1' 512 + qkv_s 1536) out
-        nbytes = (512 + 1024 + 1536 + 1536 + 512 + 1024 + 512 + ((512 + 1536) if with_qkv else 0)) * float(M)
-        flops = 2.0 * M * 256 * (256 * 2 + 768 + 256 + 2048 + (768 if with_qkv else 0)) + 4.0 * M * 16 * 256
+        mod = g.bundles[1] > 0
+        # o_s 512 + x 1024 in; [xhat_m, xm,] bf16(x2) 512 each + qkv_t 1536 + o_t 512 + x 1024 + xhat2 512 (+ xhat1' 512 + qkv_s 1536) out
+        nbytes = (512 + 1024 + (1536 if mod else 512) + 1536 + 512 + 1024 + 512 + ((512 + 1536) if with_qkv else 0)) * float(M)
+        flops = 2.0 * M * 256 * (256 * (2 if mod else 1) + 768 + 256 + 2048 + (768 if with_qkv else 0)) + 4.0 * M * 16 * 256
         self.add("hma_chain_ab_fwd", C.byref(g), flops=flops, nbytes=nbytes)
 
     def chain_a_bwd(self, M: int, use_mod: bool, **kw) -> None:

@@ -537,7 +537,9 @@ int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p);
  * out (all saved for the backward): xhat_m, xm, x2b [M,256] bf16 + rstd_m [M]; qkv_t [M,768] bf16; o_t [M,256] bf16; xhat2 [M,256] +
  * rstd2 [M]; with qkv_s != NULL also the next block's xhat1n + rstd1n and qkv_s [M,768] bf16 (NULL: last block).
  * weights (hma_chain_pack bundles): seg 0 proj_s (8), 1 linear_out (8), 2 temporal qkv (24), 3 proj_t (8), 4 the 64 alternating fc1 / fc2
- * bundles, 5 the next block's folded spatial qkv (24, or 0).  Biases as in the two chains (b1 = folded fc1 bias, required). */
+ * bundles, 5 the next block's folded spatial qkv (24, or 0).  Biases as in the two chains (b1 = folded fc1 bias, required).
+ * bundles[1] == 0: a block WITHOUT action tokens (no ModulateLayer, st_transformer.py:102-104 skipped): ss, b_lin, xhat_m, xm, rstd_m are
+ * not used and x2b = bf16(x + proj_s(o_s)) is the temporal qkv's operand (what hma_chain_a_fwd writes with use_mod = 0). */
 typedef struct {
   const void* seg[6]; int32_t bundles[6];
   const void* o_s; float* x; const float* ss;
@@ -547,6 +549,9 @@ typedef struct {
   void* xhat2; float* rstd2; void* xhat1n; float* rstd1n; void* qkv_s;
   int64_t B; int32_t T; int32_t SA;
   float attn_scale; float ln_eps;
+  /* training with mlp_drop > 0 (drop_p in (0, 1), else 0 / NULL): the two nn.Dropout sites of Mlp.forward, as in hma_chain_b_fwd_t
+   * (the same element counters and salts: hma_mlp_bwd re-creates the masks).  Needs the modulated form (bundles[1] == 8). */
+  float drop_p; int32_t drop_salt; const uint32_t* drop_seed;
 } hma_chain_ab_fwd_t;
 int hma_chain_ab_fwd(void* stream, const hma_chain_ab_fwd_t* p);
 

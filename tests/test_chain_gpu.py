@@ -400,12 +400,17 @@ def test_readout_ce_fused(B, T, S, A):
     assert rms(dl2, dl) < 5e-3
 
 
-@pytest.mark.parametrize("B,SA,with_qkv", [(1, 16, True), (2, 48, True), (3, 320, True), (2, 320, False), (32, 320, True)])
-def test_chain_ab_fwd_equals_three_launches(B, SA, with_qkv):
+@pytest.mark.parametrize("B,SA,with_qkv,use_mod,p_drop", [
+    (1, 16, True, True, 0.0), (2, 48, True, True, 0.0), (3, 320, True, True, 0.0), (2, 320, False, True, 0.0), (32, 320, True, True, 0.0),
+    # blocks without action tokens (no ModulateLayer), and the MAR configs' mlp_drop (mar_n32_h8_d256_action.json:17)
+    (2, 48, True, False, 0.0), (3, 256, True, False, 0.0), (2, 256, False, False, 0.0), (16, 256, True, False, 0.0),
+    (2, 48, True, True, 0.05), (3, 320, False, True, 0.1), (16, 320, True, True, 0.05)])
+def test_chain_ab_fwd_equals_three_launches(B, SA, with_qkv, use_mod, p_drop):
     """hma_chain_ab_fwd (chain A + causal temporal attention + chain B over columns of T = 16 frames, one launch) against the three
     launches it replaces on the same inputs -- hma_chain_a_fwd (training form), hma_attn_temporal_fwd, hma_chain_b_fwd (training form):
     the same arithmetic in the same order, so every output agrees to bf16 rounding of identical fp32 values (bit-identical where no
-    reduction order differs).  Reference: st_transformer.py:86-112 and :85-86 of the next block, attention.py:37-61."""
+    reduction order differs).  Also without the ModulateLayer (use_mod = False) and with the MLP's two nn.Dropout sites (p_drop > 0: the
+    same counter-based masks in both paths).  Reference: st_transformer.py:86-112 and :85-86 of the next block, :24-27, attention.py:37-61."""
     T, scale = 16, 0.25
     M = B * T * SA
     gq = lambda s_: torch.Generator().manual_seed(s_)
@@ -434,32 +439,44 @@ def test_chain_ab_fwd_equals_three_launches(B, SA, with_qkv):
         return dict(xhat_m=bf(M, 256), xm=bf(M, 256), rstd_m=f32(M), x2b=bf(M, 256), qkv_t=bf(M, 768), o_t=bf(M, 256), xhat2=bf(M, 256),
                     rstd2=f32(M), xhat1n=bf(M, 256), rstd1n=f32(M), qkv_s=bf(M, 768))
 
+    dkw = {}
+    if p_drop > 0:
+        seed = torch.tensor([4242], dtype=torch.int32, device=DEV)
+        dkw = dict(drop_p=p_drop, drop_salt=6, drop_seed=ops.ptr(seed))
     # ---- three launches
     r, xr = outs(), x0.clone()
-    a = ops.make_chain_a_fwd(M=M, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_l), 8), (ops.ptr(p_qt), 24)], o=ops.ptr(o_s), x=ops.ptr(xr),
-                             qkv=ops.ptr(r["qkv_t"]), ss=ops.ptr(ss), b_proj=ops.ptr(bd["bps"]), b_lin=ops.ptr(bd["bl"]),
-                             b_qkv=ops.ptr(bd["bqt"]), xhat=ops.ptr(r["xhat_m"]), xm=ops.ptr(r["xm"]), rstd=ops.ptr(r["rstd_m"]),
-                             x_bf16=ops.ptr(r["x2b"]), rows_per_frame=SA, use_mod=True)
+    if use_mod:
+        a = ops.make_chain_a_fwd(M=M, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_l), 8), (ops.ptr(p_qt), 24)], o=ops.ptr(o_s), x=ops.ptr(xr),
+                                 qkv=ops.ptr(r["qkv_t"]), ss=ops.ptr(ss), b_proj=ops.ptr(bd["bps"]), b_lin=ops.ptr(bd["bl"]),
+                                 b_qkv=ops.ptr(bd["bqt"]), xhat=ops.ptr(r["xhat_m"]), xm=ops.ptr(r["xm"]), rstd=ops.ptr(r["rstd_m"]),
+                                 x_bf16=ops.ptr(r["x2b"]), rows_per_frame=SA, use_mod=True)
+    else:
+        a = ops.make_chain_a_fwd(M=M, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_qt), 24)], o=ops.ptr(o_s), x=ops.ptr(xr),
+                                 qkv=ops.ptr(r["qkv_t"]), ss=None, b_proj=ops.ptr(bd["bps"]), b_lin=None, b_qkv=ops.ptr(bd["bqt"]),
+                                 x_bf16=ops.ptr(r["x2b"]), rows_per_frame=SA, use_mod=False)
     _lib.call("hma_chain_a_fwd", ops.stream_ptr(), C.byref(a))
     _lib.call("hma_attn_temporal_fwd", ops.stream_ptr(), ops.ptr(r["qkv_t"]), ops.ptr(r["o_t"]), B, T, SA, scale)
     kwq = dict(xhat1n=ops.ptr(r["xhat1n"]), rstd1n=ops.ptr(r["rstd1n"]), qkv=ops.ptr(r["qkv_s"]), b_qkv=ops.ptr(bd["bqs"])) if with_qkv else {}
     b = ops.make_chain_b_fwd(M=M, segs=[(ops.ptr(p_pt), 8), (ops.ptr(mlp), 64)] + ([(ops.ptr(p_qs), 24)] if with_qkv else []),
                              o=ops.ptr(r["o_t"]), x=ops.ptr(xr), b_proj=ops.ptr(bd["bpt"]), b1=ops.ptr(bd["b1"]), b2=ops.ptr(bd["b2"]),
-                             xhat2=ops.ptr(r["xhat2"]), rstd2=ops.ptr(r["rstd2"]), **kwq)
+                             xhat2=ops.ptr(r["xhat2"]), rstd2=ops.ptr(r["rstd2"]), **kwq, **dkw)
     _lib.call("hma_chain_b_fwd", ops.stream_ptr(), C.byref(b))
     # ---- one launch
     f, xf = outs(), x0.clone()
     kwq = dict(xhat1n=ops.ptr(f["xhat1n"]), rstd1n=ops.ptr(f["rstd1n"]), qkv_s=ops.ptr(f["qkv_s"]), b_qkv_s=ops.ptr(bd["bqs"])) if with_qkv else {}
-    ab = ops.make_chain_ab_fwd(B=B, SA=SA, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_l), 8), (ops.ptr(p_qt), 24), (ops.ptr(p_pt), 8), (ops.ptr(mlp), 64),
+    kwm = dict(ss=ops.ptr(ss), xhat_m=ops.ptr(f["xhat_m"]), xm=ops.ptr(f["xm"]), rstd_m=ops.ptr(f["rstd_m"]), b_lin=ops.ptr(bd["bl"])) if use_mod else {}
+    ab = ops.make_chain_ab_fwd(B=B, SA=SA, segs=[(ops.ptr(p_ps), 8), (ops.ptr(p_l), 8) if use_mod else (None, 0), (ops.ptr(p_qt), 24),
+                                                  (ops.ptr(p_pt), 8), (ops.ptr(mlp), 64),
                                                   (ops.ptr(p_qs) if with_qkv else None, 24 if with_qkv else 0)],
-                               o_s=ops.ptr(o_s), x=ops.ptr(xf), ss=ops.ptr(ss), b1=ops.ptr(bd["b1"]), xhat_m=ops.ptr(f["xhat_m"]),
-                               xm=ops.ptr(f["xm"]), rstd_m=ops.ptr(f["rstd_m"]), x2b=ops.ptr(f["x2b"]), qkv_t=ops.ptr(f["qkv_t"]),
+                               o_s=ops.ptr(o_s), x=ops.ptr(xf), b1=ops.ptr(bd["b1"]), x2b=ops.ptr(f["x2b"]), qkv_t=ops.ptr(f["qkv_t"]),
                                o_t=ops.ptr(f["o_t"]), xhat2=ops.ptr(f["xhat2"]), rstd2=ops.ptr(f["rstd2"]), attn_scale=scale,
-                               b_proj_s=ops.ptr(bd["bps"]), b_lin=ops.ptr(bd["bl"]), b_qkv_t=ops.ptr(bd["bqt"]), b_proj_t=ops.ptr(bd["bpt"]),
-                               b2=ops.ptr(bd["b2"]), **kwq)
+                               b_proj_s=ops.ptr(bd["bps"]), b_qkv_t=ops.ptr(bd["bqt"]), b_proj_t=ops.ptr(bd["bpt"]),
+                               b2=ops.ptr(bd["b2"]), **kwm, **kwq, **dkw)
     _lib.call("hma_chain_ab_fwd", ops.stream_ptr(), C.byref(ab))
     torch.cuda.synchronize()
-    names = ["xhat_m", "xm", "rstd_m", "x2b", "qkv_t", "o_t", "xhat2", "rstd2"] + (["xhat1n", "rstd1n", "qkv_s"] if with_qkv else [])
+    names = (["xhat_m", "xm", "rstd_m"] if use_mod else []) + ["x2b", "qkv_t", "o_t", "xhat2", "rstd2"] + (["xhat1n", "rstd1n", "qkv_s"] if with_qkv else [])
+    if p_drop > 0:  # the masks did something: against the same launch without them
+        assert (xf - x0).abs().max() > 0
     for k in names:
         assert torch.isfinite(f[k].float()).all(), k
         tol = 1e-5 if k.startswith("rstd") else 2 * BF

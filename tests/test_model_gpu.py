@@ -538,3 +538,40 @@ def test_shipped_config_window_against_oracle():
     _note("shipped_T12.loss_abs_err", abs(out.loss.item() - loss.item()))
     _note("shipped_T12.worst_grad_rms", worst)
     assert worst <= 3e-2, worst
+
+
+@pytest.mark.parametrize("B,T,HW", [(1, 2, 8), (1, 3, 8)])
+def test_small_pass_trains_against_oracle(B, T, HW):
+    """The smallest passes that can train (the spatial attention takes frames of 64, 256 or 320 tokens and a loss needs T >= 2: M = 128
+    and 192 rows, no action tokens).  Chain S backward leaves norm1's dgamma / dbeta to the qkv weight gradient's LDS-DMA path, which
+    needs whole 32-row stages and two 64-row slabs: M = 128 is exactly that boundary (below it the engine keeps hma_ln_bwd for norm1
+    -- `chain_s_ok` in STEngine._backward_plan, the round-5 advisor finding).  Loss and every gradient against the oracle."""
+    import math
+    from oracle.param_spec import seeded_state_dict, state_dict_spec
+    S = HW * HW
+    cfgd = dict(num_layers=2, num_heads=8, d_model=256, T=T, S=S, image_vocab_size=262144, use_mup=True, action_network="concat+modulate",
+                num_factored_vocabs=2, qkv_bias=False, proj_bias=True, attn_drop=0.0, qk_norm=False, mlp_ratio=4.0, mlp_drop=0.0, mlp_bias=True)
+    rc = R.RefConfig(**{k: v for k, v in cfgd.items() if k in R.RefConfig.__dataclass_fields__})
+    sd = seeded_state_dict(state_dict_spec(rc, [], [], []), seed=77, std=0.02, embed_std=0.02)
+    m = STMaskGIT(GenieConfig(**cfgd))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    gq = torch.Generator().manual_seed(5)
+    labels = torch.randint(0, 262144, (B, T, HW, HW), generator=gq)
+    ids = labels.clone()
+    ids[:, 1:][torch.rand(B, T - 1, HW, HW, generator=gq) < 0.6] = 262144
+    ids[:, 1, 0, 0] = 262144  # (at least one masked token per sample)
+    out = m(input_ids=ids.reshape(B, -1).to(DEV), labels=labels.reshape(B, -1).to(DEV), domain=None, h=[HW] * B, w=[HW] * B)
+    out.loss.backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, acc, logits = R.forward(params, rc, ids.reshape(B, -1), labels.reshape(B, -1), None, None, H=HW, W=HW)
+    loss.backward()
+    assert abs(out.loss.item() - loss.item()) <= 1e-3, (out.loss.item(), loss.item())
+    worst = 0.0
+    for name, p in m.named_parameters():
+        gr = params[name].grad
+        if gr is None or float(gr.abs().sum()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, rms_err(p.grad, gr))
+    assert math.isfinite(worst) and worst <= 3e-2, worst
