@@ -923,3 +923,47 @@ def test_gemm_nt_shallow_k_many_tiles(M, K):
     b = torch.randn(256, generator=g(33))
     y = ops.linear(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV), epi=EPI_BF16)
     close(y, x @ w.t() + b, BF, "shallow K, bf16 out")
+
+
+def _drop_hash_np(seed, salt, pair):
+    """numpy replica of hma_common.h drop_hash (the murmur3 finaliser over seed, salt and the element-pair index).  A version on
+    v_mad_u32_u24 (full-rate multiplies, 12 issue slots against 19) was measured in round 6: statistically indistinguishable, and the MAR
+    step 0.5 ms SLOWER (its extra live register per hash costs the dropout forms of the chains more than the multiplies did)."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+    pair = pair.astype(np.uint64)
+    x = (pair & m32) ^ (((pair >> np.uint64(32)) * np.uint64(0x9E3779B9)) & m32)
+    x ^= np.uint64((seed + 0x7F4A7C15 * (salt + 1)) & 0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & m32
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & m32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+@pytest.mark.parametrize("seed,salt,p", [(4242, 6, 0.05), (1, 0, 0.1), (506952113, 63, 0.5)])
+def test_dropout_hash_statistics_and_replica(seed, salt, p):
+    """The counter-based dropout mask (hma_common.h drop_hash: every kernel that masks -- GEMM epilogues, the chains, hma_mlp_bwd,
+    hma_dropout_bf16 -- calls the one function): the kernel's keep mask equals the numpy replica bit for bit, the keep rate is 1 - p
+    rounded down to 2^-16 within sampling noise, and neighbouring elements, rows and the two halves of a hash are uncorrelated."""
+    import numpy as np
+    M, cols = 4096, 1024
+    ones = torch.ones(M, cols, device=DEV)
+    out = torch.empty(M, cols, dtype=torch.bfloat16, device=DEV)
+    sd = torch.tensor([seed], dtype=torch.int32, device=DEV)
+    _lib.call("hma_dropout_bf16", ops.stream_ptr(), ones.data_ptr(), out.data_ptr(), M, cols, p, sd.data_ptr(), salt)
+    keep = (out.float() > 0).cpu().numpy().reshape(-1)
+    x = _drop_hash_np(seed, salt, np.arange(M * cols // 2))
+    th = int(p * 65536)
+    ref = np.empty(M * cols, dtype=bool)
+    ref[0::2] = (x & np.uint64(0xFFFF)) >= th
+    ref[1::2] = (x >> np.uint64(16)) >= th
+    assert (keep == ref).all()
+    n = keep.size
+    want = 1.0 - th / 65536.0
+    assert abs(keep.mean() - want) <= 5.0 * math.sqrt(want * (1 - want) / n) + 1e-9
+    k = keep.astype(np.float64) - keep.mean()
+    for lag in (1, 2, cols, cols + 1):
+        c = (k[:-lag] * k[lag:]).mean() / k.var()
+        assert abs(c) <= 6.0 / math.sqrt(n), (lag, c)

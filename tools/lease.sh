@@ -48,6 +48,22 @@ case "$1" in
         line $lib --frames $t
         python -c "import json; d=json.load(open('gpurun_out/_line.json')); print('  T=$t', '%.0f tokens/s' % d['value'], d['config'])"
       done; } 2>&1 | tee gpurun_out/frames.txt ;;
+  mode_ab)  # mode_ab MODE LIB_A LIB_B: interleaved same-box A / B of one bench leg (decode | mar) for two libraries, twice each
+    m=$2; a=$3; b=$4
+    { for lib in $a $b $a $b; do
+        timeout 600 python bench.py --mode $m --steps ${STEPS:-8} --warmup 3 --no-cpu-baseline --lib $lib > gpurun_out/_mode.json 2> gpurun_out/_mode.err || tail -5 gpurun_out/_mode.err
+        python -c "import json; d=json.load(open('gpurun_out/_mode.json')); print('$m $lib %.1f %s %.2f ms/step' % (d['value'], d['unit'], d.get('ms_per_step', float('nan'))), d.get('latency_b1', ''))"
+      done; } 2>&1 | tee gpurun_out/mode_ab_$m.txt ;;
+  mode)  # mode MODE [env assignments...]: one bench leg (decode | mar), its line reduced to the value and the hot kernels
+    m=$2; shift 2
+    { for e in "$@" ""; do
+        env $e timeout 600 python bench.py --mode $m --steps ${STEPS:-8} --warmup 3 --no-cpu-baseline > gpurun_out/_mode.json 2> gpurun_out/_mode.err || tail -5 gpurun_out/_mode.err
+        python - "$m" "$e" <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/_mode.json"))
+print(sys.argv[1], sys.argv[2] or "(default)", "%.1f %s" % (d["value"], d["unit"]), "%.2f ms/step" % d.get("ms_per_step", float("nan")), d.get("latency_b1", ""))
+PY
+      done; } 2>&1 | tee gpurun_out/mode_$m.txt ;;
   ab)  # ab LIB_A LIB_B [bench args]: interleaved same-box A / B of two libraries, twice each
     a=$2; b=$3; shift 3
     { for lib in $a $b $a $b; do line $lib "$@"; done; } 2>&1 | tee gpurun_out/ab.txt ;;
