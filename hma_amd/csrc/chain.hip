@@ -2538,14 +2538,22 @@ bool weights_ok(const hma_chain_weights_t& w, int expect) {
   return sum == expect;
 }
 
-// compute waves for a pass of M rows: 5 when 7-wave tiles would leave CUs without a tile and 5-wave tiles fill more of them
+// compute waves for a pass of M rows (passes that save nothing): 5 when 7-wave tiles would leave CUs without a tile and 5-wave tiles
+// fill more of them; ONE or TWO when even 16- / 32-row tiles do not fill the chip -- a tile's time is its steps (40 / 96 bundles, ~1 100
+// cycles each with five waves sharing the LDS, ~450 with one), so a pass of a few hundred rows (the interactive decode: one 320-row
+// frame, sim/simulator.py:286-293) is as fast as its tiles are small: 20 workgroups of one compute wave + loader instead of 4 of five
 int chain_waves(int64_t M) {
   if (NCW < 6) return NCW;
 #ifdef CH_NO5  // (measurement: always full tiles -- fewer CUs, less weight traffic out of L2)
   return NCW;
 #endif
+  const int cus = num_cus();
+#ifndef CH_NO_SMALL
+  if (M <= (int64_t)16 * cus) return 1;
+  if (M <= (int64_t)32 * cus) return 2;
+#endif
   const int64_t tn = (M + 16 * NCW - 1) / (16 * NCW), t5 = (M + 79) / 80;
-  return (tn < num_cus() && t5 > tn) ? 5 : NCW;
+  return (tn < cus && t5 > tn) ? 5 : NCW;
 }
 
 int chain_grid(int64_t M, int nw = NCW) {
@@ -2601,9 +2609,13 @@ extern "C" int hma_chain_a_fwd(void* stream, const hma_chain_a_fwd_t* p) {
     hipLaunchKernelGGL((chain_a_fwd_kernel<MOD_, SAVE_, NW_>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);       \
   } while (0)
   if (p->use_mod) {
-    if (save) CH_LAUNCH_A(true, true, NCW); else if (nw == 5) CH_LAUNCH_A(true, false, 5); else CH_LAUNCH_A(true, false, NCW);
+    if (save) CH_LAUNCH_A(true, true, NCW);
+    else if (nw == 1) CH_LAUNCH_A(true, false, 1); else if (nw == 2) CH_LAUNCH_A(true, false, 2);
+    else if (nw == 5) CH_LAUNCH_A(true, false, 5); else CH_LAUNCH_A(true, false, NCW);
   } else {
-    if (save) CH_LAUNCH_A(false, true, NCW); else if (nw == 5) CH_LAUNCH_A(false, false, 5); else CH_LAUNCH_A(false, false, NCW);
+    if (save) CH_LAUNCH_A(false, true, NCW);
+    else if (nw == 1) CH_LAUNCH_A(false, false, 1); else if (nw == 2) CH_LAUNCH_A(false, false, 2);
+    else if (nw == 5) CH_LAUNCH_A(false, false, 5); else CH_LAUNCH_A(false, false, NCW);
   }
 #undef CH_LAUNCH_A
   HMA_CHECK_LAUNCH();
@@ -2725,9 +2737,9 @@ extern "C" int hma_chain_b_fwd(void* stream, const hma_chain_b_fwd_t* p) {
       hipLaunchKernelGGL((chain_b_fwd_kernel<false, NCW, true>), dim3(grid), dim3(CH_THREADS), SMEM, (hipStream_t)stream, *p);
     }
   } else if (qkv) {
-    if (nw == 5) CH_LAUNCH_B(true, 5); else CH_LAUNCH_B(true, NCW);
+    if (nw == 1) CH_LAUNCH_B(true, 1); else if (nw == 2) CH_LAUNCH_B(true, 2); else if (nw == 5) CH_LAUNCH_B(true, 5); else CH_LAUNCH_B(true, NCW);
   } else {
-    if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, NCW);
+    if (nw == 1) CH_LAUNCH_B(false, 1); else if (nw == 2) CH_LAUNCH_B(false, 2); else if (nw == 5) CH_LAUNCH_B(false, 5); else CH_LAUNCH_B(false, NCW);
   }
 #undef CH_LAUNCH_B
   HMA_CHECK_LAUNCH();

@@ -48,6 +48,25 @@ case "$1" in
         line $lib --frames $t
         python -c "import json; d=json.load(open('gpurun_out/_line.json')); print('  T=$t', '%.0f tokens/s' % d['value'], d['config'])"
       done; } 2>&1 | tee gpurun_out/frames.txt ;;
+  prof)  # prof NAME bench-args...: rocprofv3 kernel-trace stats of one bench.py command -> gpurun_out/prof_NAME.txt (+ the csv)
+    name=$2; shift 2
+    out=gpurun_out/prof_$name
+    rm -rf $out; mkdir -p $out
+    ( cd /tmp && true )
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o q -- python3 bench.py "$@" > $out/bench.log 2>&1 < /dev/null
+    echo "rc=$?"; tail -1 $out/bench.log | cut -c1-400
+    f=$(find $out -name "*kernel_stats.csv" | head -1)
+    cp "$f" gpurun_out/prof_$name.csv
+    python3 - "$f" <<'PY' | tee gpurun_out/prof_$name.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:30]:
+    n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms {int(r["Calls"]):6d} calls {float(r["AverageNs"])/1e3:9.1f} us {float(r["Percentage"]):6.2f}%  {n[:100]}')
+print(f"total {tot/1e6:.1f} ms")
+PY
+    find $out -name "*kernel_trace.csv" -delete ;;
   mode_ab)  # mode_ab MODE LIB_A LIB_B: interleaved same-box A / B of one bench leg (decode | mar) for two libraries, twice each
     m=$2; a=$3; b=$4
     { for lib in $a $b $a $b; do
