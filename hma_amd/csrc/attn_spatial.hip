@@ -202,13 +202,19 @@ __device__ __forceinline__ void store_grad_tile(uint16_t* dqkv, int hb, int64_t 
 // ------------------------------------------------------------------------------------- forward
 template <int NT>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
-                                                          float* __restrict__ lse, int64_t frames, float c_log2) {
+                                                          float* __restrict__ lse, int64_t frames, float c_log2, int qsplit) {
   constexpr int N = NT * 32, LDV = N + 4;
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* Ks = smem;             // [N][LDR]
   uint16_t* Vt = smem + N * LDR;   // [32][LDV]
   int64_t frame; int head;
-  decode_block(blockIdx.x, frames, frame, head);
+  // qsplit > 1 (a handful of frames: the interactive decode's single frame is 8 workgroups on 256 CUs): the query tiles of a (frame,
+  // head) are dealt over qsplit workgroups, four tiles each -- every one stages K / V itself (L2 serves the repeats) and runs ONE round
+  // of the tile loop instead of NT / 4; the arithmetic of a tile is the same wherever it runs
+  const int64_t item = qsplit > 1 ? (int64_t)blockIdx.x / qsplit : (int64_t)blockIdx.x;
+  const int part = qsplit > 1 ? (int)(blockIdx.x - item * qsplit) : 0;
+  decode_block(item, frames, frame, head);
+  const int qt_lo = qsplit > 1 ? 4 * part : 0, qt_hi = qsplit > 1 ? (4 * part + 4 < NT ? 4 * part + 4 : NT) : NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint16_t* base = qkv + frame * N * QKV_LD + head * HD;
   {
@@ -222,10 +228,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const uint16_t* __rest
   __syncthreads();
 
   // the query tile of the NEXT trip is fetched while this one is computed (clamped re-load on the last trip)
-  const int qt0 = wave_rot(wave);
+  const int qt0 = qt_lo + wave_rot(wave);
   bf16x8_t nq0 = frag_global(base + (int64_t)min(qt0, NT - 1) * 32 * QKV_LD, QKV_LD, 0, lane);
   bf16x8_t nq1 = frag_global(base + (int64_t)min(qt0, NT - 1) * 32 * QKV_LD, QKV_LD, 1, lane);
-  for (int qt = qt0; qt < NT; qt += 4) {
+  for (int qt = qt0; qt < qt_hi; qt += 4) {
     const bf16x8_t q0 = nq0, q1 = nq1;
     {
       const uint16_t* qn = base + (int64_t)min(qt + 4, NT - 1) * 32 * QKV_LD;
@@ -1007,14 +1013,18 @@ int set_lds(int bytes) {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+int cu_count();
+
 template <int NT>
 int launch_fwd(hipStream_t s, const void* qkv, void* o, float* lse, int64_t frames, float scale) {
   constexpr int N = NT * 32, LDV = N + 4;
   constexpr int bytes = (N * LDR + 32 * LDV) * 2;
   int rc = set_lds<attn_fwd_kernel<NT>>(bytes);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3((unsigned)(frames * NH)), dim3(256), bytes, s, (const uint16_t*)qkv,
-                     (uint16_t*)o, lse, frames, scale * LOG2E);
+  // (fewer (frame, head) items than a third of the CUs: one round of query tiles per workgroup)
+  const int qsplit = (NT > 4 && frames * NH * 3 <= cu_count()) ? (NT + 3) / 4 : 1;
+  hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3((unsigned)(frames * NH * qsplit)), dim3(256), bytes, s, (const uint16_t*)qkv,
+                     (uint16_t*)o, lse, frames, scale * LOG2E, qsplit);
   HMA_CHECK_LAUNCH();
   return 0;
 }
