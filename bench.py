@@ -432,6 +432,45 @@ def launch_ranks(n: int) -> int:
     return 0
 
 
+def child_line(extra_args, env_extra, steps=8, warmup=3):
+    """One more train-leg line of this script in a CHILD process (its own model, plans and graphs; the parent's memory is released
+    first), reduced to the numbers the parent's line carries."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HMA_FORCE_COLLECTIVES", "HMA_BENCH_STEP_DOMAINS")}
+    env.update(env_extra)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--mode", "train", "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-kernel-timing"] + list(extra_args)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(lines[0])
+    keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "final_loss", "backend", "allreduce_bytes_per_step") if k in d}
+    keep["workload"] = d["config"]["workload"]
+    return keep
+
+
+def forced_collectives_check():
+    """What ONE GPU can measure of the 8-rank step: the same step with and without the reducer's collectives in a one-rank RCCL group
+    (HMA_FORCE_COLLECTIVES=1), both announcing the 8 domains an 8-rank step sees (HMA_BENCH_STEP_DOMAINS=8: 4 x (1 + 8) + 1 + 8 + 1
+    all-reduce calls, ~380-414 MB, on the side stream between the per-bucket hipGraphs).  What the delta contains: the step split into
+    one hipGraph per gradient bucket, the event waits between the two streams, RCCL's host-side enqueue -- NOT device-side contention:
+    an in-place all-reduce over one rank launches no kernel (profiles/prof_forced_r6.txt: no RCCL kernel in the trace), so the CUs
+    RCCL's ring kernels take from the persistent 256-workgroup launches at 8 ranks stay unmeasured on one GPU.
+    forced_collectives_delta_ms = step with - step without."""
+    plain = child_line([], {"HMA_BENCH_STEP_DOMAINS": "8"})
+    forced = child_line([], {"HMA_BENCH_STEP_DOMAINS": "8", "HMA_FORCE_COLLECTIVES": "1", "MASTER_ADDR": "127.0.0.1",
+                             "MASTER_PORT": str(29600 + os.getpid() % 300)})
+    res = {"announced_domains_per_step": 8, "plain": plain, "forced": forced,
+           "note": "one-rank RCCL group: the reducer's calls, streams and per-bucket graphs of an 8-rank step without device-side "
+                   "all-reduce work (RCCL launches no kernel for one rank)"}
+    if "ms_per_step" in plain and "ms_per_step" in forced:
+        res["forced_collectives_delta_ms"] = forced["ms_per_step"] - plain["ms_per_step"]
+        by = forced.get("allreduce_bytes_per_step") or []
+        res["allreduce_mb_per_step"] = (sum(by) / len(by) / 1e6) if by else None
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -514,8 +553,14 @@ def main():
     model = model.to(dev).train()
     trainer = Trainer(model, lr=1e-4 * min(max(1, B * world / 64), 8), warmup_steps=500, device=dev)
     total = args.warmup + args.steps
-    seq = domain_sequence(len(domains), total * world)
-    mine = [seq[k * world + rank] for k in range(total)]  # rank r takes every world-th draw
+    # HMA_BENCH_STEP_DOMAINS=n (one-rank runs, `forced_collectives_check` below): every step ANNOUNCES the n domains an n-rank job would
+    # see in it (this rank trains the first; the others' blocks are zeroed, all-reduced and stepped with zero gradients), so that the
+    # reducer issues the all-reduce calls and bytes of an n-rank step
+    span = world
+    if world == 1 and int(os.environ.get("HMA_BENCH_STEP_DOMAINS", "0")) > 1:
+        span = int(os.environ["HMA_BENCH_STEP_DOMAINS"])
+    seq = domain_sequence(len(domains), total * span)
+    mine = [seq[k * span + rank] for k in range(total)]  # rank r takes every world-th draw
     batches = {}
     for di in sorted(set(mine)):
         batches[di] = synthetic_batch(B, T, 100 + di, d_actions[di], dev)
@@ -527,7 +572,7 @@ def main():
         di = mine[k]
         ids, labels, act = batches[di]
         # every rank knows the whole draw sequence (one shared sampler): the step's domain set needs no collective
-        return trainer.step(ids, labels, act, [domains[di]] * B, step_domains=[domains[j] for j in seq[k * world:(k + 1) * world]])
+        return trainer.step(ids, labels, act, [domains[di]] * B, step_domains=[domains[j] for j in seq[k * span:(k + 1) * span]])
 
     # untimed preparation: every (shape, domain) pair of the schedule is run until its launch plan is captured
     # as a hipGraph (N = 1 path), so the timed steps replay graphs only -- the analogue of a compiler warm-up
@@ -539,7 +584,7 @@ def main():
             ids, labels, act = batches[mine[k]]
             if world == 1 and not first:
                 continue
-            trainer.step(ids, labels, act, [domains[mine[k]]] * B, step_domains=[domains[j] for j in seq[k * world:(k + 1) * world]])
+            trainer.step(ids, labels, act, [domains[mine[k]]] * B, step_domains=[domains[j] for j in seq[k * span:(k + 1) * span]])
             prepare_steps += 1
     for k in range(args.warmup):
         ws = one(k)
@@ -551,9 +596,13 @@ def main():
     # line reports how many gradient buckets were all-reduced from inside the backward and how many bytes went through all-reduce
     dp_check = {"steps": 0, "weights_equal": True, "early_buckets": [], "bytes_per_step": [], "buckets": len(trainer.reducer.dense_buckets)} \
         if (os.environ.get("HMA_BENCH_DP_CHECK") == "1" and (world > 1 or force)) else None
+    if force and world == 1:
+        bytes_seen = []
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
         ws = one(k)
+        if force and world == 1:
+            bytes_seen.append(int(trainer.reducer.bytes_step))
         if dp_check is not None:
             P = trainer.engine.P
             idx = torch.arange(P.numel(), device=P.device, dtype=torch.float64)
@@ -610,6 +659,8 @@ def main():
             out["power"] = power
         if dp_check is not None:
             out["dp_check"] = dp_check
+        if force and world == 1:
+            out["allreduce_bytes_per_step"] = bytes_seen
         if timer is not None:
             summ = timer.summary()
             step_ms = 1e3 * dt / args.steps
@@ -701,6 +752,11 @@ def main():
             torch.cuda.empty_cache()
             out["decode"] = decode_bench(args, dev, steps=3, warmup=2, batch=64)  # (two warm-up rollouts: a frame pass is captured on its second use)
             out["mar"] = mar_bench(args, dev, steps=5, warmup=2)
+            torch.cuda.empty_cache()
+            # the reference's own default window (train_multi.py:78-83, both shipped d256 JSONs: T = 12) and what one GPU can measure of
+            # the 8-rank risk (RCCL's kernels beside the persistent 256-workgroup launches), each in a child process of this command
+            out["train_T12"] = child_line(["--frames", "12"], {})
+            out["dp_check"] = forced_collectives_check()
         print(json.dumps(out), flush=True)
     if world > 1 or force:
         dist.destroy_process_group()

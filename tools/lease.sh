@@ -67,6 +67,8 @@ for r in rows[:30]:
 print(f"total {tot/1e6:.1f} ms")
 PY
     find $out -name "*kernel_trace.csv" -delete ;;
+  dpcheck)  # the bench line's train_T12 and dp_check sub-objects alone (child processes of bench.py)
+    python -c "import json, bench; print(json.dumps({'train_T12': bench.child_line(['--frames', '12'], {}), 'dp_check': bench.forced_collectives_check()}, indent=1))" 2>&1 | tee gpurun_out/dpcheck.txt ;;
   mode_ab)  # mode_ab MODE LIB_A LIB_B: interleaved same-box A / B of one bench leg (decode | mar) for two libraries, twice each
     m=$2; a=$3; b=$4
     { for lib in $a $b $a $b; do
