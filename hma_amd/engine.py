@@ -108,14 +108,17 @@ class STEngine(DecodeMixin):
         # linear_out (8) and its transpose.
         self.use_chain = True
         self.chain_min_rows = 0
-        self.chain_s = os.environ.get("HMA_CHAIN_S", "1") != "0"  # (0: measurement -- the spatial qkv dgrad + hma_ln_bwd as two launches)
-        self.attn_hb = os.environ.get("HMA_ATTN_HB", "1") != "0"  # (0: measurement -- the spatial attention backward's dqkv row-major)
-        self.chain_ab = os.environ.get("HMA_CHAIN_AB", "1") != "0"  # (0: measurement -- chain A, temporal attention, chain B as three launches)
-        self.chain_t = os.environ.get("HMA_CHAIN_T", "1") != "0"  # (0: measurement -- the temporal projection's dgrad + hma_attn_temporal_bwd as two launches)
-        # The seven weight gradients of a block in ONE launch at the end of its backward (hma_gemm_tn_multi): nothing reads a weight
-        # gradient before the optimizer, so they wait until every operand exists -- four bf16(dx) buffers and a second dqkv keep the
-        # operands alive.  (0: measurement -- three pair launches + linear_out's, each behind its operands)
-        self.wgrad_multi = os.environ.get("HMA_WGRAD_MULTI", "1") != "0"
+        # Which fused launches a pass takes is decided by its SHAPE alone (the `_use_*` predicates and the conditions at the call sites):
+        # the round-5 environment switches that selected the older launch sequences inside one build are gone -- a same-box A / B of a
+        # kernel change runs two builds (`bench.py --lib variants/...`).  The older sequences remain as what the shapes outside the
+        # fused kernels' reach run: T != 16 (chain A / temporal attention / chain B as three launches), T <= 8 (projection dgrad +
+        # hma_attn_temporal_bwd), qk_norm, frames that are not a multiple of 32 rows (row-major dqkv), passes below the LDS-DMA
+        # weight-gradient path (pair launches, hma_ln_bwd).
+        self.chain_s = True      # spatial qkv dgrad + norm1 backward + residual in one launch (hma_chain_s_bwd)
+        self.attn_hb = True      # the spatial attention backward's dqkv head-blocked (hma_attn_spatial_bwd_blocked)
+        self.chain_ab = True     # chain A + causal temporal attention + chain B in one launch (hma_chain_ab_fwd)
+        self.chain_t = True      # temporal projection dgrad + temporal attention backward in one launch (hma_chain_t_bwd)
+        self.wgrad_multi = True  # the block's seven weight gradients in one launch at the end of its backward (hma_gemm_tn_multi)
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN),
                    "qkv_s_T": mk(L, 24 * BUN), "proj_t_T": mk(L, 8 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
@@ -147,7 +150,7 @@ class STEngine(DecodeMixin):
         self._dplans: Dict[tuple, Plan] = {}
         self._dgraphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._dseen: Dict[tuple, int] = {}
-        self.decode_graphs = os.environ.get("HMA_DECODE_GRAPHS", "1") != "0"  # (0: measurement -- eager launches)
+        self.decode_graphs = True  # a decode frame pass is replayed as one hipGraph per (frame index, readout) after two eager runs
         self._plans: Dict[tuple, Plan] = {}
         self.scale = (8.0 / 32.0) if cfg.use_mup else 32.0 ** -0.5  # attention.py:27
         self.grad_scale = C.c_float(1.0)
@@ -1047,10 +1050,13 @@ class STEngine(DecodeMixin):
         if A > 0:
             # the adaLN stacks above ran for ALL layers from this call's action embeddings (one batched GEMM pair): the saved shift /
             # scale rows of layers outside [l0, l1) now belong to this call's a_emb -- unless it is the tensor the previous call had
-            akey = (a_emb.data_ptr(), a_emb._version, tuple(a_emb.shape), dom)
+            # ("the tensor the previous call had": address + version only mean that while the previous tensor is ALIVE -- a new tensor the
+            # caching allocator puts at a freed address starts at version 0 too -- so the engine keeps a reference to it until the next call)
+            akey = (a_emb.data_ptr(), a_emb._version, tuple(a_emb.shape), tuple(a_emb.stride()), dom)
             if akey != getattr(self, "_trunk_aemb_key", None):
                 self._invalidate_trunk_stamps(keep=range(l0, l1))
             self._trunk_aemb_key = akey
+            self._trunk_aemb_ref = a_emb
         self._trunk_counter = getattr(self, "_trunk_counter", 0) + 1
         for l in range(l0, l1):
             stamps[l] = self._trunk_counter

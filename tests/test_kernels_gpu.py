@@ -469,7 +469,8 @@ def test_gemm_tn_headblocked_operand(frames, n):
         ga = ops.make_gemm_tn(dY=ops.ptr(dyb), ldy=768, y_kind=A_BF16_HEADBLK if hb else A_BF16, y_group=(n, 0) if hb else (0, 0), A=ops.ptr(x), lda=256,
                               a_kind=A_BF16_AFFINE, gamma=ops.ptr(gam), beta=ops.ptr(bet), M=M, N=768, K=256, dW=ops.ptr(dW), lddw=256,
                               dBias=ops.ptr(db), ws=ops.ptr(ws), ws_elems=ws.numel())
-        gb = ops.make_gemm_tn(dY=ops.ptr(dy[:, :256].contiguous()), ldy=256, y_kind=A_BF16, A=ops.ptr(xb), lda=256,
+        dy256 = dy[:, :256].contiguous()  # (bound to a name: the launch reads it after this statement)
+        gb = ops.make_gemm_tn(dY=ops.ptr(dy256), ldy=256, y_kind=A_BF16, A=ops.ptr(xb), lda=256,
                               a_kind=A_BF16_HEADBLK if hb else A_BF16, a_group=(n, 0) if hb else (0, 0), M=M, N=256, K=256, dW=ops.ptr(dW2),
                               lddw=256, dBias=ops.ptr(db2), ws=ops.ptr(ws), ws_elems=ws.numel())
         _lib.call("hma_gemm_tn_pair", ops.stream_ptr(), C.byref(ga), C.byref(gb))
