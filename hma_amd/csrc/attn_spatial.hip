@@ -504,22 +504,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 // 34 % of this kernel's LDS cycles in profiles/pmc_sq_r4.txt); with 16-dword rows the four rows of a pass tile the banks exactly, and
 // the XOR keeps the row-major 16-byte reads of a 16-lane pass (16 consecutive rows, one chunk) and the staging writes (4 rows x 4
 // chunks) conflict-free as well.
+// ATTN_SWZ = 2 (round 6; measurement builds -- the default stays the padded layout, see below): the same bank picture WITHOUT the XOR -- unpadded 64-byte rows with 16 bytes of skew in front of every
+// group of four rows: offset(row, chunk) = 64 row + 16 (row >> 2) + 16 chunk bytes.  The four rows of a transposing pass are 256
+// contiguous bytes (every bank once); the 16 rows of a row-major 16-byte pass start at banks 16 b + 4 a (row = 4 a + b): all different
+// within each of the instruction's lane groups.  And the offset is ADDITIVE in the row: with row = row0 + lane part (row0 a multiple of
+// 4, a compile-time constant at every call site) the lane part is one register and row0 / chunk fold into the instruction's immediate --
+// the XOR form (ATTN_SWZ = 1, removed) needed an address register per call site (70 of them: 300 bytes of scratch in the balanced
+// kernel).  Built, parity-green, 239 registers and no scratch -- and 3-4 % SLOWER than the padded layout (standalone, head-blocked
+// backward at 512 x 320: 259.7 / 251.1 / 257.4 us padded against 267.8 / 271.1 / 261.3 us; in situ 234 against 242 us,
+// profiles/attn_lds_layout_r6.txt): the kernel's limit is its one dQ wave and its stores, not the conflict cycles.
 #ifndef ATTN_SWZ
 #define ATTN_SWZ 0
 #endif
-constexpr int LDF = ATTN_SWZ ? 32 : LDR;
-__device__ __forceinline__ int foff(int row, int chunk) {  // element offset of the 16-byte chunk `chunk` of row `row`
-  return ATTN_SWZ ? row * LDF + ((chunk ^ ((row >> 2) & 3)) << 3) : row * LDF + (chunk << 3);
+static_assert(ATTN_SWZ == 0 || ATTN_SWZ == 2, "the XOR form (1) is gone: it cost an address register per call site");
+constexpr int LDF = ATTN_SWZ == 2 ? 34 : LDR;  // (elements per row of a tile's allocation: N rows take N * LDF)
+// element offset of the 16-byte chunk `chunk` of row rc + rl: rc = the part of the row index that is a constant or wave-uniform at the
+// call site (a MULTIPLE OF 4), rl = the lane's part -- written as a sum of the two parts' offsets so that the lane part is ONE register
+// per access pattern and rc / chunk fold into the instruction's immediate offset ((rc + rl) >> 2 as one expression does not split)
+__device__ __forceinline__ int foff(int rc, int rl, int chunk) {
+  if (ATTN_SWZ == 2) return rc * 34 + rl * 32 + ((rl >> 2) << 3) + (chunk << 3);
+  return (rc + rl) * LDF + (chunk << 3);
 }
 __device__ __forceinline__ bf16x8_t frag_rows_f(const uint16_t* tile, int row0, int s, int lane) {
-  return *reinterpret_cast<const bf16x8_t*>(&tile[foff(row0 + (lane & 31), 2 * s + (lane >> 5))]);
+  return *reinterpret_cast<const bf16x8_t*>(&tile[foff(row0, lane & 31, 2 * s + (lane >> 5))]);
 }
 __device__ __forceinline__ bf16x8_t frag_tr_f(const uint16_t* tile, int row0, int lane) {
   const int i16 = lane & 15, g16 = lane >> 4;
-  const int row = row0 + 4 * (g16 >> 1) + (i16 >> 2);
+  const int rl = 4 * (g16 >> 1) + (i16 >> 2);
   const int chunk = 2 * (g16 & 1) + ((i16 & 3) >> 1), inner = 4 * (i16 & 1);
-  const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + foff(row, chunk) + inner));
-  const v4s16_t hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + foff(row + 8, chunk) + inner));
+  const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + foff(row0, rl, chunk) + inner));
+  const v4s16_t hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((HMA_LDS(v4s16_t)*)(tile + foff(row0 + 8, rl, chunk) + inner));
   typedef short v8s16_t __attribute__((ext_vector_type(8)));
   const v8s16_t v = __builtin_shufflevector(lo, hv, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8_t, v);
@@ -583,7 +597,7 @@ struct FusedStage {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int c = min(tid + i * THREADS, ITEMS - 1);
-      const int off = foff(c >> 2, c & 3);
+      const int off = foff(0, c >> 2, c & 3);
       *reinterpret_cast<uint4*>(&Qs[off]) = get(rq, i);
       *reinterpret_cast<uint4*>(&Ks[off]) = get(rk, i);
       *reinterpret_cast<uint4*>(&Vs[off]) = get(rv, i);
@@ -743,7 +757,7 @@ __global__ __launch_bounds__((NT / KT + 2) * 64, 1) void attn_bwd_fused_kernel(c
             }
             // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
             if (!(ATTN_ABL & 8)) {
-              uint16_t* T = Ts + (qt & 1) * N * LDF + foff((wave * KT + t) * 32 + (lane & 31), g);
+              uint16_t* T = Ts + (qt & 1) * N * LDF + foff((wave * KT + t) * 32, lane & 31, g);
               *reinterpret_cast<uint2*>(T + 4 * hi) =
                   make_uint2(pack_bf16(dp[t][4 * g], dp[t][4 * g + 1]), pack_bf16(dp[t][4 * g + 2], dp[t][4 * g + 3]));
             }
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_bal_kernel(const uint16_t* __
           }
           // this lane's key row of the dS tile, queries 8 g + 4 hi .. + 3
           if (!(ATTN_ABL & 8)) {
-            uint16_t* T = Ts + (qt & 1) * N * LDF + foff((kt0 + t) * 32 + (lane & 31), g);
+            uint16_t* T = Ts + (qt & 1) * N * LDF + foff((kt0 + t) * 32, lane & 31, g);
             *reinterpret_cast<uint2*>(T + 4 * hi) =
                 make_uint2(pack_bf16(dp[t][4 * g], dp[t][4 * g + 1]), pack_bf16(dp[t][4 * g + 2], dp[t][4 * g + 3]));
           }
