@@ -87,7 +87,7 @@ def pmc_traffic_per_call(kernels, count_kernel):
     sums of EVERY kernel the call launches (`kernels`: name substrings, e.g. the weight-gradient ring kernel AND its reduction) over the
     number of calls (= launches of `count_kernel`).  Comparable with `bytes_per_launch` (algorithmic bytes per call).  FETCH_SIZE is
     doubled: on gfx950 it reports half of a wide coalesced read (MI355X_MICROARCH.md, section HBM)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), "")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_r{r}.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), "")
     try:
         d = json.load(open(path))
         tot, calls = 0.0, 0
@@ -107,7 +107,7 @@ def pmc_traffic_per_call(kernels, count_kernel):
 def pmc_traffic_total(mode):
     """Whole-workload HBM bytes of the `decode` / `mar` legs from their committed PMC passes (profiles/pmc_hbm_<mode>_r4.json: FETCH_SIZE
     and WRITE_SIZE summed over every kernel of the measured unit, written by tools/prof_bench.sh MODE=<mode>)."""
-    path = os.path.join(ROOT, "profiles", f"pmc_hbm_{mode}_r4.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"pmc_hbm_{mode}_r{r}.json") for r in (6, 5, 4)) if os.path.exists(q)), "")
     try:
         return json.load(open(path))["summary"]
     except (OSError, KeyError, ValueError):
@@ -737,7 +737,7 @@ def main():
                                                "right after the timed region, on the stream the kernels run on.  The timed region replays the "
                                                "SAME launches in the SAME order on one stream as a hipGraph (round 5: no forked launches), so "
                                                "avg_launch_us is comparable with the per-kernel averages of a rocprofv3 --kernel-trace --stats "
-                                               "run of this command (profiles/kernel_stats_r5.csv; tools/roofline_check.py adds the kernels of a "
+                                               "run of this command (profiles/kernel_stats_r6.csv; tools/roofline_check.py adds the kernels of a "
                                                "C-ABI call -- for the weight gradients the ring kernel AND its reduction -- and compares).  "
                                                "Algorithmic FLOPs: recomputation is not counted",
                                    "families": fams}

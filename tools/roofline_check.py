@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reproduce the bench line's per-kernel numbers from a rocprofv3 kernel summary.
 
-    python tools/roofline_check.py [profiles/bench_r5_final.json] [profiles/kernel_stats_r5.csv]
+    python tools/roofline_check.py [profiles/bench_line_r6.json] [profiles/kernel_stats_r6.csv]
 
 The bench line times C-ABI calls with HIP events in eager steps right after the timed region; rocprofv3 --kernel-trace --stats of the
 same command gives per-KERNEL totals over the whole run (prepare + warm-up + timed graph replays + the instrumented steps: the same
@@ -72,8 +72,8 @@ def check(line_path, stats_path, tol=TOL):
 
 
 def main():
-    line_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "bench_r5_final.json")
-    stats_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "kernel_stats_r5.csv")
+    line_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "bench_line_r6.json")
+    stats_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "kernel_stats_r6.csv")
     ok, rows, dom = check(line_path, stats_path)
     print(f"{'family':30s} {'HIP events us':>14s} {'rocprof us':>11s} {'calls':>7s} {'diff':>7s} {'frac (line)':>12s} {'frac (rocprof)':>15s}")
     for fam, ev, us, calls, rel, f0, f1 in rows:
