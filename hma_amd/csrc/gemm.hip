@@ -1596,8 +1596,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
 
   // wave w fills rows 4 w .. 4 w + 3 of both tiles of a stage: two 1 KB pieces (two rows each) per tile
   // parts: bit mask of the stage's four pieces of this wave (bit 2 q + {0: dY, 1: A}); 15 = all four at once
-  auto issue_parts = [&](int st, int slot, int parts) __attribute__((always_inline)) {
+  auto issue_parts = [&](int st, int slot, int parts, int wv = -1) __attribute__((always_inline)) {
     if (ablate & 1) return;
+    if (wv < 0) wv = wave;
     const int64_t m0 = st_row0 + (int64_t)st * st_pitch;
     const uint32_t slot_b = lds_b + slot * DM_STAGE_BYTES;
 #pragma unroll
@@ -1605,7 +1606,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
       if (!((parts >> (2 * q)) & 3)) continue;
       const int rl = q * 2 + (lane >> 5);                 // row & 3 (4 w is a multiple of 4)
       const int lc = (lane & 31) ^ (rl << 2);             // logical chunk that lands in this lane's slot
-      const int64_t m = m0 + wave * 4 + rl;
+      const int64_t m = m0 + wv * 4 + rl;
       // HMA_A_BF16_FRAG32: (128-row tile, 32-column block, 32-row group) -> 2 KB = [columns 8..15 / 24..31 ? 1 : 0][column >= 16]
       // [row][8 columns] -- what hma_mlp_bwd's producers store with one contiguous 1 KB per wave instruction
       auto frag_at = [&](const uint16_t* base, int64_t ld, int64_t col) __attribute__((always_inline)) {
@@ -1626,8 +1627,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
       const uint16_t* as = p.afrag ? frag_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8)
                            : p.ahb > 0 ? hb_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8, p.ahb)
                                        : Ab + m * p.lda + lc * 8;
-      if ((parts >> (2 * q)) & 1) glds16(ys, slot_b + (wave * 4 + q * 2) * 512);
-      if ((parts >> (2 * q)) & 2) glds16(as, slot_b + DM_TILE_BYTES + (wave * 4 + q * 2) * 512);
+      if ((parts >> (2 * q)) & 1) glds16(ys, slot_b + (wv * 4 + q * 2) * 512);
+      if ((parts >> (2 * q)) & 2) glds16(as, slot_b + DM_TILE_BYTES + (wv * 4 + q * 2) * 512);
     }
   };
   auto issue = [&](int st, int slot) __attribute__((always_inline)) { issue_parts(st, slot, 15); };
@@ -1746,6 +1747,57 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
 
   // (A software-pipelined variant -- fragments read half a stage ahead, barrier in the middle of the stage -- measured
   // 10 % slower: it needs stage st + 1 landed half a stage earlier, and the DMA depth is what this loop lives on.)
+#ifdef TN_ISSUER_PROBE
+  // MEASUREMENT ONLY (results wrong): wave 7 issues EVERY piece of every stage and multiplies nothing; waves 0..6 never touch the
+  // vector-memory pipe inside the loop.  What a ring kernel with one issuing wave could reach (its eighth wave's output tile is
+  // simply left out here; the real organisation deals the 64 output blocks over seven waves).
+  static_assert(DM_STAGES == 3, "probe: 32 pieces per stage, the wait counter holds 63");
+  if (wave == 7) {
+    for (int st = 0; st < DM_STAGES - 1; ++st)
+      if (st < nst)
+        for (int wv = 0; wv < 8; ++wv) issue_parts(st, st, 15, wv);
+    int slot_i = 0;
+    for (int st = 0; st < nst; ++st) {
+      if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (st + DM_STAGES - 1 < nst)
+        for (int wv = 0; wv < 8; ++wv) issue_parts(st + DM_STAGES - 1, slot_i == 0 ? DM_STAGES - 1 : slot_i - 1, 15, wv);
+      slot_i = slot_i + 1 == DM_STAGES ? 0 : slot_i + 1;
+    }
+    return;
+  }
+  {
+    Frags f0, f1;
+    int slot = 0;
+    if (wn2 == 0) {
+      for (int st = 0; st < nst; ++st) {
+        __builtin_amdgcn_s_barrier();
+        read_frags(f0, slot, 0);
+        read_frags(f1, slot, 1);
+        mma(f0);
+        mma(f1);
+        slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();
+      read_frags(f0, 0, 0);
+      read_frags(f1, 0, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot = 1;
+      for (int st = 1; st < nst; ++st) {
+        __builtin_amdgcn_s_barrier();
+        mma(f0);
+        mma(f1);
+        read_frags(f0, slot, 0);
+        read_frags(f1, slot, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
+      }
+      mma(f0);
+      mma(f1);
+    }
+  }
+#else
 #pragma unroll
   for (int st = 0; st < DM_STAGES - 1; ++st)
     if (st < nst) issue(st, st);
@@ -1841,6 +1893,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     slot = slot + 1 == DM_STAGES ? 0 : slot + 1;
   }
 #endif
+#endif  // TN_ISSUER_PROBE
   // bf16 partial of this workgroup's 256 x 256 block, in the order the accumulators sit in the waves: piece
   // ((wave * 8 + i * 2 + j) * 2 + h) * 64 + lane is the lane's 8 values e = 8 h .. 8 h + 7 of acc[i][j], i.e. row
   // n = 128 wn2 + 32 i + r, columns k = 64 wk4 + 32 j + 16 h + 4 hi + {0..3} and the same + 8 (tn_reduce_native_kernel
