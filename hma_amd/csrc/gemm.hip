@@ -1594,6 +1594,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
+  // A piece's address = wave-uniform base (stage, row pair) + this lane's byte offset, which is the same for every stage: the lane parts
+  // of the three operand orders are computed ONCE here (two row pairs q x two operands), the uniform parts per piece in scalar registers
+  // (round 6: the per-piece 64-bit vector arithmetic of the fragment / head-blocked orders was ~170 cycles of issue per piece -- a wave
+  // spent a third of a stage computing addresses).
+  //   row-major      element (m, c) at m ld + c
+  //   HMA_A_BF16_FRAG32: (128-row tile, 32-column block, 32-row group) -> 2 KB = [columns 8..15 / 24..31 ? 1 : 0][column >= 16][row][8 columns]
+  //                  -- what hma_mlp_bwd's producers store with one contiguous 1 KB per wave instruction
+  //   HMA_A_BF16_HEADBLK: element (m, c) of a [M, 256 W] matrix at (((frame 8 + head) W + c / 256) n + m % n) 32 + c % 32, frame = m / n,
+  //                  head = (c % 256) / 32 -- what the spatial attention backward writes as whole contiguous 2 KB tiles (a stage's 32
+  //                  rows lie inside one frame)
+  // with m = mu + (lane >> 5), mu = the piece's first row (even: m >> 5 = mu >> 5), c = c0 + 8 lc, c0 a multiple of 256.
+  uint32_t loff_y[2], loff_a[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t hi5 = (uint32_t)lane >> 5;
+    const uint32_t rl = q * 2 + hi5;
+    const uint32_t lc = ((uint32_t)lane & 31u) ^ (rl << 2);  // logical chunk that lands in this lane's slot
+    auto lane_off = [&](int frag, int hb, int64_t ld) __attribute__((always_inline)) -> uint32_t {
+      if (frag) return 2u * (((lc >> 2) << 12) + ((lc & 1u) << 9) + (((lc >> 1) & 1u) << 8) + (hi5 << 3));
+      if (hb > 0) return 2u * ((((lc >> 2) * (uint32_t)(ld >> 8) * (uint32_t)hb + hi5) << 5) + (lc & 3u) * 8u);
+      return 2u * (hi5 * (uint32_t)ld + lc * 8u);
+    };
+    loff_y[q] = lane_off(p.yfrag, p.yhb, p.ldy);
+    loff_a[q] = lane_off(p.afrag, p.ahb, p.lda);
+  }
   // wave w fills rows 4 w .. 4 w + 3 of both tiles of a stage: two 1 KB pieces (two rows each) per tile
   // parts: bit mask of the stage's four pieces of this wave (bit 2 q + {0: dY, 1: A}); 15 = all four at once
   auto issue_parts = [&](int st, int slot, int parts, int wv = -1) __attribute__((always_inline)) {
@@ -1601,34 +1626,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_dma_kernel(tn_pair_args args) 
     if (wv < 0) wv = wave;
     const int64_t m0 = st_row0 + (int64_t)st * st_pitch;
     const uint32_t slot_b = lds_b + slot * DM_STAGE_BYTES;
+    auto ubase = [&](const void* mat, const uint16_t* rowmajor, int frag, int hb, int64_t ld, int64_t c0, int64_t mu) __attribute__((always_inline)) {
+      const uint16_t* base = reinterpret_cast<const uint16_t*>(mat);
+      if (frag) return base + (((((mu >> 7) * (ld >> 5) + (c0 >> 5)) << 2) + ((mu >> 5) & 3)) << 10) + ((mu & 31) << 3);
+      if (hb > 0) {
+        const uint32_t fr = (uint32_t)m0 / (uint32_t)hb;  // (ONE 32-bit division per stage, by the wave-uniform first row)
+        return base + ((((int64_t)fr * 8 * (ld >> 8) + (c0 >> 8)) * hb + (mu - (int64_t)fr * hb)) << 5);
+      }
+      return rowmajor + mu * ld;  // (host: no row groups on this path; `rowmajor` already carries the batch offset and c0)
+    };
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (!((parts >> (2 * q)) & 3)) continue;
-      const int rl = q * 2 + (lane >> 5);                 // row & 3 (4 w is a multiple of 4)
-      const int lc = (lane & 31) ^ (rl << 2);             // logical chunk that lands in this lane's slot
-      const int64_t m = m0 + wv * 4 + rl;
-      // HMA_A_BF16_FRAG32: (128-row tile, 32-column block, 32-row group) -> 2 KB = [columns 8..15 / 24..31 ? 1 : 0][column >= 16]
-      // [row][8 columns] -- what hma_mlp_bwd's producers store with one contiguous 1 KB per wave instruction
-      auto frag_at = [&](const uint16_t* base, int64_t ld, int64_t col) __attribute__((always_inline)) {
-        return base + (((((m >> 7) * (ld >> 5) + (col >> 5)) << 2) + ((m >> 5) & 3)) << 10) + (((col >> 3) & 1) << 9) +
-               (((((col >> 4) & 1) << 5) + (m & 31)) << 3);
-      };
-      // HMA_A_BF16_HEADBLK: element (m, c) of a [M, 256 W] matrix at (((frame 8 + head) W + c / 256) n + m % n) 32 + c % 32 with
-      // frame = m / n, head = (c % 256) / 32 -- what the spatial attention backward writes as whole contiguous 2 KB tiles
-      // (a stage's 32 rows lie inside one frame: ONE 32-bit division per stage, by the wave-uniform first row)
-      auto hb_at = [&](const uint16_t* base, int64_t ld, int64_t col, int n) __attribute__((always_inline)) {
-        const uint32_t fr = (uint32_t)m0 / (uint32_t)n;
-        const int64_t rr = m - (int64_t)fr * n;
-        return base + (((((int64_t)fr * 8 + ((col & 255) >> 5)) * (ld >> 8) + (col >> 8)) * n + rr) << 5) + (col & 31);
-      };
-      const uint16_t* ys = p.yfrag ? frag_at(reinterpret_cast<const uint16_t*>(p.dY), p.ldy, n0 + lc * 8)
-                           : p.yhb > 0 ? hb_at(reinterpret_cast<const uint16_t*>(p.dY), p.ldy, n0 + lc * 8, p.yhb)
-                                       : Yb + m * p.ldy + lc * 8;  // host: no row groups on this path
-      const uint16_t* as = p.afrag ? frag_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8)
-                           : p.ahb > 0 ? hb_at(reinterpret_cast<const uint16_t*>(p.A), p.lda, k0 + lc * 8, p.ahb)
-                                       : Ab + m * p.lda + lc * 8;
-      if ((parts >> (2 * q)) & 1) glds16(ys, slot_b + (wv * 4 + q * 2) * 512);
-      if ((parts >> (2 * q)) & 2) glds16(as, slot_b + DM_TILE_BYTES + (wv * 4 + q * 2) * 512);
+      const int64_t mu = m0 + wv * 4 + q * 2;
+      if ((parts >> (2 * q)) & 1) glds16s(ubase(p.dY, Yb, p.yfrag, p.yhb, p.ldy, n0, mu), loff_y[q], slot_b + (wv * 4 + q * 2) * 512);
+      if ((parts >> (2 * q)) & 2) glds16s(ubase(p.A, Ab, p.afrag, p.ahb, p.lda, k0, mu), loff_a[q], slot_b + DM_TILE_BYTES + (wv * 4 + q * 2) * 512);
     }
   };
   auto issue = [&](int st, int slot) __attribute__((always_inline)) { issue_parts(st, slot, 15); };

@@ -239,6 +239,20 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t dst) {
       : "memory");
 }
 
+// The same piece addressed as a wave-uniform base (an SGPR pair) + this lane's 32-bit byte offset: no vector arithmetic per piece when
+// the lane's offset is a loop invariant (the weight-gradient ring: a piece's address is (stage, row pair) -> uniform, (lane) -> constant)
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t dst) {
+  const uint64_t a = (uint64_t)(uintptr_t)sbase;
+  const uint64_t au = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(au), "s"(dst)
+      : "memory");
+}
+
 // Four consecutive pieces (4 KB of global memory -> 4 KB of LDS): the instruction's immediate offset advances the global
 // AND the LDS address, so one M0 set-up serves all four.
 __device__ __forceinline__ void glds16x4(const void* src, uint32_t dst) {
