@@ -190,6 +190,7 @@ _PROTOS = {
     "hma_silu_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64],
     "hma_adaln_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_i64, c_i32],
     "hma_adaln_bwd": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32],
+    "hma_adaln_bwd_acc": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32],
     "hma_gate_fwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32],
     "hma_gate_bwd": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32],
     "hma_diff_loss": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i32],

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const uint16_t* __restri
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float* __restrict__ dx, uint16_t* __restrict__ dmod,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t n, int W,
-                                                        int rows_per_wave) {
+                                                        int rows_per_wave, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   float4 dg[P], db[P];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const uint16_t* __restri
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       float4* d = reinterpret_cast<float4*>(dx + row * W + p * 256 + lane * 4);
-      float4 o = *d;
+      float4 o = accumulate ? *d : make_float4(0.f, 0.f, 0.f, 0.f);  // (accumulate = 0: the first writer of dx -- no zero-fill, no read)
       o.x += rstd * (gl[p].x - s1 - v[p].x * s2); o.y += rstd * (gl[p].y - s1 - v[p].y * s2);
       o.z += rstd * (gl[p].z - s1 - v[p].z * s2); o.w += rstd * (gl[p].w - s1 - v[p].w * s2);
       *d = o;
@@ -356,6 +356,11 @@ extern "C" int hma_adaln_fwd(void* stream, const float* x, const void* mod, int6
 extern "C" int hma_adaln_bwd(void* stream, const void* dout, const float* x, const void* mod, int64_t ldm, int32_t off_shift,
                              int32_t off_scale, const float* gamma, const float* beta, float eps, float* dx, void* dmod,
                              float* dgamma, float* dbeta, int64_t n, int32_t W) {
+  return hma_adaln_bwd_acc(stream, dout, x, mod, ldm, off_shift, off_scale, gamma, beta, eps, dx, dmod, dgamma, dbeta, n, W, 1);
+}
+extern "C" int hma_adaln_bwd_acc(void* stream, const void* dout, const float* x, const void* mod, int64_t ldm, int32_t off_shift,
+                                 int32_t off_scale, const float* gamma, const float* beta, float eps, float* dx, void* dmod,
+                                 float* dgamma, float* dbeta, int64_t n, int32_t W, int32_t accumulate) {
   if (!dout || !x || !mod || !dx || !dmod || W < 256 || W > 256 * MAXP || (W & 255)) return HMA_EINVAL;
   if (gamma && (!beta || !dgamma || !dbeta)) return HMA_EINVAL;
   if (n <= 0) return 0;
@@ -365,7 +370,7 @@ extern "C" int hma_adaln_bwd(void* stream, const void* dout, const float* x, con
   case PP:                                                                                                                      \
     hipLaunchKernelGGL(adaln_bwd_kernel<PP>, dim3(rows4(waves)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, x,  \
                        (const uint16_t*)mod, ldm, (int)off_shift, (int)off_scale, gamma, beta, eps, dx, (uint16_t*)dmod, dgamma, \
-                       dbeta, n, (int)W, rpw);                                                                                  \
+                       dbeta, n, (int)W, rpw, (int)accumulate);                                                                 \
     break;
   switch (W / 256) {
     HMA_ADALN_BWD(1) HMA_ADALN_BWD(2) HMA_ADALN_BWD(3) HMA_ADALN_BWD(4) HMA_ADALN_BWD(5) HMA_ADALN_BWD(6) HMA_ADALN_BWD(7) HMA_ADALN_BWD(8)

@@ -338,13 +338,14 @@ class DiffLoss(nn.Module):
         wgrad("lin", dout, sv["hf"], y_kind=A_F32)
         dhf = e(N, W)
         self._nt(stream, dout, Wt["lin"], None, dhf, EPI_BF16, a_kind=A_F32)
-        dx = torch.zeros(N, W, dtype=F32, device=dev)
+        # (dx and dsy are 1 GB each at the C4 shape: their first producers WRITE them -- no zero-fill, no read of zeros)
+        dx = e(N, W, dt=F32)
         dmodf = e(N, 2 * W)
-        _lib.call("hma_adaln_bwd", stream, ptr(dhf), ptr(sv["xf"]), ptr(sv["modf"]), 2 * W, 0, W, None, None, 1e-6, ptr(dx), ptr(dmodf),
-                  None, None, N, W)
+        _lib.call("hma_adaln_bwd_acc", stream, ptr(dhf), ptr(sv["xf"]), ptr(sv["modf"]), 2 * W, 0, W, None, None, 1e-6, ptr(dx), ptr(dmodf),
+                  None, None, N, W, 0)
         wgrad("fada", dmodf, sv["sy"])
-        dsy = torch.zeros(N, W, dtype=F32, device=dev)
-        self._nt(stream, dmodf, Wt["fada"], None, dsy, EPI_RESID)
+        dsy = e(N, W, dt=F32)
+        self._nt(stream, dmodf, Wt["fada"], None, dsy, EPI_F32)
         for i in reversed(range(self.depth)):
             blk = self.net.res_blocks[i]
             mod, dmod = sv[f"mod{i}"], e(N, 3 * W)

@@ -291,6 +291,10 @@ int hma_adaln_fwd(void* stream, const float* x, const void* mod, int64_t ldm, in
 int hma_adaln_bwd(void* stream, const void* dout, const float* x, const void* mod, int64_t ldm, int32_t off_shift,
                   int32_t off_scale, const float* gamma, const float* beta, float eps, float* dx, void* dmod,
                   float* dgamma, float* dbeta, int64_t n, int32_t W);
+/* the same with `accumulate` = 0: dx is WRITTEN (the first producer of a gradient buffer: no zero-fill and no read of it); 1 = as above */
+int hma_adaln_bwd_acc(void* stream, const void* dout, const float* x, const void* mod, int64_t ldm, int32_t off_shift,
+                  int32_t off_scale, const float* gamma, const float* beta, float eps, float* dx, void* dmod,
+                  float* dgamma, float* dbeta, int64_t n, int32_t W, int32_t accumulate);
 /* x += gate * h (diffloss.py:124); backward: dh = dx * gate, dmod[gate] = dx * h (dx is also the identity branch's grad) */
 int hma_gate_fwd(void* stream, float* x, const void* mod, int64_t ldm, int32_t off_gate, const void* h, int64_t n, int32_t W);
 int hma_gate_bwd(void* stream, const float* dx, const void* mod, int64_t ldm, int32_t off_gate, const void* h, void* dh,
