@@ -750,7 +750,7 @@ def main():
             model = None
             torch.cuda.empty_cache()
             out["decode"] = decode_bench(args, dev, steps=3, warmup=2, batch=64)  # (two warm-up rollouts: a frame pass is captured on its second use)
-            out["mar"] = mar_bench(args, dev, steps=5, warmup=2)
+            out["mar"] = mar_bench(args, dev, steps=5, warmup=4)  # (the step is launched eagerly: the allocator settles over the first steps)
             torch.cuda.empty_cache()
             # the reference's own default window (train_multi.py:78-83, both shipped d256 JSONs: T = 12) and what one GPU can measure of
             # the 8-rank risk (RCCL's kernels beside the persistent 256-workgroup launches), each in a child process of this command
