@@ -349,7 +349,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
             if pooled is not None:  # jointly_predict_actions (:441-446): actions sampled by the domain's action diffusion head, every step
                 akw = {} if action_draws is None else dict(noise0=action_draws[step][0], step_noises=action_draws[step][1])
                 sampled_actions = self.action_diff_losses[dom].sample(pooled.reshape(-1, pooled.shape[-1]), temperature, 1.0, clip_denoised=True, **akw)
-            xt = x[:, out_t].reshape(B, S, pc)
+            xt = x[:, out_t].reshape(B, S, pc).clone()  # (at B = 1 the frame is contiguous and reshape is a VIEW: writing it back onto itself raises)
             xt[to_pred] = smp
             x[:, out_t] = xt.reshape(B, h_, w_, pc)
         return self.unpatchify(x)[:, out_t], orig, sampled_actions

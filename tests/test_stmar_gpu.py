@@ -101,6 +101,11 @@ def test_mar_decode_matches_reference():
                      domain=["domA"] * 2, temperature=0.9)
     assert out.shape == (2, 3 * 1024, 4) and torch.isfinite(out).all()
     assert torch.equal(out[:, :1024].cpu(), D["prompt"][:, 0].reshape(2, 1024, 4))
+    # the interactive caller's batch of ONE (round 6: the frame being written is then a contiguous view of the window)
+    out1 = m.generate(D["prompt"][:1, :1].reshape(1, -1, 4).to(DEV), None, max_new_tokens=1024, action_ids=inp["actions_domA"][:1],
+                      domain=["domA"], temperature=0.9)
+    assert out1.shape == (1, 2 * 1024, 4) and torch.isfinite(out1).all()
+    assert torch.equal(out1[:, :1024].cpu(), D["prompt"][:1, 0].reshape(1, 1024, 4))
 
 
 def test_mlp_dropout_trains_and_eval_is_deterministic():
