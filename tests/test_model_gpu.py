@@ -575,3 +575,92 @@ def test_small_pass_trains_against_oracle(B, T, HW):
         assert p.grad is not None, name
         worst = max(worst, rms_err(p.grad, gr))
     assert math.isfinite(worst) and worst <= 3e-2, worst
+
+
+def _t16_model(with_actions: bool, mlp_drop: float = 0.0, layers: int = 2):
+    """A 16-frame model at `layers` layers with init-scale seeded weights, its oracle config and state dict."""
+    from oracle.param_spec import seeded_state_dict, state_dict_spec
+    cfgd = dict(num_layers=layers, num_heads=8, d_model=256, T=16, S=256, image_vocab_size=262144, use_mup=True, action_network="concat+modulate",
+                num_factored_vocabs=2, qkv_bias=False, proj_bias=True, attn_drop=0.0, qk_norm=False, mlp_ratio=4.0, mlp_drop=mlp_drop, mlp_bias=True)
+    rc = R.RefConfig(**{k: v for k, v in cfgd.items() if k in R.RefConfig.__dataclass_fields__})
+    doms, das, stats = (["domA"], [7], [TINY["action_stats"][0]]) if with_actions else ([], [], [])
+    sd = seeded_state_dict(state_dict_spec(rc, doms, das, [7] if with_actions else []), seed=41, std=0.02, embed_std=0.02)
+    if with_actions:
+        sd["action_preprocessor.domA.mean"] = torch.tensor(stats[0][0])
+        sd["action_preprocessor.domA.std"] = torch.tensor(stats[0][1])
+    m = STMaskGIT(GenieConfig(**cfgd))
+    if with_actions:
+        m.init_action_projectors(doms, das, stats, cfgd["action_network"])
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).train(), rc, sd
+
+
+def _t16_batch(B=2, seed=21):
+    import math
+    gq = torch.Generator().manual_seed(seed)
+    labels = torch.randint(0, 262144, (B, 16, 16, 16), generator=gq)
+    prob = torch.cos(torch.rand(B, 15, 1, 1, generator=gq) * math.pi / 2)
+    ids = labels.clone()
+    ids[:, 1:][torch.rand(B, 15, 16, 16, generator=gq) < prob] = 262144
+    return ids.reshape(B, -1), labels.reshape(B, -1), torch.randn(B, 16, 7, generator=gq)
+
+
+def _plan_names(m):
+    eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+    return {name for pl in eng._plans.values() for _, name, _ in pl.calls}
+
+
+def test_fused_forward_chain_without_action_tokens_vs_oracle():
+    """Round 6: blocks WITHOUT action tokens (no ModulateLayer, 256 rows per frame) take hma_chain_ab_fwd too at T = 16 (its MOD = false
+    form: chain A is the spatial projection + residual, bf16(x1) the temporal qkv's operand).  Loss and every gradient against the oracle;
+    the fused launch is asserted to be IN the plan (the T = 3 fixtures run the three-launch forward)."""
+    m, rc, sd = _t16_model(with_actions=False)
+    eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+    eng.fused_mlp_min_rows = 0
+    ids, labels, _ = _t16_batch()
+    out = m(input_ids=ids.to(DEV), labels=labels.to(DEV), domain=None)
+    out.loss.backward()
+    assert "hma_chain_ab_fwd" in _plan_names(m) and "hma_chain_t_bwd" in _plan_names(m), _plan_names(m)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss, acc, logits = R.forward(params, rc, ids, labels, None, None)
+    loss.backward()
+    assert abs(out.loss.item() - loss.item()) <= 1e-3, (out.loss.item(), loss.item())
+    assert rel_err(out.logits, logits.detach()) <= 2e-2
+    worst = 0.0
+    for name, p in m.named_parameters():
+        gr = params[name].grad
+        if gr is None or float(gr.abs().sum()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, rms_err(p.grad, gr))
+    _note("t16_noact.loss_abs_err", abs(out.loss.item() - loss.item()))
+    _note("t16_noact.worst_grad_rms", worst)
+    assert worst <= 3e-2, worst
+
+
+def test_fused_forward_chain_with_dropout_equals_epilogue_path_at_t16():
+    """Round 6: mlp_drop > 0 on the fused forward chain (hma_chain_ab_fwd's DROP form: the MAR configs train with 0.05) re-creates the SAME
+    counter-based masks as the GELU2 / RESID epilogues of the unfused path, so both give the same loss and gradients to bf16 rounding.
+    The T = 3 version of this check (test_mlp_dropout_fused_path_equals_epilogue_path) runs chain B; 16-frame windows run the fused chain."""
+    ids, labels, act = _t16_batch()
+    res = {}
+    for tag in ("fused", "unfused"):
+        m, _, _ = _t16_model(with_actions=True, mlp_drop=0.1)
+        eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+        eng.fused_mlp_min_rows = 0
+        if tag == "unfused":
+            eng.fused_mlp = False
+        out = m(input_ids=ids.to(DEV), labels=labels.to(DEV), action_ids=act.to(DEV), domain=["domA"] * 2)
+        out.loss.backward()
+        assert ("hma_chain_ab_fwd" in _plan_names(m)) == (tag == "fused"), (tag, _plan_names(m))
+        res[tag] = (out.loss.item(), {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None})
+    (la, ga), (lb, gb) = res["fused"], res["unfused"]
+    assert abs(la - lb) <= 2e-3 * abs(lb), (la, lb)
+    worst = 0.0
+    for n in gb:
+        den = gb[n].pow(2).mean().sqrt().item()
+        if den == 0:
+            continue
+        worst = max(worst, (ga[n] - gb[n]).pow(2).mean().sqrt().item() / den)
+    _note("t16_dropout.fused_vs_unfused.worst_grad_rms", worst)
+    assert worst <= 3e-2, worst
