@@ -127,6 +127,24 @@ class ChainTBwd(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """hma_pack_job_t: the arguments of one hma_chain_pack / hma_mlp_pack / hma_transpose_cast_bf16 call."""
+    _fields_ = [
+        ("src", c_vp), ("row_stride", c_i64), ("col_stride", c_i64), ("row_scale", c_vp), ("col_scale", c_vp), ("dst", c_vp),
+        ("kind", c_i32), ("rows", c_i32), ("cols", c_i32), ("batch", c_i32),
+        ("src_batch_stride", c_i64), ("dst_batch_stride", c_i64), ("bundle_stride", c_i32), ("reserved", c_i32),
+    ]
+
+
+def pack_jobs(jobs):
+    """A ctypes array of PackJob from keyword dictionaries."""
+    arr = (PackJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        for k, v in j.items():
+            setattr(a, k, v)
+    return arr
+
+
 class ChainABFwd(C.Structure):
     _fields_ = [
         ("seg", c_vp * 6), ("bundles", c_i32 * 6),
@@ -210,6 +228,9 @@ _PROTOS = {
     "hma_mlp_fwd": [c_vp, C.POINTER(MlpFwd)],
     "hma_mlp_bwd": [c_vp, C.POINTER(MlpBwd)],
     "hma_chain_pack": [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32],
+    "hma_chain_pack_multi": [c_vp, C.POINTER(PackJob), c_i32],
+    "hma_mlp_pack_multi": [c_vp, C.POINTER(PackJob), c_i32],
+    "hma_transpose_cast_bf16_multi": [c_vp, C.POINTER(PackJob), c_i32],
     "hma_readout_ce": [c_vp, C.POINTER(ReadoutCE)],
     "hma_chain_b_fwd": [c_vp, C.POINTER(ChainBFwd)],
     "hma_chain_a_fwd": [c_vp, C.POINTER(ChainAFwd)],
@@ -246,7 +267,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = c_i32
-        if lib.hma_abi_version() != 0x484D4103:
+        if lib.hma_abi_version() != 0x484D4104:
             raise HmaKernelError("libhma_hip.so ABI mismatch: rebuild with `python -m hma_amd.build --force`")
         _lib = lib
     return _lib

@@ -315,16 +315,15 @@ __device__ __forceinline__ void sync_init(HMA_LDS(char)* lds, int tid) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-__global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
-                                                         const float* __restrict__ rscale, const float* __restrict__ cscale,
-                                                         uint16_t* __restrict__ dst, int kind, int nbundles, int64_t sstride,
-                                                         int64_t dstride, int bundle_stride) {
-  const int64_t bz = blockIdx.y;
+__device__ __forceinline__ void chain_pack_body(const float* __restrict__ src, int64_t rs, int64_t cs,
+                                                const float* __restrict__ rscale, const float* __restrict__ cscale,
+                                                uint16_t* __restrict__ dst, int kind, int nbundles, int64_t sstride, int64_t dstride,
+                                                int bundle_stride, int bx, int64_t bz) {
   src += bz * sstride;
   if (rscale) rscale += bz * sstride;
   if (cscale) cscale += bz * sstride;
   dst += bz * dstride;
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // (bundle, fragment, lane)
+  const int idx = bx * 256 + threadIdx.x;  // (bundle, fragment, lane)
   if (idx >= nbundles * 1024) return;
   const int lane = idx & 63, frag = (idx >> 6) & 15, b = idx >> 10;
   const int i = lane & 15, g = lane >> 4;
@@ -347,6 +346,27 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict
     v[e] = w;
   }
   *reinterpret_cast<uint4*>(dst + ((int64_t)b * bundle_stride * 1024 + (idx & 1023)) * 8) = pack8(v);
+}
+__global__ __launch_bounds__(256) void chain_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
+                                                         const float* __restrict__ rscale, const float* __restrict__ cscale,
+                                                         uint16_t* __restrict__ dst, int kind, int nbundles, int64_t sstride,
+                                                         int64_t dstride, int bundle_stride) {
+  chain_pack_body(src, rs, cs, rscale, cscale, dst, kind, nbundles, sstride, dstride, bundle_stride, blockIdx.x, blockIdx.y);
+}
+// hma_chain_pack_multi: the jobs' (nb * 4) x batch grids laid end to end in blockIdx.x (b0 = prefix sums)
+constexpr int PACK_JOBS = 24;
+struct pack_jobs {
+  hma_pack_job_t j[PACK_JOBS];
+  int b0[PACK_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void chain_pack_multi_kernel(pack_jobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.b0[k + 1]) ++k;
+  const hma_pack_job_t& j = jobs.j[k];
+  const int nb = (j.kind == 0 ? j.rows : j.cols) / 32, rem = (int)blockIdx.x - jobs.b0[k];
+  chain_pack_body(j.src, j.row_stride, j.col_stride, j.row_scale, j.col_scale, reinterpret_cast<uint16_t*>(j.dst), j.kind, nb,
+                  j.src_batch_stride, j.dst_batch_stride, j.bundle_stride, rem % (nb * 4), rem / (nb * 4));
 }
 
 // ------------------------------------------------------------------------------------------------ rows of a workgroup
@@ -2592,6 +2612,30 @@ extern "C" int hma_chain_pack(void* stream, const float* src, int64_t row_stride
                      row_scale, col_scale, reinterpret_cast<uint16_t*>(dst), (int)kind, nb, src_batch_stride, dst_batch_stride,
                      (int)bundle_stride);
   HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_chain_pack_multi(void* stream, const hma_pack_job_t* jobs, int32_t njobs) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return HMA_EINVAL;
+  for (int i = 0; i < njobs; ++i) {
+    const hma_pack_job_t& j = jobs[i];
+    if (!j.src || !j.dst || j.batch < 1 || j.bundle_stride < 1) return HMA_EINVAL;
+    if (j.kind == 0 ? (j.cols != 256 || j.rows <= 0 || j.rows % 32) : (j.kind != 1 || j.rows != 256 || j.cols <= 0 || j.cols % 32))
+      return HMA_EINVAL;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += PACK_JOBS) {
+    pack_jobs pj;
+    pj.n = njobs - i0 < PACK_JOBS ? njobs - i0 : PACK_JOBS;
+    int blocks = 0;
+    for (int i = 0; i < pj.n; ++i) {
+      pj.j[i] = jobs[i0 + i];
+      pj.b0[i] = blocks;
+      blocks += (pj.j[i].kind == 0 ? pj.j[i].rows : pj.j[i].cols) / 32 * 4 * pj.j[i].batch;
+    }
+    pj.b0[pj.n] = blocks;
+    hipLaunchKernelGGL(chain_pack_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pj);
+    HMA_CHECK_LAUNCH();
+  }
   return 0;
 }
 

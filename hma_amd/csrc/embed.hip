@@ -88,59 +88,99 @@ __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const int64_t* __res
   atomicAdd(pm, macc.x); atomicAdd(pm + 1, macc.y); atomicAdd(pm + 2, macc.z); atomicAdd(pm + 3, macc.w);
 }
 
-// Same gradients with the atomics moved into LDS.  Both tables have only V (512) rows, so ~256 token rows land on every
-// table row and the global-atomic version above serialises on them (1.05 ms per step at the bench shape, 40x its HBM
-// time).  A workgroup takes one table, one 64-column slice (V x 64 fp32 = 128 KB of LDS) and one contiguous run of
-// token rows; a wave handles a token with one 256-byte load and one conflict-free ds_add_f32, and the slice is flushed
-// with one global atomic per non-zero entry at the end.  Mask-token rows are summed in registers (table 0 workgroups).
-__global__ __launch_bounds__(256) void embed_bwd_tok_lds_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+// Same gradients accumulated in REGISTERS.  Both tables have only V (512) rows, so ~256 token rows land on every table row and the
+// global-atomic version above serialises on them (1.05 ms per step at the bench shape, 40x its HBM time); rounds 2-5 moved the atomics
+// into LDS (a V x 64 fp32 slice per workgroup, one ds_add_f32 per token and wave), which a round-6 ablation showed to be the whole of
+// that kernel's time: a 64-lane ds_add_f32 occupies the LDS for ~87 cycles (217 us with, 46 us without the adds; 16 waves instead of 4
+// moved it by 15 %).  Now a workgroup of 16 waves takes one table, one 64-column slice and one contiguous run of token rows; wave w
+// OWNS the table rows r with r % 16 == w and keeps their 32 x 64 sums in 32 registers per lane (lane = column), so nothing is shared
+// and nothing is atomic until the flush.  Every wave scans all ids of the run (64 per step, the next step's ids in flight), queues
+// the tokens that are its own -- (token, register index) words in a 128-entry ring of its own in LDS -- and whenever 64 are queued
+// fetches their 256-byte dx pieces eight at a time and adds each to the register the (wave-uniform) index names.  Mask-token rows
+// (table 0 workgroups) are dealt over the waves by step and summed in a 33rd register.
+__global__ __launch_bounds__(1024) void embed_bwd_tok_reg_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
                                                                 float* __restrict__ dE0, float* __restrict__ dE1,
                                                                 float* __restrict__ dmask, int64_t img_rows, int S, int SA, int V,
                                                                 int64_t mask_id, int64_t rows_per_group) {
-  extern __shared__ __attribute__((aligned(16))) float tbl[];  // [V][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t queue[16][128];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int variant = blockIdx.x & 7, table = variant >> 2, cs = variant & 3;
-  const int64_t group = blockIdx.x >> 3;
-  for (int i = threadIdx.x; i < V * 64; i += 256) tbl[i] = 0.f;
-  __syncthreads();
-  const int64_t r_begin = group * rows_per_group;
+  const int64_t r_begin = (int64_t)(blockIdx.x >> 3) * rows_per_group;
   int64_t r_end = r_begin + rows_per_group;
   if (r_end > img_rows) r_end = img_rows;
+  if (r_begin >= r_end) return;
+  typedef float f32x32_t __attribute__((ext_vector_type(32)));
+  f32x32_t acc = 0.f;  // (a vector, not an array: indexed by an SGPR it stays in registers)
   float macc = 0.f;
-  // each wave walks 64-row chunks: lane i first fetches the id and the dx offset of row chunk + i, then the 64 rows are
-  // visited eight at a time (eight loads in flight, then eight LDS adds)
-  for (int64_t c0 = r_begin + wave * 64; c0 < r_end; c0 += 256) {
-    const bool mine = c0 + lane < r_end;
-    const int64_t rr = mine ? c0 + lane : r_end - 1;
-    const int64_t id = ids[rr];
-    int row = id == mask_id ? -1 : (int)(table == 0 ? id % V : (id / V) % V);
-    if (!mine) row = -2;  // past the run: loaded (clamped) but not added
-    const int64_t bt = rr / S;
-    const uint32_t off = (uint32_t)((bt * SA + (rr - bt * S)) * (D / 4));  // in 16-byte units (host: fits 32 bits)
+  uint32_t* q = queue[wave];
+  int qh = 0, qt = 0;  // ring head / tail (wave-uniform, free running)
+  const float* dxc = dx + cs * 64 + lane;
+  const uint32_t uS = (uint32_t)S, uSA = (uint32_t)SA, uV = (uint32_t)V;
+
+  auto consume = [&](int n) {  // the oldest n <= 64 queued tokens
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t e = lane < n ? q[(qh + lane) & 127] : 0xffu;
+    const uint32_t rr = (uint32_t)r_begin + (e >> 8);
+    const uint32_t bt = rr / uS;
+    const uint32_t off = (bt * uSA + (rr - bt * uS)) * (D / 4);  // in 16-byte units (host: fits 32 bits)
+    const uint32_t idx = e & 0xffu;
 #pragma unroll
     for (int j0 = 0; j0 < 64; j0 += 8) {
-      float g[8];
-      int rj[8];
+      if (j0 < n) {
+        float g[8];
+        int ij[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        rj[j] = __shfl(row, j0 + j);
-        const uint32_t oj = __shfl(off, j0 + j);
-        g[j] = dx[(int64_t)oj * 4 + cs * 64 + lane];
-      }
+        for (int j = 0; j < 8; ++j) {
+          ij[j] = __builtin_amdgcn_readlane((int)idx, j0 + j);
+          const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j0 + j);
+          g[j] = dxc[(int64_t)oj * 4];  // (lanes past n: the run's first row, loaded and dropped)
+        }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (rj[j] >= 0)
-          atomicAdd(&tbl[rj[j] * 64 + lane], g[j]);  // ds_add_f32, 64 consecutive words
-        else if (rj[j] == -1 && table == 0)
-          macc += g[j];
+        for (int j = 0; j < 8; ++j)
+          if (ij[j] < 32)
+            acc[ij[j]] += g[j];
+          else if (ij[j] == 32)
+            macc += g[j];
       }
     }
+    qh += n;
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  auto id_at = [&](int64_t c0) {
+    const int64_t rr = c0 + lane < r_end ? c0 + lane : r_end - 1;
+    return ids[rr];
+  };
+  int64_t id_next = id_at(r_begin);
+  for (int64_t c0 = r_begin; c0 < r_end; c0 += 64) {
+    const int64_t id = id_next;
+    if (c0 + 64 < r_end) id_next = id_at(c0 + 64);
+    const uint32_t tok = (uint32_t)(c0 - r_begin) + lane;
+    bool sel;
+    uint32_t idx;
+    if (id == mask_id) {
+      sel = table == 0 && ((tok >> 6) & 15) == (uint32_t)wave;
+      idx = 32;
+    } else {
+      const uint32_t u = (uint32_t)id;
+      const uint32_t row = table == 0 ? u % uV : (u / uV) % uV;
+      sel = (row & 15) == (uint32_t)wave;
+      idx = row >> 4;
+    }
+    sel = sel && c0 + lane < r_end;
+    const uint64_t m = __ballot(sel);
+    const int pos = qt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    if (sel) q[pos & 127] = (tok << 8) | idx;
+    qt += __builtin_popcountll(m);
+    if (qt - qh >= 64) consume(64);
   }
-  __syncthreads();
-  float* dE = table == 0 ? dE0 : dE1;
-  for (int i = threadIdx.x; i < V * 64; i += 256) {
-    const float v = tbl[i];
-    if (v != 0.f) atomicAdd(dE + (int64_t)(i >> 6) * D + cs * 64 + (i & 63), v);
+  if (qt > qh) consume(qt - qh);
+
+  float* dE = (table == 0 ? dE0 : dE1) + cs * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int row = 16 * k + wave;
+    if (row < V && acc[k] != 0.f) atomicAdd(dE + (int64_t)row * D, acc[k]);
   }
   if (table == 0 && macc != 0.f) atomicAdd(dmask + cs * 64 + lane, macc);
 }
@@ -253,6 +293,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   if (idx >= (int64_t)D * in_dim) return;
   const int j = (int)(idx / in_dim), i = (int)(idx % in_dim);
   float acc = 0.f, bacc = 0.f;
+#pragma unroll 8
   for (int64_t r = 0; r < rows; ++r) {
     const float g = dy[r * D + j];
     acc += g * x[r * in_dim + i];
@@ -298,22 +339,14 @@ extern "C" int hma_embed_bwd(void* stream, const int64_t* ids, const float* dx, 
                      (int)pos_frame_rows);
   HMA_CHECK_LAUNCH();
   const int64_t img_rows = B * T * S;
-  const size_t tbl_bytes = (size_t)V * 64 * sizeof(float);
-  if (tbl_bytes <= 144 * 1024 && img_rows >= 4096 && B * T * (int64_t)SA * (D / 4) < ((int64_t)1 << 32)) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_tok_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              144 * 1024) != hipSuccess)
-        return HMA_EINVAL;
-      attr_done = true;
-    }
-    // 8 (table, column slice) variants x token groups: one workgroup per CU, runs in multiples of 256 rows
+  if (V <= 512 && img_rows >= 4096 && B * T * (int64_t)SA * (D / 4) < ((int64_t)1 << 32)) {
+    // 8 (table, column slice) variants x token groups: one workgroup per CU (a group's token index has 24 bits in the queue words)
     int64_t groups = 32;
-    int64_t per = (img_rows + groups - 1) / groups;
-    per = (per + 255) & ~(int64_t)255;
+    while ((img_rows + groups - 1) / groups > ((int64_t)1 << 24)) groups *= 2;
+    const int64_t per = (((img_rows + groups - 1) / groups) + 63) & ~(int64_t)63;
     groups = (img_rows + per - 1) / per;
-    hipLaunchKernelGGL(embed_bwd_tok_lds_kernel, dim3((unsigned)(groups * 8)), dim3(256), tbl_bytes, s, ids, dx, dE0, dE1,
-                       dmask_embed, img_rows, (int)S, SA, (int)V, mask_id, per);
+    hipLaunchKernelGGL(embed_bwd_tok_reg_kernel, dim3((unsigned)(groups * 8)), dim3(1024), 0, s, ids, dx, dE0, dE1, dmask_embed,
+                       img_rows, (int)S, SA, (int)V, mask_id, per);
   } else {
     int64_t blocks = (img_rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;

@@ -55,15 +55,14 @@ __device__ __forceinline__ float4 lds_f4(HMA_LDS(char)* p) {
 // kind 1 ("H32") : logical A[256][1024]; fragment (s = 0..31, mb = 0..7, j = 0..1) holds
 //                  A[32 mb + rowmap(rho)][32 s + 16 hi + 8 j + i]
 // Both: fragment f of 512, 1 KB each, lane-linear.  A[r][c] = src[r * rs + c * cs] * rscale[r] * cscale[c].
-__global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
-                                                       const float* __restrict__ rscale, const float* __restrict__ cscale,
-                                                       uint16_t* __restrict__ dst, int kind, int64_t sstride, int64_t dstride) {
-  const int64_t bz = blockIdx.y;
+__device__ __forceinline__ void mlp_pack_body(const float* __restrict__ src, int64_t rs, int64_t cs, const float* __restrict__ rscale,
+                                              const float* __restrict__ cscale, uint16_t* __restrict__ dst, int kind, int64_t sstride,
+                                              int64_t dstride, int bx, int64_t bz) {
   src += bz * sstride;
   if (rscale) rscale += bz * sstride;
   if (cscale) cscale += bz * sstride;
   dst += bz * dstride;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = bx * 256 + threadIdx.x;
   const int lane = idx & 63, frag = idx >> 6, rho = lane & 31, hi = lane >> 5;
   int row, col0;
   if (kind == 0) {
@@ -86,6 +85,25 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__
     v[i] = w;
   }
   *reinterpret_cast<uint4*>(dst + (int64_t)idx * 8) = pack8(v);
+}
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const float* __restrict__ src, int64_t rs, int64_t cs,
+                                                       const float* __restrict__ rscale, const float* __restrict__ cscale,
+                                                       uint16_t* __restrict__ dst, int kind, int64_t sstride, int64_t dstride) {
+  mlp_pack_body(src, rs, cs, rscale, cscale, dst, kind, sstride, dstride, blockIdx.x, blockIdx.y);
+}
+// hma_mlp_pack_multi: blockIdx.y = (job, batch index) through the prefix sums of the jobs' batch counts
+constexpr int PACK_JOBS = 24;
+struct pack_jobs {
+  hma_pack_job_t j[PACK_JOBS];
+  int y0[PACK_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void mlp_pack_multi_kernel(pack_jobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.y >= jobs.y0[k + 1]) ++k;
+  const hma_pack_job_t& j = jobs.j[k];
+  mlp_pack_body(j.src, j.row_stride, j.col_stride, j.row_scale, j.col_scale, reinterpret_cast<uint16_t*>(j.dst), j.kind,
+                j.src_batch_stride, j.dst_batch_stride, blockIdx.x, (int)blockIdx.y - jobs.y0[k]);
 }
 
 // Debug builds only (tools/mlp_ablate.sh, -DMLP_ABL=bits): 1 no LDS-DMA, 2 no MFMA, 4 no GELU, 8 no barrier,
@@ -962,6 +980,26 @@ extern "C" int hma_mlp_pack(void* stream, const float* src, int64_t row_stride, 
   hipLaunchKernelGGL(mlp_pack_kernel, dim3(128, batch), dim3(256), 0, (hipStream_t)stream, src, row_stride, col_stride,
                      row_scale, col_scale, reinterpret_cast<uint16_t*>(dst), (int)kind, src_batch_stride, dst_batch_stride);
   HMA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hma_mlp_pack_multi(void* stream, const hma_pack_job_t* jobs, int32_t njobs) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return HMA_EINVAL;
+  for (int i = 0; i < njobs; ++i)
+    if (!jobs[i].src || !jobs[i].dst || (jobs[i].kind != 0 && jobs[i].kind != 1) || jobs[i].batch < 1) return HMA_EINVAL;
+  for (int i0 = 0; i0 < njobs; i0 += PACK_JOBS) {
+    pack_jobs pj;
+    pj.n = njobs - i0 < PACK_JOBS ? njobs - i0 : PACK_JOBS;
+    int gy = 0;
+    for (int i = 0; i < pj.n; ++i) {
+      pj.j[i] = jobs[i0 + i];
+      pj.y0[i] = gy;
+      gy += pj.j[i].batch;
+    }
+    pj.y0[pj.n] = gy;
+    hipLaunchKernelGGL(mlp_pack_multi_kernel, dim3(128, gy), dim3(256), 0, (hipStream_t)stream, pj);
+    HMA_CHECK_LAUNCH();
+  }
   return 0;
 }
 

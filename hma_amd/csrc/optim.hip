@@ -81,12 +81,12 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
 }
 
 // dst[b][c][r] = bf16(src[b][r][c]); 32x32 tiles through LDS
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int rows,
-                                                             int cols, int64_t src_stride, int64_t dst_stride) {
+__device__ __forceinline__ void transpose_cast_body(const float* __restrict__ src, uint16_t* __restrict__ dst, int rows, int cols,
+                                                    int64_t src_stride, int64_t dst_stride, int bx, int by, int64_t bz) {
   __shared__ float tile[32][33];
-  const float* s = src + (int64_t)blockIdx.z * src_stride;
-  uint16_t* d = dst + (int64_t)blockIdx.z * dst_stride;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const float* s = src + bz * src_stride;
+  uint16_t* d = dst + bz * dst_stride;
+  const int r0 = by * 32, c0 = bx * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int i = ty; i < 32; i += 8) {
     const int r = r0 + i, c = c0 + tx;
@@ -97,6 +97,25 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     const int c = c0 + i, r = r0 + tx;
     if (c < cols && r < rows) d[(int64_t)c * rows + r] = to_bf16(tile[tx][i]);
   }
+}
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int rows,
+                                                             int cols, int64_t src_stride, int64_t dst_stride) {
+  transpose_cast_body(src, dst, rows, cols, src_stride, dst_stride, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// hma_transpose_cast_bf16_multi: the jobs' (tiles across, tiles down, batch) grids laid end to end in blockIdx.x (b0 = prefix sums)
+constexpr int PACK_JOBS = 24;
+struct pack_jobs {
+  hma_pack_job_t j[PACK_JOBS];
+  int b0[PACK_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_cast_multi_kernel(pack_jobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.b0[k + 1]) ++k;
+  const hma_pack_job_t& j = jobs.j[k];
+  const int nx = (j.cols + 31) / 32, ny = (j.rows + 31) / 32, rem = (int)blockIdx.x - jobs.b0[k];
+  transpose_cast_body(j.src, reinterpret_cast<uint16_t*>(j.dst), j.rows, j.cols, j.src_batch_stride, j.dst_batch_stride, rem % nx,
+                      rem / nx % ny, rem / (nx * ny));
 }
 
 __global__ __launch_bounds__(256) void dropout_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n,
@@ -177,6 +196,28 @@ extern "C" int hma_transpose_cast_bf16(void* stream, const float* src, void* dst
   return 0;
 }
 
+extern "C" int hma_transpose_cast_bf16_multi(void* stream, const hma_pack_job_t* jobs, int32_t njobs) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return HMA_EINVAL;
+  for (int i = 0; i < njobs; ++i)
+    if (!jobs[i].src || !jobs[i].dst || jobs[i].rows <= 0 || jobs[i].cols <= 0 || jobs[i].batch < 0) return HMA_EINVAL;
+  for (int i0 = 0; i0 < njobs; i0 += PACK_JOBS) {
+    pack_jobs pj;
+    pj.n = njobs - i0 < PACK_JOBS ? njobs - i0 : PACK_JOBS;
+    int64_t blocks = 0;
+    for (int i = 0; i < pj.n; ++i) {
+      pj.j[i] = jobs[i0 + i];
+      pj.b0[i] = (int)blocks;
+      blocks += (int64_t)((pj.j[i].cols + 31) / 32) * ((pj.j[i].rows + 31) / 32) * pj.j[i].batch;
+      if (blocks > INT32_MAX) return HMA_EINVAL;
+    }
+    pj.b0[pj.n] = (int)blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(transpose_cast_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pj);
+    HMA_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 // One wave per weight row: Wf[n][:] = bf16(W[n][:] * gamma), bf[n] = bias[n] + W[n][:] . beta  (cols a multiple of 4)
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ bias,
@@ -214,7 +255,7 @@ extern "C" int hma_fold_ln_bf16(void* stream, const float* W, const float* gamma
   return 0;
 }
 
-extern "C" int hma_abi_version(void) { return 0x484d4103; }
+extern "C" int hma_abi_version(void) { return 0x484d4104; }
 
 extern "C" int hma_dropout_bf16(void* stream, const float* src, void* dst, int64_t rows, int32_t cols, float p, const uint32_t* seed_dev,
                                 int32_t salt) {

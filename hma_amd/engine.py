@@ -137,6 +137,7 @@ class STEngine(DecodeMixin):
         if self.qkn:
             self.use_chain = self.fused_mlp = self.fused_mlp_train = self.chain_b_ok = self.fused_ce = False
         self.buffers: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}  # domain -> (mean, std) of ActionStat
+        self._pack_jobs = {}          # None | domain -> the hma_*_multi job arrays of refresh_weights
         self._seen_version = -1       # P._version at the last refresh (detects external in-place updates)
         self._wb_ok = False           # flat bf16 copy current
         self._wt_ok = False           # dense transposed copies current
@@ -216,72 +217,101 @@ class STEngine(DecodeMixin):
             _lib.call("hma_cast_bf16", stream, self.P.data_ptr(), self.Wb.data_ptr(), lay.total)
             self._wb_ok = True
         if not self._wt_ok:
-            # layers are stored L-1 .. 0 at a constant stride: batch index j reads layer L-1-j and writes slot L-1-j
-            ls = lay.layer_stride
-            for key, suffix, rows, cols in (("qkv_s", "spatial_attn.qkv.weight", 3 * d, d),
-                                            ("proj_s", "spatial_attn.proj.weight", d, d),
-                                            ("qkv_t", "temporal_attn.qkv.weight", 3 * d, d),
-                                            ("proj_t", "temporal_attn.proj.weight", d, d),
-                                            ("fc1", "mlp.fc1.weight", hid, d), ("fc2", "mlp.fc2.weight", d, hid)):
-                _lib.call("hma_transpose_cast_bf16", stream, self._p(f"decoder.layers.{L - 1}.{suffix}"),
-                          self.WT[key][L - 1].data_ptr(), rows, cols, L, ls, -rows * cols)
-            _lib.call("hma_transpose_cast_bf16", stream, self._p("out_x_proj.weight"), self.WT["out"].data_ptr(), 1024, d, 1, 0, 0)
-            for key, lin, norm, rows, has_bias in (() if self.qkn else (("qkv_s", "spatial_attn.qkv", "norm1", 3 * d, cfg.qkv_bias),
-                                                                        ("fc1", "mlp.fc1", "norm2", hid, cfg.mlp_bias))):
-                pre = f"decoder.layers.{L - 1}."
-                _lib.call("hma_fold_ln_bf16", stream, self._p(pre + lin + ".weight"), self._p(pre + norm + ".weight"),
-                          self._p(pre + norm + ".bias"), self._p(pre + lin + ".bias") if has_bias else None,
-                          self.WF[key][L - 1].data_ptr(), self.BF[key][L - 1].data_ptr(), rows, d, L, ls, -rows * d, -rows)
-            if self.fused_mlp:
-                pre = f"decoder.layers.{L - 1}."
-                w1, w2, g2 = self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight"), self._p(pre + "norm2.weight")
-                n = 512 * 512
-                for key, src, rs, cs, rsc, csc, kind in (("w1p", w1, d, 1, None, g2, 0), ("w2p", w2, hid, 1, None, None, 1),
-                                                          ("w2tp", w2, 1, hid, None, None, 0), ("w1tp", w1, 1, d, g2, None, 1)):
-                    _lib.call("hma_mlp_pack", stream, src, rs, cs, rsc, csc, self.MP[key][L - 1].data_ptr(), kind, L, ls, -n)
-            if self.use_chain:
-                BUN = 8192
-                pre = f"decoder.layers.{L - 1}."
-                wp, wq = self._p(pre + "spatial_attn.proj.weight"), self._p(pre + "temporal_attn.qkv.weight")
-                _lib.call("hma_chain_pack", stream, wp, d, 1, None, None, self.CP["proj_s"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
-                _lib.call("hma_chain_pack", stream, wp, 1, d, None, None, self.CP["proj_s_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
-                _lib.call("hma_chain_pack", stream, wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN, 1)
-                _lib.call("hma_chain_pack", stream, self._p("out_x_proj.weight"), d, 1, None, None, self.CP["out"].data_ptr(), 0, 1024, d, 1, 0,
-                          0, 1)
-                _lib.call("hma_chain_pack", stream, self._p(pre + "temporal_attn.proj.weight"), 1, d, None, None,
-                          self.CP["proj_t_T"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)  # (chain T backward)
-                for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
-                    _lib.call("hma_chain_pack", stream, wq + 4 * c * d * d, 1, d, None, None,
-                              self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
-                wqs_, g1_ = self._p(pre + "spatial_attn.qkv.weight"), self._p(pre + "norm1.weight")
-                for c in range(3):  # the same for the spatial qkv, times norm1's gamma per OUTPUT row (d xhat = gamma . (dqkv W))
-                    _lib.call("hma_chain_pack", stream, wqs_ + 4 * c * d * d, 1, d, g1_, None,
-                              self.CP["qkv_s_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, L, ls, -24 * BUN, 1)
-                if self.chain_b_ok:
-                    # chain B (inference): proj_t, the fc1 (norm2's gamma folded in) / fc2 bundles interleaved per hidden block, and the
-                    # spatial qkv with norm1's gamma folded in (consumed by the PREVIOUS block's chain)
-                    wpt, w1, w2 = self._p(pre + "temporal_attn.proj.weight"), self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight")
-                    wqs, g1, g2 = self._p(pre + "spatial_attn.qkv.weight"), self._p(pre + "norm1.weight"), self._p(pre + "norm2.weight")
-                    _lib.call("hma_chain_pack", stream, wpt, d, 1, None, None, self.CP["proj_t"][L - 1].data_ptr(), 0, d, d, L, ls, -8 * BUN, 1)
-                    _lib.call("hma_chain_pack", stream, w1, d, 1, None, g2, self.CP["mlp"][L - 1].data_ptr(), 0, hid, d, L, ls, -64 * BUN, 2)
-                    _lib.call("hma_chain_pack", stream, w2, hid, 1, None, None, self.CP["mlp"][L - 1].data_ptr() + 2 * BUN, 1, d, hid, L, ls,
-                              -64 * BUN, 2)
-                    _lib.call("hma_chain_pack", stream, wqs, d, 1, None, g1, self.CP["qkv_s"][L - 1].data_ptr(), 0, 3 * d, d, L, ls, -24 * BUN, 1)
+            jobs = self._pack_jobs.get(None)
+            if jobs is None:
+                jobs = self._pack_jobs[None] = self._layer_pack_jobs()
+            self._run_pack_jobs(jobs, stream)
+            if not self.qkn:
+                ls = lay.layer_stride
+                for key, lin, norm, rows, has_bias in (("qkv_s", "spatial_attn.qkv", "norm1", 3 * d, cfg.qkv_bias),
+                                                       ("fc1", "mlp.fc1", "norm2", hid, cfg.mlp_bias)):
+                    pre = f"decoder.layers.{L - 1}."
+                    _lib.call("hma_fold_ln_bf16", stream, self._p(pre + lin + ".weight"), self._p(pre + norm + ".weight"),
+                              self._p(pre + norm + ".bias"), self._p(pre + lin + ".bias") if has_bias else None,
+                              self.WF[key][L - 1].data_ptr(), self.BF[key][L - 1].data_ptr(), rows, d, L, ls, -rows * d, -rows)
             self._wt_ok = True
         if domain is not None and self.modulate and domain not in self._dom_fresh:
-            pre = f"decoder.layers.0.action_projectors.{domain}"
-            ds = lay.dom_layer_stride  # (a domain's block is layer-major: the batch stride of every per-layer stack in it)
-            _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.linear_out.weight"), self.WT[f"lin:{domain}"].data_ptr(),
-                      d, d, L, ds, d * d)
-            _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.0.weight"),
-                      self.WT[f"ada0:{domain}"].data_ptr(), d, d, L, ds, d * d)
-            _lib.call("hma_transpose_cast_bf16", stream, self._p(f"{pre}.adaLN_modulation.2.weight"),
-                      self.WT[f"ada2:{domain}"].data_ptr(), 2 * d, d, L, ds, 2 * d * d)
-            if self.use_chain:
-                wl = self._p(f"{pre}.linear_out.weight")
-                _lib.call("hma_chain_pack", stream, wl, d, 1, None, None, self.CP[f"lin:{domain}"].data_ptr(), 0, d, d, L, ds, 8 * 8192, 1)
-                _lib.call("hma_chain_pack", stream, wl, 1, d, None, None, self.CP[f"lin_T:{domain}"].data_ptr(), 0, d, d, L, ds, 8 * 8192, 1)
+            jobs = self._pack_jobs.get(domain)
+            if jobs is None:
+                jobs = self._pack_jobs[domain] = self._domain_pack_jobs(domain)
+            self._run_pack_jobs(jobs, stream)
             self._dom_fresh.add(domain)
+
+    @staticmethod
+    def _run_pack_jobs(jobs, stream: int) -> None:
+        """One launch per kind of copy (hma_*_multi): transposed bf16, fused-MLP fragments, chain bundles."""
+        for fn, arr in jobs:
+            if len(arr):
+                _lib.call(fn, stream, arr, len(arr))
+
+    def _layer_pack_jobs(self):
+        """The job lists of the per-layer weight copies (built once: every pointer is into the flat buffers, which never move)."""
+        lay, cfg = self.layout, self.cfg
+        L, d = cfg.num_layers, cfg.d_model
+        hid = int(d * cfg.mlp_ratio)
+        # layers are stored L-1 .. 0 at a constant stride: batch index j reads layer L-1-j and writes slot L-1-j
+        ls = lay.layer_stride
+        pre = f"decoder.layers.{L - 1}."
+        tj, mj, cj = [], [], []
+        for key, suffix, rows, cols in (("qkv_s", "spatial_attn.qkv.weight", 3 * d, d), ("proj_s", "spatial_attn.proj.weight", d, d),
+                                        ("qkv_t", "temporal_attn.qkv.weight", 3 * d, d), ("proj_t", "temporal_attn.proj.weight", d, d),
+                                        ("fc1", "mlp.fc1.weight", hid, d), ("fc2", "mlp.fc2.weight", d, hid)):
+            tj.append(dict(src=self._p(pre + suffix), dst=self.WT[key][L - 1].data_ptr(), rows=rows, cols=cols, batch=L,
+                           src_batch_stride=ls, dst_batch_stride=-rows * cols))
+        tj.append(dict(src=self._p("out_x_proj.weight"), dst=self.WT["out"].data_ptr(), rows=1024, cols=d, batch=1))
+        if self.fused_mlp:
+            w1, w2, g2 = self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight"), self._p(pre + "norm2.weight")
+            n = 512 * 512
+            for key, src, rs, cs, rsc, csc, kind in (("w1p", w1, d, 1, None, g2, 0), ("w2p", w2, hid, 1, None, None, 1),
+                                                      ("w2tp", w2, 1, hid, None, None, 0), ("w1tp", w1, 1, d, g2, None, 1)):
+                mj.append(dict(src=src, row_stride=rs, col_stride=cs, row_scale=rsc, col_scale=csc, dst=self.MP[key][L - 1].data_ptr(),
+                               kind=kind, batch=L, src_batch_stride=ls, dst_batch_stride=-n))
+        if self.use_chain:
+            BUN = 8192
+
+            def cp(src, rs, cs, rsc, csc, dst, kind, rows, cols, batch=L, sstride=ls, dstride=0, bstride=1):
+                cj.append(dict(src=src, row_stride=rs, col_stride=cs, row_scale=rsc, col_scale=csc, dst=dst, kind=kind, rows=rows,
+                               cols=cols, batch=batch, src_batch_stride=sstride, dst_batch_stride=dstride, bundle_stride=bstride))
+
+            wp, wq = self._p(pre + "spatial_attn.proj.weight"), self._p(pre + "temporal_attn.qkv.weight")
+            cp(wp, d, 1, None, None, self.CP["proj_s"][L - 1].data_ptr(), 0, d, d, dstride=-8 * BUN)
+            cp(wp, 1, d, None, None, self.CP["proj_s_T"][L - 1].data_ptr(), 0, d, d, dstride=-8 * BUN)
+            cp(wq, d, 1, None, None, self.CP["qkv_t"][L - 1].data_ptr(), 0, 3 * d, d, dstride=-24 * BUN)
+            cp(self._p("out_x_proj.weight"), d, 1, None, None, self.CP["out"].data_ptr(), 0, 1024, d, batch=1, sstride=0)
+            cp(self._p(pre + "temporal_attn.proj.weight"), 1, d, None, None, self.CP["proj_t_T"][L - 1].data_ptr(), 0, d, d,
+               dstride=-8 * BUN)  # (chain T backward)
+            for c in range(3):  # input gradient: A[n][k] = W[256 c + k][n], one 8-bundle group per k-chunk
+                cp(wq + 4 * c * d * d, 1, d, None, None, self.CP["qkv_t_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, dstride=-24 * BUN)
+            wqs_, g1_ = self._p(pre + "spatial_attn.qkv.weight"), self._p(pre + "norm1.weight")
+            for c in range(3):  # the same for the spatial qkv, times norm1's gamma per OUTPUT row (d xhat = gamma . (dqkv W))
+                cp(wqs_ + 4 * c * d * d, 1, d, g1_, None, self.CP["qkv_s_T"][L - 1].data_ptr() + 2 * c * 8 * BUN, 0, d, d, dstride=-24 * BUN)
+            if self.chain_b_ok:
+                # chain B (inference): proj_t, the fc1 (norm2's gamma folded in) / fc2 bundles interleaved per hidden block, and the
+                # spatial qkv with norm1's gamma folded in (consumed by the PREVIOUS block's chain)
+                wpt, w1, w2 = self._p(pre + "temporal_attn.proj.weight"), self._p(pre + "mlp.fc1.weight"), self._p(pre + "mlp.fc2.weight")
+                g2 = self._p(pre + "norm2.weight")
+                cp(wpt, d, 1, None, None, self.CP["proj_t"][L - 1].data_ptr(), 0, d, d, dstride=-8 * BUN)
+                cp(w1, d, 1, None, g2, self.CP["mlp"][L - 1].data_ptr(), 0, hid, d, dstride=-64 * BUN, bstride=2)
+                cp(w2, hid, 1, None, None, self.CP["mlp"][L - 1].data_ptr() + 2 * BUN, 1, d, hid, dstride=-64 * BUN, bstride=2)
+                cp(wqs_, d, 1, None, g1_, self.CP["qkv_s"][L - 1].data_ptr(), 0, 3 * d, d, dstride=-24 * BUN)
+        return [("hma_transpose_cast_bf16_multi", _lib.pack_jobs(tj)), ("hma_mlp_pack_multi", _lib.pack_jobs(mj)),
+                ("hma_chain_pack_multi", _lib.pack_jobs(cj))]
+
+    def _domain_pack_jobs(self, domain: str):
+        lay, cfg = self.layout, self.cfg
+        L, d = cfg.num_layers, cfg.d_model
+        pre = f"decoder.layers.0.action_projectors.{domain}"
+        ds = lay.dom_layer_stride  # (a domain's block is layer-major: the batch stride of every per-layer stack in it)
+        tj = [dict(src=self._p(f"{pre}.{name}.weight"), dst=self.WT[f"{key}:{domain}"].data_ptr(), rows=rows, cols=d, batch=L,
+                   src_batch_stride=ds, dst_batch_stride=rows * d)
+              for key, name, rows in (("lin", "linear_out", d), ("ada0", "adaLN_modulation.0", d), ("ada2", "adaLN_modulation.2", 2 * d))]
+        cj = []
+        if self.use_chain:
+            wl = self._p(f"{pre}.linear_out.weight")
+            for key, rs, cs in ((f"lin:{domain}", d, 1), (f"lin_T:{domain}", 1, d)):
+                cj.append(dict(src=wl, row_stride=rs, col_stride=cs, dst=self.CP[key].data_ptr(), kind=0, rows=d, cols=d, batch=L,
+                               src_batch_stride=ds, dst_batch_stride=8 * 8192, bundle_stride=1))
+        return [("hma_transpose_cast_bf16_multi", _lib.pack_jobs(tj)), ("hma_chain_pack_multi", _lib.pack_jobs(cj))]
 
     def weights_changed(self) -> None:
         self._wb_ok = self._wt_ok = False

@@ -434,6 +434,17 @@ int hma_mlp_bwd(void* stream, const hma_mlp_bwd_t* p);
 int hma_chain_pack(void* stream, const float* src, int64_t row_stride, int64_t col_stride, const float* row_scale,
                    const float* col_scale, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t batch,
                    int64_t src_batch_stride, int64_t dst_batch_stride, int32_t bundle_stride);
+/* Several packing jobs in ONE launch each (the weight copies are rebuilt after every optimizer step -- 31 launches of ~10 us at the
+ * headline model, most of it launch and drain): a job is the argument list of hma_chain_pack / hma_mlp_pack (rows, cols and
+ * bundle_stride unused) / hma_transpose_cast_bf16 (src, dst, rows, cols, batch and the two batch strides used).  The jobs of one
+ * call must not write overlapping outputs; any number of jobs (24 per launch).  Results are identical to the single calls. */
+typedef struct {
+  const float* src; int64_t row_stride, col_stride; const float* row_scale; const float* col_scale; void* dst;
+  int32_t kind, rows, cols, batch; int64_t src_batch_stride, dst_batch_stride; int32_t bundle_stride, reserved;
+} hma_pack_job_t;
+int hma_chain_pack_multi(void* stream, const hma_pack_job_t* jobs, int32_t njobs);
+int hma_mlp_pack_multi(void* stream, const hma_pack_job_t* jobs, int32_t njobs);
+int hma_transpose_cast_bf16_multi(void* stream, const hma_pack_job_t* jobs, int32_t njobs);
 /* The packed weights of one chain: up to 4 segments of bundles, consumed in order once per 112-row tile. */
 typedef struct { const void* seg[4]; int32_t bundles[4]; } hma_chain_weights_t;
 
@@ -580,7 +591,7 @@ int hma_readout_ce(void* stream, const hma_readout_ce_t* p);
 /* n floats at p = 0 (captured in graphs in front of kernels that accumulate with atomics) */
 int hma_zero_f32(void* stream, float* p, int64_t n);
 
-/* library identity, for the loader: returns 0x484d4103 */
+/* library identity, for the loader: returns 0x484d4104 */
 int hma_abi_version(void);
 
 #ifdef __cplusplus

@@ -759,6 +759,75 @@ def test_mlp_pack_layout():
         assert p1[f, lane, i] == wt[32 * mb + rowmap(rho), 32 * s + 16 * hi + 8 * j + i]
 
 
+def test_pack_multi_equals_single_calls():
+    # hma_{chain_pack,mlp_pack,transpose_cast_bf16}_multi: several jobs (mixed shapes, batches, negative batch strides, scales,
+    # more than one launch's worth) in one call leave exactly the bytes of the single calls
+    L, d = 3, 256
+    gen = g(811)
+    W = torch.randn(L, 1024 * 256, generator=gen).to(DEV)           # L matrices, 1024*256 floats apart
+    sc = torch.rand(L, 1024 * 256, generator=gen).to(DEV) + 0.5     # scales move with the same batch stride
+    sp = ops.stream_ptr()
+    ss = 1024 * 256
+
+    def bufs(n):
+        return [torch.zeros(n, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+
+    # chain bundles: (rs, cs, row_scale, col_scale, kind, rows, cols, batch, reverse, bundle_stride)
+    cases = [(256, 1, False, False, 0, 256, 256, L, True, 1), (1, 256, True, False, 0, 256, 256, L, False, 1),
+             (256, 1, False, True, 0, 1024, 256, L, True, 2), (1024, 1, False, False, 1, 256, 1024, L, True, 2),
+             (256, 1, False, False, 0, 768, 256, 1, False, 1)] * 6      # 30 jobs: two launches
+    jobs, singles = [], []
+    for rs, cs, rsc, csc, kind, rows, cols, batch, rev, bstr in cases:
+        n = (rows if kind == 0 else cols) // 32 * 8192 * bstr
+        a, b = bufs(L * n)
+        src = ops.ptr(W) + (4 * ss * (L - 1) if rev else 0)
+        rp = (ops.ptr(sc) + (4 * ss * (L - 1) if rev else 0)) if rsc else None
+        cpn = (ops.ptr(sc) + (4 * ss * (L - 1) if rev else 0)) if csc else None
+        sst = -ss if rev else ss
+        common = dict(src=src, row_stride=rs, col_stride=cs, row_scale=rp, col_scale=cpn, kind=kind, rows=rows, cols=cols, batch=batch,
+                      src_batch_stride=sst, dst_batch_stride=n, bundle_stride=bstr)
+        jobs.append(dict(common, dst=ops.ptr(a)))
+        _lib.call("hma_chain_pack", sp, src, rs, cs, rp, cpn, ops.ptr(b), kind, rows, cols, batch, sst, n, bstr)
+        singles.append((a, b))
+    arr = _lib.pack_jobs(jobs)
+    _lib.call("hma_chain_pack_multi", sp, arr, len(arr))
+    for i, (a, b) in enumerate(singles):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"chain job {i}"
+        assert b.float().abs().sum() > 0
+    # fused-MLP fragments
+    jobs, singles = [], []
+    for rs, cs, rsc, csc, kind, batch in [(256, 1, False, True, 0, L), (1024, 1, False, False, 1, L), (1, 1024, False, False, 0, 2),
+                                          (1, 256, True, False, 1, 1)]:
+        a, b = bufs(L * 512 * 512)
+        rp, cpn = (ops.ptr(sc) if rsc else None), (ops.ptr(sc) if csc else None)
+        jobs.append(dict(src=ops.ptr(W), row_stride=rs, col_stride=cs, row_scale=rp, col_scale=cpn, dst=ops.ptr(a), kind=kind, batch=batch,
+                         src_batch_stride=ss, dst_batch_stride=512 * 512))
+        _lib.call("hma_mlp_pack", sp, ops.ptr(W), rs, cs, rp, cpn, ops.ptr(b), kind, batch, ss, 512 * 512)
+        singles.append((a, b))
+    arr = _lib.pack_jobs(jobs)
+    _lib.call("hma_mlp_pack_multi", sp, arr, len(arr))
+    for i, (a, b) in enumerate(singles):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"mlp job {i}"
+    # transposed bf16 copies (ragged 32 x 32 edge tiles included)
+    jobs, singles = [], []
+    for rows, cols, batch in [(768, 256, L), (256, 1024, L), (1024, 256, 1), (70, 45, 2), (256, 256, 0)]:
+        a, b = bufs(L * rows * cols)
+        jobs.append(dict(src=ops.ptr(W), dst=ops.ptr(a), rows=rows, cols=cols, batch=batch, src_batch_stride=ss, dst_batch_stride=rows * cols))
+        _lib.call("hma_transpose_cast_bf16", sp, ops.ptr(W), ops.ptr(b), rows, cols, batch, ss, rows * cols)
+        singles.append((a, b))
+    arr = _lib.pack_jobs(jobs)
+    _lib.call("hma_transpose_cast_bf16_multi", sp, arr, len(arr))
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(singles):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"transpose job {i}"
+    # argument errors are reported, not launched
+    bad = _lib.pack_jobs([dict(src=ops.ptr(W), dst=None, kind=0, rows=256, cols=256, batch=1, bundle_stride=1)])
+    for fn in ("hma_chain_pack_multi", "hma_mlp_pack_multi", "hma_transpose_cast_bf16_multi"):
+        with pytest.raises(_lib.HmaKernelError):
+            _lib.call(fn, sp, bad, 1)
+        _lib.call(fn, sp, None, 0)
+
+
 @pytest.mark.parametrize("M,with_ln", [(128, True), (1000, True), (5 * 128 + 37, False), (40960, True)])
 def test_mlp_fwd_fused(M, with_ln):
     w1, b1, w2, b2, gam, bet = _mlp_weights(100)

@@ -20,7 +20,7 @@ def test_header_symbols_all_exported():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.hma_abi_version() == 0x484D4103
+    assert lib.hma_abi_version() == 0x484D4104
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
