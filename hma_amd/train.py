@@ -270,6 +270,10 @@ class Trainer:
         T = self.model.config.T
         eng.grad_scale.value = 1.0 / (self.accum * red.world)
         eng.gscale.fill_(1.0)
+        # the adaLN stacks' backward per gradient bucket (a domain's slice of a bucket is final with it) -- or, with nothing to reduce,
+        # once for all layers: four batched launches instead of four per bucket (round 6: -0.3 ms of a 76 ms step)
+        segmented = red.collective or getattr(self, "force_segments", False)
+        eng.ada_group = self.layers_per_bucket if segmented else eng.cfg.num_layers
         if self.use_graphs and self.accum == 1 and eng.timer is None and eng.device.type == "cuda" and not eng.jpa:
             ws = self._graphed_micro_step(input_ids.reshape(B, T, -1), labels, action_ids, dom)
             self._micro += 1
@@ -548,6 +552,8 @@ class MarTrainer:
             fresh = [d for d in red.active_domains(dom) if d not in self._active]
             if fresh:
                 self._active = red.order(list(self._active) + fresh)  # (model.zero_grad() zeroed every block: nothing stale to clear)
+        # (the adaLN stacks' backward: per gradient bucket, or once for all layers when nothing is reduced -- see Trainer.micro_step)
+        self.engine.ada_group = self.layers_per_bucket if (red.collective or self.force_overlap) else self.engine.cfg.num_layers
         out = self.model(**batch)
         loss = out.loss.detach()
         ok = torch.isfinite(loss)
