@@ -5,6 +5,8 @@
 // additive pos_embed_TSC at hma/model/st_mask_git.py:651-672, ActionStat + BasicMLP at
 // hma/model/st_mask_git.py:134-138, 90-102.  One fused HBM-bound pass instead of ~10 ATen kernels
 // and two host syncs (the boolean indexing at factorization_utils.py:45,53).
+#include <type_traits>
+
 #include "hma_common.h"
 #include "../../include/hma_hip.h"
 
@@ -205,58 +207,88 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ a, const float* __restrict__ mean,
-                                                       const float* __restrict__ stdv, int action_dim,
-                                                       const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                       const float* __restrict__ W2, const float* __restrict__ b2,
-                                                       float* __restrict__ an_out, float* __restrict__ xhat_out,
-                                                       float* __restrict__ rstd_out, float* __restrict__ h_out,
-                                                       float* __restrict__ out, int d_a, int skip_norm) {
+// sum over the 64 lanes as a wave-uniform value: four DPP steps inside the rows of 16 and four v_readlane (wave_sum's six
+// ds_bpermute round trips per output were half of the forward kernel's time)
+__device__ __forceinline__ float wave_total(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane holds its row's sum
+  auto rl = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+// sum of one value per thread of the FIRST FOUR waves of a workgroup of SW waves (the others pass anything)
+constexpr int SW = 16;
+__device__ __forceinline__ float block_sum_first256(float v, float* red) {
+  v = wave_total(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && w < 4) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup of 16 waves per row (a row's two mat-vecs are a chain of dependent weight-row loads: the time is the outputs per wave
+// times a load latency whatever the number of rows -- 83 us with 4 waves and ds_bpermute sums, round 6: 64 outputs per wave -> 16).
+__global__ __launch_bounds__(64 * SW) void stem_fwd_kernel(const float* __restrict__ a, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, int action_dim,
+                                                          const float* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                          const float* __restrict__ W2, const float* __restrict__ b2,
+                                                          float* __restrict__ an_out, float* __restrict__ xhat_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ h_out,
+                                                          float* __restrict__ out, int d_a, int skip_norm) {
   extern __shared__ float sm[];  // an[d_a] | h[256] | red[4]
   float* an = sm;
   float* hs = sm + d_a;
   float* red = hs + D;
   const int64_t r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i = tid; i < d_a; i += 256) {
+  constexpr int PER = D / SW;  // outputs per wave
+  for (int i = tid; i < d_a; i += 64 * SW) {
     float v = a[r * d_a + i];
     if (!skip_norm) v = (v - mean[i % action_dim]) / (stdv[i % action_dim] + 1e-10f);
     an[i] = v;
     an_out[r * d_a + i] = v;
   }
   __syncthreads();
-  // pre[j]: wave w covers j = w*64 .. +63, lanes split the d_a inputs (8 outputs' weight rows in flight: one exposed L2 round trip
-  // per output made this kernel 88 us for the 64 rows of a decode frame pass)
+  // pre[j]: wave w covers j = w * PER .. + PER - 1, lanes split the d_a inputs (8 outputs' weight rows in flight)
 #pragma unroll 8
-  for (int jj = 0; jj < 64; ++jj) {
-    const int j = w * 64 + jj;
+  for (int jj = 0; jj < PER; ++jj) {
+    const int j = w * PER + jj;
     float p = 0.f;
     for (int i = lane; i < d_a; i += 64) p += an[i] * W1[(int64_t)j * d_a + i];
-    p = wave_sum(p);
+    p = wave_total(p);
     if (lane == 0) hs[j] = p + b1[j];
   }
   __syncthreads();
-  const float pre = hs[tid];
-  const float mu = block_sum_256(pre, red) * (1.0f / D);
+  const int c = tid & (D - 1);
+  const bool first = tid < D;
+  const float pre = hs[c];
+  const float mu = block_sum_first256(pre, red) * (1.0f / D);
   const float dv = pre - mu;
-  const float var = block_sum_256(dv * dv, red) * (1.0f / D);
+  const float var = block_sum_first256(dv * dv, red) * (1.0f / D);
   const float rstd = rsqrtf(var + 1e-5f);
   const float xh = dv * rstd;
-  const float hv = fmaxf(xh * ln_w[tid] + ln_b[tid], 0.f);
-  xhat_out[r * D + tid] = xh;
-  h_out[r * D + tid] = hv;
-  if (tid == 0) rstd_out[r] = rstd;
+  const float hv = fmaxf(xh * ln_w[c] + ln_b[c], 0.f);
   __syncthreads();
-  hs[tid] = hv;
+  if (first) {
+    xhat_out[r * D + c] = xh;
+    h_out[r * D + c] = hv;
+    hs[c] = hv;
+    if (tid == 0) rstd_out[r] = rstd;
+  }
   __syncthreads();
   const float4 h4 = *reinterpret_cast<const float4*>(hs + lane * 4);
 #pragma unroll 8
-  for (int jj = 0; jj < 64; ++jj) {
-    const int j = w * 64 + jj;
+  for (int jj = 0; jj < PER; ++jj) {
+    const int j = w * PER + jj;
     const float4 w4 = *reinterpret_cast<const float4*>(W2 + (int64_t)j * D + lane * 4);
     float p = h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
-    p = wave_sum(p);
+    p = wave_total(p);
     if (lane == 0) out[r * D + j] = p + b2[j];
   }
 }
@@ -274,6 +306,7 @@ __global__ __launch_bounds__(256) void stem_bwd_row_kernel(const float* __restri
   ds[i] = dout[r * D + i];
   __syncthreads();
   float dh = 0.f;
+#pragma unroll 16
   for (int j = 0; j < D; ++j) dh += ds[j] * W2[(int64_t)j * D + i];
   const float xh = xhat[r * D + i];
   const float dz = h[r * D + i] > 0.f ? dh : 0.f;
@@ -285,22 +318,34 @@ __global__ __launch_bounds__(256) void stem_bwd_row_kernel(const float* __restri
   dpre[r * D + i] = rstd[r] * (g - s1 - xh * s2);
 }
 
-// dW[j][i] += sum_r dy[r][j] * x[r][i];  db[j] += sum_r dy[r][j]   (one thread per (j, i), j < 256)
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                         float* __restrict__ dW, float* __restrict__ db, int64_t rows,
-                                                         int in_dim) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)D * in_dim) return;
-  const int j = (int)(idx / in_dim), i = (int)(idx % in_dim);
+// dW[j][i] += sum_r dy[r][j] * x[r][i];  db[j] += sum_r dy[r][j].  A workgroup owns 256 (j, i) outputs; its four groups of 256 threads
+// each sum a quarter of the rows (eight rows' loads in flight) and the quarters are added in a fixed order through LDS.  (One thread
+// per output over all 512 rows of the bench shape, one row in flight: 138 us a launch, round 6.)
+__global__ __launch_bounds__(1024) void stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dW, float* __restrict__ db, int64_t rows,
+                                                          int in_dim) {
+  __shared__ float part[2][3][256];
+  const int t = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + t;
+  const bool in = idx < (int64_t)D * in_dim;
+  const int j = in ? (int)(idx / in_dim) : 0, i = in ? (int)(idx % in_dim) : 0;
+  const int64_t per = (rows + 3) / 4, r0 = q * per, r1 = r0 + per < rows ? r0 + per : rows;
   float acc = 0.f, bacc = 0.f;
 #pragma unroll 8
-  for (int64_t r = 0; r < rows; ++r) {
+  for (int64_t r = r0; r < r1; ++r) {
     const float g = dy[r * D + j];
     acc += g * x[r * in_dim + i];
     bacc += g;
   }
-  dW[idx] += acc;
-  if (i == 0) db[j] += bacc;
+  if (q > 0) {
+    part[0][q - 1][t] = acc;
+    part[1][q - 1][t] = bacc;
+  }
+  __syncthreads();
+  if (q == 0 && in) {
+    dW[idx] += ((acc + part[0][0][t]) + part[0][1][t]) + part[0][2][t];
+    if (i == 0) db[j] += ((bacc + part[1][0][t]) + part[1][1][t]) + part[1][2][t];
+  }
 }
 
 inline unsigned wave_grid(int64_t rows) {
@@ -370,7 +415,7 @@ extern "C" int hma_action_stem_fwd(void* stream, const float* a, const float* me
   if (d_a <= 0 || d_a > 4096) return HMA_EINVAL;
   if (rows <= 0) return 0;
   const size_t smem = (size_t)(d_a + D + 4) * sizeof(float);
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)rows), dim3(256), smem, (hipStream_t)stream, a, mean, stdv,
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)rows), dim3(64 * SW), smem, (hipStream_t)stream, a, mean, stdv,
                      (int)(action_dim > 0 ? action_dim : 1), W1, b1, ln_w, ln_b, W2, b2, an, xhat, rstd, h, out, (int)d_a,
                      (int)skip_norm);
   HMA_CHECK_LAUNCH();
@@ -387,9 +432,9 @@ extern "C" int hma_action_stem_bwd(void* stream, const float* dout, const float*
   hipLaunchKernelGGL(stem_bwd_row_kernel, dim3((unsigned)rows), dim3(256), 0, s, dout, xhat, rstd, h, ln_w, W2, dln_w, dln_b,
                      scratch);
   HMA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((D * D + 255) / 256)), dim3(256), 0, s, dout, h, dW2, db2, rows, D);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)((D * D + 255) / 256)), dim3(1024), 0, s, dout, h, dW2, db2, rows, D);
   HMA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)(((int64_t)D * d_a + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)(((int64_t)D * d_a + 255) / 256)), dim3(1024), 0, s,
                      (const float*)scratch, an, dW1, db1, rows, (int)d_a);
   HMA_CHECK_LAUNCH();
   return 0;

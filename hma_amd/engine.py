@@ -1143,6 +1143,13 @@ class STEngine(DecodeMixin):
         self._forward_plan(B, T, S, A, False, domain if A > 0 else None, embed=False, l0=l0, l1=l1, readout=False).run(stream)
         return ws["x"].view(B, T, SA, D).clone()
 
+    @staticmethod
+    def zero_dx_action_rows(ws: dict, frames: int, S: int, A: int) -> None:
+        """Before the backward plan: the read-out's input gradient is STORED into the image rows of dx (hma_gemm_nt, EPI_F32 with
+        c_group = (S, S + A)), so only the A action rows of each frame have to start at zero (a fifth of the buffer)."""
+        if A > 0:
+            ws["dx"].view(frames, S + A, -1)[:, S:].zero_()
+
     def zero_grad(self, active_domains: Optional[Sequence[str]] = None) -> None:
         """Zero the whole gradient buffer, or only the ranges that can receive gradients this step."""
         if active_domains is None:
@@ -1172,7 +1179,7 @@ class STEngine(DecodeMixin):
             ws["stats"].zero_()
             self._loss_plan(B, T, S, True, fused=getattr(self, "_last_fce", False), A=A).run(stream)
         lay = self.layout
-        ws["dx"].zero_()
+        self.zero_dx_action_rows(ws, B * T, S, A)
         if A > 0:
             ws["da_emb"].zero_()
         jpa = self.jpa and A > 0 and self._act is not None

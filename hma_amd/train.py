@@ -351,7 +351,7 @@ class Trainer:
                             eng._forward_plan(Bq, Tq, Sq, A, True, domq, readout=not fce).run(stream)
                             eng._ws["stats"].zero_()
                             eng._loss_plan(Bq, Tq, Sq, True, fused=fce, A=A).run(stream)
-                            eng._ws["dx"].zero_()
+                            eng.zero_dx_action_rows(eng._ws, Bq * Tq, Sq, A)
                             if A > 0:
                                 eng._ws["da_emb"].zero_()
                         bwd.run(stream, start, stop)
