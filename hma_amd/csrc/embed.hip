@@ -5,8 +5,6 @@
 // additive pos_embed_TSC at hma/model/st_mask_git.py:651-672, ActionStat + BasicMLP at
 // hma/model/st_mask_git.py:134-138, 90-102.  One fused HBM-bound pass instead of ~10 ATen kernels
 // and two host syncs (the boolean indexing at factorization_utils.py:45,53).
-#include <type_traits>
-
 #include "hma_common.h"
 #include "../../include/hma_hip.h"
 
@@ -207,23 +205,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// sum over the 64 lanes as a wave-uniform value: four DPP steps inside the rows of 16 and four v_readlane (wave_sum's six
-// ds_bpermute round trips per output were half of the forward kernel's time)
-__device__ __forceinline__ float wave_total(float v) {
-  auto dpp = [](float x, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane holds its row's sum
-  auto rl = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
-  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
-}
 // sum of one value per thread of the FIRST FOUR waves of a workgroup of SW waves (the others pass anything)
 constexpr int SW = 16;
 __device__ __forceinline__ float block_sum_first256(float v, float* red) {
-  v = wave_total(v);
+  v = wave_sum(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0 && w < 4) red[w] = v;
@@ -261,7 +246,7 @@ __global__ __launch_bounds__(64 * SW) void stem_fwd_kernel(const float* __restri
     const int j = w * PER + jj;
     float p = 0.f;
     for (int i = lane; i < d_a; i += 64) p += an[i] * W1[(int64_t)j * d_a + i];
-    p = wave_total(p);
+    p = wave_sum(p);
     if (lane == 0) hs[j] = p + b1[j];
   }
   __syncthreads();
@@ -288,7 +273,7 @@ __global__ __launch_bounds__(64 * SW) void stem_fwd_kernel(const float* __restri
     const int j = w * PER + jj;
     const float4 w4 = *reinterpret_cast<const float4*>(W2 + (int64_t)j * D + lane * 4);
     float p = h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
-    p = wave_total(p);
+    p = wave_sum(p);
     if (lane == 0) out[r * D + j] = p + b2[j];
   }
 }

@@ -50,15 +50,30 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// Sum / maximum over the 64 lanes, in every lane: four DPP steps inside the rows of 16 (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror) and the four row results through v_readlane.  (Six __shfl_xor = six ds_bpermute round trips of ~120 cycles each were
+// half the time of the row kernels that reduce once or twice per row -- the action stem's forward 83 -> 37 us, round 6.)  Call with
+// all 64 lanes active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float readlane_f32(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
 
 // exact-erf GELU (nn.GELU() default, hma/model/st_transformer.py:20) and its derivative.
