@@ -124,6 +124,7 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
         core = self._core
         core.init_action_projectors(domains, d_actions, action_stats, action_network)  # (its unused action_out_projectors stay internal)
         self._ver_params = None  # (the parameter set the engine's version check sums over has changed)
+        self._drop_param_lists()
         self.config.init_actions = True
         self.config.action_domains, self.config.d_actions, self.config.action_stats = list(domains), list(d_actions), action_stats
         self.action_preprocessor = core.action_preprocessor
@@ -446,9 +447,15 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
             self._accum(self.mask_token, dmask_tok[:Cc].clone())
             core = self._core
             active = set(eng.layout.regions) - {"frozen", "head", "tail"} - {f"dom:{x}" for x in eng.domains if x != dom}
-            for name, prm in core.named_parameters():  # trunk / action parameters: views into the engine's gradient buffer
+            views = self.__dict__.get("_core_grad_views")
+            if views is None or views[0] is not eng.G:  # (name -> view of the flat gradient buffer: built once per buffer)
+                views = self.__dict__["_core_grad_views"] = (eng.G, {})
+            for name, prm in self._core_named():  # trunk / action parameters: views into the engine's gradient buffer
                 if eng.layout.entries[name].region in active:
-                    prm.grad = eng.view(name, eng.G)
+                    v = views[1].get(name)
+                    if v is None:
+                        v = views[1][name] = eng.view(name, eng.G)
+                    prm.grad = v
         self._saved = None
 
     def _save_pretrained(self, save_directory) -> None:
@@ -463,12 +470,40 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
     # ------------------------------------------------------------------------------------------ optimizer
     _OWN_ALIGN = 64
 
+    # A walk over the module tree costs ~25 ms of host time at 30 domains (7 763 parameters); a train step made five of them and sat
+    # at the edge of being host-bound (67 ms of GPU work; 100 ms per step on a slower host, round 6).  The lists are kept until the
+    # parameter set changes (`init_action_projectors`, `_apply`).
+    def _drop_param_lists(self) -> None:
+        for k in ("_own_named_list", "_all_params_list", "_core_named_list", "_core_grad_views"):
+            self.__dict__.pop(k, None)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_param_lists()
+        return out
+
+    def _all_params(self):
+        ps = self.__dict__.get("_all_params_list")
+        if ps is None:
+            ps = self.__dict__["_all_params_list"] = list(self.parameters())
+        return ps
+
+    def _core_named(self):
+        ps = self.__dict__.get("_core_named_list")
+        if ps is None:
+            ps = self.__dict__["_core_named_list"] = list(self._core.named_parameters())
+        return ps
+
     def _own_named(self):
         """Parameters this class owns outside the engine's flat layout (input / output stages, the DiffLoss head), in a fixed
         order.  `action_diff_losses.*` and `action_mask_tokens` never receive a gradient (jointly_predict_actions is off): like
         the reference's grad-None parameters they are never stepped."""
-        return [(n, p) for n, p in self.named_parameters()
+        named = self.__dict__.get("_own_named_list")
+        if named is None:
+            named = self.__dict__["_own_named_list"] = [
+                (n, p) for n, p in self.named_parameters()
                 if not n.startswith(("decoder.", "action_mlp.", "action_diff_losses.")) and n != "action_mask_tokens"]
+        return named
 
     def _make_flat(self, named, dev):
         """One fp32 buffer holding `named` parameters (64-element aligned) as views, with mirrored gradient and Adam-moment buffers and
@@ -574,9 +609,11 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
                       float(max_norm or 0.0), ptr(f["flags"]))
             f["calls"] += 1
 
-    def zero_grad(self, set_to_none: bool = True):
+    def zero_grad(self, set_to_none: bool = True, active_domains=None):
+        """`active_domains`: zero only the engine's dense range and these domains' blocks (a step driver that knows which domains
+        the step touches; the other blocks are never read -- their parameters' .grad is None)."""
         own = self.__dict__.get("_own")
-        for prm in self.parameters():
+        for prm in self._all_params():
             prm.grad = None
         if own is not None:  # own gradients accumulate in place in the flat buffer
             own["G"].zero_()
@@ -587,5 +624,5 @@ class STMAR(nn.Module, PyTorchModelHubMixin):
             for (_, p), gv in zip(self._act_named(dom), af["gviews"]):
                 p.grad = gv
         if self._core._engine is not None:
-            self._core._engine.zero_grad()
+            self._core._engine.zero_grad(active_domains)
         self._grads_live = False

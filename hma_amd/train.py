@@ -543,7 +543,7 @@ class MarTrainer:
         if self._micro == 0:
             self._known = step_domains is not None
             self._active = red.order(step_domains) if self._known else red.active_domains(dom)
-            self.model.zero_grad()
+            self.model.zero_grad(active_domains=self._active)  # (the dense range + these blocks: a 30-domain G is 4 GB)
             self.loss_info.zero_()
         elif self._known:
             if dom not in self._active:
@@ -551,7 +551,8 @@ class MarTrainer:
         else:
             fresh = [d for d in red.active_domains(dom) if d not in self._active]
             if fresh:
-                self._active = red.order(list(self._active) + fresh)  # (model.zero_grad() zeroed every block: nothing stale to clear)
+                self.engine.zero_grad_domains(fresh)  # (a block that was not zeroed with the first micro-batch's)
+                self._active = red.order(list(self._active) + fresh)
         # (the adaLN stacks' backward: per gradient bucket, or once for all layers when nothing is reduced -- see Trainer.micro_step)
         self.engine.ada_group = self.layers_per_bucket if (red.collective or self.force_overlap) else self.engine.cfg.num_layers
         out = self.model(**batch)
