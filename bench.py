@@ -223,6 +223,7 @@ def mar_bench(args, dev, steps=None, warmup=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = tr.step(step_domains=["dom0"], **kw)
+    t_issue = time.perf_counter() - t0  # the host is done enqueueing: below the step time means the GPU is the limit
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     tokens = B * T * 256
@@ -237,7 +238,7 @@ def mar_bench(args, dev, steps=None, warmup=None):
         "roofline": {"bound": "mfma", "kernel": "whole step (algorithmic FLOPs: trunk 3 x 1.04e8 + diffusion head 3 x 4.94e7 per patch token)",
                      "achieved": tokens / dt * MAR_FLOP_PER_TOKEN / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": tokens / dt * MAR_FLOP_PER_TOKEN / MFMA_PEAK, "traffic": None},
-        "final_loss": float(out.loss.detach())}
+        "final_loss": float(out.loss.detach()), "host_issue_ms_per_step": 1e3 * t_issue / steps}
     traffic = pmc_traffic_total("mar")
     if traffic:
         res["roofline"]["traffic"] = traffic["bytes_per_step"]
@@ -334,9 +335,11 @@ def decode_bench(args, dev, steps=None, warmup=None, batch=None):
         t0 = time.perf_counter()
         for _ in range(3):
             model.generate(p1, None, **kw1)
+        t_issue1 = (time.perf_counter() - t0) / 3
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / 3
         res["latency_b1"] = {"ms_per_frame": 1e3 * dt1 / (T - P), "frames_per_s": (T - P) / dt1,
+                             "host_ms_per_frame": 1e3 * t_issue1 / (T - P),
                              "sample": f"batch 1, {T - P} generated frames x {iters} MaskGIT iterations, 2 warm-up + mean of 3 rollouts"}
     traffic = pmc_traffic_total("decode")
     if traffic:

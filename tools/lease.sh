@@ -82,7 +82,8 @@ PY
         python - "$m" "$e" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/_mode.json"))
-print(sys.argv[1], sys.argv[2] or "(default)", "%.1f %s" % (d["value"], d["unit"]), "%.2f ms/step" % d.get("ms_per_step", float("nan")), d.get("latency_b1", ""))
+print(sys.argv[1], sys.argv[2] or "(default)", "%.1f %s" % (d["value"], d["unit"]), "%.2f ms/step" % d.get("ms_per_step", float("nan")), d.get("latency_b1", ""),
+      ("host issue %.1f ms/step" % d["host_issue_ms_per_step"]) if "host_issue_ms_per_step" in d else "")
 PY
       done; } 2>&1 | tee gpurun_out/mode_$m.txt ;;
   ab)  # ab LIB_A LIB_B [bench args]: interleaved same-box A / B of two libraries, twice each
