@@ -616,6 +616,7 @@ def main():
             dp_check["steps"] += 1
             dp_check["early_buckets"].append(int(trainer.reducer.early_buckets))
             dp_check["bytes_per_step"].append(int(trainer.reducer.bytes_step))
+    t_issue = time.perf_counter() - t0  # the host is done enqueueing the timed steps (far below dt: the GPU is the limit)
     torch.cuda.synchronize()
     if world > 1 or force:
         dist.barrier()
@@ -649,7 +650,7 @@ def main():
             "metric": "video-tokens/sec (train step: fwd+bwd+all-reduce+clip+AdamW) HMA-base T=16 16x16",
             "value": value, "unit": "video-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic", "host_issue_ms_per_step": 1e3 * t_issue / args.steps,
             "config": {"workload": f"HMA-base-disc d256/h8/L{args.layers}, {args.domains} action domains "
                                    f"({sum(p.numel() for p in model.parameters()) / 1e6:.1f}M params), synthetic VQ tokens "
                                    f"T={T} H=W=16 ids<8192 (+64 action tokens/frame), batch {B}/GPU",
