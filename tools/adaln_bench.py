@@ -18,9 +18,12 @@ mod = torch.randn(n, 6 * W, device=dev).bfloat16()
 dmod = torch.empty_like(mod)
 dx = torch.empty(n, W, device=dev)
 p = lambda t: t.data_ptr()
-for acc in (0, 1):
+gam, bet = torch.randn(W, device=dev), torch.randn(W, device=dev)
+dgam, dbet = torch.zeros(W, device=dev), torch.zeros(W, device=dev)
+for acc, aff in ((0, 0), (1, 0), (0, 1), (1, 1)):
     def run():
-        _lib.call("hma_adaln_bwd_acc", ops.stream_ptr(), p(dout), p(x), p(mod), 6 * W, 0, W, None, None, 1e-6, p(dx), p(dmod), None, None, n, W, acc)
+        _lib.call("hma_adaln_bwd_acc", ops.stream_ptr(), p(dout), p(x), p(mod), 6 * W, 0, W, p(gam) if aff else None, p(bet) if aff else None,
+                  1e-6, p(dx), p(dmod), p(dgam) if aff else None, p(dbet) if aff else None, n, W, acc)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -32,4 +35,4 @@ for acc in (0, 1):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
     gb = n * W * (4 + 2 + 2 + 4 + 4 + (4 if acc else 0)) / 1e9
-    print(f"adaln_bwd rows {n} accumulate {acc}: {us:.1f} us, {gb / us * 1e3:.2f} TB/s of algorithmic bytes")
+    print(f"adaln_bwd rows {n} accumulate {acc} affine {aff}: {us:.1f} us, {gb / us * 1e3:.2f} TB/s of algorithmic bytes")
