@@ -333,7 +333,7 @@ int hma_mar_mask_token_bwd(void* stream, const float* dpatches, int64_t ld, cons
                            int64_t frames, int32_t H, int32_t W, int32_t C, int32_t patch);
 /* x = z_proj_ln(concat(xtok rows, a_emb repeated A times) + pos_embed_TSC[t, s])  (st_mar.py:155-178; eps 1e-6, affine);
  * pos rows of frame t start at pos + t * pos_frame_stride.  backward: dxtok = d(image rows), da_emb[f] += sum over
- * the action rows, dpos / dgamma / dbeta += (atomics). */
+ * the action rows (atomics), dpos += the batch sum of every position (whole samples: frames % T == 0), dgamma / dbeta += (atomics). */
 int hma_mar_embed_fwd(void* stream, const float* xtok, const float* a_emb, const float* pos, int64_t pos_frame_stride,
                       const float* gamma, const float* beta, float eps, float* x, void* xhat, float* rstd, int64_t frames,
                       int32_t T, int32_t S, int32_t A);
@@ -341,7 +341,7 @@ int hma_mar_embed_bwd(void* stream, const float* dx, const void* xhat, const flo
                       float* da_emb, float* dpos, int64_t pos_frame_stride, float* dgamma, float* dbeta, int64_t frames,
                       int32_t T, int32_t S, int32_t A);
 /* z = decoder_norm(y) + diffusion_pos_embed_learned[t * S + s]  (st_mar.py:192-194; rows (b, t, s)); backward:
- * dy = LN-backward(dz * gamma), dpos2 / dgamma / dbeta += (atomics). */
+ * dy = LN-backward(dz * gamma), dpos2 += the batch sum of every position (rows % (T * S) == 0), dgamma / dbeta += (atomics). */
 int hma_mar_readout_fwd(void* stream, const float* y, const float* gamma, const float* beta, float eps, const float* pos2,
                         float* z, void* yhat, float* rstd, int64_t rows, int32_t T, int32_t S);
 int hma_mar_readout_bwd(void* stream, const float* dz, const void* yhat, const float* rstd, const float* gamma, float* dy,
