@@ -327,10 +327,23 @@ class DiffLoss(nn.Module):
         lin = self._linears()
         G: Dict[str, torch.Tensor] = {}
 
+        # every gradient accumulator of this backward out of ONE zero-filled buffer (46 fills of a few KB .. 4 MB were 46 launches)
+        al = lambda n: (n + 63) // 64 * 64
+        need = sum(al((w.shape[0] + po) * (w.shape[1] + pi)) + al(w.shape[0] + po) for w, _, po, pi in lin.values()) + 2 * self.depth * al(W)
+        arena, used = torch.zeros(need, dtype=F32, device=dev), [0]
+
+        def take(*shape):
+            n = 1
+            for d_ in shape:
+                n *= d_
+            t = arena[used[0]:used[0] + n].view(*shape)
+            used[0] += al(n)
+            return t
+
         def wgrad(key, dY, A, y_kind=A_BF16, a_kind=A_BF16):
             w, b, pad_out, pad_in = lin[key]
-            dW = torch.zeros(w.shape[0] + pad_out, w.shape[1] + pad_in, dtype=F32, device=dev)
-            dB = torch.zeros(w.shape[0] + pad_out, dtype=F32, device=dev)
+            dW = take(w.shape[0] + pad_out, w.shape[1] + pad_in)
+            dB = take(w.shape[0] + pad_out)
             self._tn(stream, dY, A, dW, dB, y_kind=y_kind, a_kind=a_kind)
             G[key + ".w"], G[key + ".b"] = dW[: w.shape[0], : w.shape[1]].contiguous(), dB[: w.shape[0]].contiguous()
 
@@ -357,8 +370,7 @@ class DiffLoss(nn.Module):
             wgrad(f"m0_{i}", du1, sv[f"hm{i}"])
             dhm = e(N, W)
             self._nt(stream, du1, Wt[f"m0_{i}"], None, dhm, EPI_BF16)
-            dg = torch.zeros(W, dtype=F32, device=dev)
-            db = torch.zeros(W, dtype=F32, device=dev)
+            dg, db = take(W), take(W)
             _lib.call("hma_adaln_bwd", stream, ptr(dhm), ptr(sv[f"x{i}"]), ptr(mod), 3 * W, 0, W, ptr(blk.in_ln.weight), ptr(blk.in_ln.bias),
                       1e-6, ptr(dx), ptr(dmod), ptr(dg), ptr(db), N, W)
             G[f"ln{i}.w"], G[f"ln{i}.b"] = dg, db
