@@ -154,15 +154,20 @@ class _Grads(torch.autograd.Function):
     """loss (already computed, with d loss / d params and d loss / d z in hand) -> autograd."""
 
     @staticmethod
-    def forward(ctx, loss, z, dz, grads, *params):
-        ctx.save_for_backward(dz, *grads)
+    def forward(ctx, loss, z, dz, arena, grads, *params):
+        ctx.save_for_backward(dz, arena, *grads)
         ctx.z_needs = z.requires_grad
         return loss.clone()
 
     @staticmethod
     def backward(ctx, g):
-        dz, *grads = ctx.saved_tensors
-        return (None, dz * g if ctx.z_needs else None, None, None, *[gr * g for gr in grads])
+        # the parameter gradients are views of ONE buffer (`arena`): scaled by the incoming gradient in one launch, not one per tensor
+        dz, arena, *grads = ctx.saved_tensors
+        scaled = arena * g
+        base, off0 = arena.untyped_storage().data_ptr(), arena.storage_offset()
+        out = [scaled.as_strided(gr.shape, gr.stride(), gr.storage_offset() - off0) if gr.untyped_storage().data_ptr() == base else gr * g
+               for gr in grads]
+        return (None, dz * g if ctx.z_needs else None, None, None, None, *out)
 
 
 _PAD = 128  # zero-padded columns of x_t (GEMM K) and of the output Linear (GEMM N)
@@ -317,9 +322,10 @@ class DiffLoss(nn.Module):
         self.last_net_out = out[:, : 2 * Cc]
         if not need_grad:
             return loss
-        names, grads, dz = self._backward(stream, Wb, Wt, sv, dout, xt_pad, tfreq, zc)
-        params = [dict(self.named_parameters())[n] for n in names]
-        return _Grads.apply(loss, z, dz, grads, *params)
+        names, grads, dz, arena = self._backward(stream, Wb, Wt, sv, dout, xt_pad, tfreq, zc)
+        named = dict(self.named_parameters())
+        params = [named[n] for n in names]
+        return _Grads.apply(loss, z, dz, arena, grads, *params)
 
     def _backward(self, stream, Wb, Wt, sv, dout, xt_pad, tfreq, z):
         N, W, dev, Cc = dout.shape[0], self.width, dout.device, self.in_channels
@@ -345,7 +351,7 @@ class DiffLoss(nn.Module):
             dW = take(w.shape[0] + pad_out, w.shape[1] + pad_in)
             dB = take(w.shape[0] + pad_out)
             self._tn(stream, dY, A, dW, dB, y_kind=y_kind, a_kind=a_kind)
-            G[key + ".w"], G[key + ".b"] = dW[: w.shape[0], : w.shape[1]].contiguous(), dB[: w.shape[0]].contiguous()
+            G[key + ".w"], G[key + ".b"] = dW[: w.shape[0], : w.shape[1]], dB[: w.shape[0]]  # (views: the padding is not part of them)
 
         # final layer: out = linear(adaln(x)); dout is fp32 [N, 128]
         wgrad("lin", dout, sv["hf"], y_kind=A_F32)
@@ -399,7 +405,7 @@ class DiffLoss(nn.Module):
         for i in range(self.depth):
             names += [f"net.res_blocks.{i}.in_ln.weight", f"net.res_blocks.{i}.in_ln.bias"]
             grads += [G[f"ln{i}.w"], G[f"ln{i}.b"]]
-        return names, grads, dz
+        return names, grads, dz, arena
 
     # ---------------------------------------------------------------------------------------- sampling
     @torch.no_grad()
