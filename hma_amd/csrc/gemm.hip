@@ -62,6 +62,8 @@ __device__ __forceinline__ int64_t remap_row(int64_t r, int64_t group_rows, int6
   return group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) : r;
 }
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
 // One accumulator quad: 4 consecutive output columns n..n+3 of (remapped) row crow; bias already added.
 __device__ __forceinline__ void epilogue_quad(const hma_gemm_nt_t& p, const int epi, int64_t bz, int64_t crow, int64_t n, float (&v)[4]) {
   switch (epi) {
@@ -143,13 +145,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(hma_gemm_nt_t p) {
   }
 
   uint4 ra[4][AKIND == HMA_A_F32 ? 2 : 1];
-  uint4 rw[4];
+  u32x4_t rw[4];  // (an ext vector: the uint4 struct array ended up in scratch, 80 bytes a lane)
 
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (tid >> 3) + i * 32;
-      rw[i] = *reinterpret_cast<const uint4*>(Wb + (bn + row) * p.ldw + k0 + kc * 8);
+      rw[i] = *reinterpret_cast<const u32x4_t*>(Wb + (bn + row) * p.ldw + k0 + kc * 8);
       if (a_off[i] >= 0) {
         if (AKIND == HMA_A_F32) {
           const float* s = reinterpret_cast<const float*>(Ab) + a_off[i] + k0 + kc * 8;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(hma_gemm_nt_t p) {
         v = ra[i][0];
       }
       *reinterpret_cast<uint4*>(&As[buf * TILE_ELEMS + row * LDT + kc * 8]) = v;
-      *reinterpret_cast<uint4*>(&Ws[buf * TILE_ELEMS + row * LDT + kc * 8]) = rw[i];
+      *reinterpret_cast<u32x4_t*>(&Ws[buf * TILE_ELEMS + row * LDT + kc * 8]) = rw[i];
     }
   };
 
@@ -802,7 +804,6 @@ __device__ __forceinline__ float gt_lookup(const float* tbl, uint32_t bits16) {
 }
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_run8(const hma_gemm_nt_t& p, int64_t bz, int64_t crow, int64_t n8, float (&v)[8]) {
