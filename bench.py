@@ -555,6 +555,8 @@ def main():
     model, domains, d_actions = build_model(args.domains, T, args.layers)
     model = model.to(dev).train()
     trainer = Trainer(model, lr=1e-4 * min(max(1, B * world / 64), 8), warmup_steps=500, device=dev)
+    if os.environ.get("HMA_BENCH_WGRAD_LAYERS"):  # measurement only (same-box A / B): weight gradients of 1 | 2 blocks per launch
+        trainer.engine.wgrad_layers = int(os.environ["HMA_BENCH_WGRAD_LAYERS"])
     total = args.warmup + args.steps
     # HMA_BENCH_STEP_DOMAINS=n (one-rank runs, `forced_collectives_check` below): every step ANNOUNCES the n domains an n-rank job would
     # see in it (this rank trains the first; the others' blocks are zeroed, all-reduced and stepped with zero gradients), so that the
@@ -698,8 +700,8 @@ def main():
                                       "hbm_achieved_gbs": gbs, "hbm_frac": gbs / 8000.0, "flop_per_byte": ai, "launches": len(ring),
                                       "avg_launch_us": 1e3 * ms / len(ring), "flops_per_launch": fl / len(ring),
                                       "bytes_per_launch": by / len(ring), "share_of_step_time": (ms / inst_steps) / step_ms,
-                                      "note": "the C-ABI calls that run gemm_tn_dma_kernel + tn_reduce_native_kernel for a block: per layer "
-                                              "ONE hma_gemm_tn_multi call with the block's seven weight gradients"}
+                                      "note": "the C-ABI calls that run gemm_tn_dma_kernel + tn_reduce_native_kernel: per TWO layers ONE "
+                                              "hma_gemm_tn_multi call with the blocks' fourteen weight gradients (engine.wgrad_layers)"}
             # `roofline` = the family with the largest share of the step, against the roof its arithmetic intensity puts it under
             dom_name = max(fams, key=lambda k: fams[k]["share_of_step_time"]) if fams else None
             if dom_name:

@@ -1528,7 +1528,7 @@ struct tn_prob {
   int yfrag, afrag;  // operand stored in the fused-MLP fragment order (HMA_A_BF16_FRAG32): only the DMA source address differs
   int yhb, ahb;      // > 0: operand in the head-blocked order of the spatial attention (HMA_A_BF16_HEADBLK), rows per frame
 };
-constexpr int TN_MAXP = 8;
+constexpr int TN_MAXP = 16;  // (round 6: the weight gradients of TWO blocks in one launch)
 struct tn_pair_args {
   tn_prob q[TN_MAXP];  // problem i's workgroup ids follow problem i - 1's; n problems (hma_gemm_tn: 1, _pair: 2, _multi: up to 8)
   int n;

@@ -119,6 +119,10 @@ class STEngine(DecodeMixin):
         self.chain_ab = True     # chain A + causal temporal attention + chain B in one launch (hma_chain_ab_fwd)
         self.chain_t = True      # temporal projection dgrad + temporal attention backward in one launch (hma_chain_t_bwd)
         self.wgrad_multi = True  # the block's seven weight gradients in one launch at the end of its backward (hma_gemm_tn_multi)
+        # ... and the weight gradients of this many consecutive blocks in ONE launch (2: every workgroup streams twice the rows of its
+        # 256 x 256 block, so the launch writes and its reduction reads half the partials per layer, and the launch's fixed cost is
+        # paid once per two layers; the operands of the block in waiting live in a second set of buffers)
+        self.wgrad_layers = 2
         BUN = 8192
         self.CP = {"proj_s": mk(L, 8 * BUN), "qkv_t": mk(L, 24 * BUN), "proj_s_T": mk(L, 8 * BUN), "qkv_t_T": mk(L, 24 * BUN),
                    "qkv_s_T": mk(L, 24 * BUN), "proj_t_T": mk(L, 8 * BUN)}  # (qkv_s_T: norm1's gamma folded into its output rows, for chain S backward)
@@ -406,6 +410,17 @@ class STEngine(DecodeMixin):
                 buf("dxb3", (M, 256), BF16)
                 buf("dxb4", (M, 256), BF16)
                 buf("dqkv_s", (M, 768), BF16)
+                # the second set: operands of the block whose weight gradients wait for the next block's (wgrad_layers = 2)
+                for nm in ("dxb5", "dxb6", "dxb7", "dxb8"):
+                    buf(nm, (M, 256), BF16)
+                buf("dqkv_s_b", (M, 768), BF16)
+                buf("dqkv_b", (M, 768), BF16)
+                buf("hg1_b", (Mt, 1024), BF16)
+                buf("du1_b", (Mt, 1024), BF16)
+                if "dx2b" in ws:
+                    buf("dx2b_b", (M, 256), BF16)
+                if "dxm" in ws:
+                    buf("dxm_b", (M, 256), BF16)
             buf("delta", (M, 8), F32)
             if A > 0:
                 buf("dss", (L, Fr, 512), F32)
@@ -667,7 +682,7 @@ class STEngine(DecodeMixin):
 
     def _backward_plan(self, B, T, S, A, domain) -> Plan:
         key = ("bwd", B, T, S, A, domain, self._use_fused(B * T * (S + A), True, S + A), self._use_chain(B * T * (S + A), S + A), self.ada_group,
-               self.chain_s, self.attn_hb, self.wgrad_multi, self.chain_t)
+               self.chain_s, self.attn_hb, self.wgrad_multi, self.chain_t, self.wgrad_layers)
         if key in self._plans:
             return self._plans[key]
         cfg, ws = self.cfg, self._ws
@@ -682,8 +697,15 @@ class STEngine(DecodeMixin):
         chain_s_ok = self.chain_s and (not self.qkn) and self._use_chain(M, SA) and M % 32 == 0 and M >= 128
         multi = self.wgrad_multi and "dqkv_s" in ws and self._use_fused(M, True, SA) and chain_s_ok
         dqkv_s = ws["dqkv_s"].data_ptr() if multi else dqkv
-        ring = [ws[k].data_ptr() for k in ("dxb", "dxb2", "dxb3", "dxb4")] if multi else []
-        nxt = lambda cur: ring[(ring.index(cur) + 1) % 4]  # the next bf16(dx) buffer (deferred weight gradients still read the earlier ones)
+        # `pair`: the weight gradients of two consecutive blocks in one launch -- the first block's operands (its three bf16(dx) states,
+        # both dqkv, gelu(u) / dU, the dropout and modulate copies) stay alive in the "_b" set while the second block runs
+        pair = multi and self.wgrad_layers > 1
+        ring_names = ("dxb", "dxb2", "dxb3", "dxb4") + (("dxb5", "dxb6", "dxb7", "dxb8") if pair else ())
+        ring = [ws[k].data_ptr() for k in ring_names] if multi else []
+        nxt = lambda cur: ring[(ring.index(cur) + 1) % len(ring)]  # the next bf16(dx) buffer (deferred weight gradients still read the earlier ones)
+        pend: list = []   # weight gradients waiting for their launch (`multi`)
+        pend_layers = 0
+        alt = lambda name, odd: ws[name + "_b" if (pair and odd) else name].data_ptr()
         # readout
         pl.gemm_tn(dY=ws["dlogits"].data_ptr(), ldy=1024, y_kind=A_BF16, A=x, lda=256, a_kind=A_F32, a_group=(S, SA), M=Mi,
                    N=1024, K=256, dW=self._g("out_x_proj.weight"), lddw=256, dBias=self._g("out_x_proj.bias"))
@@ -700,6 +722,9 @@ class STEngine(DecodeMixin):
         pl.dxb_in = {}  # layer -> the bf16(dx) buffer its backward reads first (an entry into the middle of the plan must fill it)
         for l in reversed(range(L)):
             pl.dxb_in[l] = dxb
+            odd = bool((L - 1 - l) & 1)  # which buffer set this block's deferred operands use
+            if multi:
+                dqkv, dqkv_s = alt("dqkv", odd), alt("dqkv_s", odd)
             xh1, rstd1 = dp(ws["xh1"], l, M * 256), dp(ws["rstd1"], l, M)
             qkv_s, o_s, lse_s = dp(ws["qkv_s"], l, M * 768), dp(ws["o_s"], l, M * 256), dp(ws["lse_s"], l, M * 8)
             x2b = dp(ws["x2b"], l, M * 256)
@@ -712,13 +737,12 @@ class STEngine(DecodeMixin):
                 # ---- MLP, fused: u recomputed from xhat2, dU / gelu(u) written once for the two weight gradients, the
                 # LayerNorm backward applied in the same kernel (its dgamma / dbeta come out of the fc1 weight-gradient
                 # reduction).  The new bf16 copy of dx goes to the other dxb buffer: fc2's weight gradient still reads the old.
-                pend = []  # this block's weight gradients, launched together at its end when `multi`
                 dxb_new = nxt(dxb) if multi else (ws["dxb2"].data_ptr() if dxb == ws["dxb"].data_ptr() else ws["dxb"].data_ptr())
-                hg, du = ws["hg1"].data_ptr(), ws["du1"].data_ptr()
+                hg, du = (alt("hg1", odd), alt("du1", odd)) if multi else (ws["hg1"].data_ptr(), ws["du1"].data_ptr())
                 dkw = self._drop_fused(True, l)
                 dy2 = dxb  # dY of the fc2 weight gradient: behind the output Dropout when there is one (written by hma_mlp_bwd)
                 if dkw:
-                    dy2 = dkw["dy_drop"] = ws["dxm"].data_ptr()
+                    dy2 = dkw["dy_drop"] = alt("dxm", odd) if multi else ws["dxm"].data_ptr()
                 pl.mlp_bwd(M, xhat=xh2, rstd=rstd2, dy=dxb, dx=dx, dx_bf16=dxb_new, w1p=dp(self.MP["w1p"], l, 512 * 512),
                            w2tp=dp(self.MP["w2tp"], l, 512 * 512), w1tp=dp(self.MP["w1tp"], l, 512 * 512),
                            b1=self.BF["fc1"][l].data_ptr(), hg=hg, du=du, **dkw)
@@ -785,14 +809,14 @@ class STEngine(DecodeMixin):
                     xhm, xm, rstdm = dp(ws["xhm"], l, M * 256), dp(ws["xm"], l, M * 256), dp(ws["rstdm"], l, M)
                     ap = f"decoder.layers.{l}.action_projectors.{domain}"
                     segs.append((self.CP[f"lin_T:{domain}"][l].data_ptr(), 8))
-                    kwm = dict(xhat=xhm, rstd=rstdm, ss=dp(ws["ss"], l, Fr * 512), dx2_bf16=ws["dx2b"].data_ptr(),
-                               dss=dp(ws["dss"], l, Fr * 512))
+                    dx2b = alt("dx2b", odd) if multi else ws["dx2b"].data_ptr()
+                    kwm = dict(xhat=xhm, rstd=rstdm, ss=dp(ws["ss"], l, Fr * 512), dx2_bf16=dx2b, dss=dp(ws["dss"], l, Fr * 512))
                 segs.append((self.CP["proj_s_T"][l].data_ptr(), 8))
                 if multi:
                     dxb = nxt(dxb)  # (the deferred temporal projection gradient still reads the previous buffer)
                 pl.chain_a_bwd(M, use_mod, segs=segs, dqkv=dqkv, dx=dx, dx1_bf16=dxb, d_o=t256, rows_per_frame=SA, **kwm)
                 if use_mod:
-                    kw_lin = dict(dY=ws["dx2b"].data_ptr(), ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
+                    kw_lin = dict(dY=dx2b, ldy=256, y_kind=A_BF16, A=xm, lda=256, a_kind=A_BF16, M=M, N=256, K=256,
                                   dW=self._g(f"{ap}.linear_out.weight"), lddw=256, dBias=self._g(f"{ap}.linear_out.bias"))
                     if multi:
                         pend.append(kw_lin)
@@ -847,8 +871,12 @@ class STEngine(DecodeMixin):
                 pl.chain_s_bwd(M, segs=[(self.CP["qkv_s_T"][l].data_ptr(), 24)], dqkv=dqkv_s, dx=dx, xhat=xh1, rstd=rstd1, dx_bf16=dxb,
                                hb_rows=SA if hb else 0)
                 if multi:
-                    # ---- the block's seven (six without the modulation) weight gradients: one launch, one reduction
-                    pl.gemm_tn_multi(pend)
+                    # ---- the seven (six without the modulation) weight gradients of this block and, `pair`, of the one before it: one
+                    # launch, one reduction.  Pairs never straddle a gradient bucket (layer marks at even distances from the top)
+                    pend_layers += 1
+                    if pend_layers == (2 if pair else 1) or l == 0:
+                        pl.gemm_tn_multi(pend)
+                        pend, pend_layers = [], 0
             else:
                 pl.gemm_nt(A=dqkv_s, lda=768, a_kind=A_BF16, W=wt("qkv_s"), ldw=768, M=M, N=256, K=768, epi=EPI_BF16, Cp=t256, ldc=256)
                 pl.add("hma_ln_bwd", t256, xh1, rstd1, self._lw(l, "norm1.weight", "p"), dx, gw("norm1.weight"), gw("norm1.bias"), M,
@@ -1107,12 +1135,12 @@ class STEngine(DecodeMixin):
         ws = self._ws
         SA, M, Fr = S + A, B * T * (S + A), B * T
         stream = torch.cuda.current_stream().cuda_stream
-        saved = self.ada_group
-        self.ada_group = 1
+        saved = self.ada_group, self.wgrad_layers
+        self.ada_group, self.wgrad_layers = 1, 1  # (a range of layers is a self-contained run of the plan: nothing deferred across layers)
         try:
             pl = self._backward_plan(B, T, S, A, dom)
         finally:
-            self.ada_group = saved
+            self.ada_group, self.wgrad_layers = saved
         ws["dx"].view(B, T, SA, 256).copy_(dy_BTSD, non_blocking=True)
         if A > 0:
             ws["da_emb"].zero_()

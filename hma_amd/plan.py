@@ -79,7 +79,7 @@ class Plan:
                  flops=sum(2.0 * g.M * g.N * g.K * max(g.batch, 1) for g in gs), nbytes=sum(self._tn_bytes(g) for g in gs))
 
     def gemm_tn_multi(self, kws: Sequence[dict]) -> None:
-        """Up to 8 weight gradients whose operands are all live, in one launch + one reduction (hma_gemm_tn_multi)."""
+        """Up to 16 weight gradients whose operands are all live, in one launch + one reduction (hma_gemm_tn_multi)."""
         gs = []
         wsb = self.tn_workspace
         for kw in kws:

@@ -117,7 +117,7 @@ int hma_gemm_tn(void* stream, const hma_gemm_tn_t* p);
  * two-stage reduction per problem.  Both must name the same workspace (>= 256 * 65792 floats); any pair that is not
  * eligible for the LDS-DMA kernel is executed as two hma_gemm_tn calls.  Same results as two calls. */
 int hma_gemm_tn_pair(void* stream, const hma_gemm_tn_t* a, const hma_gemm_tn_t* b);
-/* Up to 8 independent weight gradients in ONE launch -- e.g. the seven of an STBlock at the end of its backward (the MLP's two, the two
+/* Up to 16 independent weight gradients in ONE launch -- e.g. the seven of an STBlock (or the fourteen of two) at the end of its backward (the MLP's two, the two
  * attentions' projection + qkv pairs, the ModulateLayer's linear_out; st_transformer.py:85-112, st_mask_git.py:66-76): nothing
  * downstream reads a weight gradient before the optimizer, so the launches can wait until every operand of the block exists.  The
  * 256 workgroups are divided in proportion to the operand bytes: every problem is split over fewer M-slices (32 MB of bf16 partials
