@@ -873,8 +873,10 @@ class STEngine(DecodeMixin):
                 if multi:
                     # ---- the seven (six without the modulation) weight gradients of this block and, `pair`, of the one before it: one
                     # launch, one reduction.  Pairs never straddle a gradient bucket (layer marks at even distances from the top)
+                    # ... nor a group of `ada_group` layers: a data-parallel driver sets that to its layers per bucket, and a bucket's
+                    # gradients have to be complete at its layer mark (the all-reduce of the bucket is issued there)
                     pend_layers += 1
-                    if pend_layers == (2 if pair else 1) or l == 0:
+                    if pend_layers == (2 if pair else 1) or l == 0 or (L - l) % ada_g == 0:
                         pl.gemm_tn_multi(pend)
                         pend, pend_layers = [], 0
             else:
@@ -1061,6 +1063,8 @@ class STEngine(DecodeMixin):
         if A > 0:
             ws["da_emb"].zero_()
         fill_dx(ws)
+        if on_segment is not None and segment_layers > 0:
+            self.ada_group = segment_layers  # (the plan completes every deferred launch of a segment before its mark)
         pl = self._backward_plan(B, T, S, A, domain)
         start = pl.marks["post_readout"]
         if on_segment is not None and segment_layers > 0:
@@ -1221,6 +1225,8 @@ class STEngine(DecodeMixin):
                 self.view(f"action_out_projectors.{a['dom']}.weight", self.G).addmm_(d_out.t(), a["pooled"])
                 self.view(f"action_out_projectors.{a['dom']}.bias", self.G).add_(d_out.sum(dim=0))
                 ws["dx"].view(B * T, S + A, 256)[:, S:].add_((d_out @ W).div_(A)[:, None, :])
+        if on_segment is not None and segment_layers > 0:
+            self.ada_group = segment_layers  # (the plan completes every deferred launch of a segment before its mark)
         pl = self._backward_plan(B, T, S, A, domain)
 
         def tail(start):

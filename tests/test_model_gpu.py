@@ -610,6 +610,29 @@ def _plan_names(m):
     return {name for pl in eng._plans.values() for _, name, _ in pl.calls}
 
 
+def test_deferred_weight_gradients_are_complete_at_every_bucket_mark():
+    """The weight gradients of TWO blocks share a launch (engine.wgrad_layers), but never across a gradient bucket: a data-parallel
+    driver all-reduces a bucket at its layer mark, so every weight gradient of the bucket's layers must have been LAUNCHED by then.
+    (One rank cannot see the difference in the numbers -- its all-reduce is the identity -- so the plan itself is checked.)"""
+    L = 5
+    m, rc, sd = _t16_model(with_actions=True, layers=L)
+    eng = m._get_engine(torch.device(DEV, torch.cuda.current_device()))
+    eng.fused_mlp_min_rows = 0
+    ids, labels, act = _t16_batch()
+    eng.forward(ids.view(2, 16, 256).to(DEV), labels.to(DEV), act.to(DEV), "domA", train=True, loss_grad=True, need_logits=False)
+    for group in (1, 2, 3, L):
+        eng.ada_group = group
+        pl = eng._backward_plan(2, 16, 256, 64, "domA")
+        launched_before = lambda pos: sum(a[1] for _, name, a in pl.calls[:pos] if name == "hma_gemm_tn_multi")
+        n_multi = sum(1 for _, name, _ in pl.calls if name == "hma_gemm_tn_multi")
+        assert n_multi > 0, "the deferred weight-gradient launch is not in the plan"
+        for l in reversed(range(L)):
+            if (L - l) % group == 0 or l == 0:  # a bucket ends behind layer l
+                assert launched_before(pl.marks[f"layer{l}"]) == 7 * (L - l), (group, l, launched_before(pl.marks[f"layer{l}"]))
+        if group == L:  # nothing to respect but the end: pairs from the top, the odd layer alone
+            assert n_multi == (L + 1) // 2
+
+
 def test_fused_forward_chain_without_action_tokens_vs_oracle():
     """Round 6: blocks WITHOUT action tokens (no ModulateLayer, 256 rows per frame) take hma_chain_ab_fwd too at T = 16 (its MOD = false
     form: chain A is the spatial projection + residual, bf16(x1) the temporal qkv's operand).  Loss and every gradient against the oracle;
